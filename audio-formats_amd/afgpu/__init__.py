@@ -1,0 +1,211 @@
+"""afgpu -- Python host binding of the MI355X audio-decode transform path.
+
+Thin ctypes view of ``audio-formats_amd/lib/libafg_hip.so`` (the C ABI declared in
+``include/afg.h``).  PyTorch is used only as plumbing (device memory, streams,
+``torch.distributed``); tensors cross the boundary as raw device pointers.
+
+There is no CPU fallback: if the library or a gfx950 device is missing, every
+entry point raises ``AfgError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libafg_hip.so")
+
+MP3_STATE_FLOATS = 1536
+VORBIS_LONG, VORBIS_PREV, VORBIS_NEXT = 1, 2, 4
+FLAC_INDEPENDENT, FLAC_LEFT_SIDE, FLAC_RIGHT_SIDE, FLAC_MID_SIDE = 0, 8, 9, 10
+
+FLAC_SUBFRAME_DTYPE = np.dtype([("coef", np.int16, (32,)), ("order", np.uint8), ("shift", np.uint8),
+                                ("wasted", np.uint8), ("use64", np.uint8)], align=True)
+FLAC_FRAME_DTYPE = np.dtype([("in_off", np.uint64), ("out_off", np.uint64), ("block_size", np.uint32),
+                             ("sf_index", np.uint32), ("channels", np.uint8), ("assignment", np.uint8),
+                             ("bps", np.uint8), ("pad", np.uint8, (5,))], align=True)
+assert FLAC_SUBFRAME_DTYPE.itemsize == 68 and FLAC_FRAME_DTYPE.itemsize == 32
+
+# every symbol include/afg.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "afg_abi_version", "afg_status_string", "afg_last_error", "afg_device_count", "afg_device_name",
+    "afg_mp3_plan_create", "afg_mp3_plan_destroy", "afg_mp3_plan_blocks", "afg_mp3_plan_segments",
+    "afg_mp3_transform_hip",
+    "afg_vorbis_plan_create", "afg_vorbis_plan_destroy", "afg_vorbis_plan_packets",
+    "afg_vorbis_plan_spec_floats", "afg_vorbis_plan_out_floats", "afg_vorbis_plan_offsets",
+    "afg_vorbis_transform_hip",
+    "afg_flac_transform_hip",
+    "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
+]
+
+
+class AfgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def mp3_flags(block_type=0, n_long_bands=0, aa_bands=31):
+    """AFG_MP3_FLAGS of include/afg.h."""
+    return np.uint32(block_type | (n_long_bands << 8) | ((aa_bands + 1) << 16))
+
+
+def lib():
+    """Load the C-ABI library (once).  torch is imported first so that both share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AfgError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 so the C ABI binds to the same runtime)
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.afg_abi_version.restype = C.c_int
+    L.afg_status_string.restype = C.c_char_p
+    L.afg_status_string.argtypes = [C.c_int]
+    L.afg_last_error.restype = C.c_char_p
+    L.afg_device_count.restype = C.c_int
+    L.afg_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    L.afg_mp3_plan_create.argtypes = [C.POINTER(vp), u32, vp, vp, u32]
+    L.afg_mp3_plan_destroy.argtypes = [vp]
+    L.afg_mp3_plan_destroy.restype = None
+    L.afg_mp3_plan_blocks.argtypes = [vp]
+    L.afg_mp3_plan_blocks.restype = u64
+    L.afg_mp3_plan_segments.argtypes = [vp]
+    L.afg_mp3_plan_segments.restype = u32
+    L.afg_mp3_transform_hip.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.afg_vorbis_plan_create.argtypes = [C.POINTER(vp), u32, vp, vp, vp, vp, vp, u32]
+    L.afg_vorbis_plan_destroy.argtypes = [vp]
+    L.afg_vorbis_plan_destroy.restype = None
+    for fn in (L.afg_vorbis_plan_packets, L.afg_vorbis_plan_spec_floats, L.afg_vorbis_plan_out_floats):
+        fn.argtypes = [vp]
+        fn.restype = u64
+    L.afg_vorbis_plan_offsets.argtypes = [vp, vp, vp]
+    L.afg_vorbis_transform_hip.argtypes = [vp, vp, vp, vp]
+    L.afg_flac_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
+    L.afg_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.afg_device_free.argtypes = [vp]
+    L.afg_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
+    L.afg_memcpy_d2h.argtypes = [vp, vp, C.c_size_t, vp]
+    L.afg_stream_synchronize.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        raise AfgError(f"afg: {L.afg_status_string(rc).decode()} ({rc}): {L.afg_last_error().decode()}")
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor / int / None."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA(HIP) tensors"
+    return t.data_ptr()
+
+
+def _stream(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    return getattr(stream, "cuda_stream", stream)
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Mp3Plan:
+    """Batch description of the MP3 transform stage (afg_mp3_plan)."""
+
+    def __init__(self, granules, channels, seg_granules=0):
+        self.granules = _np(granules, np.uint32)
+        self.channels = _np(channels, np.uint8)
+        assert self.granules.shape == self.channels.shape
+        self._h = C.c_void_p()
+        check(lib().afg_mp3_plan_create(C.byref(self._h), len(self.granules), self.granules.ctypes.data,
+                                        self.channels.ctypes.data, seg_granules))
+        self.blocks = int(lib().afg_mp3_plan_blocks(self._h))
+        self.segments = int(lib().afg_mp3_plan_segments(self._h))
+
+    def transform(self, d_coef, d_flags, d_pcm, d_state=None, stream=None):
+        """Enqueue the transform (no synchronisation).  Arguments are CUDA(HIP) tensors."""
+        check(lib().afg_mp3_transform_hip(self._h, _ptr(d_coef), _ptr(d_flags), _ptr(d_pcm),
+                                          _ptr(d_state), _stream(stream)))
+
+    def close(self):
+        if self._h:
+            lib().afg_mp3_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VorbisPlan:
+    """Batch description of the Vorbis transform stage (afg_vorbis_plan)."""
+
+    def __init__(self, packets, channels, blocksize0, blocksize1, pflags, seg_packets=0):
+        self.packets = _np(packets, np.uint32)
+        self.channels = _np(channels, np.uint8)
+        self.bs0 = _np(blocksize0, np.uint16)
+        self.bs1 = _np(blocksize1, np.uint16)
+        self.pflags = _np(pflags, np.uint8)
+        assert int(self.packets.sum()) == self.pflags.size
+        self._h = C.c_void_p()
+        check(lib().afg_vorbis_plan_create(C.byref(self._h), len(self.packets), self.packets.ctypes.data,
+                                           self.channels.ctypes.data, self.bs0.ctypes.data,
+                                           self.bs1.ctypes.data, self.pflags.ctypes.data, seg_packets))
+        self.total_packets = int(lib().afg_vorbis_plan_packets(self._h))
+        self.spec_floats = int(lib().afg_vorbis_plan_spec_floats(self._h))
+        self.out_floats = int(lib().afg_vorbis_plan_out_floats(self._h))
+
+    def offsets(self):
+        so = np.zeros(self.total_packets, np.uint64)
+        oo = np.zeros(self.total_packets, np.uint64)
+        check(lib().afg_vorbis_plan_offsets(self._h, so.ctypes.data, oo.ctypes.data))
+        return so, oo
+
+    def transform(self, d_spec, d_out, stream=None):
+        check(lib().afg_vorbis_transform_hip(self._h, _ptr(d_spec), _ptr(d_out), _stream(stream)))
+
+    def close(self):
+        if self._h:
+            lib().afg_vorbis_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def flac_transform(n_frames, d_frames, d_subframes, d_res, d_out_i32=None, d_out_f32=None, stream=None):
+    """Enqueue the FLAC restore (afg_flac_transform_hip).  Records are uint8 CUDA tensors holding
+    FLAC_FRAME_DTYPE / FLAC_SUBFRAME_DTYPE arrays."""
+    check(lib().afg_flac_transform_hip(int(n_frames), _ptr(d_frames), _ptr(d_subframes), _ptr(d_res),
+                                       _ptr(d_out_i32), _ptr(d_out_f32), _stream(stream)))
+
+
+def device_count():
+    return int(lib().afg_device_count())
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(lib().afg_device_name(device, buf, 256))
+    return buf.value.decode()

@@ -1,0 +1,198 @@
+"""Synthetic, seeded transform-stage batches.
+
+These stand in for what the host parsers produce right before the transform
+stage: dequantised MP3 spectra + granule flags, Vorbis floor*residue spectra +
+packet flags, FLAC residual planes + subframe records.  numpy versions feed the
+parity tests; the torch versions build the BASELINE.json workloads directly in
+HBM for bench.py.
+"""
+import numpy as np
+
+from . import (FLAC_FRAME_DTYPE, FLAC_INDEPENDENT, FLAC_LEFT_SIDE, FLAC_MID_SIDE, FLAC_RIGHT_SIDE,
+               FLAC_SUBFRAME_DTYPE, VORBIS_LONG, VORBIS_NEXT, VORBIS_PREV, mp3_flags)
+
+# ------------------------------------------------------------------ MP3 ------
+
+MP3_CUTOFF_LINE = 418            # ~16 kHz at 44.1 kHz: lines above are zero at 128 kbps
+
+
+def mp3_tilt():
+    k = np.arange(576, dtype=np.float64)
+    t = 2.0 ** (-k / 48.0)
+    t[MP3_CUTOFF_LINE:] = 0.0
+    return t.astype(np.float32)
+
+
+def mp3_block_types(rng, n, p_event=0.02, p_mixed=0.0):
+    """Legal block-type sequence of one channel: 0* (1 2+ 3) 0* ...  Returns (block_type, mixed)."""
+    bt = np.zeros(n, np.uint8)
+    mixed = np.zeros(n, bool)
+    starts = np.flatnonzero(rng.random(n) < p_event)
+    pos = 0
+    for s in starts:
+        if s < pos:
+            continue
+        nshort = int(rng.integers(1, 4))
+        if s + nshort + 2 > n:
+            break
+        bt[s] = 1
+        bt[s + 1:s + 1 + nshort] = 2
+        bt[s + 1 + nshort] = 3
+        if p_mixed > 0:
+            mixed[s + 1:s + 1 + nshort] = rng.random(nshort) < p_mixed
+        pos = s + nshort + 2
+    return bt, mixed
+
+
+def mp3_flag_words(bt, mixed):
+    """AFG_MP3_FLAGS for MPEG-1 (n_long_bands = 2 for mixed blocks, minimp3.d:1218)."""
+    n_long = np.where(mixed & (bt == 2), 2, 0).astype(np.uint32)
+    aa = np.where(bt == 2, n_long.astype(np.int64) - 1, 31)
+    return (bt.astype(np.uint32) | (n_long << 8) | ((aa + 1).astype(np.uint32) << 16)).astype(np.uint32)
+
+
+def mp3_batch(seed, granules, channels, p_event=0.05, p_mixed=0.3, amplitude=1.0):
+    """numpy batch: returns (coef[blocks*576] f32, flags[blocks] u32)."""
+    granules = np.asarray(granules, np.uint32)
+    channels = np.asarray(channels, np.uint8)
+    tilt = mp3_tilt()
+    coefs, flags = [], []
+    for s, (ng, nc) in enumerate(zip(granules, channels)):
+        rng = np.random.default_rng([seed, s])
+        c = rng.standard_normal((int(ng), int(nc), 576)).astype(np.float32) * tilt * np.float32(amplitude)
+        f = np.zeros((int(ng), int(nc)), np.uint32)
+        for ch in range(int(nc)):
+            bt, mixed = mp3_block_types(rng, int(ng), p_event, p_mixed)
+            f[:, ch] = mp3_flag_words(bt, mixed)
+        coefs.append(c.reshape(-1))
+        flags.append(f.reshape(-1))
+    if not coefs:
+        return np.zeros(0, np.float32), np.zeros(0, np.uint32)
+    return np.concatenate(coefs), np.concatenate(flags)
+
+
+def mp3_batch_device(seed, n_files, granules_per_file, device, p_event=0.04, files_per_chunk=32):
+    """C2-shaped stereo batch built in HBM with torch.  Returns (coef, flags) CUDA tensors."""
+    import torch
+    blocks = n_files * granules_per_file * 2
+    coef = torch.empty(blocks * 576, dtype=torch.float32, device=device)
+    tilt = torch.from_numpy(mp3_tilt()).to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    per_file = granules_per_file * 2 * 576
+    for f0 in range(0, n_files, files_per_chunk):
+        f1 = min(n_files, f0 + files_per_chunk)
+        view = coef[f0 * per_file:f1 * per_file].view(-1, 576)
+        view.normal_(generator=gen)
+        view.mul_(tilt)
+    flags_np = np.zeros((n_files, granules_per_file, 2), np.uint32)
+    for f in range(n_files):
+        rng = np.random.default_rng([seed, f])
+        for ch in range(2):
+            bt, mixed = mp3_block_types(rng, granules_per_file, p_event, 0.0)
+            flags_np[f, :, ch] = mp3_flag_words(bt, mixed)
+    flags = torch.from_numpy(flags_np.reshape(-1).view(np.int32)).to(device)
+    return coef, flags
+
+
+# --------------------------------------------------------------- Vorbis ------
+
+def vorbis_floor_curve(n2):
+    k = np.arange(n2, dtype=np.float64)
+    curve = 10.0 ** (-(k / n2) * 2.5)                # ~50 dB down at Nyquist
+    curve[int(n2 * 16000 / 22050):] = 0.0            # zeros above 16 kHz
+    return curve.astype(np.float32)
+
+
+def vorbis_packet_flags(rng, npkt, p_short_run=0.05):
+    """Legal blockflag sequence with prev/next window flags (stb_vorbis2.d:2324-2331)."""
+    long_ = np.ones(npkt, bool)
+    i = 0
+    while i < npkt:
+        if rng.random() < p_short_run:
+            run = int(rng.integers(1, 9))
+            long_[i:i + run] = False
+            i += run
+        i += 1
+    pf = np.zeros(npkt, np.uint8)
+    for p in range(npkt):
+        if long_[p]:
+            prev_long = long_[p - 1] if p > 0 else True
+            next_long = long_[p + 1] if p + 1 < npkt else True
+            pf[p] = VORBIS_LONG | (VORBIS_PREV if prev_long else 0) | (VORBIS_NEXT if next_long else 0)
+    return pf
+
+
+def vorbis_batch(seed, packets, channels, bs0, bs1, p_short_run=0.05, amplitude=1.0):
+    """numpy batch: returns (pflags[total], spec[spec_floats] f32).  Spectra are laid out
+    packet after packet as [ch][n/2]."""
+    pflags, specs = [], []
+    for s, (npk, nc) in enumerate(zip(packets, channels)):
+        rng = np.random.default_rng([seed, s])
+        pf = vorbis_packet_flags(rng, int(npk), p_short_run)
+        pflags.append(pf)
+        for p in range(int(npk)):
+            n2 = (int(bs1[s]) if (pf[p] & VORBIS_LONG) else int(bs0[s])) // 2
+            x = rng.standard_normal((int(nc), n2)).astype(np.float32) * vorbis_floor_curve(n2)
+            specs.append((x * np.float32(amplitude)).reshape(-1))
+    if not specs:
+        return np.zeros(0, np.uint8), np.zeros(0, np.float32)
+    return np.concatenate(pflags), np.concatenate(specs)
+
+
+# ----------------------------------------------------------------- FLAC ------
+
+def _quantised_lpc(rng, order, precision=12):
+    """A stable AR(order) predictor quantised like a FLAC encoder would (coef, shift)."""
+    # poles inside the unit circle -> stable synthesis filter
+    npairs = order // 2
+    poles = []
+    for _ in range(npairs):
+        r = rng.uniform(0.5, 0.97)
+        th = rng.uniform(0.02, np.pi * 0.9)
+        poles += [r * np.exp(1j * th), r * np.exp(-1j * th)]
+    if order % 2:
+        poles.append(rng.uniform(-0.9, 0.9))
+    a = np.real(np.poly(poles))                      # 1 + a1 z^-1 + ...
+    lpc = -a[1:]                                      # prediction coefficients
+    cmax = np.abs(lpc).max()
+    shift = precision - 1 - int(np.floor(np.log2(cmax))) - 1
+    shift = int(np.clip(shift, 0, 15))
+    q = np.clip(np.round(lpc * (1 << shift)), -(1 << (precision - 1)), (1 << (precision - 1)) - 1)
+    return q.astype(np.int16), shift
+
+
+def flac_batch(seed, n_frames, block_size=4096, channels=2, bps=16, orders=(8, 12),
+               assignments=(FLAC_MID_SIDE, FLAC_LEFT_SIDE, FLAC_RIGHT_SIDE, FLAC_INDEPENDENT),
+               assignment_p=(0.55, 0.2, 0.1, 0.15), residual_scale=32.0, wasted_p=0.05,
+               vary_block=False):
+    """numpy batch of LPC subframes.  Returns (frames, subframes, res int32, out_total)."""
+    rng = np.random.default_rng(seed)
+    frames = np.zeros(n_frames, FLAC_FRAME_DTYPE)
+    subframes = np.zeros(n_frames * channels, FLAC_SUBFRAME_DTYPE)
+    res_parts = []
+    in_off = out_off = 0
+    for f in range(n_frames):
+        bs = int(block_size if not vary_block else rng.choice([192, 576, 1152, 4096, 4608, 1000]))
+        asg = int(rng.choice(assignments, p=assignment_p)) if channels == 2 else FLAC_INDEPENDENT
+        frames[f] = (in_off, out_off, bs, f * channels, channels, asg, bps, [0] * 5)
+        for c in range(channels):
+            side = (asg in (FLAC_LEFT_SIDE, FLAC_MID_SIDE) and c == 1) or (asg == FLAC_RIGHT_SIDE and c == 0)
+            wasted = int(rng.integers(1, 3)) if rng.random() < wasted_p else 0
+            sf_bps = bps + (1 if side else 0) - wasted
+            order = int(rng.choice(orders))
+            order = min(order, bs)
+            if order > 0:
+                coef, shift = _quantised_lpc(rng, order)
+            else:
+                coef, shift = np.zeros(0, np.int16), 0
+            sf = subframes[f * channels + c]
+            sf["coef"][:order] = coef
+            sf["order"], sf["shift"], sf["wasted"], sf["use64"] = order, shift, wasted, int(sf_bps > 16)
+            r = np.rint(rng.laplace(0.0, residual_scale, bs)).astype(np.int64)
+            lim = (1 << (sf_bps - 1)) - 1
+            r[:order] = rng.integers(-lim // 4, lim // 4 + 1, order)       # warm-up samples
+            res_parts.append(r.astype(np.int32))
+        in_off += bs * channels
+        out_off += bs * channels
+    return frames, subframes, np.concatenate(res_parts), out_off

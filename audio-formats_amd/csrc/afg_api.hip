@@ -1,0 +1,139 @@
+// afg_api.hip -- status strings, device checks and small utilities of the C ABI.
+#include "afg_common.h"
+
+#include <cstdlib>
+#include <string>
+
+namespace afg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); this library has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return AFG_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    AFG_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    AFG_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; kernels are built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+        return AFG_ERR_NO_DEVICE;
+    }
+    return AFG_OK;
+}
+
+int DeviceArray::upload(const void *host, size_t nbytes)
+{
+    release();
+    if (nbytes == 0) return AFG_OK;
+    hipError_t e = hipMalloc(&ptr, nbytes);
+    if (e != hipSuccess) {
+        ptr = nullptr;
+        set_error("hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? AFG_ERR_OOM : AFG_ERR_HIP;
+    }
+    bytes = nbytes;
+    AFG_HIP_CHECK(hipMemcpy(ptr, host, nbytes, hipMemcpyHostToDevice));
+    return AFG_OK;
+}
+
+void DeviceArray::release()
+{
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+}  // namespace afg
+
+extern "C" {
+
+int afg_abi_version(void) { return AFG_ABI_VERSION; }
+
+const char *afg_status_string(int status)
+{
+    switch (status) {
+    case AFG_OK: return "ok";
+    case AFG_ERR_INVALID: return "invalid argument";
+    case AFG_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case AFG_ERR_HIP: return "HIP runtime error";
+    case AFG_ERR_OOM: return "out of memory";
+    case AFG_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+const char *afg_last_error(void) { return afg::g_err; }
+
+int afg_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        afg::set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return e == hipErrorNoDevice ? 0 : AFG_ERR_HIP;
+    }
+    return n;
+}
+
+int afg_device_name(int device, char *buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return AFG_ERR_INVALID;
+    hipDeviceProp_t prop;
+    AFG_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return AFG_OK;
+}
+
+int afg_device_malloc(void **d_ptr, size_t bytes)
+{
+    if (!d_ptr) return AFG_ERR_INVALID;
+    *d_ptr = nullptr;
+    if (int rc = afg::require_device()) return rc;
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        afg::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? AFG_ERR_OOM : AFG_ERR_HIP;
+    }
+    return AFG_OK;
+}
+
+int afg_device_free(void *d_ptr)
+{
+    if (d_ptr) AFG_HIP_CHECK(hipFree(d_ptr));
+    return AFG_OK;
+}
+
+int afg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *hip_stream)
+{
+    AFG_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    return AFG_OK;
+}
+
+int afg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *hip_stream)
+{
+    AFG_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    return AFG_OK;
+}
+
+int afg_stream_synchronize(void *hip_stream)
+{
+    AFG_HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream));
+    return AFG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,579 @@
+// mp3_transform.hip -- MP3 Layer III transform stage on gfx950.
+//
+// Replaces, for whole batches of streams, the tail of L3_decode
+// (reference minimp3.d:1226-1228: L3_antialias -> L3_imdct_gr ->
+// L3_change_sign) and mp3d_synth_granule (minimp3.d:1408-1434, called at
+// :1553).  Every output sample is produced by the same float32 expression tree
+// as the reference (the library is compiled with -ffp-contract=off), only the
+// data movement is different:
+//
+//   * one wavefront (a 64-thread workgroup) walks `seg_granules` consecutive
+//     granules of one stream; a segment that does not start at granule 0
+//     first re-derives its carry state from the two preceding granules
+//     (PCM(g) depends on X[g], X[g-1], X[g-2] only: the IMDCT overlap written
+//     by a granule depends on that granule's spectrum alone, minimp3.d:1095,
+//     :1137-1140, and the polyphase window spans 15 earlier slots < 18);
+//   * antialias + IMDCT36/12 + frequency inversion run with lane = (channel,
+//     subband), 18 spectral lines and the 9 overlap values in registers,
+//     neighbour subbands exchanged with wave shuffles;
+//   * the 32-point DCT-II runs with lane = (channel, time slot) out of an LDS
+//     transposition buffer and writes 32-value rows of the polyphase history;
+//   * the history is a 36-row LDS ring (two granules), the 512-tap window runs
+//     with lane = (channel, output sample) and stores fully coalesced
+//     interleaved PCM.
+//
+// Coefficients are read with fully coalesced 256-byte wave loads one granule
+// ahead of their use and staged through LDS into the (channel, subband) layout.
+#include "afg_common.h"
+
+#include <vector>
+
+namespace {
+
+struct Mp3Seg {
+    uint32_t stream;
+    uint32_t g0;
+    uint32_t count;
+    uint32_t last;      // 1 if this segment ends the stream
+};
+
+struct Mp3Stream {
+    uint64_t blk_base;  // first gr-ch block of the stream
+    uint32_t ngr;
+    uint32_t nch;
+};
+
+constexpr int kHStride = 65;          // 64 values per history row (+1 pad: conflict-free row-per-lane writes)
+constexpr int kHRows = 36;            // two granules of 18 slots
+constexpr int kStateOverlap = 64 * 9; // floats of overlap in the opaque state blob
+
+// -- tables (values: minimp3.d:1004-1007, :1065-1067, :1113, :1154-1157, :1234-1236, :1336-1352) --
+__device__ const float k_aa_cs[8] = {
+    0.85749293f, 0.88174200f, 0.94962865f, 0.98331459f, 0.99551782f, 0.99916056f, 0.99989920f, 0.99999316f };
+__device__ const float k_aa_ca[8] = {
+    0.51449576f, 0.47173197f, 0.31337745f, 0.18191320f, 0.09457419f, 0.04096558f, 0.01419856f, 0.00369997f };
+
+__device__ const float k_win[15 * 16] = {
+    -1, 26, -31, 208, 218, 401, -519, 2063, 2000, 4788, -5517, 7134, 5959, 35640, -39336, 74992,
+    -1, 24, -35, 202, 222, 347, -581, 2080, 1952, 4425, -5879, 7640, 5288, 33791, -41176, 74856,
+    -1, 21, -38, 196, 225, 294, -645, 2087, 1893, 4063, -6237, 8092, 4561, 31947, -43006, 74630,
+    -1, 19, -41, 190, 227, 244, -711, 2085, 1822, 3705, -6589, 8492, 3776, 30112, -44821, 74313,
+    -1, 17, -45, 183, 228, 197, -779, 2075, 1739, 3351, -6935, 8840, 2935, 28289, -46617, 73908,
+    -1, 16, -49, 176, 228, 153, -848, 2057, 1644, 3004, -7271, 9139, 2037, 26482, -48390, 73415,
+    -2, 14, -53, 169, 227, 111, -919, 2032, 1535, 2663, -7597, 9389, 1082, 24694, -50137, 72835,
+    -2, 13, -58, 161, 224, 72, -991, 2001, 1414, 2330, -7910, 9592, 70, 22929, -51853, 72169,
+    -2, 11, -63, 154, 221, 36, -1064, 1962, 1280, 2006, -8209, 9750, -998, 21189, -53534, 71420,
+    -2, 10, -68, 147, 215, 2, -1137, 1919, 1131, 1692, -8491, 9863, -2122, 19478, -55178, 70590,
+    -3, 9, -73, 139, 208, -29, -1210, 1870, 970, 1388, -8755, 9935, -3300, 17799, -56778, 69679,
+    -3, 8, -79, 132, 200, -57, -1283, 1817, 794, 1095, -8998, 9966, -4533, 16155, -58333, 68692,
+    -4, 7, -85, 125, 189, -83, -1356, 1759, 605, 814, -9219, 9959, -5818, 14548, -59838, 67629,
+    -4, 7, -91, 117, 177, -106, -1428, 1698, 402, 545, -9416, 9916, -7154, 12980, -61289, 66494,
+    -5, 6, -97, 111, 163, -127, -1498, 1634, 185, 288, -9585, 9838, -8540, 11455, -62684, 65290 };
+
+// 9-point DCT-III; operation order of minimp3.d:1022-1060.
+__device__ __forceinline__ void dct3_9(float (&y)[9])
+{
+    float e0 = y[0], e2 = y[2], e4 = y[4], e6 = y[6], e8 = y[8];
+    float m0 = e0 + e6 * 0.5f;
+    e0 = e0 - e6;
+    float m4 = (e4 + e2) * 0.93969262f;
+    float m2 = (e8 + e2) * 0.76604444f;
+    e6 = (e4 - e8) * 0.17364818f;
+    e4 = e4 + (e8 - e2);
+
+    e2 = e0 - e4 * 0.5f;
+    y[4] = e4 + e0;
+    e8 = m0 - m2 + e6;
+    e0 = m0 - m4 + m2;
+    e4 = m0 + m4 - e6;
+
+    float o1 = y[1], o3 = y[3], o5 = y[5], o7 = y[7];
+    o3 = o3 * 0.86602540f;
+    m0 = (o5 + o1) * 0.98480775f;
+    m4 = (o5 - o7) * 0.34202014f;
+    m2 = (o1 + o7) * 0.64278761f;
+    o1 = (o1 - o5 - o7) * 0.86602540f;
+
+    o5 = m0 - o3 - m2;
+    o7 = m4 - o3 - m0;
+    o3 = m4 + o3 - m2;
+
+    y[0] = e4 - o7;
+    y[1] = e2 + o1;
+    y[2] = e0 - o3;
+    y[3] = e8 + o5;
+    y[5] = e8 - o5;
+    y[6] = e0 + o3;
+    y[7] = e2 - o1;
+    y[8] = e4 + o7;
+}
+
+// Long-block IMDCT of one subband held in registers; minimp3.d:1062-1100.
+// `stop` selects window row 1 (minimp3.d:1167).
+__device__ __forceinline__ void imdct36_lane(float (&x)[18], float (&ov)[9], bool stop)
+{
+    constexpr float tw[18] = {
+        0.73727734f, 0.79335334f, 0.84339145f, 0.88701083f, 0.92387953f, 0.95371695f, 0.97629601f, 0.99144486f, 0.99904822f,
+        0.67559021f, 0.60876143f, 0.53729961f, 0.46174861f, 0.38268343f, 0.30070580f, 0.21643961f, 0.13052619f, 0.04361938f };
+    constexpr float w0[18] = {
+        0.99904822f, 0.99144486f, 0.97629601f, 0.95371695f, 0.92387953f, 0.88701083f, 0.84339145f, 0.79335334f, 0.73727734f,
+        0.04361938f, 0.13052619f, 0.21643961f, 0.30070580f, 0.38268343f, 0.46174861f, 0.53729961f, 0.60876143f, 0.67559021f };
+    constexpr float w1[18] = {
+        1, 1, 1, 1, 1, 1, 0.99144486f, 0.92387953f, 0.79335334f,
+        0, 0, 0, 0, 0, 0, 0.13052619f, 0.38268343f, 0.60876143f };
+
+    float co[9], si[9];
+    co[0] = -x[0];
+    si[0] = x[17];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        si[8 - 2 * i] = x[4 * i + 1] - x[4 * i + 2];
+        co[1 + 2 * i] = x[4 * i + 1] + x[4 * i + 2];
+        si[7 - 2 * i] = x[4 * i + 4] - x[4 * i + 3];
+        co[2 + 2 * i] = -(x[4 * i + 3] + x[4 * i + 4]);
+    }
+    dct3_9(co);
+    dct3_9(si);
+    si[1] = -si[1];
+    si[3] = -si[3];
+    si[5] = -si[5];
+    si[7] = -si[7];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        float wa = stop ? w1[i] : w0[i];
+        float wb = stop ? w1[9 + i] : w0[9 + i];
+        float ovl = ov[i];
+        float sum = co[i] * tw[9 + i] + si[i] * tw[i];
+        ov[i] = co[i] * tw[i] - si[i] * tw[9 + i];
+        x[i] = ovl * wa - sum * wb;
+        x[17 - i] = ovl * wb + sum * wa;
+    }
+}
+
+// minimp3.d:1102-1109
+__device__ __forceinline__ void idct3(float x0, float x1, float x2, float (&dst)[3])
+{
+    float m1 = x1 * 0.86602540f;
+    float a1 = x0 - x2 * 0.5f;
+    dst[1] = x0 + x2;
+    dst[0] = a1 + m1;
+    dst[2] = a1 - m1;
+}
+
+// minimp3.d:1111-1129; x = 6 lines at stride 3 starting at `off`, dst = 6 outputs, ov = overlap[6..8]
+__device__ __forceinline__ void imdct12(const float (&t)[18], int off, float (&dst)[6], float (&ov)[3])
+{
+    constexpr float tw3[6] = { 0.79335334f, 0.92387953f, 0.99144486f, 0.60876143f, 0.38268343f, 0.13052619f };
+    float co[3], si[3];
+    idct3(-t[off + 0], t[off + 6] + t[off + 3], t[off + 12] + t[off + 9], co);
+    idct3(t[off + 15], t[off + 12] - t[off + 9], t[off + 6] - t[off + 3], si);
+    si[1] = -si[1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float ovl = ov[i];
+        float sum = co[i] * tw3[3 + i] + si[i] * tw3[i];
+        ov[i] = co[i] * tw3[i] - si[i] * tw3[3 + i];
+        dst[i] = ovl * tw3[2 - i] - sum * tw3[5 - i];
+        dst[5 - i] = ovl * tw3[5 - i] + sum * tw3[2 - i];
+    }
+}
+
+// Short-block subband; minimp3.d:1131-1142.
+__device__ __forceinline__ void imdct_short_lane(float (&x)[18], float (&ov)[9])
+{
+    float t[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) t[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = ov[i];
+    float tail[3] = { ov[6], ov[7], ov[8] };
+    float d[6];
+    imdct12(t, 0, d, tail);
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[6 + i] = d[i];
+    imdct12(t, 1, d, tail);
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[12 + i] = d[i];
+    imdct12(t, 2, d, tail);
+#pragma unroll
+    for (int i = 0; i < 6; i++) ov[i] = d[i];
+    ov[6] = tail[0];
+    ov[7] = tail[1];
+    ov[8] = tail[2];
+}
+
+// 32-point DCT-II of one time slot; minimp3.d:1232-1298.  in[b] = subband b, out[q].
+__device__ __forceinline__ void dct2_32(const float (&in)[32], float (&out)[32])
+{
+    constexpr float sec[24] = {
+        10.19000816f, 0.50060302f, 0.50241929f, 3.40760851f, 0.50547093f, 0.52249861f, 2.05778098f, 0.51544732f,
+        0.56694406f, 1.48416460f, 0.53104258f, 0.64682180f, 1.16943991f, 0.55310392f, 0.78815460f, 0.97256821f,
+        0.58293498f, 1.06067765f, 0.83934963f, 0.62250412f, 1.72244716f, 0.74453628f, 0.67480832f, 5.10114861f };
+    float t[4][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float x0 = in[i];
+        float x1 = in[15 - i];
+        float x2 = in[16 + i];
+        float x3 = in[31 - i];
+        float t0 = x0 + x3;
+        float t1 = x1 + x2;
+        float t2 = (x1 - x2) * sec[3 * i + 0];
+        float t3 = (x0 - x3) * sec[3 * i + 1];
+        t[0][i] = t0 + t1;
+        t[1][i] = (t0 - t1) * sec[3 * i + 2];
+        t[2][i] = t3 + t2;
+        t[3][i] = (t3 - t2) * sec[3 * i + 2];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float x0 = t[r][0], x1 = t[r][1], x2 = t[r][2], x3 = t[r][3];
+        float x4 = t[r][4], x5 = t[r][5], x6 = t[r][6], x7 = t[r][7], xt;
+        xt = x0 - x7; x0 = x0 + x7;
+        x7 = x1 - x6; x1 = x1 + x6;
+        x6 = x2 - x5; x2 = x2 + x5;
+        x5 = x3 - x4; x3 = x3 + x4;
+        x4 = x0 - x3; x0 = x0 + x3;
+        x3 = x1 - x2; x1 = x1 + x2;
+        t[r][0] = x0 + x1;
+        t[r][4] = (x0 - x1) * 0.70710677f;
+        x5 = x5 + x6;
+        x6 = (x6 + x7) * 0.70710677f;
+        x7 = x7 + xt;
+        x3 = (x3 + x4) * 0.70710677f;
+        x5 = x5 - x7 * 0.198912367f;
+        x7 = x7 + x5 * 0.382683432f;
+        x5 = x5 - x7 * 0.198912367f;
+        x0 = xt - x6; xt = xt + x6;
+        t[r][1] = (xt + x7) * 0.50979561f;
+        t[r][2] = (x4 + x3) * 0.54119611f;
+        t[r][3] = (x0 - x5) * 0.60134488f;
+        t[r][5] = (x0 + x5) * 0.89997619f;
+        t[r][6] = (x4 - x3) * 1.30656302f;
+        t[r][7] = (xt - x7) * 2.56291556f;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        out[4 * i + 0] = t[0][i];
+        out[4 * i + 1] = t[2][i] + t[3][i] + t[3][i + 1];
+        out[4 * i + 2] = t[1][i] + t[1][i + 1];
+        out[4 * i + 3] = t[2][i + 1] + t[3][i] + t[3][i + 1];
+    }
+    out[28] = t[0][7];
+    out[29] = t[2][7] + t[3][7];
+    out[30] = t[1][7];
+    out[31] = t[3][7];
+}
+
+// LDS float offset of the history row of time slot `t_rel` (-15..17) relative to
+// the granule of parity p.
+__device__ __forceinline__ int hrow(int p, int t_rel)
+{
+    int r = (t_rel >= 0) ? (p * 18 + t_rel) : ((1 - p) * 18 + 18 + t_rel);
+    return r * kHStride;
+}
+
+__global__ __launch_bounds__(64) void mp3_transform_kernel(
+    const Mp3Seg *__restrict__ segs, const Mp3Stream *__restrict__ streams,
+    const float *__restrict__ coef, const uint32_t *__restrict__ flags,
+    float *__restrict__ pcm, float *__restrict__ state)
+{
+    __shared__ float buf[2 * 576];
+    __shared__ float H[kHRows * kHStride];
+
+    const int lane = threadIdx.x;
+    const Mp3Seg seg = segs[blockIdx.x];
+    const Mp3Stream st = streams[seg.stream];
+    const int nch = (int)st.nch;
+    const int nval = nch * 576;                 // floats per granule
+
+    // role A: lane = (channel, subband) for antialias / IMDCT
+    const int ch = lane >> 5;
+    const int band = lane & 31;
+    // role C: lane = (channel, output sample j) for the polyphase window
+    const int j = lane & 31;
+
+    // ---- polyphase weights of this lane (minimp3.d:1388-1395 ladder) ----------
+    // main lanes: acc = sum_k vz_k * wa[k] + vy_k * wb[k]
+    float wa[8], wb[8];
+    int i_col = 0;
+    {
+        const bool is_a = (j >= 1 && j <= 15);
+        const bool is_b = (j >= 17);
+        i_col = is_a ? (15 - j) : (is_b ? (j - 17) : 0);
+        const float *w = k_win + (14 - i_col) * 16;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float w0 = w[2 * k], w1 = w[2 * k + 1];
+            if (is_a) {
+                wa[k] = (k & 1) ? -w0 : w0;
+                wb[k] = (k & 1) ? w1 : -w1;
+            } else {
+                wa[k] = w1;
+                wb[k] = w0;
+            }
+        }
+    }
+    const int col_hi = ch * 32 + 31 - i_col;
+    const int col_lo = ch * 32 + 1 + i_col;
+
+    // ---- carry state ------------------------------------------------------------
+    float ov[9];
+    const int n_warm = seg.g0 < 2u ? (int)seg.g0 : 2;
+    const int g_first = (int)seg.g0 - n_warm;
+    const bool from_state = (g_first == 0) && (state != nullptr);
+    float *st_blob = state ? state + (size_t)seg.stream * AFG_MP3_STATE_FLOATS : nullptr;
+#pragma unroll
+    for (int i = 0; i < 9; i++) ov[i] = from_state ? st_blob[lane * 9 + i] : 0.0f;
+    {
+        // history rows of the granule "before" g_first live in the parity-(1-p) half
+        const int p0 = g_first & 1;
+        for (int r = 0; r < 15; r++) {
+            float v = from_state ? st_blob[kStateOverlap + r * 64 + lane] : 0.0f;
+            H[hrow(p0, r - 15) + lane] = v;
+        }
+    }
+
+    // ---- prefetch of the first granule ------------------------------------------
+    const int g_end = (int)(seg.g0 + seg.count);
+    float pre[18];
+    {
+        const float *src = coef + (st.blk_base + (uint64_t)g_first * nch) * 576;
+#pragma unroll
+        for (int q = 0; q < 18; q++) {
+            int idx = lane + 64 * q;
+            pre[q] = (idx < nval) ? src[idx] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 18; q++) buf[lane + 64 * q] = pre[q];
+    }
+    __syncthreads();
+
+    for (int g = g_first; g < g_end; g++) {
+        const int p = g & 1;
+        const bool do_synth = g >= (int)seg.g0;
+        const bool do_dct = g >= (int)seg.g0 - 1;
+
+        // 1. (channel, subband) registers out of the staging buffer
+        float x[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++) x[i] = buf[lane * 18 + i];
+        uint32_t fl = 0;
+        if (ch < nch) fl = flags[st.blk_base + (uint64_t)g * nch + ch];
+
+        // 2. issue the next granule's coalesced loads now, park them in registers
+        const bool have_next = (g + 1 < g_end);
+        if (have_next) {
+            const float *src = coef + (st.blk_base + (uint64_t)(g + 1) * nch) * 576;
+#pragma unroll
+            for (int q = 0; q < 18; q++) {
+                int idx = lane + 64 * q;
+                pre[q] = (idx < nval) ? src[idx] : 0.0f;
+            }
+        }
+
+        // 3. alias reduction across subband boundaries, minimp3.d:1002-1020
+        {
+            const int block_type = (int)(fl & 3u);
+            const int n_long = (int)((fl >> 8) & 0xffu);
+            const int aa = (int)((fl >> 16) & 0xffu) - 1;
+            const bool lower = (band >= 1) && (band - 1 < aa);   // boundary (band-1 | band)
+            const bool upper = (band < aa);                        // boundary (band | band+1)
+            float nl[8], nh[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float d_prev = __shfl_up(x[17 - i], 1);            // line 17-i of subband band-1
+                float u_next = __shfl_down(x[i], 1);               // line i of subband band+1
+                nl[i] = x[i] * k_aa_cs[i] - d_prev * k_aa_ca[i];
+                nh[i] = u_next * k_aa_ca[i] + x[17 - i] * k_aa_cs[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                x[i] = lower ? nl[i] : x[i];
+                x[17 - i] = upper ? nh[i] : x[17 - i];
+            }
+
+            // 4. IMDCT + overlap, minimp3.d:1152-1168
+            const bool is_short = (block_type == 2) && (band >= n_long);
+            if (is_short) {
+                imdct_short_lane(x, ov);
+            } else {
+                const bool stop = (block_type == 3) && (band >= n_long);
+                imdct36_lane(x, ov, stop);
+            }
+            // 5. frequency inversion, minimp3.d:1144-1150
+            if (band & 1) {
+#pragma unroll
+                for (int i = 1; i < 18; i += 2) x[i] = -x[i];
+            }
+        }
+
+        __syncthreads();     // everyone has read its staging lines
+        if (do_dct) {
+#pragma unroll
+            for (int i = 0; i < 18; i++) buf[lane * 18 + i] = x[i];
+        }
+        __syncthreads();
+
+        // 6. 32-point DCT-II, lane = (channel, slot); minimp3.d:1232-1298
+        if (do_dct && band < 18 && ch < nch) {
+            float in[32], out[32];
+#pragma unroll
+            for (int b = 0; b < 32; b++) in[b] = buf[ch * 576 + b * 18 + band];
+            dct2_32(in, out);
+            float *row = H + hrow(p, band) + ch * 32;
+#pragma unroll
+            for (int q = 0; q < 32; q++) row[q] = out[q];
+        }
+        __syncthreads();
+
+        // 7. park the prefetched spectrum in the staging buffer (it is free now)
+        if (have_next) {
+#pragma unroll
+            for (int q = 0; q < 18; q++) buf[lane + 64 * q] = pre[q];
+        }
+
+        // 8. polyphase window, lane = (channel, sample j); minimp3.d:1305-1406
+        if (do_synth && ch < nch) {
+            float *dst = pcm + (st.blk_base + (uint64_t)g * nch) * 576 + ch;
+            for (int t = 0; t < 18; t++) {
+                float acc;
+                if (j == 0) {
+                    // synth_pair first half, minimp3.d:1308-1316; z[m] = slot t-15+m, column 16
+                    const int c16 = ch * 32 + 16;
+                    float z[15];
+#pragma unroll
+                    for (int m = 0; m < 15; m++) z[m] = H[hrow(p, t - 15 + m) + c16];
+                    acc  = (z[14] - z[0]) * 29;
+                    acc += (z[1] + z[13]) * 213;
+                    acc += (z[12] - z[2]) * 459;
+                    acc += (z[3] + z[11]) * 2037;
+                    acc += (z[10] - z[4]) * 5153;
+                    acc += (z[5] + z[9]) * 6574;
+                    acc += (z[8] - z[6]) * 37489;
+                    acc += z[7] * 75038;
+                } else if (j == 16) {
+                    // synth_pair second half, minimp3.d:1318-1327; column 0
+                    const int c0 = ch * 32;
+                    float z[8];
+#pragma unroll
+                    for (int m = 0; m < 8; m++) z[m] = H[hrow(p, t - 15 + 2 * m) + c0];
+                    acc  = z[7] * 104;
+                    acc += z[6] * 1567;
+                    acc += z[5] * 9727;
+                    acc += z[4] * 64019;
+                    acc += z[3] * -9975;
+                    acc += z[2] * -45;
+                    acc += z[1] * 146;
+                    acc += z[0] * -5;
+                } else {
+                    // window ladder, minimp3.d:1388-1395
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        float vz = H[hrow(p, t - k) + ((k & 1) ? col_lo : col_hi)];
+                        float vy = H[hrow(p, t - 15 + k) + ((k & 1) ? col_hi : col_lo)];
+                        float term = vz * wa[k] + vy * wb[k];
+                        acc = (k == 0) ? term : (acc + term);
+                    }
+                }
+                dst[(t * 32 + j) * nch] = acc * (1.0f / 32768.0f);      // mp3d_scale_pcm, :1300
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- hand the carry state on (chunked decoding) ------------------------------
+    if (st_blob && seg.last) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) st_blob[lane * 9 + i] = ov[i];
+        const int p = (g_end - 1) & 1;
+        for (int r = 0; r < 15; r++)
+            st_blob[kStateOverlap + r * 64 + lane] = H[hrow(p, 3 + r) + lane];
+    }
+}
+
+}  // namespace
+
+struct afg_mp3_plan {
+    uint32_t n_streams = 0;
+    uint32_t n_segs = 0;
+    uint64_t blocks = 0;
+    afg::DeviceArray d_segs, d_streams;
+};
+
+extern "C" {
+
+int afg_mp3_plan_create(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t *granules,
+                        const uint8_t *channels, uint32_t seg_granules)
+{
+    if (!plan) return AFG_ERR_INVALID;
+    *plan = nullptr;
+    if (n_streams && (!granules || !channels)) {
+        afg::set_error("afg_mp3_plan_create: NULL stream description");
+        return AFG_ERR_INVALID;
+    }
+    if (int rc = afg::require_device()) return rc;
+    if (seg_granules == 0) seg_granules = 48;
+
+    std::vector<Mp3Stream> streams(n_streams);
+    std::vector<Mp3Seg> segs;
+    uint64_t blk = 0;
+    for (uint32_t s = 0; s < n_streams; s++) {
+        if (channels[s] != 1 && channels[s] != 2) {
+            afg::set_error("afg_mp3_plan_create: stream %u has %u channels (1 or 2 expected)", s, channels[s]);
+            return AFG_ERR_INVALID;
+        }
+        streams[s] = Mp3Stream{ blk, granules[s], channels[s] };
+        for (uint32_t g0 = 0; g0 < granules[s]; g0 += seg_granules) {
+            uint32_t cnt = granules[s] - g0 < seg_granules ? granules[s] - g0 : seg_granules;
+            segs.push_back(Mp3Seg{ s, g0, cnt, (g0 + cnt == granules[s]) ? 1u : 0u });
+        }
+        blk += (uint64_t)granules[s] * channels[s];
+    }
+    if (segs.size() > 0x7fffffffu) {
+        afg::set_error("afg_mp3_plan_create: too many segments");
+        return AFG_ERR_INVALID;
+    }
+    afg_mp3_plan *p = new (std::nothrow) afg_mp3_plan;
+    if (!p) return AFG_ERR_OOM;
+    p->n_streams = n_streams;
+    p->n_segs = (uint32_t)segs.size();
+    p->blocks = blk;
+    int rc = p->d_segs.upload(segs.data(), segs.size() * sizeof(Mp3Seg));
+    if (!rc) rc = p->d_streams.upload(streams.data(), streams.size() * sizeof(Mp3Stream));
+    if (rc) {
+        afg_mp3_plan_destroy(p);
+        return rc;
+    }
+    *plan = p;
+    return AFG_OK;
+}
+
+void afg_mp3_plan_destroy(afg_mp3_plan *plan)
+{
+    if (!plan) return;
+    plan->d_segs.release();
+    plan->d_streams.release();
+    delete plan;
+}
+
+uint64_t afg_mp3_plan_blocks(const afg_mp3_plan *plan) { return plan ? plan->blocks : 0; }
+uint32_t afg_mp3_plan_segments(const afg_mp3_plan *plan) { return plan ? plan->n_segs : 0; }
+
+int afg_mp3_transform_hip(const afg_mp3_plan *plan, const float *d_coef, const uint32_t *d_flags,
+                          float *d_pcm, float *d_state, void *hip_stream)
+{
+    if (!plan) return AFG_ERR_INVALID;
+    if (plan->n_segs == 0) return AFG_OK;
+    if (!d_coef || !d_flags || !d_pcm) {
+        afg::set_error("afg_mp3_transform_hip: NULL device pointer");
+        return AFG_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(mp3_transform_kernel, dim3(plan->n_segs), dim3(64), 0, (hipStream_t)hip_stream,
+                       (const Mp3Seg *)plan->d_segs.ptr, (const Mp3Stream *)plan->d_streams.ptr,
+                       d_coef, d_flags, d_pcm, d_state);
+    AFG_HIP_CHECK(hipGetLastError());
+    return AFG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,543 @@
+// vorbis_transform.hip -- Vorbis inverse MDCT + window/overlap-add on gfx950.
+//
+// Replaces, for whole batches of streams, reference stb_vorbis2.d:2526-2527
+// (inverse_mdct per channel, :1941-2242), vorbis_finish_frame (:2606-2657) and
+// the interleave of stb_vorbis_get_samples_float_interleaved (:3927-3952).
+// Every output sample is produced by the same float32 expression tree as the
+// reference (library built with -ffp-contract=off); only the schedule differs:
+//
+//   * one 256-thread workgroup walks `seg_packets` consecutive packets of one
+//     stream with all its channels resident in LDS; a segment that does not
+//     start at packet 0 first redoes the IMDCT of the preceding packet to get
+//     its right half (the only carried state, stb_vorbis2.d:2641-2643);
+//   * every pass of the reference's in-place algorithm is a set of independent
+//     butterflies; passes are spread over the 256 threads with a barrier
+//     between passes.  Step 3's iter0 / inner_r / inner_s loops (:1720-1864)
+//     are one formula: stage l, group i < 2^(l+1), butterfly b < n >> (l+4):
+//         p = n/2-1 - (n >> (l+2))*i - 2b,  q = p - (n >> (l+3)),  twiddle A[b << (l+3)]
+//   * spectra are read with coalesced row loads, PCM leaves as interleaved
+//     rows; twiddle/window tables (host-computed exactly as :851-881) are
+//     shared by all workgroups and served from L2.
+#include "afg_common.h"
+
+#include <cmath>
+#include <map>
+#include <vector>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct VorbisSeg {
+    uint32_t stream;
+    uint32_t p0;       // first packet (stream-relative)
+    uint32_t count;
+    uint32_t pad;
+};
+
+struct VorbisStream {
+    uint64_t pkt_base;     // index of the stream's first packet in the batch-wide arrays
+    uint32_t npkt;
+    uint32_t nch;
+    uint32_t bs[2];
+    uint32_t tab[2];       // float offset of each blocksize's table set: A[n/2] B[n/2] C[n/4] W[n/2]
+};
+
+__device__ __forceinline__ void bfly(float *p, float *q, float c0, float c1)
+{
+    float d0 = p[0] - q[0];
+    float d1 = p[-1] - q[-1];
+    p[0] = p[0] + q[0];
+    p[-1] = p[-1] + q[-1];
+    q[0] = d0 * c0 - d1 * c1;
+    q[-1] = d1 * c0 + d0 * c1;
+}
+
+// stb_vorbis2.d:1866-1896
+__device__ __forceinline__ void iter_54(float *z)
+{
+    float k00 = z[0] - z[-4];
+    float y0 = z[0] + z[-4];
+    float y2 = z[-2] + z[-6];
+    float k22 = z[-2] - z[-6];
+    z[0] = y0 + y2;
+    z[-2] = y0 - y2;
+    float k33 = z[-3] - z[-7];
+    z[-4] = k00 + k33;
+    z[-6] = k00 - k33;
+    float k11 = z[-1] - z[-5];
+    float y1 = z[-1] + z[-5];
+    float y3 = z[-3] + z[-7];
+    z[-1] = y1 + y3;
+    z[-3] = y1 - y3;
+    z[-5] = k11 - k22;
+    z[-7] = k11 + k22;
+}
+
+// In-place inverse MDCT of one channel held in LDS; buffer[0..n/2) spectrum in,
+// buffer[0..n) samples out; buf2 = n/2 floats of scratch.  stb_vorbis2.d:1941-2242.
+__device__ void inverse_mdct_lds(float *buffer, float *buf2, int n, int ld,
+                                 const float *__restrict__ A, const float *__restrict__ B,
+                                 const float *__restrict__ C)
+{
+    const int tid = threadIdx.x;
+    const int n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+    float *u = buffer, *v = buf2;
+
+    // copy-and-reflect + step 0, :1972-1994 (n/4 items)
+    for (int it = tid; it < n4; it += kThreads) {
+        if (it < n8) {
+            const float *e = buffer + 4 * it;
+            float *d = buf2 + n2 - 2 - 2 * it;
+            const float *AA = A + 2 * it;
+            d[1] = (e[0] * AA[0] - e[2] * AA[1]);
+            d[0] = (e[0] * AA[1] + e[2] * AA[0]);
+        } else {
+            const int q = it - n8;
+            const float *e = buffer + n2 - 3 - 4 * q;
+            float *d = buf2 + n4 - 2 - 2 * q;
+            const float *AA = A + n4 + 2 * q;
+            d[1] = (-e[2] * AA[0] - -e[0] * AA[1]);
+            d[0] = (-e[2] * AA[1] + -e[0] * AA[0]);
+        }
+    }
+    __syncthreads();
+
+    // step 2, :2006-2040 (n/8 half-iterations)
+    for (int it = tid; it < n8; it += kThreads) {
+        const int q = it >> 1, h = it & 1;
+        const float *AA = A + n2 - 8 - 8 * q;
+        const float *e0 = v + n4 + 4 * q, *e1 = v + 4 * q;
+        float *d0 = u + n4 + 4 * q, *d1 = u + 4 * q;
+        if (h == 0) {
+            float v41_21 = e0[1] - e1[1];
+            float v40_20 = e0[0] - e1[0];
+            d0[1] = e0[1] + e1[1];
+            d0[0] = e0[0] + e1[0];
+            d1[1] = v41_21 * AA[4] - v40_20 * AA[5];
+            d1[0] = v40_20 * AA[4] + v41_21 * AA[5];
+        } else {
+            float v41_21 = e0[3] - e1[3];
+            float v40_20 = e0[2] - e1[2];
+            d0[3] = e0[3] + e1[3];
+            d0[2] = e0[2] + e1[2];
+            d1[3] = v41_21 * AA[0] - v40_20 * AA[1];
+            d1[2] = v40_20 * AA[0] + v41_21 * AA[1];
+        }
+    }
+    __syncthreads();
+
+    // step 3 stages l = 0 .. ld-7, :2053-2083 (n/8 butterflies each)
+    for (int l = 0; l <= ld - 7; l++) {
+        const int k0 = n >> (l + 2);
+        const int nb_log = ld - (l + 4);          // butterflies per group = n >> (l+4)
+        const int nb_mask = (1 << nb_log) - 1;
+        for (int it = tid; it < n8; it += kThreads) {
+            const int i = it >> nb_log, b = it & nb_mask;
+            float *p = u + n2 - 1 - k0 * i - 2 * b;
+            const float *a = A + (b << (l + 3));
+            bfly(p, p - (k0 >> 1), a[0], a[1]);
+        }
+        __syncthreads();
+    }
+
+    // last three stages fused, :1898-1939 (n/32 blocks of 16 floats)
+    {
+        const float A2 = A[n >> 3];
+        for (int it = tid; it < (n >> 5); it += kThreads) {
+            float *z = u + n2 - 1 - 16 * it;
+            float k00, k11, l00, l11;
+            k00 = z[0] - z[-8];
+            k11 = z[-1] - z[-9];
+            l00 = z[-2] - z[-10];
+            l11 = z[-3] - z[-11];
+            z[0] = z[0] + z[-8];
+            z[-1] = z[-1] + z[-9];
+            z[-2] = z[-2] + z[-10];
+            z[-3] = z[-3] + z[-11];
+            z[-8] = k00;
+            z[-9] = k11;
+            z[-10] = (l00 + l11) * A2;
+            z[-11] = (l11 - l00) * A2;
+
+            k00 = z[-4] - z[-12];
+            k11 = z[-5] - z[-13];
+            l00 = z[-6] - z[-14];
+            l11 = z[-7] - z[-15];
+            z[-4] = z[-4] + z[-12];
+            z[-5] = z[-5] + z[-13];
+            z[-6] = z[-6] + z[-14];
+            z[-7] = z[-7] + z[-15];
+            z[-12] = k11;
+            z[-13] = -k00;
+            z[-14] = (l11 - l00) * A2;
+            z[-15] = (l00 + l11) * -A2;
+
+            iter_54(z);
+            iter_54(z - 8);
+        }
+    }
+    __syncthreads();
+
+    // steps 4-6: bit-reversed gather u -> v, :2096-2124 (n/8 entries; table of :875-881 computed inline)
+    for (int e = tid; e < n8; e += kThreads) {
+        const int k4 = (int)((__brev((unsigned)e) >> (32 - ld + 3)) << 2);
+        const int q = e >> 1;
+        float *d0 = v + n4 - 4 - 4 * q;
+        float *d1 = v + n2 - 4 - 4 * q;
+        if ((e & 1) == 0) {
+            d1[3] = u[k4 + 0];
+            d1[2] = u[k4 + 1];
+            d0[3] = u[k4 + 2];
+            d0[2] = u[k4 + 3];
+        } else {
+            d1[1] = u[k4 + 0];
+            d1[0] = u[k4 + 1];
+            d0[1] = u[k4 + 2];
+            d0[0] = u[k4 + 3];
+        }
+    }
+    __syncthreads();
+
+    // step 7, :2133-2175 (n/8 half-iterations)
+    for (int it = tid; it < n8; it += kThreads) {
+        const int q = it >> 1, h = it & 1;
+        float *d = v + 4 * q;
+        float *e = v + n2 - 4 - 4 * q;
+        const float *CC = C + 4 * q;
+        if (h == 0) {
+            float a02 = d[0] - e[2];
+            float a11 = d[1] + e[3];
+            float b0 = CC[1] * a02 + CC[0] * a11;
+            float b1 = CC[1] * a11 - CC[0] * a02;
+            float b2 = d[0] + e[2];
+            float b3 = d[1] - e[3];
+            d[0] = b2 + b0;
+            d[1] = b3 + b1;
+            e[2] = b2 - b0;
+            e[3] = b1 - b3;
+        } else {
+            float a02 = d[2] - e[0];
+            float a11 = d[3] + e[1];
+            float b0 = CC[3] * a02 + CC[2] * a11;
+            float b1 = CC[3] * a11 - CC[2] * a02;
+            float b2 = d[2] + e[0];
+            float b3 = d[3] - e[1];
+            d[2] = b2 + b0;
+            d[3] = b3 + b1;
+            e[0] = b2 - b0;
+            e[1] = b1 - b3;
+        }
+    }
+    __syncthreads();
+
+    // step 8 + decode, :2187-2238 (n/4 items)
+    for (int it = tid; it < n4; it += kThreads) {
+        const int q = it >> 2, m = it & 3;
+        const float *BB = B + n2 - 8 - 8 * q;
+        const float *e = buf2 + n2 - 8 - 8 * q;
+        const float ea = e[6 - 2 * m], eb = e[7 - 2 * m];
+        const float ba = BB[6 - 2 * m], bb = BB[7 - 2 * m];
+        const float pa = ea * bb - eb * ba;
+        const float pb = -ea * ba - eb * bb;
+        buffer[4 * q + m] = pa;
+        buffer[n2 - 4 - 4 * q + 3 - m] = -pa;
+        buffer[n2 + 4 * q + m] = pb;
+        buffer[n - 4 - 4 * q + 3 - m] = pb;
+    }
+    __syncthreads();
+}
+
+// stb_vorbis2.d:2333-2349
+__device__ __forceinline__ void window_bounds(int bs0, int bs1, unsigned fl, int &n, int &left_start,
+                                              int &right_start, int &right_end)
+{
+    const bool lng = (fl & AFG_VORBIS_LONG) != 0;
+    const bool prev = lng && (fl & AFG_VORBIS_PREV);
+    const bool next = lng && (fl & AFG_VORBIS_NEXT);
+    n = lng ? bs1 : bs0;
+    left_start = (lng && !prev) ? ((n - bs0) >> 2) : 0;
+    if (lng && !next) {
+        right_start = (n * 3 - bs0) >> 2;
+        right_end = (n * 3 + bs0) >> 2;
+    } else {
+        right_start = n >> 1;
+        right_end = n;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void vorbis_transform_kernel(
+    const VorbisSeg *__restrict__ segs, const VorbisStream *__restrict__ streams,
+    const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
+    const uint64_t *__restrict__ out_off, const float *__restrict__ tables,
+    const float *__restrict__ spec, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const VorbisSeg seg = segs[blockIdx.x];
+    const VorbisStream st = streams[seg.stream];
+    const int C = (int)st.nch;
+    const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
+    const int nmax = bs1;
+
+    float *chan = smem;                          // C * nmax   (channel_buffers)
+    float *buf2 = chan + C * nmax;               // nmax / 2   (temp buffer of inverse_mdct)
+    float *prevw = buf2 + nmax / 2;              // C * nmax/2 (previous_window)
+
+    int previous_length = 0;
+    const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
+    const int p_end = (int)(seg.p0 + seg.count);
+
+    for (int p = p_first; p < p_end; p++) {
+        const uint64_t gp = st.pkt_base + (uint64_t)p;
+        const unsigned fl = pflags[gp];
+        int n, left, right, right_end;
+        window_bounds(bs0, bs1, fl, n, left, right, right_end);
+        const int n2 = n >> 1;
+        const int which = (fl & AFG_VORBIS_LONG) ? 1 : 0;
+        const int ld = 31 - __clz(n);
+        const float *T = tables + st.tab[which];
+        const float *A = T, *B = T + n2, *Ct = T + n;
+
+        // spectrum -> LDS (coalesced rows)
+        const float *src = spec + spec_off[gp];
+        for (int c = 0; c < C; c++)
+            for (int k = tid; k < n2; k += kThreads) chan[c * nmax + k] = src[c * n2 + k];
+        __syncthreads();
+
+        for (int c = 0; c < C; c++) inverse_mdct_lds(chan + c * nmax, buf2, n, ld, A, B, Ct);   // :2526-2527
+
+        // vorbis_finish_frame, :2606-2657
+        const bool emit = (p >= (int)seg.p0) && previous_length > 0;
+        if (emit) {
+            const int pn = previous_length;
+            const float *w = tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);   // window of size 2*pn (:2245-2251)
+            float *o = out + out_off[gp];
+            const int total = (right - left) * C;
+            for (int idx = tid; idx < total; idx += kThreads) {
+                const int jj = idx / C, c = idx - jj * C;
+                float vcur = chan[c * nmax + left + jj];
+                if (jj < pn) vcur = vcur * w[jj] + prevw[c * (nmax / 2) + jj] * w[pn - 1 - jj];   // :2624-2626
+                o[idx] = vcur;                                                                   // :3927-3952
+            }
+        }
+        __syncthreads();
+        // last half of this data becomes previous window, :2633-2643
+        previous_length = right_end - right;
+        for (int c = 0; c < C; c++)
+            for (int k = tid; k < previous_length; k += kThreads)
+                prevw[c * (nmax / 2) + k] = chan[c * nmax + right + k];
+        __syncthreads();
+    }
+}
+
+int ilog_host(int n)       // stb_vorbis2.d:634-650
+{
+    int r = 0;
+    while (n > 0) { r++; n >>= 1; }
+    return r;
+}
+
+// Table set of one blocksize, exactly as stb_vorbis2.d:851-873 (float angle, double cos/sin).
+void build_tables(int n, std::vector<float> &t)
+{
+    const float pi_f = 3.14159265358979323846264f;   // :652 (float enum)
+    const int n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
+    const size_t base = t.size();
+    t.resize(base + (size_t)n2 + n2 + n4 + n2);
+    float *A = t.data() + base, *B = A + n2, *C = B + n2, *W = C + n4;
+    for (int k = 0, k2 = 0; k < n4; ++k, k2 += 2) {
+        float a0 = (float)(4 * k) * pi_f / (float)n;
+        float a1 = (float)(k2 + 1) * pi_f / (float)n / (float)2;
+        A[k2] = (float)std::cos((double)a0);
+        A[k2 + 1] = (float)-std::sin((double)a0);
+        B[k2] = (float)std::cos((double)a1) * 0.5f;
+        B[k2 + 1] = (float)std::sin((double)a1) * 0.5f;
+    }
+    for (int k = 0, k2 = 0; k < n8; ++k, k2 += 2) {
+        float a2 = (float)(2 * (k2 + 1)) * pi_f / (float)n;
+        C[k2] = (float)std::cos((double)a2);
+        C[k2 + 1] = (float)-std::sin((double)a2);
+    }
+    for (int i = 0; i < n2; ++i) {
+        double inner = std::sin((i - 0 + 0.5) / n2 * 0.5 * (double)pi_f);
+        float sq = (float)inner;
+        sq = sq * sq;
+        W[i] = (float)std::sin(0.5 * (double)pi_f * (double)sq);
+    }
+}
+
+}  // namespace
+
+struct afg_vorbis_plan {
+    uint32_t n_streams = 0;
+    uint32_t n_segs = 0;
+    uint64_t n_packets = 0;
+    uint64_t spec_floats = 0;
+    uint64_t out_floats = 0;
+    size_t lds_bytes = 0;
+    std::vector<uint64_t> h_spec_off, h_out_off;
+    afg::DeviceArray d_segs, d_streams, d_pflags, d_spec_off, d_out_off, d_tables;
+};
+
+extern "C" {
+
+int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uint32_t *packets,
+                           const uint8_t *channels, const uint16_t *blocksize0,
+                           const uint16_t *blocksize1, const uint8_t *pflags, uint32_t seg_packets)
+{
+    if (!plan) return AFG_ERR_INVALID;
+    *plan = nullptr;
+    if (n_streams && (!packets || !channels || !blocksize0 || !blocksize1)) {
+        afg::set_error("afg_vorbis_plan_create: NULL stream description");
+        return AFG_ERR_INVALID;
+    }
+    if (int rc = afg::require_device()) return rc;
+    if (seg_packets == 0) seg_packets = 16;
+
+    std::vector<VorbisStream> streams(n_streams);
+    std::vector<VorbisSeg> segs;
+    std::vector<float> tables;
+    std::map<int, uint32_t> tab_of;
+    auto p = new (std::nothrow) afg_vorbis_plan;
+    if (!p) return AFG_ERR_OOM;
+
+    uint64_t pkt = 0, so = 0, oo = 0;
+    size_t lds = 0;
+    for (uint32_t s = 0; s < n_streams; s++) {
+        const int bs[2] = { blocksize0[s], blocksize1[s] };
+        for (int b = 0; b < 2; b++) {
+            const int n = bs[b];
+            // 64/128 are legal Vorbis sizes but the reference transform is wrong for them
+            // (stb_vorbis2.d:2053-2090 applies a butterfly stage twice when n < 256): rejected.
+            if (n < 256 || n > 8192 || (n & (n - 1))) {
+                afg::set_error("afg_vorbis_plan_create: stream %u blocksize %d unsupported (256..8192, power of two)", s, n);
+                delete p;
+                return AFG_ERR_UNSUPPORTED;
+            }
+            if (!tab_of.count(n)) {
+                tab_of[n] = (uint32_t)tables.size();
+                build_tables(n, tables);
+            }
+        }
+        if (bs[0] > bs[1] || channels[s] < 1 || channels[s] > 16) {
+            afg::set_error("afg_vorbis_plan_create: stream %u: bad block sizes/channels", s);
+            delete p;
+            return AFG_ERR_INVALID;
+        }
+        if (packets[s] && !pflags) {
+            delete p;
+            return AFG_ERR_INVALID;
+        }
+        VorbisStream &st = streams[s];
+        st.pkt_base = pkt;
+        st.npkt = packets[s];
+        st.nch = channels[s];
+        st.bs[0] = bs[0];
+        st.bs[1] = bs[1];
+        st.tab[0] = tab_of[bs[0]];
+        st.tab[1] = tab_of[bs[1]];
+        const size_t need = sizeof(float) * ((size_t)channels[s] * bs[1] + bs[1] / 2 + (size_t)channels[s] * bs[1] / 2);
+        lds = need > lds ? need : lds;
+
+        int prev_len = 0;
+        for (uint32_t q = 0; q < packets[s]; q++, pkt++) {
+            const unsigned fl = pflags[pkt];
+            const bool lng = fl & AFG_VORBIS_LONG;
+            const bool prevf = lng && (fl & AFG_VORBIS_PREV), nextf = lng && (fl & AFG_VORBIS_NEXT);
+            const int n = lng ? bs[1] : bs[0];
+            const int left = (lng && !prevf) ? ((n - bs[0]) >> 2) : 0;                 // :2336-2342
+            const int right = (lng && !nextf) ? ((n * 3 - bs[0]) >> 2) : (n >> 1);     // :2343-2349
+            const int right_end = (lng && !nextf) ? ((n * 3 + bs[0]) >> 2) : n;
+            const int left_end = (lng && !prevf) ? ((n + bs[0]) >> 2) : (n >> 1);
+            if (prev_len && prev_len != left_end - left) {
+                afg::set_error("afg_vorbis_plan_create: stream %u packet %u: window flags inconsistent with the previous packet", s, q);
+                delete p;
+                return AFG_ERR_INVALID;
+            }
+            p->h_spec_off.push_back(so);
+            p->h_out_off.push_back(oo);
+            so += (uint64_t)(n / 2) * channels[s];
+            if (prev_len) oo += (uint64_t)(right - left) * channels[s];                // :2645-2656
+            prev_len = right_end - right;
+        }
+        for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
+            uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
+            segs.push_back(VorbisSeg{ s, p0, cnt, 0 });
+        }
+    }
+    if (lds > 160 * 1024) {
+        afg::set_error("afg_vorbis_plan_create: %zu bytes of LDS needed (channels x blocksize too large)", lds);
+        delete p;
+        return AFG_ERR_UNSUPPORTED;
+    }
+    p->n_streams = n_streams;
+    p->n_segs = (uint32_t)segs.size();
+    p->n_packets = pkt;
+    p->spec_floats = so;
+    p->out_floats = oo;
+    p->lds_bytes = lds;
+    int rc = p->d_segs.upload(segs.data(), segs.size() * sizeof(VorbisSeg));
+    if (!rc) rc = p->d_streams.upload(streams.data(), streams.size() * sizeof(VorbisStream));
+    if (!rc) rc = p->d_pflags.upload(pflags, (size_t)pkt);
+    if (!rc) rc = p->d_spec_off.upload(p->h_spec_off.data(), p->h_spec_off.size() * sizeof(uint64_t));
+    if (!rc) rc = p->d_out_off.upload(p->h_out_off.data(), p->h_out_off.size() * sizeof(uint64_t));
+    if (!rc) rc = p->d_tables.upload(tables.data(), tables.size() * sizeof(float));
+    if (!rc && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)vorbis_transform_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            afg::set_error("hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e));
+            rc = AFG_ERR_HIP;
+        }
+    }
+    if (rc) {
+        afg_vorbis_plan_destroy(p);
+        return rc;
+    }
+    *plan = p;
+    return AFG_OK;
+}
+
+void afg_vorbis_plan_destroy(afg_vorbis_plan *plan)
+{
+    if (!plan) return;
+    plan->d_segs.release();
+    plan->d_streams.release();
+    plan->d_pflags.release();
+    plan->d_spec_off.release();
+    plan->d_out_off.release();
+    plan->d_tables.release();
+    delete plan;
+}
+
+uint64_t afg_vorbis_plan_packets(const afg_vorbis_plan *plan) { return plan ? plan->n_packets : 0; }
+uint64_t afg_vorbis_plan_spec_floats(const afg_vorbis_plan *plan) { return plan ? plan->spec_floats : 0; }
+uint64_t afg_vorbis_plan_out_floats(const afg_vorbis_plan *plan) { return plan ? plan->out_floats : 0; }
+
+int afg_vorbis_plan_offsets(const afg_vorbis_plan *plan, uint64_t *spec_off, uint64_t *out_off)
+{
+    if (!plan) return AFG_ERR_INVALID;
+    if (spec_off) std::memcpy(spec_off, plan->h_spec_off.data(), plan->h_spec_off.size() * sizeof(uint64_t));
+    if (out_off) std::memcpy(out_off, plan->h_out_off.data(), plan->h_out_off.size() * sizeof(uint64_t));
+    return AFG_OK;
+}
+
+int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, float *d_out, void *hip_stream)
+{
+    if (!plan) return AFG_ERR_INVALID;
+    if (plan->n_segs == 0) return AFG_OK;
+    if (!d_spec || (!d_out && plan->out_floats)) {
+        afg::set_error("afg_vorbis_transform_hip: NULL device pointer");
+        return AFG_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(vorbis_transform_kernel, dim3(plan->n_segs), dim3(kThreads), plan->lds_bytes,
+                       (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_segs.ptr,
+                       (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
+                       (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
+                       (const float *)plan->d_tables.ptr, d_spec, d_out);
+    AFG_HIP_CHECK(hipGetLastError());
+    return AFG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+/*
+ * afg.h -- C ABI of the MI355X-native batched audio-decode transform path.
+ *
+ * Drop-in boundary for the transform stage of AuburnSounds/audio-formats'
+ * decoders (reference paths are relative to /root/reference).  The reference
+ * is pure D and has no FFI layer; the seams below are the D function calls a
+ * maintainer would redirect to this library (binding stub: INTEGRATION.md,
+ * bindings/d/afgpu.d).  Bitstream / entropy decoding stays on the host; only
+ * the per-frame transform stage runs on the device.
+ *
+ * Conventions (reference: stream.d:31-33, :105, internals.d:16-23):
+ *   - no exceptions, nothing aborts; every entry returns an afg_status (0 = ok)
+ *   - a handle is not thread-safe; distinct handles share no mutable state
+ *   - d_* pointers are device (HIP) pointers, everything else is host memory
+ *   - hip_stream is a hipStream_t passed as void* (NULL = default stream);
+ *     *_hip entries only enqueue work, they never synchronise
+ *   - the library fails loudly (AFG_ERR_NO_DEVICE) when no gfx950 device or
+ *     no device code is available: there is no CPU fallback in the product.
+ */
+#ifndef AFG_H
+#define AFG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFG_ABI_VERSION 1
+
+typedef enum afg_status {
+    AFG_OK              =  0,
+    AFG_ERR_INVALID     = -1,   /* bad argument / inconsistent batch description */
+    AFG_ERR_NO_DEVICE   = -2,   /* no HIP device, or device code not loadable    */
+    AFG_ERR_HIP         = -3,   /* a HIP runtime call failed (see afg_last_error) */
+    AFG_ERR_OOM         = -4,
+    AFG_ERR_UNSUPPORTED = -5
+} afg_status;
+
+int         afg_abi_version(void);
+const char *afg_status_string(int status);
+const char *afg_last_error(void);          /* thread-local detail of the last failure, never NULL */
+int         afg_device_count(void);        /* number of HIP devices visible, <0 on error */
+int         afg_device_name(int device, char *buf, size_t buflen);
+
+/* ========================================================================== *
+ *  MP3 Layer III transform stage
+ *  replaces, for every granule of every stream of a batch:
+ *    minimp3.d:1226-1228  L3_antialias -> L3_imdct_gr -> L3_change_sign
+ *    minimp3.d:1553       mp3d_synth_granule (mp3d_DCT_II + 9 x mp3d_synth)
+ *  Input is the dequantised, stereo-processed, reordered spectrum that
+ *  L3_decode holds in scratch.grbuf right before minimp3.d:1226.
+ * ========================================================================== */
+
+/* per gr-ch flag word */
+#define AFG_MP3_FLAGS(block_type, n_long_bands, aa_bands) \
+    ((uint32_t)(block_type) | ((uint32_t)(n_long_bands) << 8) | ((uint32_t)((aa_bands) + 1) << 16))
+/*   block_type    gr_info.block_type (0 normal, 1 start, 2 short, 3 stop)
+ *   n_long_bands  minimp3.d:1218 (0, 2 or 4)
+ *   aa_bands      minimp3.d:1217/1222 (31, or n_long_bands-1 for short blocks; -1 = none) */
+
+#define AFG_MP3_STATE_FLOATS 1536   /* opaque per-stream carry state (same size as mdct_overlap+qmf_state, minimp3.d:40-41) */
+
+typedef struct afg_mp3_plan afg_mp3_plan;
+
+/* Describe a batch: stream s has granules[s] granules of channels[s] (1|2)
+ * channels.  Blocks of 576 floats are laid out stream after stream, inside a
+ * stream as [granule][channel]; PCM uses the same float offsets, 576*nch
+ * interleaved floats per granule (minimp3.d:1549 `pcm += 576*channels`).
+ * seg_granules = granules a wavefront walks sequentially (0 = default). */
+int      afg_mp3_plan_create(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t *granules,
+                             const uint8_t *channels, uint32_t seg_granules);
+void     afg_mp3_plan_destroy(afg_mp3_plan *plan);
+uint64_t afg_mp3_plan_blocks(const afg_mp3_plan *plan);     /* total gr-ch blocks = floats/576 */
+uint32_t afg_mp3_plan_segments(const afg_mp3_plan *plan);   /* workgroups one launch uses */
+
+/* d_coef   : blocks*576 floats      d_flags : blocks words (AFG_MP3_FLAGS)
+ * d_pcm    : blocks*576 floats, scaled by 1/32768, not clipped (minimp3.d:1300)
+ * d_state  : NULL (every stream starts from zero state, minimp3.d:1509) or
+ *            n_streams*AFG_MP3_STATE_FLOATS floats read at the first granule of
+ *            each stream and rewritten after its last (chunked decoding). */
+int afg_mp3_transform_hip(const afg_mp3_plan *plan, const float *d_coef, const uint32_t *d_flags,
+                          float *d_pcm, float *d_state, void *hip_stream);
+
+/* ========================================================================== *
+ *  Vorbis transform stage
+ *  replaces stb_vorbis2.d:2526-2527 (inverse_mdct per channel) and
+ *  stb_vorbis2.d:2606-2657 (vorbis_finish_frame: window + overlap-add),
+ *  plus the interleave of stb_vorbis2.d:3927-3952.  Tables are those of
+ *  stb_vorbis2.d:851-898, built on the host at plan creation.
+ * ========================================================================== */
+
+#define AFG_VORBIS_LONG 1u   /* mode blockflag          (stb_vorbis2.d:2324) */
+#define AFG_VORBIS_PREV 2u   /* previous-window flag    (stb_vorbis2.d:2326) */
+#define AFG_VORBIS_NEXT 4u   /* next-window flag        (stb_vorbis2.d:2327) */
+
+typedef struct afg_vorbis_plan afg_vorbis_plan;
+
+/* Stream s: packets[s] audio packets, channels[s] channels, block sizes
+ * blocksize0/1[s] (powers of two, 256..8192; 64/128 are rejected).
+ * pflags: one byte per packet, streams concatenated.
+ * Packet p reads channels*(n/2) floats ([ch][n/2]) at spec offset p and writes
+ * (right_start-left_start)*channels interleaved floats at out offset p; the
+ * first packet of a stream produces no output (stb_vorbis2.d:2645-2649). */
+int      afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uint32_t *packets,
+                                const uint8_t *channels, const uint16_t *blocksize0,
+                                const uint16_t *blocksize1, const uint8_t *pflags, uint32_t seg_packets);
+void     afg_vorbis_plan_destroy(afg_vorbis_plan *plan);
+uint64_t afg_vorbis_plan_packets(const afg_vorbis_plan *plan);
+uint64_t afg_vorbis_plan_spec_floats(const afg_vorbis_plan *plan);
+uint64_t afg_vorbis_plan_out_floats(const afg_vorbis_plan *plan);
+/* copies the per-packet float offsets (total packets entries each; either may be NULL) */
+int      afg_vorbis_plan_offsets(const afg_vorbis_plan *plan, uint64_t *spec_off, uint64_t *out_off);
+
+int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, float *d_out, void *hip_stream);
+
+/* ========================================================================== *
+ *  FLAC sample restore
+ *  replaces drflac.d:1235 (residual + drflac__calculate_prediction_32/_64,
+ *  drflac.d:1060-1140) for whole subframes, and the decorrelate / shift /
+ *  interleave of drflac_read_s32 (drflac.d:2885-2941); optionally also the
+ *  int32 -> float conversion of stream.d:505-511.  Bit-exact int32.
+ * ========================================================================== */
+
+#define AFG_FLAC_INDEPENDENT 0
+#define AFG_FLAC_LEFT_SIDE   8    /* DRFLAC_CHANNEL_ASSIGNMENT_LEFT_SIDE  */
+#define AFG_FLAC_RIGHT_SIDE  9    /* DRFLAC_CHANNEL_ASSIGNMENT_RIGHT_SIDE */
+#define AFG_FLAC_MID_SIDE   10    /* DRFLAC_CHANNEL_ASSIGNMENT_MID_SIDE   */
+
+typedef struct afg_flac_subframe {
+    int16_t coef[32];   /* LPC coefficients (fixed predictors: drflac.d:1397-1403 table, shift 0) */
+    uint8_t order;      /* 0..32; warm-up samples occupy res[0..order) (constant/verbatim: order 0) */
+    uint8_t shift;      /* lpcShift 0..31 */
+    uint8_t wasted;     /* wastedBitsPerSample */
+    uint8_t use64;      /* subframe bitsPerSample > 16 -> 64-bit accumulator (drflac.d:1308) */
+} afg_flac_subframe;     /* 68 bytes */
+
+typedef struct afg_flac_frame {
+    uint64_t in_off;      /* int32 index of channel 0's residual plane; channel c at in_off + c*block_size */
+    uint64_t out_off;     /* int32 index of the interleaved output (block_size*channels samples) */
+    uint32_t block_size;
+    uint32_t sf_index;    /* index of channel 0's afg_flac_subframe; channel c at sf_index + c */
+    uint8_t  channels;    /* 1..8 */
+    uint8_t  assignment;  /* AFG_FLAC_* */
+    uint8_t  bps;         /* STREAMINFO bitsPerSample */
+    uint8_t  pad[5];
+} afg_flac_frame;         /* 32 bytes */
+
+/* d_out_i32 and/or d_out_f32 may be NULL (at least one must be given). */
+int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
+                           const afg_flac_subframe *d_subframes, const int32_t *d_res,
+                           int32_t *d_out_i32, float *d_out_f32, void *hip_stream);
+
+/* ========================================================================== *
+ *  Utilities used by the host mirror, the tests and bench.py
+ * ========================================================================== */
+int afg_device_malloc(void **d_ptr, size_t bytes);
+int afg_device_free(void *d_ptr);
+int afg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *hip_stream);
+int afg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *hip_stream);
+int afg_stream_synchronize(void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFG_H */

@@ -1,0 +1,171 @@
+/*
+ * afg_oracle.h -- CPU restatement of the audio-formats transform stage.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call it, and there only as the checker / reported baseline.
+ *
+ * PARITY UNPINNED by the reference's own tests: the reference
+ * (AuburnSounds/audio-formats, D) ships no golden vectors, known-answer
+ * tests or fixtures for any decoder, and no D compiler exists in this image
+ * or on the GPU box, so the reference cannot be run (oracle/_ref is
+ * unbuildable).  What pins this restatement instead is listed in DESIGN.md:
+ * float64 textbook definitions of every transform (tests/test_oracle_*.py),
+ * lossless FLAC/QOA encode->decode round trips, and frozen golden vectors
+ * under tests/golden/.
+ *
+ * Every function cites the reference file:line (relative to /root/reference)
+ * whose arithmetic -- operation order, operand widths, constants -- it follows.
+ * Build with -ffp-contract=off: the D reference has no fused multiply-adds.
+ */
+#ifndef AFG_ORACLE_H
+#define AFG_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ MP3 -- */
+
+/* Per gr-ch flag word (same packing as include/afg.h AFG_MP3_FLAGS):
+ *   bits 0..1  block_type (0 normal, 1 start, 2 short, 3 stop)
+ *   bits 8..15 n_long_bands (0, 2 or 4)       minimp3.d:1218
+ *   bits 16..23 aa_bands + 1 (0..32)           minimp3.d:1217,1222
+ */
+#define AFGO_MP3_FLAGS(block_type, n_long_bands, aa_bands) \
+    ((uint32_t)(block_type) | ((uint32_t)(n_long_bands) << 8) | ((uint32_t)((aa_bands) + 1) << 16))
+
+/* Persistent per-stream transform state, minimp3.d:38-46 (mdct_overlap, qmf_state). */
+typedef struct afgo_mp3_state {
+    float mdct_overlap[2][9 * 32];
+    float qmf_state[15 * 2 * 32];
+} afgo_mp3_state;
+
+/* Single pieces, exposed so tests can pin each against its float64 definition. */
+void afgo_mp3_antialias(float *grbuf, int nbands);                       /* minimp3.d:1002-1020 */
+void afgo_mp3_imdct_gr(float *grbuf, float *overlap, unsigned block_type,
+                       unsigned n_long_bands);                           /* minimp3.d:1152-1168 */
+void afgo_mp3_change_sign(float *grbuf);                                 /* minimp3.d:1144-1150 */
+void afgo_mp3_dct2(float *grbuf, int n);                                 /* minimp3.d:1232-1298 */
+void afgo_mp3_synth_granule(float *qmf_state, float *grbuf, int nbands, int nch,
+                            float *pcm, float *lins);                    /* minimp3.d:1408-1434 */
+
+/* One granule of one stream: the transform tail of L3_decode (minimp3.d:1215-1229)
+ * for every channel followed by mp3d_synth_granule (minimp3.d:1553).
+ * coef: nch*576 floats ([ch][576], post-dequant/stereo/reorder), modified in place.
+ * flags: nch words.  pcm: 576*nch floats, interleaved. */
+void afgo_mp3_granule(afgo_mp3_state *st, float *coef, const uint32_t *flags, int nch, float *pcm);
+
+/* Whole batch.  Stream s owns blocks [blk_base, blk_base + ngr[s]*nch[s]) of 576
+ * floats each in `coef` (order [granule][ch]) where blk_base is the running sum
+ * over earlier streams; `pcm` has the same float count, 576*nch per granule.
+ * Each stream starts from zero state (minimp3.d:1509).  coef is NOT modified.
+ * If states != NULL it receives the final state of every stream. */
+void afgo_mp3_transform(uint32_t n_streams, const uint32_t *ngr, const uint8_t *nch,
+                        const float *coef, const uint32_t *flags, float *pcm,
+                        afgo_mp3_state *states);
+
+/* --------------------------------------------------------------- Vorbis -- */
+
+/* Tables of one blocksize, stb_vorbis2.d:851-898. */
+typedef struct afgo_vorbis_tables {
+    int n;
+    float *A;            /* n/2 */
+    float *B;            /* n/2 */
+    float *C;            /* n/4 */
+    float *window;       /* n/2 */
+    uint16_t *bitrev;    /* n/8 */
+} afgo_vorbis_tables;
+
+int  afgo_vorbis_tables_init(afgo_vorbis_tables *t, int n);  /* stb_vorbis2.d:883-898 */
+void afgo_vorbis_tables_free(afgo_vorbis_tables *t);
+
+/* In-place n/2 spectrum -> n time samples, stb_vorbis2.d:1941-2242.
+ * buffer holds n floats, scratch n/2 floats. */
+void afgo_vorbis_inverse_mdct(float *buffer, int n, const afgo_vorbis_tables *t, float *scratch);
+
+/* Packet flag byte (same packing as include/afg.h):
+ *   bit 0 blockflag (long block), bit 1 prev-window flag, bit 2 next-window flag
+ *   (stb_vorbis2.d:2324-2331). */
+#define AFGO_VORBIS_LONG 1u
+#define AFGO_VORBIS_PREV 2u
+#define AFGO_VORBIS_NEXT 4u
+
+/* Window bounds of one packet, stb_vorbis2.d:2333-2349. */
+void afgo_vorbis_window_bounds(int blocksize0, int blocksize1, unsigned pflags,
+                               int *n, int *left_start, int *left_end,
+                               int *right_start, int *right_end);
+
+/* Whole batch: per stream, inverse_mdct per channel (stb_vorbis2.d:2526-2527)
+ * then vorbis_finish_frame (stb_vorbis2.d:2606-2657) for each packet in order,
+ * starting with previous_length = 0, and the interleave of
+ * stb_vorbis_get_samples_float_interleaved (stb_vorbis2.d:3927-3952).
+ *
+ * Streams are concatenated: stream s has npkt[s] packets and nch[s] channels.
+ * Packet p of a stream reads nch*(n/2) floats from `spec` at spec_off[p]
+ * ([ch][n/2]) and writes (right_start-left_start)*nch interleaved floats at
+ * out_off[p] (in floats); the first packet of a stream writes nothing.
+ * spec_off/out_off are absolute (batch-wide) and have total_packets entries.
+ * Returns 0, or -1 on a window mismatch (get_window() == NULL, :2621). */
+int afgo_vorbis_transform(uint32_t n_streams, const uint32_t *npkt, const uint8_t *nch,
+                          const uint16_t *blocksize0, const uint16_t *blocksize1,
+                          const uint8_t *pflags, const uint64_t *spec_off,
+                          const uint64_t *out_off, const float *spec, float *out);
+
+/* Output frames (per channel) of each packet and the running total; helper that
+ * mirrors the return value of vorbis_finish_frame for a flag sequence. */
+uint64_t afgo_vorbis_layout(uint32_t npkt, int nch, int blocksize0, int blocksize1,
+                            const uint8_t *pflags, uint64_t spec_base, uint64_t out_base,
+                            uint64_t *spec_off, uint64_t *out_off, uint64_t *spec_total);
+
+/* ----------------------------------------------------------------- FLAC -- */
+
+/* drflac.d:1060-1140 */
+int32_t afgo_flac_prediction_32(unsigned order, int shift, const int16_t *coef, const int32_t *p);
+int32_t afgo_flac_prediction_64(unsigned order, int shift, const int16_t *coef, const int32_t *p);
+
+/* Subframe record (same layout as include/afg.h afg_flac_subframe). */
+typedef struct afgo_flac_subframe {
+    int16_t coef[32];
+    uint8_t order;      /* 0..32; warm-up samples sit in res[0..order) */
+    uint8_t shift;      /* lpcShift, 0..31 (negative shifts are rejected by the host) */
+    uint8_t wasted;     /* wastedBitsPerSample, drflac.d:1561-1566 */
+    uint8_t use64;      /* subframe bitsPerSample > 16, drflac.d:1308 */
+} afgo_flac_subframe;
+
+/* Frame record (same layout as include/afg.h afg_flac_frame). */
+typedef struct afgo_flac_frame {
+    uint64_t in_off;      /* int32 index of channel 0's residual plane; channel c at in_off + c*block_size */
+    uint64_t out_off;     /* int32 index of the interleaved output */
+    uint32_t block_size;
+    uint32_t sf_index;    /* index of channel 0's subframe record; channel c at sf_index + c */
+    uint8_t  channels;    /* 1..8 */
+    uint8_t  assignment;  /* 0 independent, 8 left/side, 9 right/side, 10 mid/side (drflac.d channelAssignment) */
+    uint8_t  bps;         /* STREAMINFO bitsPerSample (pFlac.bitsPerSample) */
+    uint8_t  pad[5];
+} afgo_flac_frame;
+
+#define AFGO_FLAC_INDEPENDENT 0
+#define AFGO_FLAC_LEFT_SIDE   8
+#define AFGO_FLAC_RIGHT_SIDE  9
+#define AFGO_FLAC_MID_SIDE   10
+
+/* LPC restore of one subframe in place (drflac.d:1235, :1264-1269). */
+void afgo_flac_restore_subframe(const afgo_flac_subframe *sf, int32_t *samples, uint32_t block_size);
+
+/* Whole batch: restore every subframe, then the decorrelate + shift + interleave
+ * of drflac_read_s32 (drflac.d:2885-2941).  subframes are indexed
+ * frames[f].sf_index + channel.
+ * out_i32 receives drflac_read_s32-identical samples; if out_f32 != NULL it
+ * also receives stream.d:505-511's float conversion.  res is NOT modified. */
+void afgo_flac_transform(uint64_t n_frames, const afgo_flac_frame *frames,
+                         const afgo_flac_subframe *subframes, const int32_t *res,
+                         int32_t *out_i32, float *out_f32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

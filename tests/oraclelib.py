@@ -1,0 +1,172 @@
+"""ctypes view of oracle/liboracle_afg.so (the CPU restatement; test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle_afg.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+
+
+class VorbisTables(C.Structure):
+    _fields_ = [("n", C.c_int), ("A", C.POINTER(C.c_float)), ("B", C.POINTER(C.c_float)),
+                ("C", C.POINTER(C.c_float)), ("window", C.POINTER(C.c_float)),
+                ("bitrev", C.POINTER(C.c_uint16))]
+
+
+FLAC_SUBFRAME_DTYPE = np.dtype([("coef", np.int16, (32,)), ("order", np.uint8), ("shift", np.uint8),
+                                ("wasted", np.uint8), ("use64", np.uint8)], align=True)
+FLAC_FRAME_DTYPE = np.dtype([("in_off", np.uint64), ("out_off", np.uint64), ("block_size", np.uint32),
+                             ("sf_index", np.uint32), ("channels", np.uint8), ("assignment", np.uint8),
+                             ("bps", np.uint8), ("pad", np.uint8, (5,))], align=True)
+assert FLAC_SUBFRAME_DTYPE.itemsize == 68 and FLAC_FRAME_DTYPE.itemsize == 32
+
+MP3_STATE_FLOATS = 2 * 288 + 960
+
+
+def mp3_flags(block_type=0, n_long_bands=0, aa_bands=31):
+    return np.uint32(block_type | (n_long_bands << 8) | ((aa_bands + 1) << 16))
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    L.afgo_mp3_antialias.argtypes = [f32p, C.c_int]
+    L.afgo_mp3_imdct_gr.argtypes = [f32p, f32p, C.c_uint, C.c_uint]
+    L.afgo_mp3_change_sign.argtypes = [f32p]
+    L.afgo_mp3_dct2.argtypes = [f32p, C.c_int]
+    L.afgo_mp3_synth_granule.argtypes = [f32p, f32p, C.c_int, C.c_int, f32p, f32p]
+    L.afgo_mp3_transform.argtypes = [C.c_uint32, u32p, u8p, f32p, u32p, f32p, C.c_void_p]
+    for fn in (L.afgo_mp3_antialias, L.afgo_mp3_imdct_gr, L.afgo_mp3_change_sign, L.afgo_mp3_dct2,
+               L.afgo_mp3_synth_granule, L.afgo_mp3_transform):
+        fn.restype = None
+    L.afgo_vorbis_tables_init.argtypes = [C.POINTER(VorbisTables), C.c_int]
+    L.afgo_vorbis_tables_init.restype = C.c_int
+    L.afgo_vorbis_tables_free.argtypes = [C.POINTER(VorbisTables)]
+    L.afgo_vorbis_tables_free.restype = None
+    L.afgo_vorbis_inverse_mdct.argtypes = [f32p, C.c_int, C.POINTER(VorbisTables), f32p]
+    L.afgo_vorbis_inverse_mdct.restype = None
+    L.afgo_vorbis_layout.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, u8p, C.c_uint64, C.c_uint64,
+                                     u64p, u64p, C.POINTER(C.c_uint64)]
+    L.afgo_vorbis_layout.restype = C.c_uint64
+    L.afgo_vorbis_transform.argtypes = [C.c_uint32, u32p, u8p, u16p, u16p, u8p, u64p, u64p, f32p, f32p]
+    L.afgo_vorbis_transform.restype = C.c_int
+    L.afgo_flac_prediction_32.argtypes = [C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
+    L.afgo_flac_prediction_32.restype = C.c_int32
+    L.afgo_flac_prediction_64.argtypes = [C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
+    L.afgo_flac_prediction_64.restype = C.c_int32
+    L.afgo_flac_transform.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, i32p, i32p, C.c_void_p]
+    L.afgo_flac_transform.restype = None
+    _lib = L
+    return L
+
+
+# ---------------------------------------------------------------- MP3 ------
+def mp3_transform(ngr, nch, coef, flags, want_state=False):
+    """Whole-batch MP3 transform stage on the CPU oracle.  Returns pcm (and states)."""
+    ngr = np.ascontiguousarray(ngr, np.uint32)
+    nch = np.ascontiguousarray(nch, np.uint8)
+    coef = np.ascontiguousarray(coef, np.float32).reshape(-1)
+    flags = np.ascontiguousarray(flags, np.uint32)
+    nblk = int((ngr.astype(np.int64) * nch).sum())
+    assert coef.size == nblk * 576 and flags.size == nblk
+    pcm = np.zeros(nblk * 576, np.float32)
+    states = np.zeros((len(ngr), MP3_STATE_FLOATS), np.float32) if want_state else None
+    lib().afgo_mp3_transform(len(ngr), ngr, nch, coef, flags, pcm,
+                             states.ctypes.data if want_state else None)
+    return (pcm, states) if want_state else pcm
+
+
+# ------------------------------------------------------------- Vorbis ------
+def vorbis_tables(n):
+    t = VorbisTables()
+    assert lib().afgo_vorbis_tables_init(C.byref(t), n) == 0
+    out = dict(
+        A=np.ctypeslib.as_array(t.A, (n // 2,)).copy(), B=np.ctypeslib.as_array(t.B, (n // 2,)).copy(),
+        C=np.ctypeslib.as_array(t.C, (n // 4,)).copy(), window=np.ctypeslib.as_array(t.window, (n // 2,)).copy(),
+        bitrev=np.ctypeslib.as_array(t.bitrev, (n // 8,)).copy())
+    lib().afgo_vorbis_tables_free(C.byref(t))
+    return out
+
+
+def vorbis_inverse_mdct(spec, n):
+    t = VorbisTables()
+    assert lib().afgo_vorbis_tables_init(C.byref(t), n) == 0
+    buf = np.zeros(n, np.float32)
+    buf[: n // 2] = spec
+    scratch = np.zeros(n // 2, np.float32)
+    lib().afgo_vorbis_inverse_mdct(buf, n, C.byref(t), scratch)
+    lib().afgo_vorbis_tables_free(C.byref(t))
+    return buf
+
+
+def vorbis_layout(npkt, nch, bs0, bs1, pflags):
+    """Batch-wide spec/out offsets (in floats) for concatenated streams."""
+    npkt = np.ascontiguousarray(npkt, np.uint32)
+    pflags = np.ascontiguousarray(pflags, np.uint8)
+    tot = int(npkt.sum())
+    spec_off = np.zeros(tot, np.uint64)
+    out_off = np.zeros(tot, np.uint64)
+    sb, ob, p0 = 0, 0, 0
+    for s in range(len(npkt)):
+        st = C.c_uint64(0)
+        k = int(npkt[s])
+        so = np.zeros(k, np.uint64)
+        oo = np.zeros(k, np.uint64)
+        ob = lib().afgo_vorbis_layout(k, int(nch[s]), int(bs0[s]), int(bs1[s]),
+                                      np.ascontiguousarray(pflags[p0:p0 + k]), sb, ob, so, oo, C.byref(st))
+        spec_off[p0:p0 + k] = so
+        out_off[p0:p0 + k] = oo
+        sb = st.value
+        p0 += k
+    return spec_off, out_off, sb, ob
+
+
+def vorbis_transform(npkt, nch, bs0, bs1, pflags, spec_off, out_off, spec, out_total):
+    out = np.zeros(int(out_total), np.float32)
+    rc = lib().afgo_vorbis_transform(
+        len(npkt), np.ascontiguousarray(npkt, np.uint32), np.ascontiguousarray(nch, np.uint8),
+        np.ascontiguousarray(bs0, np.uint16), np.ascontiguousarray(bs1, np.uint16),
+        np.ascontiguousarray(pflags, np.uint8), np.ascontiguousarray(spec_off, np.uint64),
+        np.ascontiguousarray(out_off, np.uint64), np.ascontiguousarray(spec, np.float32), out)
+    assert rc == 0, rc
+    return out
+
+
+# --------------------------------------------------------------- FLAC ------
+def flac_transform(frames, subframes, res, out_total, want_float=False):
+    frames = np.ascontiguousarray(frames, FLAC_FRAME_DTYPE)
+    subframes = np.ascontiguousarray(subframes, FLAC_SUBFRAME_DTYPE)
+    res = np.ascontiguousarray(res, np.int32)
+    out = np.zeros(int(out_total), np.int32)
+    outf = np.zeros(int(out_total), np.float32) if want_float else None
+    lib().afgo_flac_transform(len(frames), frames.ctypes.data, subframes.ctypes.data, res, out,
+                              outf.ctypes.data if want_float else None)
+    return (out, outf) if want_float else out

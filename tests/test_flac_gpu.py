@@ -1,0 +1,70 @@
+"""FLAC restore: HIP path vs the CPU oracle, bit-exact int32 and float, through the C ABI."""
+import numpy as np
+import pytest
+
+import oraclelib
+import afgpu
+from afgpu import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(gpu, frames, subframes, res, out_total, want_float=True):
+    import torch
+    d_frames = torch.from_numpy(frames.view(np.uint8).copy()).to(gpu)
+    d_sub = torch.from_numpy(subframes.view(np.uint8).copy()).to(gpu)
+    d_res = torch.from_numpy(res).to(gpu)
+    d_i32 = torch.full((out_total,), -12345, dtype=torch.int32, device=gpu)
+    d_f32 = torch.full((out_total,), float("nan"), dtype=torch.float32, device=gpu) if want_float else None
+    afgpu.flac_transform(len(frames), d_frames, d_sub, d_res, d_i32, d_f32)
+    torch.cuda.synchronize()
+    return d_i32.cpu().numpy(), (d_f32.cpu().numpy() if want_float else None)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_frames=130, block_size=4096, orders=(8, 12)),
+    dict(n_frames=70, block_size=1152, orders=(0, 1, 2, 3, 4)),
+    dict(n_frames=65, block_size=4096, orders=(13, 16, 24, 32)),
+    dict(n_frames=200, vary_block=True, orders=(2, 8, 12, 31)),
+    dict(n_frames=33, block_size=576, channels=1, orders=(8, 12)),
+    dict(n_frames=20, block_size=500, channels=6, orders=(4, 8)),
+    dict(n_frames=40, block_size=4096, bps=24, orders=(8, 12), residual_scale=3000.0),
+    dict(n_frames=1, block_size=16, orders=(8,)),
+])
+def test_flac_bit_exact(gpu, kw):
+    frames, subframes, res, total = synthetic.flac_batch(17, **kw)
+    want_i, want_f = oraclelib.flac_transform(frames, subframes, res, total, want_float=True)
+    got_i, got_f = run_gpu(gpu, frames, subframes, res, total)
+    assert (got_i == want_i).all(), f"{int((got_i != want_i).sum())} int32 mismatches"
+    assert (got_f.view(np.uint32) == want_f.view(np.uint32)).all()
+
+
+def test_flac_wrapping_arithmetic(gpu):
+    """Garbage-in must equal garbage-out: huge residuals/coefficients exercise the int32 wrap of
+    drflac__calculate_prediction_32 and the int64 path of _64."""
+    rng = np.random.default_rng(5)
+    frames, subframes, res, total = synthetic.flac_batch(23, n_frames=96, block_size=1024, orders=(12, 32))
+    subframes["coef"] = rng.integers(-32768, 32768, subframes["coef"].shape).astype(np.int16)
+    for sf in subframes:
+        sf["coef"][sf["order"]:] = 0
+    subframes["shift"] = rng.integers(0, 32, len(subframes)).astype(np.uint8)
+    subframes["use64"] = rng.integers(0, 2, len(subframes)).astype(np.uint8)
+    res = rng.integers(-2**31, 2**31, res.shape, dtype=np.int64).astype(np.int32)
+    want_i = oraclelib.flac_transform(frames, subframes, res, total)
+    got_i, _ = run_gpu(gpu, frames, subframes, res, total, want_float=False)
+    assert (got_i == want_i).all()
+
+
+def test_flac_float_only_output(gpu):
+    import torch
+    frames, subframes, res, total = synthetic.flac_batch(29, n_frames=10, block_size=256)
+    _, want_f = oraclelib.flac_transform(frames, subframes, res, total, want_float=True)
+    d_frames = torch.from_numpy(frames.view(np.uint8).copy()).to(gpu)
+    d_sub = torch.from_numpy(subframes.view(np.uint8).copy()).to(gpu)
+    d_res = torch.from_numpy(res).to(gpu)
+    d_f32 = torch.zeros(total, dtype=torch.float32, device=gpu)
+    afgpu.flac_transform(len(frames), d_frames, d_sub, d_res, None, d_f32)
+    torch.cuda.synchronize()
+    assert (d_f32.cpu().numpy().view(np.uint32) == want_f.view(np.uint32)).all()
+    with pytest.raises(afgpu.AfgError):
+        afgpu.flac_transform(len(frames), d_frames, d_sub, d_res, None, None)
