@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libafg_hip.so")
+LIB_PATH = os.environ.get("AFG_LIB_PATH", os.path.join(PKG_ROOT, "lib", "libafg_hip.so"))   # override: A/B builds only
 
 MP3_STATE_FLOATS = 1536
 VORBIS_LONG, VORBIS_PREV, VORBIS_NEXT = 1, 2, 4

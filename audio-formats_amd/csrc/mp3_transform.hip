@@ -43,8 +43,6 @@ struct Mp3Stream {
     uint32_t nch;
 };
 
-constexpr int kHStride = 65;          // 64 values per history row (+1 pad: conflict-free row-per-lane writes)
-constexpr int kHRows = 36;            // two granules of 18 slots
 constexpr int kStateOverlap = 64 * 9; // floats of overlap in the opaque state blob
 
 // -- tables (values: minimp3.d:1004-1007, :1065-1067, :1113, :1154-1157, :1234-1236, :1336-1352) --
@@ -265,57 +263,66 @@ __device__ __forceinline__ void dct2_32(const float (&in)[32], float (&out)[32])
     out[31] = t[3][7];
 }
 
-// LDS float offset of the history row of time slot `t_rel` (-15..17) relative to
-// the granule of parity p.
-__device__ __forceinline__ int hrow(int p, int t_rel)
+// ---------------------------------------------------------------------------------------
+// LDS layout of one wavefront (floats).  H holds the polyphase history as 33 rows of
+// kHS floats: row r = time slot (r - 15) relative to the current granule, rows 0..14 are
+// the 15 slots carried from the previous granule (minimp3.d:1416), rows 15..32 the 18
+// slots of this granule.  Inside a row the 32 DCT outputs V[q] of a channel are stored
+// as 16 pairs  P[i] = (V[31-i], V[1+i]) (i < 15),  P[15] = (V[16], V[0])  -- the two
+// columns every window tap pair needs -- at  c*32 + 2*i.
+// Rows 15..32 double as the (channel, subband) -> (channel, slot) transposition buffer;
+// rows 0..8 are reused, slot by slot as the window leaves them behind, as the PCM staging
+// area of slots 0..8 (slots 9..17 stage in P1).  Program order inside the wavefront keeps
+// the uses apart.
+constexpr int kHS = 66;                      // row stride: even (8-byte pair reads), 66 mod 32 = 2
+constexpr int kHistRows = 15;
+constexpr int kRegion = kHistRows * kHS;     // float offset of row 15
+constexpr int kLdsFloats = 33 * kHS;
+
+struct alignas(8) f2 { float x, y; };
+
+// value of the lane below / above (wave_shr:1 / wave_shl:1); lane 0 / 63 get 0
+__device__ __forceinline__ float from_lane_below(float v)
 {
-    int r = (t_rel >= 0) ? (p * 18 + t_rel) : ((1 - p) * 18 + 18 + t_rel);
-    return r * kHStride;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
-__global__ __launch_bounds__(64) void mp3_transform_kernel(
+#ifndef AFG_MP3_MIN_WAVES
+#define AFG_MP3_MIN_WAVES 3
+#endif
+
+__global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
     const Mp3Seg *__restrict__ segs, const Mp3Stream *__restrict__ streams,
     const float *__restrict__ coef, const uint32_t *__restrict__ flags,
     float *__restrict__ pcm, float *__restrict__ state)
 {
-    __shared__ float buf[2 * 576];
-    __shared__ float H[kHRows * kHStride];
+    __shared__ __attribute__((aligned(16))) float H[kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float P1[576];          // PCM staging of slots 9..17
+    __shared__ __attribute__((aligned(16))) float Wt[15 * 16];      // g_win, re-read every granule (saves 16 VGPRs)
+    float *const R = H + kRegion;
 
     const int lane = threadIdx.x;
+    for (int i = lane; i < 15 * 16; i += 64) Wt[i] = k_win[i];
+
     const Mp3Seg seg = segs[blockIdx.x];
     const Mp3Stream st = streams[seg.stream];
     const int nch = (int)st.nch;
     const int nval = nch * 576;                 // floats per granule
 
-    // role A: lane = (channel, subband) for antialias / IMDCT
+    // role A: lane = (channel, subband): antialias / IMDCT
     const int ch = lane >> 5;
     const int band = lane & 31;
-    // role C: lane = (channel, output sample j) for the polyphase window
-    const int j = lane & 31;
+    // role C: lane = (slot half, channel, column pair i): polyphase window
+    const int s2 = lane >> 5;
+    const int sc = (lane >> 4) & 1;
+    const int si = lane & 15;
 
-    // ---- polyphase weights of this lane (minimp3.d:1388-1395 ladder) ----------
-    // main lanes: acc = sum_k vz_k * wa[k] + vy_k * wb[k]
-    float wa[8], wb[8];
-    int i_col = 0;
-    {
-        const bool is_a = (j >= 1 && j <= 15);
-        const bool is_b = (j >= 17);
-        i_col = is_a ? (15 - j) : (is_b ? (j - 17) : 0);
-        const float *w = k_win + (14 - i_col) * 16;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float w0 = w[2 * k], w1 = w[2 * k + 1];
-            if (is_a) {
-                wa[k] = (k & 1) ? -w0 : w0;
-                wb[k] = (k & 1) ? w1 : -w1;
-            } else {
-                wa[k] = w1;
-                wb[k] = w0;
-            }
-        }
-    }
-    const int col_hi = ch * 32 + 31 - i_col;
-    const int col_lo = ch * 32 + 1 + i_col;
+    // window taps of this lane's column pair: row 14-i of g_win (minimp3.d:1336-1352, :1388-1395)
+    const f2 *const wrow = (const f2 *)(Wt + (14 - (si < 15 ? si : 14)) * 16);
 
     // ---- carry state ------------------------------------------------------------
     float ov[9];
@@ -325,54 +332,40 @@ __global__ __launch_bounds__(64) void mp3_transform_kernel(
     float *st_blob = state ? state + (size_t)seg.stream * AFG_MP3_STATE_FLOATS : nullptr;
 #pragma unroll
     for (int i = 0; i < 9; i++) ov[i] = from_state ? st_blob[lane * 9 + i] : 0.0f;
-    {
-        // history rows of the granule "before" g_first live in the parity-(1-p) half
-        const int p0 = g_first & 1;
-        for (int r = 0; r < 15; r++) {
-            float v = from_state ? st_blob[kStateOverlap + r * 64 + lane] : 0.0f;
-            H[hrow(p0, r - 15) + lane] = v;
-        }
-    }
+    for (int r = 0; r < kHistRows; r++)
+        H[r * kHS + lane] = from_state ? st_blob[kStateOverlap + r * 64 + lane] : 0.0f;
 
-    // ---- prefetch of the first granule ------------------------------------------
+    // ---- first granule's spectrum: 18 consecutive lines of this lane's subband --------
     const int g_end = (int)(seg.g0 + seg.count);
-    float pre[18];
+    const bool ch_on = ch < nch;
+    f2 pre[9];
     {
-        const float *src = coef + (st.blk_base + (uint64_t)g_first * nch) * 576;
+        const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)g_first * nch) * 576) + lane * 9;
 #pragma unroll
-        for (int q = 0; q < 18; q++) {
-            int idx = lane + 64 * q;
-            pre[q] = (idx < nval) ? src[idx] : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 18; q++) buf[lane + 64 * q] = pre[q];
+        for (int q = 0; q < 9; q++) pre[q] = ch_on ? src[q] : f2{ 0.0f, 0.0f };
     }
     __syncthreads();
 
     for (int g = g_first; g < g_end; g++) {
-        const int p = g & 1;
         const bool do_synth = g >= (int)seg.g0;
         const bool do_dct = g >= (int)seg.g0 - 1;
 
-        // 1. (channel, subband) registers out of the staging buffer
+        // A. this granule's lines; B. issue the next granule's loads (consumed one iteration later)
         float x[18];
 #pragma unroll
-        for (int i = 0; i < 18; i++) x[i] = buf[lane * 18 + i];
+        for (int m = 0; m < 9; m++) {
+            x[2 * m] = pre[m].x;
+            x[2 * m + 1] = pre[m].y;
+        }
         uint32_t fl = 0;
-        if (ch < nch) fl = flags[st.blk_base + (uint64_t)g * nch + ch];
-
-        // 2. issue the next granule's coalesced loads now, park them in registers
-        const bool have_next = (g + 1 < g_end);
-        if (have_next) {
-            const float *src = coef + (st.blk_base + (uint64_t)(g + 1) * nch) * 576;
+        if (ch_on) fl = flags[st.blk_base + (uint64_t)g * nch + ch];
+        if (g + 1 < g_end) {
+            const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)(g + 1) * nch) * 576) + lane * 9;
 #pragma unroll
-            for (int q = 0; q < 18; q++) {
-                int idx = lane + 64 * q;
-                pre[q] = (idx < nval) ? src[idx] : 0.0f;
-            }
+            for (int q = 0; q < 9; q++) pre[q] = ch_on ? src[q] : f2{ 0.0f, 0.0f };
         }
 
-        // 3. alias reduction across subband boundaries, minimp3.d:1002-1020
+        // C. alias reduction (minimp3.d:1002-1020), IMDCT (:1152-1168), frequency inversion (:1144-1150)
         {
             const int block_type = (int)(fl & 3u);
             const int n_long = (int)((fl >> 8) & 0xffu);
@@ -382,8 +375,8 @@ __global__ __launch_bounds__(64) void mp3_transform_kernel(
             float nl[8], nh[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                float d_prev = __shfl_up(x[17 - i], 1);            // line 17-i of subband band-1
-                float u_next = __shfl_down(x[i], 1);               // line i of subband band+1
+                float d_prev = from_lane_below(x[17 - i]);         // line 17-i of subband band-1
+                float u_next = from_lane_above(x[i]);              // line i of subband band+1
                 nl[i] = x[i] * k_aa_cs[i] - d_prev * k_aa_ca[i];
                 nh[i] = u_next * k_aa_ca[i] + x[17 - i] * k_aa_cs[i];
             }
@@ -392,8 +385,6 @@ __global__ __launch_bounds__(64) void mp3_transform_kernel(
                 x[i] = lower ? nl[i] : x[i];
                 x[17 - i] = upper ? nh[i] : x[17 - i];
             }
-
-            // 4. IMDCT + overlap, minimp3.d:1152-1168
             const bool is_short = (block_type == 2) && (band >= n_long);
             if (is_short) {
                 imdct_short_lane(x, ov);
@@ -401,82 +392,135 @@ __global__ __launch_bounds__(64) void mp3_transform_kernel(
                 const bool stop = (block_type == 3) && (band >= n_long);
                 imdct36_lane(x, ov, stop);
             }
-            // 5. frequency inversion, minimp3.d:1144-1150
             if (band & 1) {
 #pragma unroll
                 for (int i = 1; i < 18; i += 2) x[i] = -x[i];
             }
         }
 
-        __syncthreads();     // everyone has read its staging lines
         if (do_dct) {
+            // D. transposition buffer <- x
 #pragma unroll
-            for (int i = 0; i < 18; i++) buf[lane * 18 + i] = x[i];
-        }
-        __syncthreads();
+            for (int m = 0; m < 9; m++) ((f2 *)R)[lane * 9 + m] = f2{ x[2 * m], x[2 * m + 1] };
+            __syncthreads();
 
-        // 6. 32-point DCT-II, lane = (channel, slot); minimp3.d:1232-1298
-        if (do_dct && band < 18 && ch < nch) {
-            float in[32], out[32];
+            // E. 32-point DCT-II, lane = (channel, slot) (minimp3.d:1232-1298); all reads of the
+            //    transposition buffer precede the row writes in program order
+            float out[32];
+            const bool dct_lane = (band < 18) && ch_on;
+            {
+                float in[32];
+                const float *col = R + ch * 576 + (dct_lane ? band : 0);
 #pragma unroll
-            for (int b = 0; b < 32; b++) in[b] = buf[ch * 576 + b * 18 + band];
-            dct2_32(in, out);
-            float *row = H + hrow(p, band) + ch * 32;
+                for (int b = 0; b < 32; b++) in[b] = col[b * 18];
+                dct2_32(in, out);
+            }
+            __syncthreads();
+            if (dct_lane) {
+                f2 *row = (f2 *)(R + band * kHS + ch * 32);
 #pragma unroll
-            for (int q = 0; q < 32; q++) row[q] = out[q];
+                for (int i = 0; i < 15; i++) row[i] = f2{ out[31 - i], out[1 + i] };
+                row[15] = f2{ out[16], out[0] };
+            }
+            __syncthreads();
         }
-        __syncthreads();
 
-        // 7. park the prefetched spectrum in the staging buffer (it is free now)
-        if (have_next) {
+        if (do_synth) {
+            // G. samples 0 and 16 of every slot (mp3d_synth_pair, :1305-1328), lane = (channel, slot)
+            float op0 = 0.0f, op16 = 0.0f;
+            const bool pair_lane = (band < 18) && ch_on;
+            if (pair_lane) {
+                const f2 *base = (const f2 *)(H + band * kHS + ch * 32) + 15;
+                f2 z[15];
 #pragma unroll
-            for (int q = 0; q < 18; q++) buf[lane + 64 * q] = pre[q];
-        }
+                for (int m = 0; m < 15; m++) z[m] = base[m * (kHS / 2)];     // slot t-15+m: (V[16], V[0])
+                float a;
+                a  = (z[14].x - z[0].x) * 29;
+                a += (z[1].x + z[13].x) * 213;
+                a += (z[12].x - z[2].x) * 459;
+                a += (z[3].x + z[11].x) * 2037;
+                a += (z[10].x - z[4].x) * 5153;
+                a += (z[5].x + z[9].x) * 6574;
+                a += (z[8].x - z[6].x) * 37489;
+                a += z[7].x * 75038;
+                op0 = a * (1.0f / 32768.0f);                                  // mp3d_scale_pcm, :1300
+                a  = z[14].y * 104;
+                a += z[12].y * 1567;
+                a += z[10].y * 9727;
+                a += z[8].y * 64019;
+                a += z[6].y * -9975;
+                a += z[4].y * -45;
+                a += z[2].y * 146;
+                a += z[0].y * -5;
+                op16 = a * (1.0f / 32768.0f);
+            }
 
-        // 8. polyphase window, lane = (channel, sample j); minimp3.d:1305-1406
-        if (do_synth && ch < nch) {
-            float *dst = pcm + (st.blk_base + (uint64_t)g * nch) * 576 + ch;
-            for (int t = 0; t < 18; t++) {
-                float acc;
-                if (j == 0) {
-                    // synth_pair first half, minimp3.d:1308-1316; z[m] = slot t-15+m, column 16
-                    const int c16 = ch * 32 + 16;
-                    float z[15];
+            // F. 512-tap window (minimp3.d:1371-1405), streamed: lane (s2, c, i) walks slots
+            //    t' = 9*s2 + n, n = 0..8, over a sliding window of 16 rows.  For slot t' and tap k:
+            //        vz = row(15+t'-k) element (k odd ? lo : hi),  vy = row(t'+k) element (k odd ? hi : lo)
+            //    i.e. with rw[m] = row(t0 + m):  vz = rw[15+n-k],  vy = rw[n+k]   (24 distinct rows).
+            //    PCM of slot n (s2 = 0) lands in H floats [64n, 64n+64) = rows <= n, dead by then.
+            f2 w[8];
 #pragma unroll
-                    for (int m = 0; m < 15; m++) z[m] = H[hrow(p, t - 15 + m) + c16];
-                    acc  = (z[14] - z[0]) * 29;
-                    acc += (z[1] + z[13]) * 213;
-                    acc += (z[12] - z[2]) * 459;
-                    acc += (z[3] + z[11]) * 2037;
-                    acc += (z[10] - z[4]) * 5153;
-                    acc += (z[5] + z[9]) * 6574;
-                    acc += (z[8] - z[6]) * 37489;
-                    acc += z[7] * 75038;
-                } else if (j == 16) {
-                    // synth_pair second half, minimp3.d:1318-1327; column 0
-                    const int c0 = ch * 32;
-                    float z[8];
+            for (int k = 0; k < 8; k++) w[k] = wrow[k];                       // (w0, w1) of tap k
+            const bool main_lane = (si < 15) && (sc < nch);
+            const int t0 = 9 * s2;
+            const f2 *base = (const f2 *)(H + t0 * kHS + sc * 32) + (si < 15 ? si : 14);
+            float *const pdst = (s2 ? P1 : H) + sc;
+            f2 rw[24];
 #pragma unroll
-                    for (int m = 0; m < 8; m++) z[m] = H[hrow(p, t - 15 + 2 * m) + c0];
-                    acc  = z[7] * 104;
-                    acc += z[6] * 1567;
-                    acc += z[5] * 9727;
-                    acc += z[4] * 64019;
-                    acc += z[3] * -9975;
-                    acc += z[2] * -45;
-                    acc += z[1] * 146;
-                    acc += z[0] * -5;
-                } else {
-                    // window ladder, minimp3.d:1388-1395
+            for (int m = 0; m < 16; m++) rw[m] = base[m * (kHS / 2)];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        float vz = H[hrow(p, t - k) + ((k & 1) ? col_lo : col_hi)];
-                        float vy = H[hrow(p, t - 15 + k) + ((k & 1) ? col_hi : col_lo)];
-                        float term = vz * wa[k] + vy * wb[k];
-                        acc = (k == 0) ? term : (acc + term);
-                    }
+            for (int n = 0; n < 9; n++) {
+                if (n > 0) rw[15 + n] = base[(15 + n) * (kHS / 2)];
+                float a = 0.0f, b = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const f2 zp = rw[15 + n - k], yp = rw[n + k];
+                    const float vz = (k & 1) ? zp.y : zp.x;
+                    const float vy = (k & 1) ? yp.x : yp.y;
+                    const float tb = vz * w[k].y + vy * w[k].x;
+                    const float ta = (k & 1) ? (vy * w[k].y - vz * w[k].x) : (vz * w[k].x - vy * w[k].y);
+                    b = (k == 0) ? tb : (b + tb);
+                    a = (k == 0) ? ta : (a + ta);
                 }
-                dst[(t * 32 + j) * nch] = acc * (1.0f / 32768.0f);      // mp3d_scale_pcm, :1300
+                if (main_lane) {
+                    pdst[(n * 32 + 15 - si) * nch] = a * (1.0f / 32768.0f);
+                    pdst[(n * 32 + 17 + si) * nch] = b * (1.0f / 32768.0f);
+                }
+            }
+            if (pair_lane) {
+                float *pp = (band < 9 ? H + (band * 32) * nch : P1 + ((band - 9) * 32) * nch) + ch;
+                pp[0] = op0;
+                pp[16 * nch] = op16;
+            }
+            __syncthreads();
+            // I. 16-byte coalesced PCM stores: first half of the granule from H, second from P1
+            float4 *dst = (float4 *)(pcm + (st.blk_base + (uint64_t)g * nch) * 576);
+            const int half4 = nval / 8;                     // float4 per half
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int idx = lane + 64 * q;
+                if (idx < 2 * half4)
+                    dst[idx] = (idx < half4) ? ((const float4 *)H)[idx] : ((const float4 *)P1)[idx - half4];
+            }
+        }
+        __syncthreads();
+
+        // H. the last 15 slots become the history of the next granule (:1432)
+        if (do_dct) {
+            constexpr int n2 = kHistRows * kHS / 2;         // 495 float pairs, one contiguous block
+            const f2 *srcp = (const f2 *)(H + 18 * kHS);
+            f2 hcp[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int idx = lane + 64 * q;
+                hcp[q] = (idx < n2) ? srcp[idx] : f2{ 0.0f, 0.0f };
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int idx = lane + 64 * q;
+                if (idx < n2) ((f2 *)H)[idx] = hcp[q];
             }
         }
         __syncthreads();
@@ -486,9 +530,7 @@ __global__ __launch_bounds__(64) void mp3_transform_kernel(
     if (st_blob && seg.last) {
 #pragma unroll
         for (int i = 0; i < 9; i++) st_blob[lane * 9 + i] = ov[i];
-        const int p = (g_end - 1) & 1;
-        for (int r = 0; r < 15; r++)
-            st_blob[kStateOverlap + r * 64 + lane] = H[hrow(p, 3 + r) + lane];
+        for (int r = 0; r < kHistRows; r++) st_blob[kStateOverlap + r * 64 + lane] = H[r * kHS + lane];
     }
 }
 

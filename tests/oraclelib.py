@@ -104,6 +104,12 @@ def mp3_transform(ngr, nch, coef, flags, want_state=False):
     return (pcm, states) if want_state else pcm
 
 
+def mp3_transform_into(ngr, nch, coef, flags, pcm):
+    """Same as mp3_transform but into a caller-owned buffer (no allocation: used when timing)."""
+    lib().afgo_mp3_transform(len(ngr), ngr, nch, coef, flags, pcm, None)
+    return pcm
+
+
 # ------------------------------------------------------------- Vorbis ------
 def vorbis_tables(n):
     t = VorbisTables()
