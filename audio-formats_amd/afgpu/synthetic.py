@@ -196,3 +196,85 @@ def flac_batch(seed, n_frames, block_size=4096, channels=2, bps=16, orders=(8, 1
         in_off += bs * channels
         out_off += bs * channels
     return frames, subframes, np.concatenate(res_parts), out_off
+
+
+# ------------------------------------------------- device-resident BASELINE workloads ------
+
+def vorbis_batch_device(seed, n_files, packets_per_file, device, bs0=256, bs1=2048, channels=2,
+                        p_short_run=0.02, files_per_chunk=32):
+    """C3-shaped batch built in HBM.  All files share one packet-flag sequence per seed%16 family
+    so that spectra can be generated as dense tensors; returns (pflags_all, spec CUDA tensor, plan args)."""
+    import torch
+    from . import VorbisPlan
+    fams = []
+    for f in range(16):
+        rng = np.random.default_rng([seed, f])
+        fams.append(vorbis_packet_flags(rng, packets_per_file, p_short_run))
+    pflags = np.concatenate([fams[f % 16] for f in range(n_files)])
+    packets = np.full(n_files, packets_per_file, np.uint32)
+    plan = VorbisPlan(packets, np.full(n_files, channels, np.uint8), np.full(n_files, bs0, np.uint16),
+                      np.full(n_files, bs1, np.uint16), pflags, 0)
+    spec = torch.empty(plan.spec_floats, dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    chunk = 1 << 28
+    for o in range(0, plan.spec_floats, chunk):
+        spec[o:o + chunk].normal_(generator=gen)
+    # spectral shape: apply the long-block floor curve to long packets (dense majority); short packets keep N(0,1)*0.1
+    so, _ = plan.offsets()
+    curve = torch.from_numpy(vorbis_floor_curve(bs1 // 2)).to(device)
+    is_long = (pflags & VORBIS_LONG) != 0
+    if is_long.all():
+        spec.view(-1, bs1 // 2).mul_(curve)
+    else:
+        spec.mul_(0.25)
+    return plan, spec
+
+
+def flac_batch_device(seed, n_files, frames_per_file, device, block_size=4096, bps=16):
+    """C4-shaped batch built in HBM: stereo, LPC order 8 (even files) / 12 (odd files), Laplacian
+    residuals (scale 2^5), 60 % MID_SIDE / 25 % LEFT_SIDE / 15 % independent.  Returns
+    (frames u8 tensor, subframes u8 tensor, res int32 tensor, n_frames, out_total)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    n_frames = n_files * frames_per_file
+    pool = {o: [_quantised_lpc(np.random.default_rng([seed, o, i]), o) for i in range(64)] for o in (8, 12)}
+    frames = np.zeros(n_frames, FLAC_FRAME_DTYPE)
+    idx = np.arange(n_frames, dtype=np.uint64)
+    frames["in_off"] = idx * np.uint64(block_size * 2)
+    frames["out_off"] = idx * np.uint64(block_size * 2)
+    frames["block_size"] = block_size
+    frames["sf_index"] = (idx * 2).astype(np.uint32)
+    frames["channels"] = 2
+    frames["bps"] = bps
+    asg = rng.choice([FLAC_MID_SIDE, FLAC_LEFT_SIDE, FLAC_INDEPENDENT], size=n_frames, p=[0.6, 0.25, 0.15])
+    frames["assignment"] = asg.astype(np.uint8)
+    subframes = np.zeros(n_frames * 2, FLAC_SUBFRAME_DTYPE)
+    file_of = (idx // np.uint64(frames_per_file)).astype(np.int64)
+    for order in (8, 12):
+        sel_frames = np.flatnonzero((file_of % 2) == (0 if order == 8 else 1))
+        for c in range(2):
+            sidx = sel_frames * 2 + c
+            pick = rng.integers(0, 64, sidx.size)
+            coefs = np.stack([pool[order][i][0] for i in range(64)])        # [64, order]
+            shifts = np.array([pool[order][i][1] for i in range(64)], np.uint8)
+            subframes["coef"][sidx, :order] = coefs[pick]
+            subframes["order"][sidx] = order
+            subframes["shift"][sidx] = shifts[pick]
+    side = np.zeros(n_frames * 2, bool)
+    side[1::2] = np.isin(asg, [FLAC_MID_SIDE, FLAC_LEFT_SIDE])
+    subframes["use64"] = side.astype(np.uint8)                                # subframe bps 17 > 16
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    total = n_frames * 2 * block_size
+    res = torch.empty(total, dtype=torch.int32, device=device)
+    chunk = 1 << 28
+    for o in range(0, total, chunk):
+        n = min(chunk, total - o)
+        e = torch.empty(n, dtype=torch.float32, device=device).exponential_(1.0 / 32.0, generator=gen)
+        sgn = torch.empty(n, dtype=torch.float32, device=device).uniform_(-1.0, 1.0, generator=gen).sign_()
+        res[o:o + n] = (e * sgn).round_().to(torch.int32)
+        del e, sgn
+    d_frames = torch.from_numpy(frames.view(np.uint8).copy()).to(device)
+    d_sub = torch.from_numpy(subframes.view(np.uint8).copy()).to(device)
+    return d_frames, d_sub, res, n_frames, total, frames, subframes

@@ -8,23 +8,25 @@
 //
 //   * the LPC recurrence is serial inside a subframe (floor shift: not a scan),
 //     so the parallel axis is frames: one lane owns one frame and runs the
-//     recurrence of its (up to two at a time) channels with the last `order`
-//     samples and the coefficients in registers;
-//   * both reference accumulators come out of ONE int64 multiply-add chain: the
-//     low 32 bits of the 64-bit sum are exactly the wrapping int32 sum of
-//     drflac__calculate_prediction_32, so `use64` only selects which bits are
-//     shifted (drflac.d:1098 vs :1139);
+//     recurrence of its channels (two at a time) with the last `order` samples
+//     and the coefficients in registers;
+//   * prediction_32 is a wrapping int32 sum: v_mul_lo_u32 + add per tap.  When a
+//     wavefront holds `use64` subframes the sum is kept in int64 instead; its low
+//     32 bits are exactly the wrapping sum, so the flag only selects which bits
+//     are shifted (drflac.d:1098 vs :1139);
 //   * residual planes are subframe-major in HBM (what the Rice decoder writes),
-//     so a wavefront moves 64 frames x 2 channels x 32 samples through an LDS
-//     tile per step: coalesced 128-byte row reads in, one-row-per-lane in the
-//     recurrence (row stride 65 words: conflict-free), coalesced 256-byte
-//     interleaved rows out with the decorrelation done on the way out.
+//     so a wavefront moves 64 frames x 2 channels x 16 samples per step through
+//     an LDS tile.  The next step's rows are already in flight (16-byte loads
+//     parked in registers) while the current step runs its recurrence; the tile
+//     is stored as 16-byte pieces rotated by row/2, which makes the
+//     one-row-per-lane 16-byte accesses of the recurrence conflict-free; outputs
+//     leave as interleaved 16-byte stores with the decorrelation done on the way.
 #include "afg_common.h"
 
 namespace {
 
-constexpr int kT = 32;                 // samples per tile step
-constexpr int kRow = 2 * kT + 1;       // LDS row: [ch0 | ch1] + 1 pad word
+constexpr int kT = 16;                 // samples per tile step
+constexpr int kRowWords = 2 * kT;      // LDS row: [channel A | channel B], 8 pieces of 4 words
 
 struct RowMeta {                       // what the load/store phases need to know about a lane's frame
     uint64_t in_off;
@@ -43,48 +45,163 @@ __device__ __forceinline__ int wave_max(int v)
     return v;
 }
 
-// One tile of one channel of this lane's frame: kT steps of
-//   s[t] = r[t] + (sum_k coef[k]*s[t-1-k]) >> shift        (drflac.d:1235)
-// for t >= order, verbatim warm-up below (drflac.d:1406-1410, :1419-1423).
-template <int MAXORD>
-__device__ __forceinline__ void restore_tile(int32_t *row, int t0, int bs, int order, int shift, bool use64,
-                                             const int32_t (&c)[MAXORD], int32_t (&h)[MAXORD])
+// word offset of 16-byte piece `piece` (0..7) of tile row `row`
+__device__ __forceinline__ int piece_off(int row, int piece)
 {
-#pragma unroll
-    for (int j = 0; j < kT; j++) {
-        const int t = t0 + j;
-        int32_t r = row[j];
-        // taps on the older samples first: they do not wait for the newest output
-        int64_t acc = 0;
-#pragma unroll
-        for (int k = MAXORD - 1; k >= 1; k--) acc += (int64_t)c[k] * (int64_t)h[k];
-        acc += (int64_t)c[0] * (int64_t)h[0];
-        const int32_t p32 = (int32_t)(uint32_t)(uint64_t)acc >> shift;   // prediction_32: wrapped int32 sum, arithmetic shift
-        const int32_t p64 = (int32_t)(uint32_t)(uint64_t)(acc >> shift); // prediction_64: shift in 64 bits, then truncate
-        const int32_t pred = use64 ? p64 : p32;
-        const int32_t s = (t >= order) ? (int32_t)((uint32_t)r + (uint32_t)pred) : r;
-        if (t < bs) {
-            row[j] = s;
-#pragma unroll
-            for (int k = MAXORD - 1; k >= 1; k--) h[k] = h[k - 1];
-            h[0] = s;
-        }
-    }
+    return row * kRowWords + (((piece + (row >> 1)) & 7) << 2);
 }
 
 __device__ __forceinline__ int32_t shl32(int32_t v, unsigned sh) { return (int32_t)((uint32_t)v << (sh & 31u)); }
 
-template <int MAXORD>
+// One tile of one channel of this lane's frame: kT steps of
+//   s[t] = r[t] + (sum_k coef[k]*s[t-1-k]) >> shift        (drflac.d:1235)
+// for t >= order, verbatim warm-up below (drflac.d:1406-1410, :1419-1423).
+// Coefficients past `order` are zero, values past the end of the block are never stored:
+// no branches, so the unrolled history shift is pure register renaming.
+template <int MAXORD, bool WIDE>
+__device__ __forceinline__ void restore_tile(int32_t *tile, int row, int chan, int t0, int order, int shift,
+                                             bool use64, const int32_t (&c)[MAXORD], int32_t (&h)[MAXORD])
+{
+#pragma unroll
+    for (int q = 0; q < kT / 4; q++) {
+        int4 *pp = (int4 *)(tile + piece_off(row, chan * 4 + q));
+        int4 v = *pp;
+        int32_t r[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int t = t0 + 4 * q + e;
+            int32_t pred;
+            if (WIDE) {
+                // taps on the older samples first: they do not wait for the newest output
+                int64_t acc = 0;
+#pragma unroll
+                for (int k = MAXORD - 1; k >= 0; k--) acc += (int64_t)c[k] * (int64_t)h[k];
+                const int32_t p32 = (int32_t)(uint32_t)(uint64_t)acc >> shift;     // prediction_32 (:1098)
+                const int32_t p64 = (int32_t)(uint32_t)(uint64_t)(acc >> shift);   // prediction_64 (:1139)
+                pred = use64 ? p64 : p32;
+            } else {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = MAXORD - 1; k >= 0; k--) acc += (uint32_t)c[k] * (uint32_t)h[k];
+                pred = (int32_t)acc >> shift;
+            }
+            const int32_t s = (t >= order) ? (int32_t)((uint32_t)r[e] + (uint32_t)pred) : r[e];
+            r[e] = s;
+#pragma unroll
+            for (int k = MAXORD - 1; k >= 1; k--) h[k] = h[k - 1];
+            h[0] = s;
+        }
+        *pp = make_int4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// Issue the 16-byte loads of one tile step: instruction i covers row-chunks 16i .. 16i+15,
+// row-chunk rc = (row rc>>1, channel slot rc&1), lane&3 = 16-byte piece of the 64-byte chunk.
+__device__ __forceinline__ void load_tile(int4 (&nxt)[8], const RowMeta *meta, const int32_t *__restrict__ res,
+                                          int pair, int t0)
+{
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int rc = 16 * i + (lane >> 2);
+        const int row = rc >> 1, slot = rc & 1, p = lane & 3;
+        const RowMeta m = meta[row];
+        const int C = (int)(m.info & 0xff);
+        const int cidx = 2 * pair + slot;
+        const int t = t0 + 4 * p;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (cidx < C && t < (int)m.bs) {
+            const int32_t *src = res + m.in_off + (uint64_t)cidx * m.bs + (uint64_t)t;
+            if (t + 3 < (int)m.bs) {
+                v = *(const int4 *)src;                              // may be 4-byte aligned only (odd block sizes)
+            } else {
+                v.x = src[0];
+                if (t + 1 < (int)m.bs) v.y = src[1];
+                if (t + 2 < (int)m.bs) v.z = src[2];
+            }
+        }
+        nxt[i] = v;
+    }
+}
+
+__device__ __forceinline__ void park_tile(int32_t *tile, const int4 (&nxt)[8])
+{
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int rc = 16 * i + (lane >> 2);
+        *(int4 *)(tile + piece_off(rc >> 1, (rc & 1) * 4 + (lane & 3))) = nxt[i];
+    }
+}
+
+// decorrelate (drflac.d:2885-2941), shift, interleave, convert; 8 rows per instruction
+__device__ __forceinline__ void store_tile(const int32_t *tile, const RowMeta *meta, const uint32_t *row_shift,
+                                           int32_t *__restrict__ out_i32, float *__restrict__ out_f32,
+                                           int pair, int t0)
+{
+    const int lane = threadIdx.x;
+#pragma unroll 2
+    for (int i = 0; i < 8; i++) {
+        const int row = 8 * i + (lane >> 3);
+        const int q = lane & 7;                                      // samples 2q, 2q+1 of the tile
+        const RowMeta m = meta[row];
+        const int C = (int)(m.info & 0xff);
+        const int asg = (int)((m.info >> 8) & 0xff);
+        const int t = t0 + 2 * q;
+        if (2 * pair >= C || t >= (int)m.bs) continue;
+        const int2 a = *(const int2 *)(tile + piece_off(row, q >> 1) + 2 * (q & 1));
+        const int2 b = *(const int2 *)(tile + piece_off(row, 4 + (q >> 1)) + 2 * (q & 1));
+        const bool two = (C - 2 * pair) >= 2;
+        int32_t l0, r0, l1, r1;
+        if (asg == AFG_FLAC_LEFT_SIDE) {                             // :2886-2897
+            l0 = a.x; r0 = (int32_t)((uint32_t)a.x - (uint32_t)b.x);
+            l1 = a.y; r1 = (int32_t)((uint32_t)a.y - (uint32_t)b.y);
+        } else if (asg == AFG_FLAC_RIGHT_SIDE) {                     // :2899-2909
+            l0 = (int32_t)((uint32_t)b.x + (uint32_t)a.x); r0 = b.x;
+            l1 = (int32_t)((uint32_t)b.y + (uint32_t)a.y); r1 = b.y;
+        } else if (asg == AFG_FLAC_MID_SIDE) {                       // :2911-2920
+            const int32_t m0 = (int32_t)(((uint32_t)a.x << 1) | (uint32_t)(b.x & 1));
+            const int32_t m1 = (int32_t)(((uint32_t)a.y << 1) | (uint32_t)(b.y & 1));
+            l0 = (int32_t)((uint32_t)m0 + (uint32_t)b.x) >> 1; r0 = (int32_t)((uint32_t)m0 - (uint32_t)b.x) >> 1;
+            l1 = (int32_t)((uint32_t)m1 + (uint32_t)b.y) >> 1; r1 = (int32_t)((uint32_t)m1 - (uint32_t)b.y) >> 1;
+        } else {                                                     // :2922-2940
+            l0 = a.x; r0 = b.x; l1 = a.y; r1 = b.y;
+        }
+        const unsigned shA = row_shift[row * 8 + 2 * pair];
+        const unsigned shB = row_shift[row * 8 + ((2 * pair + 1) & 7)];
+        l0 = shl32(l0, shA); l1 = shl32(l1, shA);
+        r0 = shl32(r0, shB); r1 = shl32(r1, shB);
+        const bool second = (t + 1 < (int)m.bs);
+        const double factor = 1.0 / 2147483647.0;                    // stream.d:507
+        if (C == 2 && second) {
+            const uint64_t o = m.out_off + (uint64_t)t * 2;
+            if (out_i32) *(int4 *)(out_i32 + o) = make_int4(l0, r0, l1, r1);
+            if (out_f32)
+                *(float4 *)(out_f32 + o) = make_float4((float)((double)l0 * factor), (float)((double)r0 * factor),
+                                                       (float)((double)l1 * factor), (float)((double)r1 * factor));
+        } else {
+            const int32_t vals[4] = { l0, r0, l1, r1 };
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int smp = e >> 1, slot = e & 1;
+                if ((slot && !two) || (smp && !second)) continue;
+                const uint64_t o = m.out_off + (uint64_t)(t + smp) * C + (2 * pair + slot);
+                if (out_i32) out_i32[o] = vals[e];
+                if (out_f32) out_f32[o] = (float)((double)vals[e] * factor);
+            }
+        }
+    }
+}
+
+template <int MAXORD, bool WIDE>
 __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, const RowMeta &me, bool valid,
                                            const afg_flac_subframe *__restrict__ subframes, uint32_t sf_index,
                                            const int32_t *__restrict__ res, int32_t *__restrict__ out_i32,
                                            float *__restrict__ out_f32, int max_bs, int max_pairs,
-                                           const uint32_t *row_shift /* LDS [64][8] packed shifts */)
+                                           const uint32_t *row_shift /* LDS [64][8] */)
 {
     const int lane = threadIdx.x;
     const int my_ch = valid ? (int)(me.info & 0xff) : 0;
-    const int half = lane >> 5;       // channel slot in load phase
-    const int w = lane & 31;
 
     for (int pair = 0; pair < max_pairs; pair++) {
         // this lane's two subframes of the pair
@@ -108,69 +225,36 @@ __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, c
             for (int k = 0; k < MAXORD; k++) c1[k] = (k < order1) ? (int32_t)sf->coef[k] : 0;
         }
 
+        int4 nxt[8];
+        load_tile(nxt, meta, res, pair, 0);
+        park_tile(tile, nxt);
+        __syncthreads();
         for (int t0 = 0; t0 < max_bs; t0 += kT) {
-            // ---- load: row r <- frame r, lanes 0..31 channel A, lanes 32..63 channel B (128 B each)
-            for (int r = 0; r < 64; r++) {
-                const RowMeta m = meta[r];
-                const int C = (int)(m.info & 0xff);
-                const int cidx = 2 * pair + half;
-                const int t = t0 + w;
-                int32_t v = 0;
-                if (cidx < C && t < (int)m.bs) v = res[m.in_off + (uint64_t)cidx * m.bs + (uint64_t)t];
-                tile[r * kRow + half * kT + w] = v;
-            }
-            __syncthreads();
+            if (t0 + kT < max_bs) load_tile(nxt, meta, res, pair, t0 + kT);   // in flight during the recurrence
 
-            // ---- recurrence: lane = frame
             if (t0 < (int)me.bs) {
-                if (chA < my_ch) restore_tile<MAXORD>(tile + lane * kRow, t0, (int)me.bs, order0, shift0, u0, c0, h0);
-                if (chB < my_ch) restore_tile<MAXORD>(tile + lane * kRow + kT, t0, (int)me.bs, order1, shift1, u1, c1, h1);
+                if (chA < my_ch) restore_tile<MAXORD, WIDE>(tile, lane, 0, t0, order0, shift0, u0, c0, h0);
+                if (chB < my_ch) restore_tile<MAXORD, WIDE>(tile, lane, 1, t0, order1, shift1, u1, c1, h1);
             }
             __syncthreads();
-
-            // ---- store: decorrelate (drflac.d:2885-2941), shift, interleave; row by row
-            for (int r = 0; r < 64; r++) {
-                const RowMeta m = meta[r];
-                const int C = (int)(m.info & 0xff);
-                const int asg = (int)((m.info >> 8) & 0xff);
-                if (2 * pair >= C) continue;
-                const int npair = (C - 2 * pair) >= 2 ? 2 : 1;        // channels of this pair present
-                // lane -> (sample j, channel slot s)
-                const int j = (npair == 2) ? (lane >> 1) : lane;
-                const int s = (npair == 2) ? (lane & 1) : 0;
-                const int t = t0 + j;
-                if (j >= kT || t >= (int)m.bs) continue;
-                const int32_t a = tile[r * kRow + j];
-                const int32_t b = tile[r * kRow + kT + j];
-                int32_t v;
-                if (asg == AFG_FLAC_LEFT_SIDE) {                      // :2886-2897
-                    v = s ? (int32_t)((uint32_t)a - (uint32_t)b) : a;
-                } else if (asg == AFG_FLAC_RIGHT_SIDE) {              // :2899-2909
-                    v = s ? b : (int32_t)((uint32_t)b + (uint32_t)a);
-                } else if (asg == AFG_FLAC_MID_SIDE) {                // :2911-2920
-                    const int32_t mid = (int32_t)(((uint32_t)a << 1) | (uint32_t)(b & 1));
-                    v = s ? ((int32_t)((uint32_t)mid - (uint32_t)b) >> 1)
-                          : ((int32_t)((uint32_t)mid + (uint32_t)b) >> 1);
-                } else {                                              // :2922-2940
-                    v = s ? b : a;
-                }
-                const int cidx = 2 * pair + s;
-                v = shl32(v, row_shift[r * 8 + cidx]);
-                const uint64_t o = m.out_off + (uint64_t)t * C + cidx;
-                if (out_i32) out_i32[o] = v;
-                if (out_f32) out_f32[o] = (float)((double)v * (1.0 / 2147483647.0));   // stream.d:507-510
-            }
+            store_tile(tile, meta, row_shift, out_i32, out_f32, pair, t0);
+            __syncthreads();
+            if (t0 + kT < max_bs) park_tile(tile, nxt);
             __syncthreads();
         }
     }
 }
 
+// One kernel per (order bucket, accumulator width): a wavefront only runs in the instantiation
+// that matches the largest LPC order / widest accumulator among its 64 frames and leaves the
+// others at once, so every instantiation gets its own (small) register allocation.
+template <int LO, int MAXORD, bool WIDE>
 __global__ __launch_bounds__(64) void flac_restore_kernel(
     const afg_flac_frame *__restrict__ frames, const afg_flac_subframe *__restrict__ subframes,
     const int32_t *__restrict__ res, int32_t *__restrict__ out_i32, float *__restrict__ out_f32,
     uint64_t n_frames)
 {
-    __shared__ int32_t tile[64 * kRow];
+    __shared__ __attribute__((aligned(16))) int32_t tile[64 * kRowWords];
     __shared__ RowMeta meta[64];
     __shared__ uint32_t row_shift[64 * 8];
 
@@ -181,21 +265,29 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(
     RowMeta me;
     me.in_off = 0; me.out_off = 0; me.bs = 0; me.info = 0;
     uint32_t sf_index = 0;
-    int my_order = 0;
+    int my_order = 0, my_wide = 0;
+    afg_flac_frame fr;
     if (valid) {
-        const afg_flac_frame fr = frames[f];
+        fr = frames[f];
+        sf_index = fr.sf_index;
+        for (int c = 0; c < (int)fr.channels && c < 8; c++) {
+            const afg_flac_subframe *sf = subframes + sf_index + c;
+            my_order = sf->order > my_order ? sf->order : my_order;
+            my_wide |= sf->use64;
+        }
+    }
+    const int max_order = wave_max(my_order);
+    const bool wide = wave_max(my_wide) != 0;
+    if (!(max_order > LO && max_order <= MAXORD && wide == WIDE)) return;
+
+    if (valid) {
         me.in_off = fr.in_off;
         me.out_off = fr.out_off;
         me.bs = fr.block_size;
         me.info = (uint32_t)fr.channels | ((uint32_t)fr.assignment << 8) | ((uint32_t)fr.bps << 16);
-        sf_index = fr.sf_index;
         for (int c = 0; c < 8; c++) {
             uint32_t sh = 0;
-            if (c < (int)fr.channels) {
-                const afg_flac_subframe *sf = subframes + sf_index + c;
-                sh = (32u - fr.bps) + sf->wasted;                     // drflac.d:2883, :2894
-                my_order = sf->order > my_order ? sf->order : my_order;
-            }
+            if (c < (int)fr.channels) sh = (32u - fr.bps) + subframes[sf_index + c].wasted;   // drflac.d:2883, :2894
             row_shift[lane * 8 + c] = sh;
         }
     } else {
@@ -206,16 +298,8 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(
 
     const int max_bs = wave_max((int)me.bs);
     const int max_pairs = wave_max(((int)(me.info & 0xff) + 1) >> 1);
-    const int max_order = wave_max(my_order);
-
-#define AFG_FLAC_RUN(N) run_frames<N>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, \
-                                      max_bs, max_pairs, row_shift)
-    if (max_order <= 4) AFG_FLAC_RUN(4);
-    else if (max_order <= 8) AFG_FLAC_RUN(8);
-    else if (max_order <= 12) AFG_FLAC_RUN(12);
-    else if (max_order <= 16) AFG_FLAC_RUN(16);
-    else AFG_FLAC_RUN(32);
-#undef AFG_FLAC_RUN
+    run_frames<MAXORD, WIDE>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32,
+                             max_bs, max_pairs, row_shift);
 }
 
 }  // namespace
@@ -235,8 +319,16 @@ extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d
         afg::set_error("afg_flac_transform_hip: too many frames in one call");
         return AFG_ERR_INVALID;
     }
-    hipLaunchKernelGGL(flac_restore_kernel, dim3((uint32_t)groups), dim3(64), 0, (hipStream_t)hip_stream,
-                       d_frames, d_subframes, d_res, d_out_i32, d_out_f32, n_frames);
+#define AFG_FLAC_LAUNCH(LO, HI)                                                                               \
+    hipLaunchKernelGGL((flac_restore_kernel<LO, HI, false>), dim3((uint32_t)groups), dim3(64), 0,              \
+                       (hipStream_t)hip_stream, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, n_frames); \
+    hipLaunchKernelGGL((flac_restore_kernel<LO, HI, true>), dim3((uint32_t)groups), dim3(64), 0,               \
+                       (hipStream_t)hip_stream, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, n_frames)
+    AFG_FLAC_LAUNCH(-1, 4);
+    AFG_FLAC_LAUNCH(4, 8);
+    AFG_FLAC_LAUNCH(8, 12);
+    AFG_FLAC_LAUNCH(12, 32);
+#undef AFG_FLAC_LAUNCH
     AFG_HIP_CHECK(hipGetLastError());
     return AFG_OK;
 }

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Development bench for the Vorbis (C3) and FLAC (C4) transform kernels: device-resident batches of
+BASELINE.json's shapes, events on the launch stream, parity of the first file(s) against the oracle."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "audio-formats_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def time_launches(fn, steps, warmup):
+    stream = torch.cuda.current_stream()
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for s, e in ev:
+        s.record(stream)
+        fn()
+        e.record(stream)
+    torch.cuda.synchronize()
+    return [s.elapsed_time(e) for s, e in ev]
+
+
+def bench_vorbis(dev, files, packets, steps, warmup, seg):
+    import afgpu
+    import oraclelib
+    from afgpu import synthetic
+    plan, spec = synthetic.vorbis_batch_device(0x0662, files, packets, dev)
+    if seg:
+        plan = afgpu.VorbisPlan(plan.packets, plan.channels, plan.bs0, plan.bs1, plan.pflags, seg)
+    out = torch.empty(plan.out_floats, dtype=torch.float32, device=dev)
+    ms = time_launches(lambda: plan.transform(spec, out), steps, warmup)
+    avg = sum(ms) / len(ms) * 1e-3
+    # algorithmic bytes: spectrum in + one flag byte per packet + PCM out
+    alg = 4 * plan.spec_floats + plan.total_packets + 4 * plan.out_floats
+    # parity on the first file
+    so, oo = plan.offsets()
+    npk = int(plan.packets[0])
+    s_end = int(so[npk]) if plan.total_packets > npk else plan.spec_floats
+    o_end = int(oo[npk]) if plan.total_packets > npk else plan.out_floats
+    want = oraclelib.vorbis_transform(plan.packets[:1], plan.channels[:1], plan.bs0[:1], plan.bs1[:1],
+                                      plan.pflags[:npk], so[:npk], oo[:npk], spec[:s_end].cpu().numpy(), o_end)
+    got = out[:o_end].cpu().numpy()
+    return {"workload": f"{files} x Ogg Vorbis stereo, {packets} packets, blocksize 2048/256",
+            "samples_per_step": plan.out_floats, "avg_kernel_ms": avg * 1e3,
+            "samples_per_s": plan.out_floats / avg, "achieved_GBs": alg / avg / 1e9,
+            "frac": alg / avg / 1e9 / HBM_PEAK_GBS,
+            "bitwise_mismatches": int((got.view(np.uint32) != want.view(np.uint32)).sum()),
+            "rms_error": float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)))}
+
+
+def bench_flac(dev, files, frames_per_file, steps, warmup, want_float):
+    import afgpu
+    import oraclelib
+    from afgpu import synthetic
+    d_frames, d_sub, res, n_frames, total, frames, subframes = synthetic.flac_batch_device(
+        0xF1AC, files, frames_per_file, dev)
+    out_i = torch.empty(total, dtype=torch.int32, device=dev)
+    out_f = torch.empty(total, dtype=torch.float32, device=dev) if want_float else None
+    ms = time_launches(lambda: afgpu.flac_transform(n_frames, d_frames, d_sub, res, out_i, out_f), steps, warmup)
+    avg = sum(ms) / len(ms) * 1e-3
+    alg = 4 * total + 4 * total * (2 if want_float else 1) + n_frames * (32 + 2 * 68)
+    nchk = min(n_frames, 2 * frames_per_file)
+    cnt = int(frames["in_off"][nchk]) if nchk < n_frames else total
+    want = oraclelib.flac_transform(frames[:nchk], subframes[:2 * nchk], res[:cnt].cpu().numpy(), cnt)
+    got = out_i[:cnt].cpu().numpy()
+    return {"workload": f"{files} x FLAC 16-bit stereo, {frames_per_file} frames of 4096, LPC order 8/12",
+            "samples_per_step": total, "avg_kernel_ms": avg * 1e3, "samples_per_s": total / avg,
+            "achieved_GBs": alg / avg / 1e9, "frac": alg / avg / 1e9 / HBM_PEAK_GBS,
+            "int32_mismatches": int((got != want).sum())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--codec", default="all")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--vorbis-files", type=int, default=1024)
+    ap.add_argument("--vorbis-packets", type=int, default=2584)
+    ap.add_argument("--vorbis-seg", type=int, default=0)
+    ap.add_argument("--flac-files", type=int, default=4096)
+    ap.add_argument("--flac-frames", type=int, default=323)
+    ap.add_argument("--flac-float", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    res = {}
+    if args.codec in ("all", "vorbis"):
+        res["vorbis"] = bench_vorbis(dev, args.vorbis_files, args.vorbis_packets, args.steps, args.warmup,
+                                     args.vorbis_seg)
+        torch.cuda.empty_cache()
+    if args.codec in ("all", "flac"):
+        res["flac"] = bench_flac(dev, args.flac_files, args.flac_frames, args.steps, args.warmup, args.flac_float)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
