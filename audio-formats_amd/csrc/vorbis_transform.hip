@@ -76,6 +76,7 @@ __device__ __forceinline__ void iter_54(float *z)
 
 // In-place inverse MDCT of one channel held in LDS; buffer[0..n/2) spectrum in,
 // buffer[0..n) samples out; buf2 = n/2 floats of scratch.  stb_vorbis2.d:1941-2242.
+template <int kThreads>
 __device__ void inverse_mdct_lds(float *buffer, float *buf2, int n, int ld,
                                  const float *__restrict__ A, const float *__restrict__ B,
                                  const float *__restrict__ C)
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void vorbis_transform_kernel(
             for (int k = tid; k < n2; k += kThreads) chan[c * nmax + k] = src[c * n2 + k];
         __syncthreads();
 
-        for (int c = 0; c < C; c++) inverse_mdct_lds(chan + c * nmax, buf2, n, ld, A, B, Ct);   // :2526-2527
+        for (int c = 0; c < C; c++) inverse_mdct_lds<kThreads>(chan + c * nmax, buf2, n, ld, A, B, Ct);   // :2526-2527
 
         // vorbis_finish_frame, :2606-2657
         const bool emit = (p >= (int)seg.p0) && previous_length > 0;
@@ -328,6 +329,371 @@ __global__ __launch_bounds__(kThreads) void vorbis_transform_kernel(
             for (int k = tid; k < previous_length; k += kThreads)
                 prevw[c * (nmax / 2) + k] = chan[c * nmax + right + k];
         __syncthreads();
+    }
+}
+
+
+// =========================================================================================
+// Fast path: one wavefront per (stream, packet segment), blocksize_1 == 2048, <= 2 channels.
+//
+// The whole transform of a channel lives in 8.7 KB of LDS: the n/4 = 512 complex points
+// E[m] = (u[n/2-1-2m], u[n/2-2-2m]) of the reference's step 3 are kept as float2 at index
+// m + (m >> 3) (one pad per 8 points: every access pattern below is conflict-free or 2-way),
+// buf2 as 512 linear float2, and the n output samples alias both once they are dead.
+// The 8 radix-2 stages of :2053-2090 run as three register passes (distances 128/64,
+// 32/16/8 and the reference's own fused 4/2/1 pass), steps 7 and 8 are fused (each step-7
+// butterfly feeds exactly two step-8 items), the spectrum is consumed straight from HBM
+// with 16-byte loads issued one transform ahead, the previous window half lives in
+// registers, and stereo PCM leaves as interleaved 8-byte stores.
+// Arithmetic per output is the reference's, operation for operation.
+// =========================================================================================
+constexpr int kNL = 2048;
+constexpr int kUFloats = kNL / 2 + kNL / 16;       // 1152: padded complex buffer
+constexpr int kWaveLds = kUFloats + kNL / 2;        // + buf2 = 2176 floats >= n
+
+struct alignas(8) f2 { float x, y; };
+
+__device__ __forceinline__ int pad_e(int m) { return m + (m >> 3); }
+
+__device__ __forceinline__ void bfly2(f2 &p, f2 &q, f2 c)
+{
+    const float d0 = p.x - q.x;
+    const float d1 = p.y - q.y;
+    p.x = p.x + q.x;
+    p.y = p.y + q.y;
+    q.x = d0 * c.x - d1 * c.y;
+    q.y = d1 * c.x + d0 * c.y;
+}
+
+// issue the loads of one channel spectrum (n = 2048): 4 x 16 bytes per lane
+__device__ __forceinline__ void load_spectrum(float4 (&x)[4], const float *__restrict__ X)
+{
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = __builtin_nontemporal_load((const v4f *)X + lane + 64 * r);   // read once: keep L1 for the tables
+        x[r] = make_float4(t.x, t.y, t.z, t.w);
+    }
+}
+
+// inverse_mdct for n = 2048 (stb_vorbis2.d:1941-2242); result in smem[0..2048)
+__device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *smem,
+                                                const float *__restrict__ A, const float *__restrict__ B,
+                                                const float *__restrict__ C)
+{
+    constexpr int n = kNL, n2 = n / 2, n4 = n / 4, n8 = n / 8;
+    const int lane = threadIdx.x;
+    f2 *const U = (f2 *)smem;
+    f2 *const V = (f2 *)(smem + kUFloats);
+    const f2 *const A2p = (const f2 *)A;
+
+    // step 0 (:1972-1994): item q and the mirrored item n8-1-q share one 16-byte load
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int q = lane + 64 * r, qm = n8 - 1 - q;
+        const float4 x = xin[r];
+        const f2 a0 = A2p[q];                       // A[2q], A[2q+1]
+        const f2 a1 = A2p[n8 + qm];                 // A[n4+2q'], A[n4+2q'+1]
+        f2 d;
+        d.y = (x.x * a0.x - x.z * a0.y);
+        d.x = (x.x * a0.y + x.z * a0.x);
+        V[n4 - 1 - q] = d;                          // buf2[n2-2-2q], [n2-1-2q]
+        f2 g;
+        g.y = (-x.w * a1.x - -x.y * a1.y);
+        g.x = (-x.w * a1.y + -x.y * a1.x);
+        V[q] = g;                                   // buf2[n4-2-2q'] = buf2[2q]
+    }
+    __syncthreads();
+
+    // step 2 (:2006-2040): half-iteration `it` makes points n4-1-it and n8-1-it
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int it = lane + 64 * r;
+        const f2 e0 = V[n8 + it];                   // v[n4+o], v[n4+o+1], o = 2 it
+        const f2 e1 = V[it];
+        const f2 aa = A2p[n4 - 2 - 2 * it];         // A[n2-4-2o], A[n2-3-2o]
+        const float v41_21 = e0.y - e1.y;
+        const float v40_20 = e0.x - e1.x;
+        f2 hi, lo;
+        hi.x = e0.y + e1.y;                         // d0[1]
+        hi.y = e0.x + e1.x;                         // d0[0]
+        lo.x = v41_21 * aa.x - v40_20 * aa.y;       // d1[1]
+        lo.y = v40_20 * aa.x + v41_21 * aa.y;       // d1[0]
+        U[pad_e(n8 - 1 - it)] = hi;
+        U[pad_e(n4 - 1 - it)] = lo;
+    }
+    __syncthreads();
+
+    // stages l = 0, 1 (:2053-2060): point sets {base + j + 64 r}, lane j, both halves
+    {
+        const int j = lane;
+        const f2 w00 = A2p[4 * j];                  // A[(j) << 3]
+        const f2 w01 = A2p[4 * (j + 64)];           // A[(j+64) << 3]
+        const f2 w1 = A2p[8 * j];                   // A[j << 4]
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++) {
+            const int base = hb * (n4 / 2) + j;
+            f2 e[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) e[r] = U[pad_e(base + 64 * r)];
+            bfly2(e[0], e[2], w00);
+            bfly2(e[1], e[3], w01);
+            bfly2(e[0], e[1], w1);
+            bfly2(e[2], e[3], w1);
+#pragma unroll
+            for (int r = 0; r < 4; r++) U[pad_e(base + 64 * r)] = e[r];
+        }
+    }
+    __syncthreads();
+
+    // stages l = 2, 3, 4 (:2062-2083): point sets {64 g + j' + 8 e}
+    {
+        const int g = lane >> 3, jp = lane & 7;
+        const int base = 64 * g + jp;
+        f2 e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = U[pad_e(base + 8 * k)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) bfly2(e[k], e[k + 4], A2p[16 * (jp + 8 * k)]);     // A[b << 5]
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const f2 w = A2p[32 * (jp + 8 * k)];                                          // A[b << 6]
+            bfly2(e[k], e[k + 2], w);
+            bfly2(e[k + 4], e[k + 6], w);
+        }
+        {
+            const f2 w = A2p[64 * jp];                                                    // A[b << 7]
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) bfly2(e[k], e[k + 1], w);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) U[pad_e(base + 8 * k)] = e[k];
+    }
+    __syncthreads();
+
+    // last three stages, the reference's fused loop (:1898-1939) on points 8 it .. 8 it + 7;
+    // zz[i] = z[-i]
+    {
+        const float A2 = A[n >> 3];
+        const int b9 = 9 * lane;                    // pad_e(8 lane)
+        float zz[16];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const f2 t = U[b9 + k];
+            zz[2 * k] = t.x;
+            zz[2 * k + 1] = t.y;
+        }
+        float k00, k11, l00, l11;
+        k00 = zz[0] - zz[8];
+        k11 = zz[1] - zz[9];
+        l00 = zz[2] - zz[10];
+        l11 = zz[3] - zz[11];
+        zz[0] = zz[0] + zz[8];
+        zz[1] = zz[1] + zz[9];
+        zz[2] = zz[2] + zz[10];
+        zz[3] = zz[3] + zz[11];
+        zz[8] = k00;
+        zz[9] = k11;
+        zz[10] = (l00 + l11) * A2;
+        zz[11] = (l11 - l00) * A2;
+
+        k00 = zz[4] - zz[12];
+        k11 = zz[5] - zz[13];
+        l00 = zz[6] - zz[14];
+        l11 = zz[7] - zz[15];
+        zz[4] = zz[4] + zz[12];
+        zz[5] = zz[5] + zz[13];
+        zz[6] = zz[6] + zz[14];
+        zz[7] = zz[7] + zz[15];
+        zz[12] = k11;
+        zz[13] = -k00;
+        zz[14] = (l11 - l00) * A2;
+        zz[15] = (l00 + l11) * -A2;
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {           // iter_54 (:1866-1896) on z and z-8
+            const float i00 = zz[h + 0] - zz[h + 4];
+            const float y0 = zz[h + 0] + zz[h + 4];
+            const float y2 = zz[h + 2] + zz[h + 6];
+            const float i22 = zz[h + 2] - zz[h + 6];
+            zz[h + 0] = y0 + y2;
+            zz[h + 2] = y0 - y2;
+            const float i33 = zz[h + 3] - zz[h + 7];
+            zz[h + 4] = i00 + i33;
+            zz[h + 6] = i00 - i33;
+            const float i11 = zz[h + 1] - zz[h + 5];
+            const float y1 = zz[h + 1] + zz[h + 5];
+            const float y3 = zz[h + 3] + zz[h + 7];
+            zz[h + 1] = y1 + y3;
+            zz[h + 3] = y1 - y3;
+            zz[h + 5] = i11 - i22;
+            zz[h + 7] = i11 + i22;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) U[b9 + k] = f2{ zz[2 * k], zz[2 * k + 1] };
+    }
+    __syncthreads();
+
+    // steps 4-6 (:2096-2124): entry e takes points 511-2*brev8(e) and 510-2*brev8(e)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int e = lane + 64 * r;
+        const int br = (int)(__brev((unsigned)e) >> 24);
+        const f2 pa = U[pad_e(n4 - 1 - 2 * br)];
+        const f2 pb = U[pad_e(n4 - 2 - 2 * br)];
+        V[n4 - 1 - e] = pa;                         // (v[n2-2-2e], v[n2-1-2e]) = (u[k4+1], u[k4])
+        V[n8 - 1 - e] = pb;                         // (v[n4-2-2e], v[n4-1-2e]) = (u[k4+3], u[k4+2])
+    }
+    __syncthreads();
+
+    // step 7 (:2133-2175) fused with step 8 (:2187-2238).  Item s works on pairs v2[s] and
+    // v2[n4-1-s]; the results feed step-8 items x = n4-1-s and x = s.  All of buf2 is read
+    // before the first output is written (the output aliases it).
+    {
+        const f2 *const C2 = (const f2 *)C;
+        const f2 *const B2 = (const f2 *)B;
+        f2 dn[4], en[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int sidx = lane + 64 * r;
+            dn[r] = V[sidx];
+            en[r] = V[n4 - 1 - sidx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int sidx = lane + 64 * r;
+            const f2 cc = C2[sidx];
+            const float a02 = dn[r].x - en[r].x;
+            const float a11 = dn[r].y + en[r].y;
+            const float b0 = cc.y * a02 + cc.x * a11;
+            const float b1 = cc.y * a11 - cc.x * a02;
+            const float b2 = dn[r].x + en[r].x;
+            const float b3 = dn[r].y - en[r].y;
+            const f2 dnew = f2{ b2 + b0, b3 + b1 };
+            const f2 enew = f2{ b2 - b0, b1 - b3 };
+            // step 8 for x = sidx (pair v2[n4-1-x] = enew) and x = n4-1-sidx (pair v2[sidx] = dnew)
+            {
+                const int x = sidx;
+                const f2 bb = B2[n4 - 1 - x];
+                const float pa = enew.x * bb.y - enew.y * bb.x;
+                const float pb = -enew.x * bb.x - enew.y * bb.y;
+                smem[x] = pa;
+                smem[n2 - 1 - x] = -pa;
+                smem[n2 + x] = pb;
+                smem[n - 1 - x] = pb;
+            }
+            {
+                const int x = n4 - 1 - sidx;
+                const f2 bb = B2[sidx];
+                const float pa = dnew.x * bb.y - dnew.y * bb.x;
+                const float pb = -dnew.x * bb.x - dnew.y * bb.y;
+                smem[x] = pa;
+                smem[n2 - 1 - x] = -pa;
+                smem[n2 + x] = pb;
+                smem[n - 1 - x] = pb;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64, 2) void vorbis_wave_kernel(
+    const VorbisSeg *__restrict__ segs, const VorbisStream *__restrict__ streams,
+    const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
+    const uint64_t *__restrict__ out_off, const float *__restrict__ tables,
+    const float *__restrict__ spec, float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float smem[kWaveLds];
+    const int lane = threadIdx.x;
+    const VorbisSeg seg = segs[blockIdx.x];
+    const VorbisStream st = streams[seg.stream];
+    const int C = (int)st.nch;                       // 1 or 2 on this path
+    const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
+
+    float prev[2][16];                               // previous_window, 1024 values per channel
+#pragma unroll
+    for (int r = 0; r < 16; r++) prev[0][r] = prev[1][r] = 0.0f;
+    int previous_length = 0;
+    const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
+    const int p_end = (int)(seg.p0 + seg.count);
+
+    // spectrum of the first transform
+    float4 xin[4];
+    {
+        const uint64_t gp = st.pkt_base + (uint64_t)p_first;
+        if (pflags[gp] & AFG_VORBIS_LONG) load_spectrum(xin, spec + spec_off[gp]);
+    }
+
+    for (int p = p_first; p < p_end; p++) {
+        const uint64_t gp = st.pkt_base + (uint64_t)p;
+        const unsigned fl = pflags[gp];
+        int n, left, right, right_end;
+        window_bounds(bs0, bs1, fl, n, left, right, right_end);
+        const int n2 = n >> 1;
+        const int which = (fl & AFG_VORBIS_LONG) ? 1 : 0;
+        const float *T = tables + st.tab[which];
+        const float *A = T, *B = T + n2, *Ct = T + n;
+        const float *src = spec + spec_off[gp];
+        const bool emit = (p >= (int)seg.p0) && previous_length > 0;
+        const int pn = previous_length;
+        const float *w = tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);   // get_window(pn), :2245-2251
+        const int nout = right - left;
+        float *o = out + out_off[gp];
+        float o0[24];
+
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (c < C) {
+                if (which) {
+                    float4 xcur[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) xcur[r] = xin[r];
+                    // next transform's spectrum: other channel of this packet, or channel 0 of the next
+                    {
+                        const bool more_here = (c + 1 < C);
+                        const int pnx = more_here ? p : p + 1;
+                        if (pnx < p_end) {
+                            const uint64_t gq = st.pkt_base + (uint64_t)pnx;
+                            if (pflags[gq] & AFG_VORBIS_LONG)
+                                load_spectrum(xin, spec + spec_off[gq] + (more_here ? (c + 1) * (kNL / 2) : 0));
+                        }
+                    }
+                    imdct_2048_wave(xcur, smem, A, B, Ct);                           // :2526-2527
+                } else {
+                    for (int k = lane; k < n2; k += 64) smem[k] = src[c * n2 + k];
+                    __syncthreads();
+                    inverse_mdct_lds<64>(smem, smem + n, n, 31 - __clz(n), A, B, Ct);
+                    // the following transform (if long) was not prefetched while this one ran
+                    if (c + 1 == C && p + 1 < p_end) {
+                        const uint64_t gq = st.pkt_base + (uint64_t)(p + 1);
+                        if (pflags[gq] & AFG_VORBIS_LONG) load_spectrum(xin, spec + spec_off[gq]);
+                    }
+                }
+                // vorbis_finish_frame (:2606-2657) for this channel
+#pragma unroll
+                for (int r = 0; r < 24; r++) {                  // right_start - left_start < 1536 for n = 2048
+                    const int jj = lane + 64 * r;
+                    float vcur = 0.0f;
+                    if (emit && jj < nout) {
+                        vcur = smem[left + jj];
+                        if (r < 16 && jj < pn) vcur = vcur * w[jj] + prev[c][r < 16 ? r : 0] * w[pn - 1 - jj];   // :2624-2626
+                    }
+                    if (c == 0) o0[r] = vcur;
+                    if (emit && jj < nout) {
+                        if (C == 1) o[jj] = vcur;
+                        else if (c == 1) *(f2 *)(o + 2 * jj) = f2{ o0[r], vcur };         // :3927-3952
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int k = lane + 64 * r;
+                    if (k < right_end - right) prev[c][r] = smem[right + k];              // :2641-2643
+                }
+                __syncthreads();
+            }
+        }
+        previous_length = right_end - right;
     }
 }
 
@@ -377,7 +743,8 @@ struct afg_vorbis_plan {
     uint64_t out_floats = 0;
     size_t lds_bytes = 0;
     std::vector<uint64_t> h_spec_off, h_out_off;
-    afg::DeviceArray d_segs, d_streams, d_pflags, d_spec_off, d_out_off, d_tables;
+    uint32_t n_wave_segs = 0;      // segments of streams on the wave-level fast path
+    afg::DeviceArray d_segs, d_wave_segs, d_streams, d_pflags, d_spec_off, d_out_off, d_tables;
 };
 
 extern "C" {
@@ -396,7 +763,7 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
     if (seg_packets == 0) seg_packets = 16;
 
     std::vector<VorbisStream> streams(n_streams);
-    std::vector<VorbisSeg> segs;
+    std::vector<VorbisSeg> segs, wave_segs;
     std::vector<float> tables;
     std::map<int, uint32_t> tab_of;
     auto p = new (std::nothrow) afg_vorbis_plan;
@@ -437,8 +804,9 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
         st.bs[1] = bs[1];
         st.tab[0] = tab_of[bs[0]];
         st.tab[1] = tab_of[bs[1]];
+        const bool fast = (bs[1] == kNL) && (bs[0] <= kNL / 2) && channels[s] <= 2;
         const size_t need = sizeof(float) * ((size_t)channels[s] * bs[1] + bs[1] / 2 + (size_t)channels[s] * bs[1] / 2);
-        lds = need > lds ? need : lds;
+        if (!fast) lds = need > lds ? need : lds;
 
         int prev_len = 0;
         for (uint32_t q = 0; q < packets[s]; q++, pkt++) {
@@ -463,7 +831,7 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
         }
         for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
             uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
-            segs.push_back(VorbisSeg{ s, p0, cnt, 0 });
+            (fast ? wave_segs : segs).push_back(VorbisSeg{ s, p0, cnt, 0 });
         }
     }
     if (lds > 160 * 1024) {
@@ -473,11 +841,13 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
     }
     p->n_streams = n_streams;
     p->n_segs = (uint32_t)segs.size();
+    p->n_wave_segs = (uint32_t)wave_segs.size();
     p->n_packets = pkt;
     p->spec_floats = so;
     p->out_floats = oo;
     p->lds_bytes = lds;
     int rc = p->d_segs.upload(segs.data(), segs.size() * sizeof(VorbisSeg));
+    if (!rc) rc = p->d_wave_segs.upload(wave_segs.data(), wave_segs.size() * sizeof(VorbisSeg));
     if (!rc) rc = p->d_streams.upload(streams.data(), streams.size() * sizeof(VorbisStream));
     if (!rc) rc = p->d_pflags.upload(pflags, (size_t)pkt);
     if (!rc) rc = p->d_spec_off.upload(p->h_spec_off.data(), p->h_spec_off.size() * sizeof(uint64_t));
@@ -503,6 +873,7 @@ void afg_vorbis_plan_destroy(afg_vorbis_plan *plan)
 {
     if (!plan) return;
     plan->d_segs.release();
+    plan->d_wave_segs.release();
     plan->d_streams.release();
     plan->d_pflags.release();
     plan->d_spec_off.release();
@@ -526,16 +897,23 @@ int afg_vorbis_plan_offsets(const afg_vorbis_plan *plan, uint64_t *spec_off, uin
 int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, float *d_out, void *hip_stream)
 {
     if (!plan) return AFG_ERR_INVALID;
-    if (plan->n_segs == 0) return AFG_OK;
+    if (plan->n_segs == 0 && plan->n_wave_segs == 0) return AFG_OK;
     if (!d_spec || (!d_out && plan->out_floats)) {
         afg::set_error("afg_vorbis_transform_hip: NULL device pointer");
         return AFG_ERR_INVALID;
     }
-    hipLaunchKernelGGL(vorbis_transform_kernel, dim3(plan->n_segs), dim3(kThreads), plan->lds_bytes,
-                       (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_segs.ptr,
-                       (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
-                       (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
-                       (const float *)plan->d_tables.ptr, d_spec, d_out);
+    if (plan->n_wave_segs)
+        hipLaunchKernelGGL(vorbis_wave_kernel, dim3(plan->n_wave_segs), dim3(64), 0,
+                           (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_wave_segs.ptr,
+                           (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
+                           (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
+                           (const float *)plan->d_tables.ptr, d_spec, d_out);
+    if (plan->n_segs)
+        hipLaunchKernelGGL(vorbis_transform_kernel, dim3(plan->n_segs), dim3(kThreads), plan->lds_bytes,
+                           (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_segs.ptr,
+                           (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
+                           (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
+                           (const float *)plan->d_tables.ptr, d_spec, d_out);
     AFG_HIP_CHECK(hipGetLastError());
     return AFG_OK;
 }
