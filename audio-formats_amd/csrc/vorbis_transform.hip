@@ -77,7 +77,7 @@ __device__ __forceinline__ void iter_54(float *z)
 // In-place inverse MDCT of one channel held in LDS; buffer[0..n/2) spectrum in,
 // buffer[0..n) samples out; buf2 = n/2 floats of scratch.  stb_vorbis2.d:1941-2242.
 template <int kThreads>
-__device__ void inverse_mdct_lds(float *buffer, float *buf2, int n, int ld,
+__device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float *buf2, int n, int ld,
                                  const float *__restrict__ A, const float *__restrict__ B,
                                  const float *__restrict__ C)
 {
@@ -355,6 +355,17 @@ struct alignas(8) f2 { float x, y; };
 
 __device__ __forceinline__ int pad_e(int m) { return m + (m >> 3); }
 
+// Opaque copy of a (wave-uniform) table pointer.  Without it the compiler hoists the 64-bit
+// address of every table access out of the packet loop (two VGPRs each, ~120 in total);
+// laundering the base per pass keeps addresses as SGPR base + 32-bit lane offset, live
+// only inside the pass.
+template <typename T>
+__device__ __forceinline__ const T *fresh(const T *p)
+{
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 __device__ __forceinline__ void bfly2(f2 &p, f2 &q, f2 c)
 {
     const float d0 = p.x - q.x;
@@ -379,14 +390,13 @@ __device__ __forceinline__ void load_spectrum(float4 (&x)[4], const float *__res
 
 // inverse_mdct for n = 2048 (stb_vorbis2.d:1941-2242); result in smem[0..2048)
 __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *smem,
-                                                const float *__restrict__ A, const float *__restrict__ B,
-                                                const float *__restrict__ C)
+                                                const float *A, const float *B, const float *C)
 {
     constexpr int n = kNL, n2 = n / 2, n4 = n / 4, n8 = n / 8;
     const int lane = threadIdx.x;
     f2 *const U = (f2 *)smem;
     f2 *const V = (f2 *)(smem + kUFloats);
-    const f2 *const A2p = (const f2 *)A;
+    const f2 *A2p = fresh((const f2 *)A);
 
     // step 0 (:1972-1994): item q and the mirrored item n8-1-q share one 16-byte load
 #pragma unroll
@@ -407,6 +417,7 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     __syncthreads();
 
     // step 2 (:2006-2040): half-iteration `it` makes points n4-1-it and n8-1-it
+    A2p = fresh(A2p);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int it = lane + 64 * r;
@@ -427,6 +438,7 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 
     // stages l = 0, 1 (:2053-2060): point sets {base + j + 64 r}, lane j, both halves
     {
+        A2p = fresh(A2p);
         const int j = lane;
         const f2 w00 = A2p[4 * j];                  // A[(j) << 3]
         const f2 w01 = A2p[4 * (j + 64)];           // A[(j+64) << 3]
@@ -449,6 +461,7 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 
     // stages l = 2, 3, 4 (:2062-2083): point sets {64 g + j' + 8 e}
     {
+        A2p = fresh(A2p);
         const int g = lane >> 3, jp = lane & 7;
         const int base = 64 * g + jp;
         f2 e[8];
@@ -475,7 +488,7 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     // last three stages, the reference's fused loop (:1898-1939) on points 8 it .. 8 it + 7;
     // zz[i] = z[-i]
     {
-        const float A2 = A[n >> 3];
+        const float A2 = fresh(A)[n >> 3];
         const int b9 = 9 * lane;                    // pad_e(8 lane)
         float zz[16];
 #pragma unroll
@@ -550,8 +563,8 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     // v2[n4-1-s]; the results feed step-8 items x = n4-1-s and x = s.  All of buf2 is read
     // before the first output is written (the output aliases it).
     {
-        const f2 *const C2 = (const f2 *)C;
-        const f2 *const B2 = (const f2 *)B;
+        const f2 *const C2 = fresh((const f2 *)C);
+        const f2 *const B2 = fresh((const f2 *)B);
         f2 dn[4], en[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -598,22 +611,20 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64, 2) void vorbis_wave_kernel(
-    const VorbisSeg *__restrict__ segs, const VorbisStream *__restrict__ streams,
+#ifndef AFG_VORBIS_MIN_WAVES
+#define AFG_VORBIS_MIN_WAVES 2
+#endif
+template <int C>                                     // channels: 1 or 2 on this path
+__device__ __forceinline__ void vorbis_wave_body(
+    float *smem, const VorbisSeg &seg, const VorbisStream &st,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
-    const uint64_t *__restrict__ out_off, const float *__restrict__ tables,
+    const uint64_t *__restrict__ out_off, const float *tables,
     const float *__restrict__ spec, float *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) float smem[kWaveLds];
     const int lane = threadIdx.x;
-    const VorbisSeg seg = segs[blockIdx.x];
-    const VorbisStream st = streams[seg.stream];
-    const int C = (int)st.nch;                       // 1 or 2 on this path
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
 
-    float prev[2][16];                               // previous_window, 1024 values per channel
-#pragma unroll
-    for (int r = 0; r < 16; r++) prev[0][r] = prev[1][r] = 0.0f;
+    float *const prevw = smem + kWaveLds;             // previous_window: C x 1024 floats behind the transform area
     int previous_length = 0;
     const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
     const int p_end = (int)(seg.p0 + seg.count);
@@ -640,11 +651,10 @@ __global__ __launch_bounds__(64, 2) void vorbis_wave_kernel(
         const float *w = tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);   // get_window(pn), :2245-2251
         const int nout = right - left;
         float *o = out + out_off[gp];
-        float o0[24];
 
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            if (c < C) {
+        for (int c = 0; c < C; c++) {
+            {
                 if (which) {
                     float4 xcur[4];
 #pragma unroll
@@ -670,31 +680,36 @@ __global__ __launch_bounds__(64, 2) void vorbis_wave_kernel(
                         if (pflags[gq] & AFG_VORBIS_LONG) load_spectrum(xin, spec + spec_off[gq]);
                     }
                 }
-                // vorbis_finish_frame (:2606-2657) for this channel
-#pragma unroll
-                for (int r = 0; r < 24; r++) {                  // right_start - left_start < 1536 for n = 2048
-                    const int jj = lane + 64 * r;
-                    float vcur = 0.0f;
-                    if (emit && jj < nout) {
-                        vcur = smem[left + jj];
-                        if (r < 16 && jj < pn) vcur = vcur * w[jj] + prev[c][r < 16 ? r : 0] * w[pn - 1 - jj];   // :2624-2626
-                    }
-                    if (c == 0) o0[r] = vcur;
-                    if (emit && jj < nout) {
-                        if (C == 1) o[jj] = vcur;
-                        else if (c == 1) *(f2 *)(o + 2 * jj) = f2{ o0[r], vcur };         // :3927-3952
-                    }
+                // vorbis_finish_frame (:2606-2657) + interleave (:3927-3952) for this channel: each
+                // channel stores its own 4-byte column of the interleaved frames (merged in L2)
+                if (emit) {
+                    const float *wt = fresh(w);
+                    const float *pw = prevw + c * 1024;
+                    const int nwin = pn < nout ? pn : nout;
+                    for (int jj = lane; jj < nwin; jj += 64)
+                        o[jj * C + c] = smem[left + jj] * wt[jj] + pw[jj] * wt[pn - 1 - jj];   // :2624-2626
+                    for (int jj = nwin + lane; jj < nout; jj += 64) o[jj * C + c] = smem[left + jj];
                 }
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int k = lane + 64 * r;
-                    if (k < right_end - right) prev[c][r] = smem[right + k];              // :2641-2643
-                }
+                for (int k = lane; k < right_end - right; k += 64)
+                    prevw[c * 1024 + k] = smem[right + k];                                     // :2641-2643
                 __syncthreads();
             }
         }
         previous_length = right_end - right;
     }
+}
+
+__global__ __launch_bounds__(64, AFG_VORBIS_MIN_WAVES) void vorbis_wave_kernel(
+    const VorbisSeg *__restrict__ segs, const VorbisStream *__restrict__ streams,
+    const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
+    const uint64_t *__restrict__ out_off, const float *tables,
+    const float *__restrict__ spec, float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float smem[kWaveLds + 2 * 1024];
+    const VorbisSeg seg = segs[blockIdx.x];
+    const VorbisStream st = streams[seg.stream];
+    if (st.nch == 1) vorbis_wave_body<1>(smem, seg, st, pflags, spec_off, out_off, tables, spec, out);
+    else vorbis_wave_body<2>(smem, seg, st, pflags, spec_off, out_off, tables, spec, out);
 }
 
 int ilog_host(int n)       // stb_vorbis2.d:634-650
