@@ -380,7 +380,12 @@ void afgo_mp3_synth_granule(float *qmf_state, float *grbuf, int nbands, int nch,
 /* ---- one granule: L3_decode tail (:1215-1229) + synth (:1553) ------------- */
 void afgo_mp3_granule(afgo_mp3_state *st, float *coef, const uint32_t *flags, int nch, float *pcm)
 {
+    /* The reference's line buffer is an uninitialised stack local (mp3dec_scratch_t, minimp3.d:1497);
+     * a few of its slots (lanes 2,3 of the last row, and odd lanes for mono) are copied into
+     * qmf_state before ever being written and are overwritten before ever being read.  Zeroed here
+     * so that the saved state is deterministic. */
     float lins[(18 + 15) * 64];
+    memset(lins, 0, sizeof(lins));
     for (int c = 0; c < nch; c++) {
         unsigned block_type = flags[c] & 3u;
         unsigned n_long = (flags[c] >> 8) & 0xffu;

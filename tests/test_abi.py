@@ -1,0 +1,63 @@
+"""The C-ABI library loads and exports every symbol include/afg.h declares (no compute calls:
+this runs without a GPU).  Also checks that the product never links or loads the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "afg.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(afg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import afgpu
+    lib = afgpu.lib()
+    names = declared_symbols()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(afgpu.ABI_SYMBOLS) == names          # the Python binding knows all of them
+    assert lib.afg_abi_version() == 1
+    assert lib.afg_status_string(0) == b"ok"
+    assert lib.afg_status_string(-2) == b"no usable gfx950 device"
+
+
+def test_record_layouts_match_the_header():
+    import afgpu
+    assert afgpu.FLAC_SUBFRAME_DTYPE.itemsize == 68 and afgpu.FLAC_FRAME_DTYPE.itemsize == 32
+    assert afgpu.FLAC_FRAME_DTYPE.fields["sf_index"][1] == 20 and afgpu.FLAC_FRAME_DTYPE.fields["channels"][1] == 24
+    assert int(afgpu.mp3_flags(3, 2, 1)) == 3 | (2 << 8) | (2 << 16)
+
+
+def test_fails_loudly_without_a_device():
+    import torch
+    import afgpu
+    if torch.cuda.is_available():
+        return
+    try:
+        afgpu.Mp3Plan([4], [2])
+    except afgpu.AfgError as e:
+        assert "no CPU fallback" in str(e) or "no usable gfx950 device" in str(e)
+    else:
+        raise AssertionError("plan creation must fail without a GPU: there is no CPU path")
+
+
+def test_product_does_not_depend_on_the_oracle():
+    lib = os.path.join(ROOT, "audio-formats_amd", "lib", "libafg_hip.so")
+    needed = subprocess.check_output(["readelf", "-d", lib], text=True)
+    assert "oracle" not in needed
+    syms = subprocess.check_output(["nm", "-D", lib], text=True)
+    assert "afgo_" not in syms
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "audio-formats_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oraclelib" not in text and "liboracle" not in text, f

@@ -1,0 +1,84 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py): the oracle must keep
+reproducing them on CPU; on the GPU box the HIP path must reproduce them through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(HERE, name))
+
+
+def same_bits(a, b):
+    return a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_oracle_reproduces_mp3_fixture():
+    g = load("mp3_transform.npz")
+    assert same_bits(oraclelib.mp3_transform(g["granules"], g["channels"], g["coef"], g["flags"]), g["pcm"])
+
+
+def test_oracle_reproduces_vorbis_fixture():
+    g = load("vorbis_transform.npz")
+    out = oraclelib.vorbis_transform(g["packets"], g["channels"], g["bs0"], g["bs1"], g["pflags"],
+                                     g["spec_off"], g["out_off"], g["spec"], g["out"].size)
+    assert same_bits(out, g["out"])
+
+
+def test_oracle_reproduces_flac_fixture():
+    g = load("flac_restore.npz")
+    frames = g["frames"].view(oraclelib.FLAC_FRAME_DTYPE)
+    sub = g["subframes"].view(oraclelib.FLAC_SUBFRAME_DTYPE)
+    oi, of = oraclelib.flac_transform(frames, sub, g["res"], g["out_i32"].size, want_float=True)
+    assert (oi == g["out_i32"]).all() and same_bits(of, g["out_f32"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_mp3_fixture(gpu):
+    import torch
+    from afgpu import Mp3Plan
+    g = load("mp3_transform.npz")
+    plan = Mp3Plan(g["granules"], g["channels"], 4)
+    d_pcm = torch.zeros(g["pcm"].size, dtype=torch.float32, device=gpu)
+    plan.transform(torch.from_numpy(g["coef"]).to(gpu), torch.from_numpy(g["flags"].view(np.int32)).to(gpu), d_pcm)
+    torch.cuda.synchronize()
+    got = d_pcm.cpu().numpy()
+    rms = float(np.sqrt(np.mean((got.astype(np.float64) - g["pcm"]) ** 2)))
+    assert rms <= 1e-5                      # north_star tolerance (float)
+    assert same_bits(got, g["pcm"])         # and in fact bit-exact (library built with -ffp-contract=off)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_vorbis_fixture(gpu):
+    import torch
+    from afgpu import VorbisPlan
+    g = load("vorbis_transform.npz")
+    plan = VorbisPlan(g["packets"], g["channels"], g["bs0"], g["bs1"], g["pflags"], 3)
+    so, oo = plan.offsets()
+    assert (so == g["spec_off"]).all() and (oo == g["out_off"]).all()
+    d_out = torch.zeros(g["out"].size, dtype=torch.float32, device=gpu)
+    plan.transform(torch.from_numpy(g["spec"]).to(gpu), d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert float(np.sqrt(np.mean((got.astype(np.float64) - g["out"]) ** 2))) <= 1e-5
+    assert same_bits(got, g["out"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_flac_fixture(gpu):
+    import torch
+    import afgpu
+    g = load("flac_restore.npz")
+    n = g["frames"].size // 32
+    d_i = torch.zeros(g["out_i32"].size, dtype=torch.int32, device=gpu)
+    d_f = torch.zeros(g["out_i32"].size, dtype=torch.float32, device=gpu)
+    afgpu.flac_transform(n, torch.from_numpy(g["frames"]).to(gpu), torch.from_numpy(g["subframes"]).to(gpu),
+                         torch.from_numpy(g["res"]).to(gpu), d_i, d_f)
+    torch.cuda.synchronize()
+    assert (d_i.cpu().numpy() == g["out_i32"]).all()                   # bit-exact int32
+    assert same_bits(d_f.cpu().numpy(), g["out_f32"])
