@@ -1,0 +1,96 @@
+/// afgpu.d -- D binding of the MI355X transform-stage library (include/afg.h, ABI version 1).
+///
+/// Source only: no D compiler exists in the build image, so this file is exercised through the
+/// same C symbols from C/Python harnesses instead.  Every prototype carries `nothrow @nogc`, which is
+/// what makes it callable from audio-formats' `nothrow @nogc` decoder modules
+/// (source/audioformats/minimp3.d:16-17, stb_vorbis2.d:110-111, drflac.d:21).
+module audioformats.afgpu;
+
+nothrow @nogc extern (C):
+
+enum AFG_ABI_VERSION = 1;
+
+enum afg_status : int
+{
+    AFG_OK = 0,
+    AFG_ERR_INVALID = -1,
+    AFG_ERR_NO_DEVICE = -2,
+    AFG_ERR_HIP = -3,
+    AFG_ERR_OOM = -4,
+    AFG_ERR_UNSUPPORTED = -5,
+}
+
+int afg_abi_version();
+const(char)* afg_status_string(int status);
+const(char)* afg_last_error();
+int afg_device_count();
+int afg_device_name(int device, char* buf, size_t buflen);
+
+// ---- MP3 (replaces minimp3.d:1226-1228 + :1553) ------------------------------------------
+struct afg_mp3_plan;
+enum AFG_MP3_STATE_FLOATS = 1536;
+
+uint AFG_MP3_FLAGS(uint block_type, uint n_long_bands, int aa_bands) pure
+{
+    return block_type | (n_long_bands << 8) | (cast(uint)(aa_bands + 1) << 16);
+}
+
+int afg_mp3_plan_create(afg_mp3_plan** plan, uint n_streams, const(uint)* granules,
+                        const(ubyte)* channels, uint seg_granules);
+void afg_mp3_plan_destroy(afg_mp3_plan* plan);
+ulong afg_mp3_plan_blocks(const(afg_mp3_plan)* plan);
+uint afg_mp3_plan_segments(const(afg_mp3_plan)* plan);
+int afg_mp3_transform_hip(const(afg_mp3_plan)* plan, const(float)* d_coef, const(uint)* d_flags,
+                          float* d_pcm, float* d_state, void* hip_stream);
+
+// ---- Vorbis (replaces stb_vorbis2.d:2526-2527 + :2606-2657 + :3927-3952) ---------------------
+struct afg_vorbis_plan;
+enum AFG_VORBIS_LONG = 1u, AFG_VORBIS_PREV = 2u, AFG_VORBIS_NEXT = 4u;
+
+int afg_vorbis_plan_create(afg_vorbis_plan** plan, uint n_streams, const(uint)* packets,
+                           const(ubyte)* channels, const(ushort)* blocksize0,
+                           const(ushort)* blocksize1, const(ubyte)* pflags, uint seg_packets);
+void afg_vorbis_plan_destroy(afg_vorbis_plan* plan);
+ulong afg_vorbis_plan_packets(const(afg_vorbis_plan)* plan);
+ulong afg_vorbis_plan_spec_floats(const(afg_vorbis_plan)* plan);
+ulong afg_vorbis_plan_out_floats(const(afg_vorbis_plan)* plan);
+int afg_vorbis_plan_offsets(const(afg_vorbis_plan)* plan, ulong* spec_off, ulong* out_off);
+int afg_vorbis_transform_hip(const(afg_vorbis_plan)* plan, const(float)* d_spec, float* d_out,
+                             void* hip_stream);
+
+// ---- FLAC (replaces drflac.d:1235 prediction half + :2885-2941, optionally stream.d:505-511) --
+enum AFG_FLAC_INDEPENDENT = 0, AFG_FLAC_LEFT_SIDE = 8, AFG_FLAC_RIGHT_SIDE = 9, AFG_FLAC_MID_SIDE = 10;
+
+struct afg_flac_subframe
+{
+    short[32] coef;
+    ubyte order;
+    ubyte shift;
+    ubyte wasted;
+    ubyte use64;
+}
+static assert(afg_flac_subframe.sizeof == 68);
+
+struct afg_flac_frame
+{
+    ulong in_off;
+    ulong out_off;
+    uint block_size;
+    uint sf_index;
+    ubyte channels;
+    ubyte assignment;
+    ubyte bps;
+    ubyte[5] pad;
+}
+static assert(afg_flac_frame.sizeof == 32);
+
+int afg_flac_transform_hip(ulong n_frames, const(afg_flac_frame)* d_frames,
+                           const(afg_flac_subframe)* d_subframes, const(int)* d_res,
+                           int* d_out_i32, float* d_out_f32, void* hip_stream);
+
+// ---- utilities ----------------------------------------------------------------------------------
+int afg_device_malloc(void** d_ptr, size_t bytes);
+int afg_device_free(void* d_ptr);
+int afg_memcpy_h2d(void* d_dst, const(void)* src, size_t bytes, void* hip_stream);
+int afg_memcpy_d2h(void* dst, const(void)* d_src, size_t bytes, void* hip_stream);
+int afg_stream_synchronize(void* hip_stream);
