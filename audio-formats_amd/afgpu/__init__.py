@@ -26,6 +26,9 @@ FLAC_FRAME_DTYPE = np.dtype([("in_off", np.uint64), ("out_off", np.uint64), ("bl
                              ("sf_index", np.uint32), ("channels", np.uint8), ("assignment", np.uint8),
                              ("bps", np.uint8), ("pad", np.uint8, (5,))], align=True)
 assert FLAC_SUBFRAME_DTYPE.itemsize == 68 and FLAC_FRAME_DTYPE.itemsize == 32
+QOA_FRAME_DTYPE = np.dtype([("byte_off", np.uint64), ("out_off", np.uint64), ("samples", np.uint16),
+                            ("channels", np.uint8), ("pad", np.uint8, (5,))], align=True)
+assert QOA_FRAME_DTYPE.itemsize == 24
 
 # every symbol include/afg.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -36,6 +39,7 @@ ABI_SYMBOLS = [
     "afg_vorbis_plan_spec_floats", "afg_vorbis_plan_out_floats", "afg_vorbis_plan_offsets",
     "afg_vorbis_transform_hip",
     "afg_flac_transform_hip",
+    "afg_qoa_transform_hip",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
 ]
 
@@ -89,6 +93,7 @@ def lib():
     L.afg_vorbis_plan_offsets.argtypes = [vp, vp, vp]
     L.afg_vorbis_transform_hip.argtypes = [vp, vp, vp, vp]
     L.afg_flac_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
+    L.afg_qoa_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp]
     L.afg_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.afg_device_free.argtypes = [vp]
     L.afg_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
@@ -199,6 +204,35 @@ def flac_transform(n_frames, d_frames, d_subframes, d_res, d_out_i32=None, d_out
     FLAC_FRAME_DTYPE / FLAC_SUBFRAME_DTYPE arrays."""
     check(lib().afg_flac_transform_hip(int(n_frames), _ptr(d_frames), _ptr(d_subframes), _ptr(d_res),
                                        _ptr(d_out_i32), _ptr(d_out_f32), _stream(stream)))
+
+
+def qoa_frames(file_bytes, out_base=0, byte_base=0):
+    """Locate the frames of one QOA file (host side of qoa.d:413-486: magic, frame headers).
+    Returns (QOA_FRAME_DTYPE array, channels, samplerate, total samples per channel)."""
+    b = np.frombuffer(file_bytes, np.uint8)
+    if b.size < 16 or bytes(b[:4]) != b"qoaf":
+        raise AfgError("not a QOA file")
+    total = int.from_bytes(bytes(b[4:8]), "big")
+    recs, pos, out = [], 8, out_base
+    channels = rate = 0
+    while pos + 8 <= b.size:
+        hdr = int.from_bytes(bytes(b[pos:pos + 8]), "big")
+        ch, sr, smp, fsz = (hdr >> 56) & 0xff, (hdr >> 32) & 0xffffff, (hdr >> 16) & 0xffff, hdr & 0xffff
+        if ch == 0 or fsz < 8 + 16 * ch or pos + fsz > b.size:
+            break
+        channels, rate = channels or ch, rate or sr
+        if ch != channels or sr != rate or smp * ch > ((fsz - 8 - 16 * ch) // 8) * 20:
+            break                                                    # qoa.d:478-486: inconsistent frame ends decoding
+        recs.append((byte_base + pos, out, smp, ch, [0] * 5))
+        out += smp * ch
+        pos += fsz
+    return np.array(recs, QOA_FRAME_DTYPE), channels, rate, total
+
+
+def qoa_transform(n_frames, d_frames, d_bytes, d_out_i16=None, d_out_f32=None, stream=None):
+    """Enqueue the QOA frame decode (afg_qoa_transform_hip)."""
+    check(lib().afg_qoa_transform_hip(int(n_frames), _ptr(d_frames), _ptr(d_bytes), _ptr(d_out_i16),
+                                      _ptr(d_out_f32), _stream(stream)))
 
 
 def device_count():

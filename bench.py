@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--seg", type=int, default=0, help="granules per wavefront segment (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the Vorbis (C3) / FLAC (C4) kernel timings")
     return ap.parse_args()
 
 
@@ -186,6 +187,21 @@ def main():
         except Exception:
             traffic = None
 
+    # ---- the other two codecs of the metric (BASELINE configs[2], configs[3]), kernel-level, N = 1 only ----
+    other = None
+    if world == 1 and not args.no_extra:
+        del coef, pcm, flags
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_codecs
+        other = {}
+        try:
+            other["vorbis_c3"] = bench_codecs.bench_vorbis(dev, 1024, 2584, 3, 1, 0)
+            torch.cuda.empty_cache()
+            other["flac_c4"] = bench_codecs.bench_flac(dev, 4096, 323, 3, 1, False)
+        except Exception as e:          # the headline line must still print
+            other["error"] = repr(e)
+
     line = {
         "metric": "decoded samples/sec (batched MP3+OGG+FLAC) at 1/2/4/8 MI355X vs CPU ref",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,6 +219,7 @@ def main():
                      "algorithmic_bytes_per_launch": int(alg_bytes)},
         "cpu_baseline": cpu,
         "parity": parity,
+        "other_workloads": other,
     }
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -153,6 +153,26 @@ int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
                            int32_t *d_out_i32, float *d_out_f32, void *hip_stream);
 
 /* ========================================================================== *
+ *  QOA frame decode (LMS predict / dequantise / clamp / update)
+ *  replaces the slice loop of qoa_decode_frame (qoa.d:489-530, qoa_lms_predict /
+ *  qoa_lms_update :231-254) and the float conversion of QOADecoder.readSamples
+ *  (qoa.d:831-838).  Input is the raw file bytes: the host only locates frames
+ *  (qoa.d:465-486) -- the LMS state and the 64-bit slices are read on the device.
+ * ========================================================================== */
+
+typedef struct afg_qoa_frame {
+    uint64_t byte_off;    /* offset of the 8-byte frame header in the byte plane (multiple of 8) */
+    uint64_t out_off;     /* index of the frame's first output value (interleaved) */
+    uint16_t samples;     /* samples per channel in this frame, <= 5120 (header field, qoa.d:476) */
+    uint8_t  channels;    /* 1..8 (header field) */
+    uint8_t  pad[5];
+} afg_qoa_frame;           /* 24 bytes */
+
+/* d_out_i16 (qoa_decode_frame's sample_data) and/or d_out_f32 (value * (1.0f/32767)) may be NULL. */
+int afg_qoa_transform_hip(uint64_t n_frames, const afg_qoa_frame *d_frames, const uint8_t *d_bytes,
+                          int16_t *d_out_i16, float *d_out_f32, void *hip_stream);
+
+/* ========================================================================== *
  *  Utilities used by the host mirror, the tests and bench.py
  * ========================================================================== */
 int afg_device_malloc(void **d_ptr, size_t bytes);

@@ -165,6 +165,24 @@ void afgo_flac_transform(uint64_t n_frames, const afgo_flac_frame *frames,
                          const afgo_flac_subframe *subframes, const int32_t *res,
                          int32_t *out_i32, float *out_f32);
 
+/* ------------------------------------------------------------------ QOA -- */
+
+/* Frame record (same layout as include/afg.h afg_qoa_frame). */
+typedef struct afgo_qoa_frame {
+    uint64_t byte_off;    /* offset of the 8-byte frame header in the byte plane */
+    uint64_t out_off;     /* index of the frame's first output value (frames * channels so far) */
+    uint16_t samples;     /* samples per channel in this frame (<= 5120), qoa.d:476 */
+    uint8_t  channels;    /* 1..8 */
+    uint8_t  pad[5];
+} afgo_qoa_frame;
+
+uint32_t afgo_qoa_decode_frame(const uint8_t *frame, size_t avail, int expect_channels,
+                               int16_t *sample_data);                        /* qoa.d:455-534 */
+void afgo_qoa_transform(uint64_t n_frames, const afgo_qoa_frame *frames, const uint8_t *bytes,
+                        int16_t *out_i16, float *out_f32);
+size_t afgo_qoa_encode(const int16_t *pcm, uint32_t samples, int channels, uint32_t samplerate,
+                       uint8_t *out, int16_t *recon);                        /* qoa.d:295-399 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,10 @@ FLAC_FRAME_DTYPE = np.dtype([("in_off", np.uint64), ("out_off", np.uint64), ("bl
                              ("bps", np.uint8), ("pad", np.uint8, (5,))], align=True)
 assert FLAC_SUBFRAME_DTYPE.itemsize == 68 and FLAC_FRAME_DTYPE.itemsize == 32
 
+QOA_FRAME_DTYPE = np.dtype([("byte_off", np.uint64), ("out_off", np.uint64), ("samples", np.uint16),
+                            ("channels", np.uint8), ("pad", np.uint8, (5,))], align=True)
+assert QOA_FRAME_DTYPE.itemsize == 24
+
 MP3_STATE_FLOATS = 2 * 288 + 960
 
 
@@ -84,6 +88,10 @@ def lib():
     L.afgo_flac_prediction_64.restype = C.c_int32
     L.afgo_flac_transform.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, i32p, i32p, C.c_void_p]
     L.afgo_flac_transform.restype = None
+    L.afgo_qoa_transform.argtypes = [C.c_uint64, C.c_void_p, u8p, C.c_void_p, C.c_void_p]
+    L.afgo_qoa_transform.restype = None
+    L.afgo_qoa_encode.argtypes = [i16p, C.c_uint32, C.c_int, C.c_uint32, u8p, C.c_void_p]
+    L.afgo_qoa_encode.restype = C.c_size_t
     _lib = L
     return L
 
@@ -176,3 +184,25 @@ def flac_transform(frames, subframes, res, out_total, want_float=False):
     lib().afgo_flac_transform(len(frames), frames.ctypes.data, subframes.ctypes.data, res, out,
                               outf.ctypes.data if want_float else None)
     return (out, outf) if want_float else out
+
+
+# ---------------------------------------------------------------- QOA ------
+def qoa_encode(pcm, samplerate=44100):
+    """pcm: int16 [frames, channels].  Returns (file bytes, the encoder's own reconstruction)."""
+    pcm = np.ascontiguousarray(pcm, np.int16)
+    n, ch = pcm.shape
+    nfr = (n + 5119) // 5120
+    out = np.zeros(8 + nfr * (8 + 16 * ch + 8 * 256 * ch) + 64, np.uint8)
+    recon = np.zeros_like(pcm)
+    size = lib().afgo_qoa_encode(pcm.reshape(-1), n, ch, samplerate, out, recon.ctypes.data)
+    return out[:size].copy(), recon
+
+
+def qoa_transform(frames, data, out_total, want_float=True):
+    frames = np.ascontiguousarray(frames, QOA_FRAME_DTYPE)
+    data = np.ascontiguousarray(data, np.uint8)
+    oi = np.zeros(int(out_total), np.int16)
+    of = np.zeros(int(out_total), np.float32) if want_float else None
+    lib().afgo_qoa_transform(len(frames), frames.ctypes.data, data, oi.ctypes.data,
+                             of.ctypes.data if want_float else None)
+    return (oi, of) if want_float else oi
