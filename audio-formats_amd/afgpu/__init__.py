@@ -26,6 +26,12 @@ FLAC_FRAME_DTYPE = np.dtype([("in_off", np.uint64), ("out_off", np.uint64), ("bl
                              ("sf_index", np.uint32), ("channels", np.uint8), ("assignment", np.uint8),
                              ("bps", np.uint8), ("pad", np.uint8, (5,))], align=True)
 assert FLAC_SUBFRAME_DTYPE.itemsize == 68 and FLAC_FRAME_DTYPE.itemsize == 32
+CELT_FRAME_DTYPE = np.dtype([("coef_off", np.uint64), ("out_off", np.uint64), ("out_stride", np.uint32),
+                             ("frame_size", np.uint16), ("blocks", np.uint8), ("pad", np.uint8),
+                             ("pf_period_new", np.int32), ("pf_gains_new", np.float32, (3,)),
+                             ("imdct_scale", np.float32), ("pad2", np.uint32)], align=True)
+assert CELT_FRAME_DTYPE.itemsize == 48
+CELT_STATE_FLOATS = 2064
 QOA_FRAME_DTYPE = np.dtype([("byte_off", np.uint64), ("out_off", np.uint64), ("samples", np.uint16),
                             ("channels", np.uint8), ("pad", np.uint8, (5,))], align=True)
 assert QOA_FRAME_DTYPE.itemsize == 24
@@ -40,6 +46,7 @@ ABI_SYMBOLS = [
     "afg_vorbis_transform_hip",
     "afg_flac_transform_hip",
     "afg_qoa_transform_hip",
+    "afg_celt_transform_hip",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
 ]
 
@@ -94,6 +101,7 @@ def lib():
     L.afg_vorbis_transform_hip.argtypes = [vp, vp, vp, vp]
     L.afg_flac_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
     L.afg_qoa_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp]
+    L.afg_celt_transform_hip.argtypes = [u32, vp, vp, vp, vp, vp, vp]
     L.afg_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.afg_device_free.argtypes = [vp]
     L.afg_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
@@ -233,6 +241,12 @@ def qoa_transform(n_frames, d_frames, d_bytes, d_out_i16=None, d_out_f32=None, s
     """Enqueue the QOA frame decode (afg_qoa_transform_hip)."""
     check(lib().afg_qoa_transform_hip(int(n_frames), _ptr(d_frames), _ptr(d_bytes), _ptr(d_out_i16),
                                       _ptr(d_out_f32), _stream(stream)))
+
+
+def celt_transform(n_chan, d_rec_base, d_recs, d_coeffs, d_out, d_states=None, stream=None):
+    """Enqueue the CELT transform stage (afg_celt_transform_hip)."""
+    check(lib().afg_celt_transform_hip(int(n_chan), _ptr(d_rec_base), _ptr(d_recs), _ptr(d_coeffs), _ptr(d_out),
+                                       _ptr(d_states), _stream(stream)))
 
 
 def device_count():

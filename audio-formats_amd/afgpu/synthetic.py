@@ -8,7 +8,7 @@ HBM for bench.py.
 """
 import numpy as np
 
-from . import (FLAC_FRAME_DTYPE, FLAC_INDEPENDENT, FLAC_LEFT_SIDE, FLAC_MID_SIDE, FLAC_RIGHT_SIDE,
+from . import (CELT_FRAME_DTYPE, FLAC_FRAME_DTYPE, FLAC_INDEPENDENT, FLAC_LEFT_SIDE, FLAC_MID_SIDE, FLAC_RIGHT_SIDE,
                FLAC_SUBFRAME_DTYPE, VORBIS_LONG, VORBIS_NEXT, VORBIS_PREV, mp3_flags)
 
 # ------------------------------------------------------------------ MP3 ------
@@ -278,3 +278,46 @@ def flac_batch_device(seed, n_files, frames_per_file, device, block_size=4096, b
     d_frames = torch.from_numpy(frames.view(np.uint8).copy()).to(device)
     d_sub = torch.from_numpy(subframes.view(np.uint8).copy()).to(device)
     return d_frames, d_sub, res, n_frames, total, frames, subframes
+
+
+# ----------------------------------------------------------------- CELT ------
+
+def celt_batch(seed, frames_per_stream, channels, p_transient=0.15, p_postfilter=0.3, frame_sizes=(960,)):
+    """numpy batch of CELT transform-stage records.  One channel sequence per (stream, channel);
+    output interleaved per stream ([frame][sample][channel]).  Returns (rec_base, recs, coeffs, out_total)."""
+    taps = np.array([[0.3066406250, 0.2170410156, 0.1296386719], [0.4638671875, 0.2680664062, 0.0],
+                     [0.7998046875, 0.1000976562, 0.0]], np.float32)            # dopus.d:3382-3386
+    recs, rec_base, coefs = [], [0], []
+    coef_off = out_base = 0
+    for s, (nf, C) in enumerate(zip(frames_per_stream, channels)):
+        rng = np.random.default_rng([seed, s])
+        sizes = rng.choice(frame_sizes, nf)
+        trans = rng.random(nf) < p_transient
+        haspf = rng.random(nf) < p_postfilter
+        period = rng.integers(15, 1023, nf)
+        gain = (0.09375 * (rng.integers(0, 8, nf) + 1)).astype(np.float32)      # dopus.d:3400
+        tapset = rng.integers(0, 3, nf)
+        starts = np.concatenate([[0], np.cumsum(sizes)])
+        last_period = 0
+        per_frame = []
+        for f in range(nf):
+            fs = int(sizes[f])
+            blocks = (fs // 120) if trans[f] and fs > 120 else 1
+            if haspf[f]:
+                last_period = int(period[f])
+                g = (gain[f] * taps[tapset[f]]).astype(np.float32)
+            else:
+                g = np.zeros(3, np.float32)                                     # gains reset, period kept (:3391)
+            per_frame.append((fs, blocks, last_period, g))
+        for c in range(C):
+            for f in range(nf):
+                fs, blocks, per, g = per_frame[f]
+                k = np.arange(fs, dtype=np.float64)
+                x = rng.standard_normal(fs) * 2000.0 * 10.0 ** (-(k / fs) * 2.0)
+                coefs.append(x.astype(np.float32))
+                recs.append((coef_off, out_base + int(starts[f]) * C + c, C, fs, blocks, 0, per, tuple(g), 1.0, 0))
+                coef_off += fs
+            rec_base.append(len(recs))
+        out_base += int(starts[-1]) * C
+    return (np.array(rec_base, np.uint64), np.array(recs, CELT_FRAME_DTYPE),
+            np.concatenate(coefs) if coefs else np.zeros(0, np.float32), out_base)

@@ -173,6 +173,39 @@ int afg_qoa_transform_hip(uint64_t n_frames, const afg_qoa_frame *d_frames, cons
                           int16_t *d_out_i16, float *d_out_f32, void *hip_stream);
 
 /* ========================================================================== *
+ *  Opus / CELT transform stage
+ *  replaces the per-channel tail of ff_celt_decode_frame (dopus.d:3680-3702):
+ *  imdct15_half (dopus.d:1611-1637) + vector_fmul_window (dopus.d:230-243) per
+ *  block, celt_postfilter (dopus.d:3281-3378) and de-emphasis / output scaling
+ *  (dopus.d:3695-3701).  Input is coeffs[ch] after celt_denormalize / downmix
+ *  (dopus.d:3653-3668); output is ff_celt_decode_frame's float output[ch][].
+ *  The post-filter and de-emphasis are recursive over the whole stream, so the
+ *  unit of parallelism is a channel sequence: all frames of one output channel
+ *  of one stream, processed in order.
+ * ========================================================================== */
+
+typedef struct afg_celt_frame {
+    uint64_t coef_off;       /* float index of coeffs[ch][0]: frame_size floats, short blocks interleaved */
+    uint64_t out_off;        /* float index of output sample 0 */
+    uint32_t out_stride;     /* distance between consecutive output samples (1 = planar) */
+    uint16_t frame_size;     /* 120, 240, 480 or 960 */
+    uint8_t  blocks;         /* 1, or 1 << duration when transient (dopus.d:3630) */
+    uint8_t  pad;
+    int32_t  pf_period_new;  /* dopus.d:3407 (>= 15) */
+    float    pf_gains_new[3];
+    float    imdct_scale;    /* 1.0, or 0.5 for the stereo -> mono downmix (dopus.d:3665) */
+    uint32_t pad2;
+} afg_celt_frame;            /* 48 bytes */
+
+#define AFG_CELT_STATE_FLOATS 2064   /* afg_celt_state: buf[2048] + post-filter + de-emphasis memory */
+
+/* Channel sequence k owns records [rec_base[k], rec_base[k+1]) (n_chan + 1 entries).
+ * d_states: NULL (zero state: a fresh decoder) or n_chan * AFG_CELT_STATE_FLOATS words read
+ * before the first and rewritten after the last frame of each sequence (chunked decoding). */
+int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
+                           const float *d_coeffs, float *d_out, float *d_states, void *hip_stream);
+
+/* ========================================================================== *
  *  Utilities used by the host mirror, the tests and bench.py
  * ========================================================================== */
 int afg_device_malloc(void **d_ptr, size_t bytes);

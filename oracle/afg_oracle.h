@@ -183,6 +183,39 @@ void afgo_qoa_transform(uint64_t n_frames, const afgo_qoa_frame *frames, const u
 size_t afgo_qoa_encode(const int16_t *pcm, uint32_t samples, int channels, uint32_t samplerate,
                        uint8_t *out, int16_t *recon);                        /* qoa.d:295-399 */
 
+/* ----------------------------------------------------------------- CELT -- */
+
+/* Per-channel carry state (the transform-stage part of CeltFrame, dopus.d:1645-1663). */
+typedef struct afgo_celt_state {
+    float   buf[2048];
+    int32_t pf_period;
+    float   pf_gains[3];
+    int32_t pf_period_old;
+    float   pf_gains_old[3];
+    float   deemph_coeff;
+    int32_t pad[7];
+} afgo_celt_state;          /* 8256 bytes; same layout as include/afg.h afg_celt_state */
+
+/* One CELT frame of one output channel (same layout as include/afg.h afg_celt_frame). */
+typedef struct afgo_celt_frame {
+    uint64_t coef_off;       /* float index of coeffs[ch][0] (frame_size floats, blocks interleaved, dopus.d:3688) */
+    uint64_t out_off;        /* float index of output sample 0 */
+    uint32_t out_stride;     /* distance between consecutive output samples (1 = planar) */
+    uint16_t frame_size;     /* 120, 240, 480 or 960 */
+    uint8_t  blocks;         /* 1, or 1 << duration when transient (dopus.d:3630) */
+    uint8_t  pad;
+    int32_t  pf_period_new;  /* dopus.d:3407 */
+    float    pf_gains_new[3];
+    float    imdct_scale;    /* 1.0, or 0.5 for the stereo->mono downmix (dopus.d:3665) */
+    uint32_t pad2;
+} afgo_celt_frame;           /* 48 bytes */
+
+void afgo_celt_imdct_half(int N, float *dst, const float *src, int stride, float scale);   /* dopus.d:1611-1637 */
+void afgo_celt_frame_channel(afgo_celt_state *f, const afgo_celt_frame *fr, const float *coeffs,
+                             float *out, int out_stride);                                   /* dopus.d:3680-3702 */
+void afgo_celt_transform(uint32_t n_chan, const uint64_t *rec_base, const afgo_celt_frame *recs,
+                         const float *coeffs, float *out, afgo_celt_state *states);
+
 #ifdef __cplusplus
 }
 #endif

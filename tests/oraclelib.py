@@ -46,6 +46,12 @@ FLAC_FRAME_DTYPE = np.dtype([("in_off", np.uint64), ("out_off", np.uint64), ("bl
                              ("bps", np.uint8), ("pad", np.uint8, (5,))], align=True)
 assert FLAC_SUBFRAME_DTYPE.itemsize == 68 and FLAC_FRAME_DTYPE.itemsize == 32
 
+CELT_FRAME_DTYPE = np.dtype([("coef_off", np.uint64), ("out_off", np.uint64), ("out_stride", np.uint32),
+                             ("frame_size", np.uint16), ("blocks", np.uint8), ("pad", np.uint8),
+                             ("pf_period_new", np.int32), ("pf_gains_new", np.float32, (3,)),
+                             ("imdct_scale", np.float32), ("pad2", np.uint32)], align=True)
+assert CELT_FRAME_DTYPE.itemsize == 48
+CELT_STATE_FLOATS = 2064
 QOA_FRAME_DTYPE = np.dtype([("byte_off", np.uint64), ("out_off", np.uint64), ("samples", np.uint16),
                             ("channels", np.uint8), ("pad", np.uint8, (5,))], align=True)
 assert QOA_FRAME_DTYPE.itemsize == 24
@@ -88,6 +94,10 @@ def lib():
     L.afgo_flac_prediction_64.restype = C.c_int32
     L.afgo_flac_transform.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, i32p, i32p, C.c_void_p]
     L.afgo_flac_transform.restype = None
+    L.afgo_celt_imdct_half.argtypes = [C.c_int, f32p, f32p, C.c_int, C.c_float]
+    L.afgo_celt_imdct_half.restype = None
+    L.afgo_celt_transform.argtypes = [C.c_uint32, u64p, C.c_void_p, f32p, f32p, C.c_void_p]
+    L.afgo_celt_transform.restype = None
     L.afgo_qoa_transform.argtypes = [C.c_uint64, C.c_void_p, u8p, C.c_void_p, C.c_void_p]
     L.afgo_qoa_transform.restype = None
     L.afgo_qoa_encode.argtypes = [i16p, C.c_uint32, C.c_int, C.c_uint32, u8p, C.c_void_p]
@@ -206,3 +216,14 @@ def qoa_transform(frames, data, out_total, want_float=True):
     lib().afgo_qoa_transform(len(frames), frames.ctypes.data, data, oi.ctypes.data,
                              of.ctypes.data if want_float else None)
     return (oi, of) if want_float else oi
+
+
+# --------------------------------------------------------------- CELT ------
+def celt_transform(rec_base, recs, coeffs, out_total, states=None):
+    rec_base = np.ascontiguousarray(rec_base, np.uint64)
+    recs = np.ascontiguousarray(recs, CELT_FRAME_DTYPE)
+    out = np.zeros(int(out_total), np.float32)
+    lib().afgo_celt_transform(len(rec_base) - 1, rec_base, recs.ctypes.data,
+                              np.ascontiguousarray(coeffs, np.float32), out,
+                              states.ctypes.data if states is not None else None)
+    return out

@@ -1,0 +1,64 @@
+"""CELT transform stage: HIP path vs the CPU oracle through the C ABI (north-star tolerance 1e-5 RMS
+on the API scale; the expression trees are the reference's, so the match is expected to be bitwise)."""
+import numpy as np
+import pytest
+
+import afgpu
+import oraclelib
+from afgpu import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(gpu, rec_base, recs, coeffs, total, states=None):
+    import torch
+    d_out = torch.full((total,), float("nan"), dtype=torch.float32, device=gpu)
+    d_states = None if states is None else torch.from_numpy(states).to(gpu)
+    afgpu.celt_transform(len(rec_base) - 1, torch.from_numpy(rec_base.view(np.int64)).to(gpu),
+                         torch.from_numpy(recs.view(np.uint8).copy()).to(gpu), torch.from_numpy(coeffs).to(gpu),
+                         d_out, d_states)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy(), (None if states is None else d_states.cpu().numpy())
+
+
+def check(got, want):
+    assert not np.isnan(got).any(), "unwritten output"
+    rms = float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)))
+    assert rms <= 1e-5, rms
+    return int((got.view(np.uint32) != want.view(np.uint32)).sum())
+
+
+@pytest.mark.parametrize("kw", [
+    dict(frames_per_stream=[6, 3, 9], channels=[2, 1, 2]),
+    dict(frames_per_stream=[12], channels=[2], p_transient=1.0, p_postfilter=1.0),
+    dict(frames_per_stream=[10, 7], channels=[1, 2], frame_sizes=(120, 240, 480, 960), p_transient=0.5, p_postfilter=0.6),
+    dict(frames_per_stream=[8], channels=[1], p_postfilter=0.0),
+])
+def test_celt_matches_oracle(gpu, kw):
+    rec_base, recs, coeffs, total = synthetic.celt_batch(5, **kw)
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    assert check(got, want) == 0
+
+
+def test_celt_short_period_postfilter(gpu):
+    rec_base, recs, coeffs, total = synthetic.celt_batch(8, [6], [2], p_postfilter=1.0)
+    recs["pf_period_new"] = np.where(np.arange(len(recs)) % 2, 15, 16)       # minimum lags: 13-sample steps
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    assert check(got, want) == 0
+
+
+def test_celt_chunked_with_state_equals_whole(gpu):
+    rec_base, recs, coeffs, total = synthetic.celt_batch(9, [10], [2], p_postfilter=0.7, p_transient=0.3)
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    states = np.zeros((2, afgpu.CELT_STATE_FLOATS), np.float32)
+    out = np.full(total, np.nan, np.float32)
+    for lo, hi in ((0, 4), (4, 10)):
+        sel = np.concatenate([np.arange(int(rec_base[c]) + lo, int(rec_base[c]) + hi) for c in range(2)])
+        rb = np.array([0, hi - lo, 2 * (hi - lo)], np.uint64)
+        got, st = run_gpu(gpu, rb, recs[sel].copy(), coeffs, total, states.reshape(-1).copy())
+        states = st.reshape(2, -1)
+        m = ~np.isnan(got)
+        out[m] = got[m]
+    assert check(out, want) == 0
