@@ -88,6 +88,40 @@ int afg_flac_transform_hip(ulong n_frames, const(afg_flac_frame)* d_frames,
                            const(afg_flac_subframe)* d_subframes, const(int)* d_res,
                            int* d_out_i32, float* d_out_f32, void* hip_stream);
 
+// ---- QOA (replaces the slice loop of qoa_decode_frame, qoa.d:489-530, and qoa.d:831-838) --------
+struct afg_qoa_frame
+{
+    ulong byte_off;
+    ulong out_off;
+    ushort samples;
+    ubyte channels;
+    ubyte[5] pad;
+}
+static assert(afg_qoa_frame.sizeof == 24);
+
+int afg_qoa_transform_hip(ulong n_frames, const(afg_qoa_frame)* d_frames, const(ubyte)* d_bytes,
+                          short* d_out_i16, float* d_out_f32, void* hip_stream);
+
+// ---- Opus/CELT (replaces the per-channel tail of ff_celt_decode_frame, dopus.d:3680-3702) -------
+struct afg_celt_frame
+{
+    ulong coef_off;
+    ulong out_off;
+    uint out_stride;
+    ushort frame_size;
+    ubyte blocks;
+    ubyte pad;
+    int pf_period_new;
+    float[3] pf_gains_new;
+    float imdct_scale;
+    uint pad2;
+}
+static assert(afg_celt_frame.sizeof == 48);
+enum AFG_CELT_STATE_FLOATS = 2064;
+
+int afg_celt_transform_hip(uint n_chan, const(ulong)* d_rec_base, const(afg_celt_frame)* d_recs,
+                           const(float)* d_coeffs, float* d_out, float* d_states, void* hip_stream);
+
 // ---- utilities ----------------------------------------------------------------------------------
 int afg_device_malloc(void** d_ptr, size_t bytes);
 int afg_device_free(void* d_ptr);

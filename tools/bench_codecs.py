@@ -80,6 +80,62 @@ def bench_flac(dev, files, frames_per_file, steps, warmup, want_float):
             "int32_mismatches": int((got != want).sum())}
 
 
+def bench_qoa(dev, files, seconds, steps, warmup):
+    """`files` copies of one encoded stereo file of `seconds` s (the encoder is the slow CPU fixture generator)."""
+    import afgpu
+    import oraclelib
+    n = int(44100 * seconds)
+    t = np.arange(n)
+    pcm = np.stack([9000 * np.sin(0.02 * t) + 500 * np.random.default_rng(1).standard_normal(n),
+                    7000 * np.sin(0.031 * t + 1)], 1).round().astype(np.int16)
+    data, _ = oraclelib.qoa_encode(pcm)
+    pad = (-data.size) % 8
+    one = np.concatenate([data, np.zeros(pad, np.uint8)])
+    fr, ch, _, total = afgpu.qoa_frames(data.tobytes())
+    frames = np.tile(fr, files)
+    k = np.repeat(np.arange(files, dtype=np.uint64), len(fr))
+    frames["byte_off"] += k * np.uint64(one.size)
+    frames["out_off"] += k * np.uint64(total * ch)
+    d_bytes = torch.from_numpy(np.tile(one, files)).to(dev)
+    d_frames = torch.from_numpy(frames.view(np.uint8).copy()).to(dev)
+    nout = total * ch * files
+    d_f = torch.empty(nout, dtype=torch.float32, device=dev)
+    ms = time_launches(lambda: afgpu.qoa_transform(len(frames), d_frames, d_bytes, None, d_f), steps, warmup)
+    avg = sum(ms) / len(ms) * 1e-3
+    want = oraclelib.qoa_transform(fr, data, total * ch)[1]
+    got = d_f[:total * ch].cpu().numpy()
+    alg = d_bytes.numel() + 4 * nout
+    return {"workload": f"{files} x QOA stereo {seconds} s", "samples_per_step": nout, "avg_kernel_ms": avg * 1e3,
+            "samples_per_s": nout / avg, "achieved_GBs": alg / avg / 1e9, "frac": alg / avg / 1e9 / HBM_PEAK_GBS,
+            "mismatches": int((got.view(np.uint32) != want.view(np.uint32)).sum())}
+
+
+def bench_celt(dev, streams, frames_per_stream, steps, warmup):
+    import afgpu
+    import oraclelib
+    from afgpu import synthetic
+    rb1, recs1, coef1, tot1 = synthetic.celt_batch(0x0905, [frames_per_stream], [2])
+    nrec = len(recs1)
+    recs = np.tile(recs1, streams)
+    k = np.repeat(np.arange(streams, dtype=np.uint64), nrec)
+    recs["coef_off"] += k * np.uint64(coef1.size)
+    recs["out_off"] += k * np.uint64(tot1)
+    rec_base = np.concatenate([(rb1[:-1] + np.uint64(s * nrec)) for s in range(streams)] + [np.array([streams * nrec], np.uint64)])
+    d_coef = torch.from_numpy(np.tile(coef1, streams)).to(dev)
+    d_recs = torch.from_numpy(recs.view(np.uint8).copy()).to(dev)
+    d_rb = torch.from_numpy(rec_base.view(np.int64)).to(dev)
+    d_out = torch.empty(tot1 * streams, dtype=torch.float32, device=dev)
+    ms = time_launches(lambda: afgpu.celt_transform(len(rec_base) - 1, d_rb, d_recs, d_coef, d_out), steps, warmup)
+    avg = sum(ms) / len(ms) * 1e-3
+    want = oraclelib.celt_transform(rb1, recs1, coef1, tot1)
+    got = d_out[:tot1].cpu().numpy()
+    alg = 8 * tot1 * streams
+    return {"workload": f"{streams} x Opus/CELT stereo, {frames_per_stream} frames of 960", "samples_per_step": tot1 * streams,
+            "avg_kernel_ms": avg * 1e3, "samples_per_s": tot1 * streams / avg, "achieved_GBs": alg / avg / 1e9,
+            "frac": alg / avg / 1e9 / HBM_PEAK_GBS,
+            "bitwise_mismatches": int((got.view(np.uint32) != want.view(np.uint32)).sum())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--codec", default="all")
@@ -100,6 +156,12 @@ def main():
         torch.cuda.empty_cache()
     if args.codec in ("all", "flac"):
         res["flac"] = bench_flac(dev, args.flac_files, args.flac_frames, args.steps, args.warmup, args.flac_float)
+    if args.codec in ("all", "qoa"):
+        torch.cuda.empty_cache()
+        res["qoa"] = bench_qoa(dev, 4096, 4.0, args.steps, args.warmup)
+    if args.codec in ("all", "celt"):
+        torch.cuda.empty_cache()
+        res["celt"] = bench_celt(dev, 8192, 200, args.steps, args.warmup)
     print(json.dumps(res))
 
 
