@@ -281,6 +281,11 @@ constexpr int kLdsFloats = 33 * kHS;
 
 struct alignas(8) f2 { float x, y; };
 
+// The workgroup is ONE wavefront: its LDS accesses execute in program order, so phases only need a
+// compiler-level ordering point.  (__syncthreads() would also drain vmcnt, i.e. wait for the
+// spectrum loads that were issued a whole granule ahead precisely to stay in flight.)
+#define WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+
 // value of the lane below / above (wave_shr:1 / wave_shl:1); lane 0 / 63 get 0
 __device__ __forceinline__ float from_lane_below(float v)
 {
@@ -301,7 +306,6 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
     float *__restrict__ pcm, float *__restrict__ state)
 {
     __shared__ __attribute__((aligned(16))) float H[kLdsFloats];
-    __shared__ __attribute__((aligned(16))) float P1[576];          // PCM staging of slots 9..17
     __shared__ __attribute__((aligned(16))) float Wt[15 * 16];      // g_win, re-read every granule (saves 16 VGPRs)
     float *const R = H + kRegion;
 
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
     // role A: lane = (channel, subband): antialias / IMDCT
     const int ch = lane >> 5;
     const int band = lane & 31;
-    // role C: lane = (slot half, channel, column pair i): polyphase window
+    // role C: lane = (slot parity, channel, column pair i): polyphase window
     const int s2 = lane >> 5;
     const int sc = (lane >> 4) & 1;
     const int si = lane & 15;
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
 #pragma unroll
         for (int q = 0; q < 9; q++) pre[q] = ch_on ? src[q] : f2{ 0.0f, 0.0f };
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     for (int g = g_first; g < g_end; g++) {
         const bool do_synth = g >= (int)seg.g0;
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
             // D. transposition buffer <- x
 #pragma unroll
             for (int m = 0; m < 9; m++) ((f2 *)R)[lane * 9 + m] = f2{ x[2 * m], x[2 * m + 1] };
-            __syncthreads();
+            WAVE_SYNC();
 
             // E. 32-point DCT-II, lane = (channel, slot) (minimp3.d:1232-1298); all reads of the
             //    transposition buffer precede the row writes in program order
@@ -415,14 +419,14 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
                 for (int b = 0; b < 32; b++) in[b] = col[b * 18];
                 dct2_32(in, out);
             }
-            __syncthreads();
+            WAVE_SYNC();
             if (dct_lane) {
                 f2 *row = (f2 *)(R + band * kHS + ch * 32);
 #pragma unroll
                 for (int i = 0; i < 15; i++) row[i] = f2{ out[31 - i], out[1 + i] };
                 row[15] = f2{ out[16], out[0] };
             }
-            __syncthreads();
+            WAVE_SYNC();
         }
 
         if (do_synth) {
@@ -464,48 +468,52 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
 #pragma unroll
             for (int k = 0; k < 8; k++) w[k] = wrow[k];                       // (w0, w1) of tap k
             const bool main_lane = (si < 15) && (sc < nch);
-            const int t0 = 9 * s2;
-            const f2 *base = (const f2 *)(H + t0 * kHS + sc * 32) + (si < 15 ? si : 14);
-            float *const pdst = (s2 ? P1 : H) + sc;
-            f2 rw[24];
+            const f2 *base = (const f2 *)(H + s2 * kHS + sc * 32) + (si < 15 ? si : 14);
+            // Only one element of each row pair is ever needed by a lane: relative row m (absolute
+            // row s2 + 2n + m) feeds tap vy_k (m = k < 8) or vz_k (m = 15 - k), and in both cases the
+            // element is hi for odd m, lo for even m.  rw[m] = that element of row(s2 + m).
+            const float *rbase = (const float *)base;
+            float rw[32];
 #pragma unroll
-            for (int m = 0; m < 16; m++) rw[m] = base[m * (kHS / 2)];
+            for (int m = 0; m < 18; m++) rw[m] = rbase[m * kHS + (((m & 1) ^ 0) ? 0 : 1)];
 #pragma unroll
-            for (int n = 0; n < 9; n++) {
-                if (n > 0) rw[15 + n] = base[(15 + n) * (kHS / 2)];
+            for (int n = 0; n < 9; n++) {                   // slot t = 2n + s2
+                if (n + 1 < 9 && n > 0) {                   // rows of the NEXT step: in flight during this one
+                    rw[16 + 2 * n] = rbase[(16 + 2 * n) * kHS + 1];
+                    rw[17 + 2 * n] = rbase[(17 + 2 * n) * kHS + 0];
+                }
                 float a = 0.0f, b = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const f2 zp = rw[15 + n - k], yp = rw[n + k];
-                    const float vz = (k & 1) ? zp.y : zp.x;
-                    const float vy = (k & 1) ? yp.x : yp.y;
+                    const float vz = rw[15 + 2 * n - k];
+                    const float vy = rw[2 * n + k];
                     const float tb = vz * w[k].y + vy * w[k].x;
                     const float ta = (k & 1) ? (vy * w[k].y - vz * w[k].x) : (vz * w[k].x - vy * w[k].y);
                     b = (k == 0) ? tb : (b + tb);
                     a = (k == 0) ? ta : (a + ta);
                 }
+                // PCM of slot t goes to floats [64t, 64t+64) (stereo) = rows <= t, which no later step reads
                 if (main_lane) {
-                    pdst[(n * 32 + 15 - si) * nch] = a * (1.0f / 32768.0f);
-                    pdst[(n * 32 + 17 + si) * nch] = b * (1.0f / 32768.0f);
+                    float *pdst = H + ((2 * n + s2) * 32) * nch + sc;
+                    pdst[(15 - si) * nch] = a * (1.0f / 32768.0f);
+                    pdst[(17 + si) * nch] = b * (1.0f / 32768.0f);
                 }
             }
             if (pair_lane) {
-                float *pp = (band < 9 ? H + (band * 32) * nch : P1 + ((band - 9) * 32) * nch) + ch;
+                float *pp = H + (band * 32) * nch + ch;
                 pp[0] = op0;
                 pp[16 * nch] = op16;
             }
-            __syncthreads();
-            // I. 16-byte coalesced PCM stores: first half of the granule from H, second from P1
+            WAVE_SYNC();
+            // I. 16-byte coalesced PCM stores
             float4 *dst = (float4 *)(pcm + (st.blk_base + (uint64_t)g * nch) * 576);
-            const int half4 = nval / 8;                     // float4 per half
 #pragma unroll
             for (int q = 0; q < 5; q++) {
                 const int idx = lane + 64 * q;
-                if (idx < 2 * half4)
-                    dst[idx] = (idx < half4) ? ((const float4 *)H)[idx] : ((const float4 *)P1)[idx - half4];
+                if (4 * idx < nval) dst[idx] = ((const float4 *)H)[idx];
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
 
         // H. the last 15 slots become the history of the next granule (:1432)
         if (do_dct) {
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
                 if (idx < n2) ((f2 *)H)[idx] = hcp[q];
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
 
     // ---- hand the carry state on (chunked decoding) ------------------------------
