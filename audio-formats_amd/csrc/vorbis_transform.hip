@@ -76,12 +76,22 @@ __device__ __forceinline__ void iter_54(float *z)
 
 // In-place inverse MDCT of one channel held in LDS; buffer[0..n/2) spectrum in,
 // buffer[0..n) samples out; buf2 = n/2 floats of scratch.  stb_vorbis2.d:1941-2242.
+// A workgroup of one wavefront -- or wavefronts that never share data -- only needs its own LDS
+// accesses ordered, which the hardware does in program order: a compiler-level ordering point is
+// enough, and unlike __syncthreads() it does not drain the spectrum loads that are in flight.
 template <int kThreads>
-__device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float *buf2, int n, int ld,
+__device__ __forceinline__ void pass_sync()
+{
+    if (kThreads > 64) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
+}
+
+template <int kThreads>
+__device__ void inverse_mdct_lds(float *buffer, float *buf2, int n, int ld,
                                  const float *__restrict__ A, const float *__restrict__ B,
                                  const float *__restrict__ C)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & (kThreads - 1);
     const int n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
     float *u = buffer, *v = buf2;
 
@@ -102,7 +112,7 @@ __device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float 
             d[0] = (-e[2] * AA[1] + -e[0] * AA[0]);
         }
     }
-    __syncthreads();
+    pass_sync<kThreads>();
 
     // step 2, :2006-2040 (n/8 half-iterations)
     for (int it = tid; it < n8; it += kThreads) {
@@ -126,7 +136,7 @@ __device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float 
             d1[2] = v40_20 * AA[0] + v41_21 * AA[1];
         }
     }
-    __syncthreads();
+    pass_sync<kThreads>();
 
     // step 3 stages l = 0 .. ld-7, :2053-2083 (n/8 butterflies each)
     for (int l = 0; l <= ld - 7; l++) {
@@ -139,7 +149,7 @@ __device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float 
             const float *a = A + (b << (l + 3));
             bfly(p, p - (k0 >> 1), a[0], a[1]);
         }
-        __syncthreads();
+        pass_sync<kThreads>();
     }
 
     // last three stages fused, :1898-1939 (n/32 blocks of 16 floats)
@@ -178,7 +188,7 @@ __device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float 
             iter_54(z - 8);
         }
     }
-    __syncthreads();
+    pass_sync<kThreads>();
 
     // steps 4-6: bit-reversed gather u -> v, :2096-2124 (n/8 entries; table of :875-881 computed inline)
     for (int e = tid; e < n8; e += kThreads) {
@@ -198,7 +208,7 @@ __device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float 
             d0[0] = u[k4 + 3];
         }
     }
-    __syncthreads();
+    pass_sync<kThreads>();
 
     // step 7, :2133-2175 (n/8 half-iterations)
     for (int it = tid; it < n8; it += kThreads) {
@@ -230,7 +240,7 @@ __device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float 
             e[1] = b1 - b3;
         }
     }
-    __syncthreads();
+    pass_sync<kThreads>();
 
     // step 8 + decode, :2187-2238 (n/4 items)
     for (int it = tid; it < n4; it += kThreads) {
@@ -246,7 +256,7 @@ __device__ __attribute__((noinline)) void inverse_mdct_lds(float *buffer, float 
         buffer[n2 + 4 * q + m] = pb;
         buffer[n - 4 - 4 * q + 3 - m] = pb;
     }
-    __syncthreads();
+    pass_sync<kThreads>();
 }
 
 // stb_vorbis2.d:2333-2349
@@ -359,6 +369,15 @@ __device__ __forceinline__ int pad_e(int m) { return m + (m >> 3); }
 // address of every table access out of the packet loop (two VGPRs each, ~120 in total);
 // laundering the base per pass keeps addresses as SGPR base + 32-bit lane offset, live
 // only inside the pass.
+// Opaque copy of the lane id: address arithmetic derived from it cannot be hoisted out of the
+// packet loop (where it would sit in VGPRs for the whole kernel), it is recomputed per pass.
+__device__ __forceinline__ int fresh_lane()
+{
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
 template <typename T>
 __device__ __forceinline__ const T *fresh(const T *p)
 {
@@ -379,7 +398,7 @@ __device__ __forceinline__ void bfly2(f2 &p, f2 &q, f2 c)
 // issue the loads of one channel spectrum (n = 2048): 4 x 16 bytes per lane
 __device__ __forceinline__ void load_spectrum(float4 (&x)[4], const float *__restrict__ X)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         typedef float v4f __attribute__((ext_vector_type(4)));
@@ -393,10 +412,10 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
                                                 const float *A, const float *B, const float *C)
 {
     constexpr int n = kNL, n2 = n / 2, n4 = n / 4, n8 = n / 8;
-    const int lane = threadIdx.x;
+    int lane = fresh_lane();
     f2 *const U = (f2 *)smem;
     f2 *const V = (f2 *)(smem + kUFloats);
-    const f2 *A2p = fresh((const f2 *)A);
+    const f2 *A2p = (const f2 *)A;
 
     // step 0 (:1972-1994): item q and the mirrored item n8-1-q share one 16-byte load
 #pragma unroll
@@ -414,10 +433,10 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         g.x = (-x.w * a1.y + -x.y * a1.x);
         V[q] = g;                                   // buf2[n4-2-2q'] = buf2[2q]
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
 
     // step 2 (:2006-2040): half-iteration `it` makes points n4-1-it and n8-1-it
-    A2p = fresh(A2p);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int it = lane + 64 * r;
@@ -434,12 +453,12 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         U[pad_e(n8 - 1 - it)] = hi;
         U[pad_e(n4 - 1 - it)] = lo;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
 
     // stages l = 0, 1 (:2053-2060): point sets {base + j + 64 r}, lane j, both halves
     {
-        A2p = fresh(A2p);
-        const int j = lane;
+            const int j = lane;
         const f2 w00 = A2p[4 * j];                  // A[(j) << 3]
         const f2 w01 = A2p[4 * (j + 64)];           // A[(j+64) << 3]
         const f2 w1 = A2p[8 * j];                   // A[j << 4]
@@ -457,12 +476,12 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
             for (int r = 0; r < 4; r++) U[pad_e(base + 64 * r)] = e[r];
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
 
     // stages l = 2, 3, 4 (:2062-2083): point sets {64 g + j' + 8 e}
     {
-        A2p = fresh(A2p);
-        const int g = lane >> 3, jp = lane & 7;
+            const int g = lane >> 3, jp = lane & 7;
         const int base = 64 * g + jp;
         f2 e[8];
 #pragma unroll
@@ -483,12 +502,13 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 #pragma unroll
         for (int k = 0; k < 8; k++) U[pad_e(base + 8 * k)] = e[k];
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
 
     // last three stages, the reference's fused loop (:1898-1939) on points 8 it .. 8 it + 7;
     // zz[i] = z[-i]
     {
-        const float A2 = fresh(A)[n >> 3];
+        const float A2 = A[n >> 3];
         const int b9 = 9 * lane;                    // pad_e(8 lane)
         float zz[16];
 #pragma unroll
@@ -545,7 +565,8 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 #pragma unroll
         for (int k = 0; k < 8; k++) U[b9 + k] = f2{ zz[2 * k], zz[2 * k + 1] };
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
 
     // steps 4-6 (:2096-2124): entry e takes points 511-2*brev8(e) and 510-2*brev8(e)
 #pragma unroll
@@ -557,14 +578,15 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         V[n4 - 1 - e] = pa;                         // (v[n2-2-2e], v[n2-1-2e]) = (u[k4+1], u[k4])
         V[n8 - 1 - e] = pb;                         // (v[n4-2-2e], v[n4-1-2e]) = (u[k4+3], u[k4+2])
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
 
     // step 7 (:2133-2175) fused with step 8 (:2187-2238).  Item s works on pairs v2[s] and
     // v2[n4-1-s]; the results feed step-8 items x = n4-1-s and x = s.  All of buf2 is read
     // before the first output is written (the output aliases it).
     {
-        const f2 *const C2 = fresh((const f2 *)C);
-        const f2 *const B2 = fresh((const f2 *)B);
+        const f2 *const C2 = (const f2 *)C;
+        const f2 *const B2 = (const f2 *)B;
         f2 dn[4], en[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -572,7 +594,8 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
             dn[r] = V[sidx];
             en[r] = V[n4 - 1 - sidx];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int sidx = lane + 64 * r;
@@ -608,7 +631,8 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
             }
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
 }
 
 #ifndef AFG_VORBIS_MIN_WAVES
@@ -616,12 +640,12 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 #endif
 template <int C>                                     // channels: 1 or 2 on this path
 __device__ __forceinline__ void vorbis_wave_body(
-    float *smem, const VorbisSeg &seg, const VorbisStream &st,
+    float *smem, const float *ltab, const VorbisSeg &seg, const VorbisStream &st,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
     const uint64_t *__restrict__ out_off, const float *tables,
     const float *__restrict__ spec, float *__restrict__ out)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
 
     float *const prevw = smem + kWaveLds;             // previous_window: C x 1024 floats behind the transform area
@@ -648,7 +672,8 @@ __device__ __forceinline__ void vorbis_wave_body(
         const float *src = spec + spec_off[gp];
         const bool emit = (p >= (int)seg.p0) && previous_length > 0;
         const int pn = previous_length;
-        const float *w = tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);   // get_window(pn), :2245-2251
+        const float *w = (pn * 2 == kNL) ? ltab + kNL + kNL / 4                                 // get_window(pn), :2245-2251
+                                         : tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);
         const int nout = right - left;
         float *o = out + out_off[gp];
 
@@ -669,10 +694,10 @@ __device__ __forceinline__ void vorbis_wave_body(
                                 load_spectrum(xin, spec + spec_off[gq] + (more_here ? (c + 1) * (kNL / 2) : 0));
                         }
                     }
-                    imdct_2048_wave(xcur, smem, A, B, Ct);                           // :2526-2527
+                    imdct_2048_wave(xcur, smem, ltab, ltab + kNL / 2, ltab + kNL);   // :2526-2527, tables in LDS
                 } else {
                     for (int k = lane; k < n2; k += 64) smem[k] = src[c * n2 + k];
-                    __syncthreads();
+                    __builtin_amdgcn_wave_barrier();
                     inverse_mdct_lds<64>(smem, smem + n, n, 31 - __clz(n), A, B, Ct);
                     // the following transform (if long) was not prefetched while this one ran
                     if (c + 1 == C && p + 1 < p_end) {
@@ -683,7 +708,7 @@ __device__ __forceinline__ void vorbis_wave_body(
                 // vorbis_finish_frame (:2606-2657) + interleave (:3927-3952) for this channel: each
                 // channel stores its own 4-byte column of the interleaved frames (merged in L2)
                 if (emit) {
-                    const float *wt = fresh(w);
+                    const float *wt = w;
                     const float *pw = prevw + c * 1024;
                     const int nwin = pn < nout ? pn : nout;
                     for (int jj = lane; jj < nwin; jj += 64)
@@ -692,24 +717,34 @@ __device__ __forceinline__ void vorbis_wave_body(
                 }
                 for (int k = lane; k < right_end - right; k += 64)
                     prevw[c * 1024 + k] = smem[right + k];                                     // :2641-2643
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
             }
         }
         previous_length = right_end - right;
     }
 }
 
-__global__ __launch_bounds__(64, AFG_VORBIS_MIN_WAVES) void vorbis_wave_kernel(
-    const VorbisSeg *__restrict__ segs, const VorbisStream *__restrict__ streams,
+constexpr int kWavesPerGroup = 8;
+constexpr int kWaveStride = kWaveLds + 2 * 1024;      // transform area + previous_window of two channels
+constexpr int kTabFloats = kNL / 2 + kNL / 2 + kNL / 4 + kNL / 2;     // A B C window of n = 2048
+
+__global__ __launch_bounds__(64 * kWavesPerGroup) void vorbis_wave_kernel(
+    const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
-    const uint64_t *__restrict__ out_off, const float *tables,
+    const uint64_t *__restrict__ out_off, const float *tables, uint32_t tab2048,
     const float *__restrict__ spec, float *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) float smem[kWaveLds + 2 * 1024];
-    const VorbisSeg seg = segs[blockIdx.x];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ltab = lds;                                                   // one copy per workgroup
+    for (int i = threadIdx.x; i < kTabFloats; i += 64 * kWavesPerGroup) ltab[i] = tables[tab2048 + i];
+    __syncthreads();                                                     // the only block-level barrier
+    const uint32_t sidx = blockIdx.x * kWavesPerGroup + (threadIdx.x >> 6);
+    if (sidx >= n_segs) return;
+    float *smem = lds + kTabFloats + (threadIdx.x >> 6) * kWaveStride;
+    const VorbisSeg seg = segs[sidx];
     const VorbisStream st = streams[seg.stream];
-    if (st.nch == 1) vorbis_wave_body<1>(smem, seg, st, pflags, spec_off, out_off, tables, spec, out);
-    else vorbis_wave_body<2>(smem, seg, st, pflags, spec_off, out_off, tables, spec, out);
+    if (st.nch == 1) vorbis_wave_body<1>(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
+    else vorbis_wave_body<2>(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
 }
 
 int ilog_host(int n)       // stb_vorbis2.d:634-650
@@ -759,6 +794,7 @@ struct afg_vorbis_plan {
     size_t lds_bytes = 0;
     std::vector<uint64_t> h_spec_off, h_out_off;
     uint32_t n_wave_segs = 0;      // segments of streams on the wave-level fast path
+    uint32_t tab2048 = 0;          // float offset of the n = 2048 table set
     afg::DeviceArray d_segs, d_wave_segs, d_streams, d_pflags, d_spec_off, d_out_off, d_tables;
 };
 
@@ -857,6 +893,7 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
     p->n_streams = n_streams;
     p->n_segs = (uint32_t)segs.size();
     p->n_wave_segs = (uint32_t)wave_segs.size();
+    p->tab2048 = tab_of.count(kNL) ? tab_of[kNL] : 0;
     p->n_packets = pkt;
     p->spec_floats = so;
     p->out_floats = oo;
@@ -868,6 +905,14 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
     if (!rc) rc = p->d_spec_off.upload(p->h_spec_off.data(), p->h_spec_off.size() * sizeof(uint64_t));
     if (!rc) rc = p->d_out_off.upload(p->h_out_off.data(), p->h_out_off.size() * sizeof(uint64_t));
     if (!rc) rc = p->d_tables.upload(tables.data(), tables.size() * sizeof(float));
+    if (!rc && p->n_wave_segs) {
+        hipError_t e = hipFuncSetAttribute((const void *)vorbis_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(float) * (kTabFloats + kWavesPerGroup * kWaveStride)));
+        if (e != hipSuccess) {
+            afg::set_error("hipFuncSetAttribute(wave kernel) failed: %s", hipGetErrorString(e));
+            rc = AFG_ERR_HIP;
+        }
+    }
     if (!rc && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)vorbis_transform_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -918,11 +963,12 @@ int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, f
         return AFG_ERR_INVALID;
     }
     if (plan->n_wave_segs)
-        hipLaunchKernelGGL(vorbis_wave_kernel, dim3(plan->n_wave_segs), dim3(64), 0,
-                           (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_wave_segs.ptr,
+        hipLaunchKernelGGL(vorbis_wave_kernel, dim3((plan->n_wave_segs + kWavesPerGroup - 1) / kWavesPerGroup),
+                           dim3(64 * kWavesPerGroup), sizeof(float) * (kTabFloats + kWavesPerGroup * kWaveStride),
+                           (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_wave_segs.ptr, plan->n_wave_segs,
                            (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
                            (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
-                           (const float *)plan->d_tables.ptr, d_spec, d_out);
+                           (const float *)plan->d_tables.ptr, plan->tab2048, d_spec, d_out);
     if (plan->n_segs)
         hipLaunchKernelGGL(vorbis_transform_kernel, dim3(plan->n_segs), dim3(kThreads), plan->lds_bytes,
                            (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_segs.ptr,
