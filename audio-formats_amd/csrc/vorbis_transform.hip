@@ -408,7 +408,33 @@ __device__ __forceinline__ void load_spectrum(float4 (&x)[4], const float *__res
 }
 
 // inverse_mdct for n = 2048 (stb_vorbis2.d:1941-2242); result in smem[0..2048)
-__device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *smem,
+// Twiddles of the passes whose lane -> table index mapping is strided (they would hit a few LDS
+// banks only): they do not depend on the packet, so each lane keeps its own in registers.
+struct LaneTwiddles {
+    f2 p1[4];       // step 2:        A[n2-4-2o], o = 2 (lane + 64 r)
+    f2 pa[3];       // stages 0, 1:   A[j << 3], A[(j+64) << 3], A[j << 4]
+    f2 pb[7];       // stages 2..4:   A[(jp+8k) << 5] k<4, A[(jp+8k) << 6] k<2, A[jp << 7]
+};
+
+__device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &t, const float *A)
+{
+    constexpr int n4 = kNL / 4;
+    const int lane = threadIdx.x & 63;
+    const f2 *A2p = (const f2 *)A;
+#pragma unroll
+    for (int r = 0; r < 4; r++) t.p1[r] = A2p[n4 - 2 - 2 * (lane + 64 * r)];
+    t.pa[0] = A2p[4 * lane];
+    t.pa[1] = A2p[4 * (lane + 64)];
+    t.pa[2] = A2p[8 * lane];
+    const int jp = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.pb[k] = A2p[16 * (jp + 8 * k)];
+#pragma unroll
+    for (int k = 0; k < 2; k++) t.pb[4 + k] = A2p[32 * (jp + 8 * k)];
+    t.pb[6] = A2p[64 * jp];
+}
+
+__device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *smem, const LaneTwiddles &tw,
                                                 const float *A, const float *B, const float *C)
 {
     constexpr int n = kNL, n2 = n / 2, n4 = n / 4, n8 = n / 8;
@@ -442,7 +468,7 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         const int it = lane + 64 * r;
         const f2 e0 = V[n8 + it];                   // v[n4+o], v[n4+o+1], o = 2 it
         const f2 e1 = V[it];
-        const f2 aa = A2p[n4 - 2 - 2 * it];         // A[n2-4-2o], A[n2-3-2o]
+        const f2 aa = tw.p1[r];                     // A[n2-4-2o], A[n2-3-2o]
         const float v41_21 = e0.y - e1.y;
         const float v40_20 = e0.x - e1.x;
         f2 hi, lo;
@@ -459,9 +485,9 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     // stages l = 0, 1 (:2053-2060): point sets {base + j + 64 r}, lane j, both halves
     {
             const int j = lane;
-        const f2 w00 = A2p[4 * j];                  // A[(j) << 3]
-        const f2 w01 = A2p[4 * (j + 64)];           // A[(j+64) << 3]
-        const f2 w1 = A2p[8 * j];                   // A[j << 4]
+        const f2 w00 = tw.pa[0];                    // A[(j) << 3]
+        const f2 w01 = tw.pa[1];                    // A[(j+64) << 3]
+        const f2 w1 = tw.pa[2];                     // A[j << 4]
 #pragma unroll
         for (int hb = 0; hb < 2; hb++) {
             const int base = hb * (n4 / 2) + j;
@@ -487,15 +513,15 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 #pragma unroll
         for (int k = 0; k < 8; k++) e[k] = U[pad_e(base + 8 * k)];
 #pragma unroll
-        for (int k = 0; k < 4; k++) bfly2(e[k], e[k + 4], A2p[16 * (jp + 8 * k)]);     // A[b << 5]
+        for (int k = 0; k < 4; k++) bfly2(e[k], e[k + 4], tw.pb[k]);                    // A[b << 5]
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const f2 w = A2p[32 * (jp + 8 * k)];                                          // A[b << 6]
+            const f2 w = tw.pb[4 + k];                                                    // A[b << 6]
             bfly2(e[k], e[k + 2], w);
             bfly2(e[k + 4], e[k + 6], w);
         }
         {
-            const f2 w = A2p[64 * jp];                                                    // A[b << 7]
+            const f2 w = tw.pb[6];                                                        // A[b << 7]
 #pragma unroll
             for (int k = 0; k < 8; k += 2) bfly2(e[k], e[k + 1], w);
         }
@@ -649,6 +675,8 @@ __device__ __forceinline__ void vorbis_wave_body(
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
 
     float *const prevw = smem + kWaveLds;             // previous_window: C x 1024 floats behind the transform area
+    LaneTwiddles tw;
+    load_lane_twiddles(tw, ltab);
     int previous_length = 0;
     const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
     const int p_end = (int)(seg.p0 + seg.count);
@@ -694,7 +722,7 @@ __device__ __forceinline__ void vorbis_wave_body(
                                 load_spectrum(xin, spec + spec_off[gq] + (more_here ? (c + 1) * (kNL / 2) : 0));
                         }
                     }
-                    imdct_2048_wave(xcur, smem, ltab, ltab + kNL / 2, ltab + kNL);   // :2526-2527, tables in LDS
+                    imdct_2048_wave(xcur, smem, tw, ltab, ltab + kNL / 2, ltab + kNL);   // :2526-2527, tables in LDS
                 } else {
                     for (int k = lane; k < n2; k += 64) smem[k] = src[c * n2 + k];
                     __builtin_amdgcn_wave_barrier();
