@@ -25,8 +25,13 @@
 
 namespace {
 
-constexpr int kT = 16;                 // samples per tile step
-constexpr int kRowWords = 2 * kT;      // LDS row: [channel A | channel B], 8 pieces of 4 words
+#ifndef AFG_FLAC_TILE
+#define AFG_FLAC_TILE 16
+#endif
+constexpr int kT = AFG_FLAC_TILE;      // samples per tile step (16 or 32)
+constexpr int kRowWords = 2 * kT;      // LDS row: [channel A | channel B], 2*kT/4 pieces of 4 words
+constexpr int kPieces = kT / 4;        // 16-byte pieces per channel chunk
+constexpr int kLoads = 2 * kPieces;    // 16-byte load instructions per tile step
 
 struct RowMeta {                       // what the load/store phases need to know about a lane's frame
     uint64_t in_off;
@@ -48,7 +53,10 @@ __device__ __forceinline__ int wave_max(int v)
 // word offset of 16-byte piece `piece` (0..7) of tile row `row`
 __device__ __forceinline__ int piece_off(int row, int piece)
 {
-    return row * kRowWords + (((piece + (row >> 1)) & 7) << 2);
+    // rotation making the one-row-per-lane 16-byte accesses conflict-free: row/2 for 8 pieces per
+    // row (two rows share a 256-byte bank row), row for 16 pieces per row
+    const int rot = (kT == 16) ? (row >> 1) : row;
+    return row * kRowWords + (((piece + rot) & (2 * kPieces - 1)) << 2);
 }
 
 __device__ __forceinline__ int32_t shl32(int32_t v, unsigned sh) { return (int32_t)((uint32_t)v << (sh & 31u)); }
@@ -58,53 +66,80 @@ __device__ __forceinline__ int32_t shl32(int32_t v, unsigned sh) { return (int32
 // for t >= order, verbatim warm-up below (drflac.d:1406-1410, :1419-1423).
 // Coefficients past `order` are zero, values past the end of the block are never stored:
 // no branches, so the unrolled history shift is pure register renaming.
+// prediction of one sample from the history h (h[k] = s[t-1-k]); two independent partial sums
+// halve the dependent multiply-add chain (integer sums are associative: same bits).
 template <int MAXORD, bool WIDE>
-__device__ __forceinline__ void restore_tile(int32_t *tile, int row, int chan, int t0, int order, int shift,
-                                             bool use64, const int32_t (&c)[MAXORD], int32_t (&h)[MAXORD])
+__device__ __forceinline__ int32_t predict(const int32_t (&c)[MAXORD], const int32_t (&h)[MAXORD], int shift, bool use64)
+{
+    if (WIDE) {
+        int64_t a0 = 0, a1 = 0;
+#pragma unroll
+        for (int k = MAXORD - 1; k >= 1; k -= 2) {            // older taps first: they do not wait for the newest output
+            a1 += (int64_t)c[k] * (int64_t)h[k];
+            a0 += (int64_t)c[k - 1] * (int64_t)h[k - 1];
+        }
+        const int64_t acc = a0 + a1;
+        const int32_t p32 = (int32_t)(uint32_t)(uint64_t)acc >> shift;     // prediction_32 (:1098)
+        const int32_t p64 = (int32_t)(uint32_t)(uint64_t)(acc >> shift);   // prediction_64 (:1139)
+        return use64 ? p64 : p32;
+    } else {
+        uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+        for (int k = MAXORD - 1; k >= 1; k -= 2) {
+            a1 += (uint32_t)c[k] * (uint32_t)h[k];
+            a0 += (uint32_t)c[k - 1] * (uint32_t)h[k - 1];
+        }
+        return (int32_t)(a0 + a1) >> shift;
+    }
+}
+
+// One tile of the (up to) two channels of this lane's frame, interleaved so that the two serial
+// recurrences overlap: kT steps of
+//   s[t] = r[t] + (sum_k coef[k]*s[t-1-k]) >> shift        (drflac.d:1235)
+// for t >= order, verbatim warm-up below (drflac.d:1406-1410, :1419-1423).
+// Coefficients past `order` are zero, values past the end of the block are never stored:
+// no branches, so the unrolled history shift is pure register renaming.  An absent channel runs
+// with zero coefficients on zero residuals.
+template <int MAXORD, bool WIDE_A, bool WIDE_B>
+__device__ __forceinline__ void restore_tile2(int32_t *tile, int row, int t0,
+                                              int order0, int shift0, bool u0, const int32_t (&c0)[MAXORD], int32_t (&h0)[MAXORD],
+                                              int order1, int shift1, bool u1, const int32_t (&c1)[MAXORD], int32_t (&h1)[MAXORD])
 {
 #pragma unroll
     for (int q = 0; q < kT / 4; q++) {
-        int4 *pp = (int4 *)(tile + piece_off(row, chan * 4 + q));
-        int4 v = *pp;
-        int32_t r[4] = { v.x, v.y, v.z, v.w };
+        int4 *pa = (int4 *)(tile + piece_off(row, q));
+        int4 *pb = (int4 *)(tile + piece_off(row, kPieces + q));
+        const int4 va = *pa, vb = *pb;
+        int32_t ra[4] = { va.x, va.y, va.z, va.w }, rb[4] = { vb.x, vb.y, vb.z, vb.w };
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int t = t0 + 4 * q + e;
-            int32_t pred;
-            if (WIDE) {
-                // taps on the older samples first: they do not wait for the newest output
-                int64_t acc = 0;
+            const int32_t pA = predict<MAXORD, WIDE_A>(c0, h0, shift0, u0);
+            const int32_t pB = predict<MAXORD, WIDE_B>(c1, h1, shift1, u1);
+            const int32_t sA = (t >= order0) ? (int32_t)((uint32_t)ra[e] + (uint32_t)pA) : ra[e];
+            const int32_t sB = (t >= order1) ? (int32_t)((uint32_t)rb[e] + (uint32_t)pB) : rb[e];
+            ra[e] = sA;
+            rb[e] = sB;
 #pragma unroll
-                for (int k = MAXORD - 1; k >= 0; k--) acc += (int64_t)c[k] * (int64_t)h[k];
-                const int32_t p32 = (int32_t)(uint32_t)(uint64_t)acc >> shift;     // prediction_32 (:1098)
-                const int32_t p64 = (int32_t)(uint32_t)(uint64_t)(acc >> shift);   // prediction_64 (:1139)
-                pred = use64 ? p64 : p32;
-            } else {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int k = MAXORD - 1; k >= 0; k--) acc += (uint32_t)c[k] * (uint32_t)h[k];
-                pred = (int32_t)acc >> shift;
-            }
-            const int32_t s = (t >= order) ? (int32_t)((uint32_t)r[e] + (uint32_t)pred) : r[e];
-            r[e] = s;
-#pragma unroll
-            for (int k = MAXORD - 1; k >= 1; k--) h[k] = h[k - 1];
-            h[0] = s;
+            for (int k = MAXORD - 1; k >= 1; k--) { h0[k] = h0[k - 1]; h1[k] = h1[k - 1]; }
+            h0[0] = sA;
+            h1[0] = sB;
         }
-        *pp = make_int4(r[0], r[1], r[2], r[3]);
+        *pa = make_int4(ra[0], ra[1], ra[2], ra[3]);
+        *pb = make_int4(rb[0], rb[1], rb[2], rb[3]);
     }
 }
 
 // Issue the 16-byte loads of one tile step: instruction i covers row-chunks 16i .. 16i+15,
 // row-chunk rc = (row rc>>1, channel slot rc&1), lane&3 = 16-byte piece of the 64-byte chunk.
-__device__ __forceinline__ void load_tile(int4 (&nxt)[8], const RowMeta *meta, const int32_t *__restrict__ res,
+__device__ __forceinline__ void load_tile(int4 (&nxt)[kLoads], const RowMeta *meta, const int32_t *__restrict__ res,
                                           int pair, int t0)
 {
     const int lane = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int rc = 16 * i + (lane >> 2);
-        const int row = rc >> 1, slot = rc & 1, p = lane & 3;
+    for (int i = 0; i < kLoads; i++) {
+        const int rc = (64 / kPieces) * i + lane / kPieces;
+        const int row = rc >> 1, slot = rc & 1, p = lane % kPieces;
         const RowMeta m = meta[row];
         const int C = (int)(m.info & 0xff);
         const int cidx = 2 * pair + slot;
@@ -124,13 +159,13 @@ __device__ __forceinline__ void load_tile(int4 (&nxt)[8], const RowMeta *meta, c
     }
 }
 
-__device__ __forceinline__ void park_tile(int32_t *tile, const int4 (&nxt)[8])
+__device__ __forceinline__ void park_tile(int32_t *tile, const int4 (&nxt)[kLoads])
 {
     const int lane = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int rc = 16 * i + (lane >> 2);
-        *(int4 *)(tile + piece_off(rc >> 1, (rc & 1) * 4 + (lane & 3))) = nxt[i];
+    for (int i = 0; i < kLoads; i++) {
+        const int rc = (64 / kPieces) * i + lane / kPieces;
+        *(int4 *)(tile + piece_off(rc >> 1, (rc & 1) * kPieces + lane % kPieces)) = nxt[i];
     }
 }
 
@@ -141,16 +176,16 @@ __device__ __forceinline__ void store_tile(const int32_t *tile, const RowMeta *m
 {
     const int lane = threadIdx.x;
 #pragma unroll 2
-    for (int i = 0; i < 8; i++) {
-        const int row = 8 * i + (lane >> 3);
-        const int q = lane & 7;                                      // samples 2q, 2q+1 of the tile
+    for (int i = 0; i < kT / 2; i++) {
+        const int row = (128 / kT) * i + lane / (kT / 2);
+        const int q = lane % (kT / 2);                               // samples 2q, 2q+1 of the tile
         const RowMeta m = meta[row];
         const int C = (int)(m.info & 0xff);
         const int asg = (int)((m.info >> 8) & 0xff);
         const int t = t0 + 2 * q;
         if (2 * pair >= C || t >= (int)m.bs) continue;
         const int2 a = *(const int2 *)(tile + piece_off(row, q >> 1) + 2 * (q & 1));
-        const int2 b = *(const int2 *)(tile + piece_off(row, 4 + (q >> 1)) + 2 * (q & 1));
+        const int2 b = *(const int2 *)(tile + piece_off(row, kPieces + (q >> 1)) + 2 * (q & 1));
         const bool two = (C - 2 * pair) >= 2;
         int32_t l0, r0, l1, r1;
         if (asg == AFG_FLAC_LEFT_SIDE) {                             // :2886-2897
@@ -193,7 +228,7 @@ __device__ __forceinline__ void store_tile(const int32_t *tile, const RowMeta *m
     }
 }
 
-template <int MAXORD, bool WIDE>
+template <int MAXORD, bool WIDE_A, bool WIDE_B>
 __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, const RowMeta &me, bool valid,
                                            const afg_flac_subframe *__restrict__ subframes, uint32_t sf_index,
                                            const int32_t *__restrict__ res, int32_t *__restrict__ out_i32,
@@ -225,7 +260,7 @@ __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, c
             for (int k = 0; k < MAXORD; k++) c1[k] = (k < order1) ? (int32_t)sf->coef[k] : 0;
         }
 
-        int4 nxt[8];
+        int4 nxt[kLoads];
         load_tile(nxt, meta, res, pair, 0);
         park_tile(tile, nxt);
         __syncthreads();
@@ -233,8 +268,8 @@ __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, c
             if (t0 + kT < max_bs) load_tile(nxt, meta, res, pair, t0 + kT);   // in flight during the recurrence
 
             if (t0 < (int)me.bs) {
-                if (chA < my_ch) restore_tile<MAXORD, WIDE>(tile, lane, 0, t0, order0, shift0, u0, c0, h0);
-                if (chB < my_ch) restore_tile<MAXORD, WIDE>(tile, lane, 1, t0, order1, shift1, u1, c1, h1);
+                restore_tile2<MAXORD, WIDE_A, WIDE_B>(tile, lane, t0, order0, shift0, u0, c0, h0,
+                                                      order1, shift1, u1, c1, h1);
             }
             __syncthreads();
             store_tile(tile, meta, row_shift, out_i32, out_f32, pair, t0);
@@ -245,10 +280,10 @@ __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, c
     }
 }
 
-// One kernel per (order bucket, accumulator width): a wavefront only runs in the instantiation
+// One kernel per (order bucket, accumulator width of the even / odd channel slot): a wavefront only runs in the instantiation
 // that matches the largest LPC order / widest accumulator among its 64 frames and leaves the
 // others at once, so every instantiation gets its own (small) register allocation.
-template <int LO, int MAXORD, bool WIDE>
+template <int LO, int MAXORD, bool WIDE_A, bool WIDE_B>
 __global__ __launch_bounds__(64) void flac_restore_kernel(
     const afg_flac_frame *__restrict__ frames, const afg_flac_subframe *__restrict__ subframes,
     const int32_t *__restrict__ res, int32_t *__restrict__ out_i32, float *__restrict__ out_f32,
@@ -265,7 +300,7 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(
     RowMeta me;
     me.in_off = 0; me.out_off = 0; me.bs = 0; me.info = 0;
     uint32_t sf_index = 0;
-    int my_order = 0, my_wide = 0;
+    int my_order = 0, my_wide_a = 0, my_wide_b = 0;    // even / odd channel slots
     afg_flac_frame fr;
     if (valid) {
         fr = frames[f];
@@ -273,12 +308,12 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(
         for (int c = 0; c < (int)fr.channels && c < 8; c++) {
             const afg_flac_subframe *sf = subframes + sf_index + c;
             my_order = sf->order > my_order ? sf->order : my_order;
-            my_wide |= sf->use64;
+            if (c & 1) my_wide_b |= sf->use64; else my_wide_a |= sf->use64;
         }
     }
     const int max_order = wave_max(my_order);
-    const bool wide = wave_max(my_wide) != 0;
-    if (!(max_order > LO && max_order <= MAXORD && wide == WIDE)) return;
+    const bool wide_a = wave_max(my_wide_a) != 0, wide_b = wave_max(my_wide_b) != 0;
+    if (!(max_order > LO && max_order <= MAXORD && wide_a == WIDE_A && wide_b == WIDE_B)) return;
 
     if (valid) {
         me.in_off = fr.in_off;
@@ -298,7 +333,7 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(
 
     const int max_bs = wave_max((int)me.bs);
     const int max_pairs = wave_max(((int)(me.info & 0xff) + 1) >> 1);
-    run_frames<MAXORD, WIDE>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32,
+    run_frames<MAXORD, WIDE_A, WIDE_B>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32,
                              max_bs, max_pairs, row_shift);
 }
 
@@ -319,15 +354,19 @@ extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d
         afg::set_error("afg_flac_transform_hip: too many frames in one call");
         return AFG_ERR_INVALID;
     }
-#define AFG_FLAC_LAUNCH(LO, HI)                                                                               \
-    hipLaunchKernelGGL((flac_restore_kernel<LO, HI, false>), dim3((uint32_t)groups), dim3(64), 0,              \
-                       (hipStream_t)hip_stream, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, n_frames); \
-    hipLaunchKernelGGL((flac_restore_kernel<LO, HI, true>), dim3((uint32_t)groups), dim3(64), 0,               \
+#define AFG_FLAC_LAUNCH1(LO, HI, WA, WB)                                                                      \
+    hipLaunchKernelGGL((flac_restore_kernel<LO, HI, WA, WB>), dim3((uint32_t)groups), dim3(64), 0,             \
                        (hipStream_t)hip_stream, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, n_frames)
+#define AFG_FLAC_LAUNCH(LO, HI)            \
+    AFG_FLAC_LAUNCH1(LO, HI, false, false); \
+    AFG_FLAC_LAUNCH1(LO, HI, false, true);  \
+    AFG_FLAC_LAUNCH1(LO, HI, true, false);  \
+    AFG_FLAC_LAUNCH1(LO, HI, true, true)
     AFG_FLAC_LAUNCH(-1, 4);
     AFG_FLAC_LAUNCH(4, 8);
     AFG_FLAC_LAUNCH(8, 12);
     AFG_FLAC_LAUNCH(12, 32);
+#undef AFG_FLAC_LAUNCH1
 #undef AFG_FLAC_LAUNCH
     AFG_HIP_CHECK(hipGetLastError());
     return AFG_OK;

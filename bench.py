@@ -115,6 +115,7 @@ def main():
     pcm = torch.empty_like(coef)
     stream = torch.cuda.current_stream()
     samples_per_step = plan.blocks * 576
+    coef_numel = coef.numel()
 
     def barrier():
         if world > 1:
@@ -135,6 +136,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+
+    # device-to-device copy of the same byte volume (spectrum plane -> PCM plane): the practical HBM ceiling
+    # of this box for a read-N/write-N stream, reported next to the 8 TB/s spec the roofline is priced against
+    copy_ms = []
+    if rank == 0:
+        scratch = torch.empty_like(coef)
+        for i in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            scratch.copy_(coef)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if i:
+                copy_ms.append(e0.elapsed_time(e1))
+        del scratch
 
     if world > 1:
         import torch.distributed as dist
@@ -216,6 +232,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "mp3_transform_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                     "measured_copy_GBs": (2 * 4 * coef_numel / (min(copy_ms) * 1e-3) / 1e9) if copy_ms else None,
                      "algorithmic_bytes_per_launch": int(alg_bytes)},
         "cpu_baseline": cpu,
         "parity": parity,
