@@ -47,12 +47,38 @@ ABI_SYMBOLS = [
     "afg_flac_transform_hip",
     "afg_qoa_transform_hip",
     "afg_celt_transform_hip",
+    "afg_open_from_memory", "afg_is_error", "afg_error_message", "afg_get_format", "afg_get_num_channels",
+    "afg_get_length_in_frames", "afg_get_samplerate", "afg_read_samples_float", "afg_close",
+    "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse",
+    "afg_batch_decode", "afg_batch_free",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
 ]
 
 
 class AfgError(RuntimeError):
     pass
+
+
+# AudioFileFormat (stream.d:36-47), in the reference's order
+FORMAT_NAMES = ["wav", "mp3", "flac", "ogg", "opus", "qoa", "mod", "xm", "unknown"]
+FORMAT_WAV, FORMAT_MP3, FORMAT_FLAC, FORMAT_OGG, FORMAT_OPUS, FORMAT_QOA, FORMAT_MOD, FORMAT_XM, FORMAT_UNKNOWN = range(9)
+UNKNOWN_LENGTH = -1   # audiostreamUnknownLength, stream.d:90
+
+
+class FlacParsed(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("channels", C.c_uint32), ("bps", C.c_uint32), ("max_block", C.c_uint32),
+                ("total_samples", C.c_uint64), ("n_frames", C.c_uint64), ("n_subframes", C.c_uint64),
+                ("n_res", C.c_uint64), ("out_samples", C.c_uint64), ("frames", C.c_void_p),
+                ("subframes", C.c_void_p), ("res", C.c_void_p), ("owner", C.c_void_p)]
+
+
+class BatchItem(C.Structure):
+    _fields_ = [("status", C.c_int), ("message", C.c_char_p), ("format", C.c_int), ("channels", C.c_int),
+                ("samplerate", C.c_float), ("frames", C.c_int64), ("pcm", C.POINTER(C.c_float))]
+
+
+class BatchResult(C.Structure):
+    _fields_ = [("n_files", C.c_int), ("items", C.POINTER(BatchItem)), ("owner", C.c_void_p)]
 
 
 _lib = None
@@ -102,6 +128,28 @@ def lib():
     L.afg_flac_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
     L.afg_qoa_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp]
     L.afg_celt_transform_hip.argtypes = [u32, vp, vp, vp, vp, vp, vp]
+    L.afg_open_from_memory.argtypes = [vp, C.c_size_t]
+    L.afg_open_from_memory.restype = vp
+    L.afg_is_error.argtypes = [vp]
+    L.afg_error_message.argtypes = [vp]
+    L.afg_error_message.restype = C.c_char_p
+    L.afg_get_format.argtypes = [vp]
+    L.afg_get_num_channels.argtypes = [vp]
+    L.afg_get_length_in_frames.argtypes = [vp]
+    L.afg_get_length_in_frames.restype = C.c_int64
+    L.afg_get_samplerate.argtypes = [vp]
+    L.afg_get_samplerate.restype = C.c_float
+    L.afg_read_samples_float.argtypes = [vp, vp, C.c_int]
+    L.afg_close.argtypes = [vp]
+    L.afg_close.restype = None
+    L.afg_flac_parse.argtypes = [vp, C.c_size_t, C.POINTER(FlacParsed)]
+    L.afg_flac_parsed_free.argtypes = [C.POINTER(FlacParsed)]
+    L.afg_flac_parsed_free.restype = None
+    L.afg_qoa_parse.argtypes = [vp, C.c_size_t, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, C.c_size_t,
+                                C.POINTER(C.c_size_t)]
+    L.afg_batch_decode.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(BatchResult)]
+    L.afg_batch_free.argtypes = [C.POINTER(BatchResult)]
+    L.afg_batch_free.restype = None
     L.afg_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.afg_device_free.argtypes = [vp]
     L.afg_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
@@ -247,6 +295,104 @@ def celt_transform(n_chan, d_rec_base, d_recs, d_coeffs, d_out, d_states=None, s
     """Enqueue the CELT transform stage (afg_celt_transform_hip)."""
     check(lib().afg_celt_transform_hip(int(n_chan), _ptr(d_rec_base), _ptr(d_recs), _ptr(d_coeffs), _ptr(d_out),
                                        _ptr(d_states), _stream(stream)))
+
+
+def flac_parse(file_bytes):
+    """Host front-end only (afg_flac_parse): returns (info dict, frames, subframes, residual planes) as numpy
+    copies of the transform-stage records.  Needs no device."""
+    buf = bytes(file_bytes)
+    out = FlacParsed()
+    check(lib().afg_flac_parse(buf, len(buf), C.byref(out)))
+    try:
+        def view(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype)
+            raw = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(raw, dtype=dtype, count=count).copy()
+        info = {k: int(getattr(out, k)) for k in ("sample_rate", "channels", "bps", "max_block", "total_samples",
+                                                  "out_samples")}
+        return (info, view(out.frames, out.n_frames, FLAC_FRAME_DTYPE),
+                view(out.subframes, out.n_subframes, FLAC_SUBFRAME_DTYPE), view(out.res, out.n_res, np.int32))
+    finally:
+        lib().afg_flac_parsed_free(C.byref(out))
+
+
+def qoa_parse(file_bytes):
+    """afg_qoa_parse: (QOA_FRAME_DTYPE array, channels, samplerate, samples per channel)."""
+    buf = bytes(file_bytes)
+    ch, sr, smp, n = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_size_t()
+    check(lib().afg_qoa_parse(buf, len(buf), C.byref(ch), C.byref(sr), C.byref(smp), None, 0, C.byref(n)))
+    frames = np.zeros(n.value, QOA_FRAME_DTYPE)
+    check(lib().afg_qoa_parse(buf, len(buf), None, None, None, frames.ctypes.data, n.value, None))
+    return frames, ch.value, sr.value, smp.value
+
+
+class AudioStream:
+    """The reading half of the reference's AudioStream (stream.d:102-637) over afg_open_from_memory: same method
+    names, same never-throw / error-state contract (stream.d:31-33)."""
+
+    def __init__(self):
+        self._h = None
+        self._keep = None
+
+    def openFromMemory(self, data):
+        self.cleanUp()
+        self._keep = bytes(data)
+        self._h = lib().afg_open_from_memory(self._keep, len(self._keep))
+
+    def cleanUp(self):
+        if self._h:
+            lib().afg_close(self._h)
+        self._h = None
+
+    __del__ = cleanUp
+
+    def isError(self):
+        return bool(lib().afg_is_error(self._h))
+
+    def errorMessage(self):
+        m = lib().afg_error_message(self._h)
+        return None if m is None else m.decode()
+
+    def getFormat(self):
+        return int(lib().afg_get_format(self._h))
+
+    def getNumChannels(self):
+        return int(lib().afg_get_num_channels(self._h))
+
+    def getLengthInFrames(self):
+        return int(lib().afg_get_length_in_frames(self._h))
+
+    def getSamplerate(self):
+        return float(lib().afg_get_samplerate(self._h))
+
+    def readSamplesFloat(self, out):
+        """out: float32 numpy array whose size is a multiple of the channel count; returns frames read."""
+        ch = max(1, self.getNumChannels())
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size % ch == 0
+        return int(lib().afg_read_samples_float(self._h, out.ctypes.data, out.size // ch))
+
+
+def batch_decode(files, n_threads=0):
+    """afg_batch_decode: list of dicts (status, message, format, channels, samplerate, frames, pcm ndarray)."""
+    bufs = [bytes(f) for f in files]
+    n = len(bufs)
+    ptrs = (C.c_char_p * max(n, 1))(*bufs)
+    lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
+    res = BatchResult()
+    check(lib().afg_batch_decode(ptrs, lens, n, n_threads, C.byref(res)))
+    try:
+        out = []
+        for i in range(res.n_files):
+            it = res.items[i]
+            cnt = it.frames * it.channels
+            pcm = np.ctypeslib.as_array(it.pcm, shape=(cnt,)).copy().reshape(-1, max(1, it.channels)) if cnt and it.pcm else None
+            out.append({"status": it.status, "message": None if it.message is None else it.message.decode(),
+                        "format": it.format, "channels": it.channels, "samplerate": it.samplerate,
+                        "frames": it.frames, "pcm": pcm})
+        return out
+    finally:
+        lib().afg_batch_free(C.byref(res))
 
 
 def device_count():

@@ -206,6 +206,81 @@ int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const af
                            const float *d_coeffs, float *d_out, float *d_states, void *hip_stream);
 
 /* ========================================================================== *
+ *  Outer surface: the AudioStream subset (stream.d:102-637) over the host front-ends
+ *  that exist so far -- FLAC (native container, drflac.d:680-1695, :1887-2153) and QOA
+ *  (qoa.d:413-486, :703-851).  Other formats report "unrecognized encoding" until their
+ *  host parsers land (MP3, Vorbis, Opus: SURVEY 8f).  The host parses the whole file into
+ *  transform-stage records, the device restores the samples, the stream serves them.
+ * ========================================================================== */
+
+typedef enum afg_format {          /* AudioFileFormat, stream.d:36-47 */
+    AFG_FORMAT_WAV = 0, AFG_FORMAT_MP3 = 1, AFG_FORMAT_FLAC = 2, AFG_FORMAT_OGG = 3, AFG_FORMAT_OPUS = 4,
+    AFG_FORMAT_QOA = 5, AFG_FORMAT_MOD = 6, AFG_FORMAT_XM = 7, AFG_FORMAT_UNKNOWN = 8
+} afg_format;
+
+#define AFG_UNKNOWN_LENGTH (-1)    /* audiostreamUnknownLength, stream.d:90 */
+
+typedef struct afg_stream afg_stream;
+
+/* openFromMemory (stream.d:150-170): copies nothing it does not need after the call returns; never
+ * throws; returns NULL only when out of memory.  On failure the stream is in error state with the
+ * reference's message (internals.d:16-23). */
+afg_stream *afg_open_from_memory(const uint8_t *data, size_t length);
+int         afg_is_error(const afg_stream *s);                 /* stream.d:295-301 */
+const char *afg_error_message(const afg_stream *s);            /* NULL when valid, stream.d:310-316 */
+int         afg_get_format(const afg_stream *s);               /* afg_format */
+int         afg_get_num_channels(const afg_stream *s);
+int64_t     afg_get_length_in_frames(const afg_stream *s);     /* AFG_UNKNOWN_LENGTH if unknown */
+float       afg_get_samplerate(const afg_stream *s);
+/* readSamplesFloat (stream.d:429-637): interleaved, returns frames read (< frames: end or error). */
+int         afg_read_samples_float(afg_stream *s, float *out, int frames);
+void        afg_close(afg_stream *s);
+
+/* Host front-ends on their own (no device needed): what the stream and batch entry points run
+ * before the device stage.  afg_flac_parse walks the native FLAC container (drflac.d:1901-2118),
+ * every frame and subframe header (drflac.d:1444-1569) and the Rice residuals (drflac.d:1279-1328)
+ * and returns transform-stage records; it stops at the first frame that does not parse, like the
+ * reference's read loop (drflac.d:2860).  afg_qoa_parse validates the headers (qoa.d:413-486). */
+typedef struct afg_flac_parsed {
+    uint32_t sample_rate, channels, bps, max_block;
+    uint64_t total_samples;        /* per channel, from STREAMINFO; 0 = unknown */
+    uint64_t n_frames, n_subframes, n_res, out_samples;
+    afg_flac_frame    *frames;
+    afg_flac_subframe *subframes;
+    int32_t           *res;
+    void              *owner;      /* internal */
+} afg_flac_parsed;
+
+int  afg_flac_parse(const uint8_t *data, size_t length, afg_flac_parsed *out);  /* AFG_ERR_UNSUPPORTED: not FLAC */
+void afg_flac_parsed_free(afg_flac_parsed *parsed);
+/* frames may be NULL (count only); at most frame_cap records are written, *n_frames gets the total. */
+int  afg_qoa_parse(const uint8_t *data, size_t length, uint32_t *channels, uint32_t *samplerate,
+                   uint32_t *samples, afg_qoa_frame *frames, size_t frame_cap, size_t *n_frames);
+
+/* Batch decode (no reference counterpart: the throughput path).  Files are parsed by n_threads
+ * host threads (0 = hardware concurrency), restored on the current device in one launch per
+ * format, and returned as interleaved float PCM owned by the result. */
+typedef struct afg_batch_item {
+    int         status;        /* afg_status of this file: a bad file never poisons the batch */
+    const char *message;       /* static string, NULL when ok */
+    int         format;        /* afg_format */
+    int         channels;
+    float       samplerate;
+    int64_t     frames;
+    float      *pcm;           /* frames * channels floats, NULL on error */
+} afg_batch_item;
+
+typedef struct afg_batch_result {
+    int             n_files;
+    afg_batch_item *items;
+    void           *owner;     /* internal */
+} afg_batch_result;
+
+int  afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_files, int n_threads,
+                      afg_batch_result *out);
+void afg_batch_free(afg_batch_result *result);
+
+/* ========================================================================== *
  *  Utilities used by the host mirror, the tests and bench.py
  * ========================================================================== */
 int afg_device_malloc(void **d_ptr, size_t bytes);

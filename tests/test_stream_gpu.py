@@ -1,0 +1,110 @@
+"""End to end through the outer surface of the C ABI on the device: file bytes -> afg_open_from_memory /
+afg_batch_decode -> interleaved floats, against (host front-end records -> oracle restore) and against the
+PCM that was encoded.  Reference behaviour: stream.d:150-170, :295-412, :492-513 (FLAC read), :576-588 (QOA
+read), qoa.d:810-851."""
+import numpy as np
+import pytest
+
+import afgpu
+import flac_bitstream as fb
+import flac_ref_encoder as enc
+import oraclelib
+from test_flac_frontend import make_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+def flac_expected(data):
+    info, frames, subframes, res = afgpu.flac_parse(data)
+    _, f32 = oraclelib.flac_transform(frames, subframes, res, info["out_samples"], want_float=True)
+    return info, f32.reshape(-1, info["channels"])
+
+
+def qoa_file(n, channels, rate, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    pcm = np.stack([9000 * np.sin(0.02 * (c + 1) * t) + 300 * rng.standard_normal(n) for c in range(channels)], 1)
+    data, _ = oraclelib.qoa_encode(pcm.round().astype(np.int16), rate)
+    frames, ch, _, total = afgpu.qoa_frames(data.tobytes())
+    want = oraclelib.qoa_transform(frames, data, total * ch)[1].reshape(-1, ch)
+    return data.tobytes(), want
+
+
+def read_all(stream, channels, chunk):
+    parts = []
+    while True:
+        buf = np.full(chunk * channels, np.nan, np.float32)
+        got = stream.readSamplesFloat(buf)
+        parts.append(buf[:got * channels])
+        if got < chunk:
+            break
+    return np.concatenate(parts).reshape(-1, channels)
+
+
+@pytest.mark.parametrize("channels,bps,block,n", [(2, 16, 4096, 4096 * 5 + 123), (2, 24, 1152, 1152 * 3), (1, 8, 576, 2000)])
+def test_flac_stream(gpu, channels, bps, block, n):
+    pcm = make_pcm(n, channels, bps, 21)
+    data, _ = fb.encode_file(pcm, bps, block, sample_rate=48000, assignments=(enc.INDEPENDENT, enc.LEFT_SIDE, enc.MID_SIDE))
+    info, want = flac_expected(data)
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    assert not s.isError(), s.errorMessage()
+    assert s.errorMessage() is None
+    assert s.getFormat() == afgpu.FORMAT_FLAC and afgpu.FORMAT_NAMES[s.getFormat()] == "flac"
+    assert s.getNumChannels() == channels and s.getSamplerate() == 48000.0 and s.getLengthInFrames() == n
+    got = read_all(s, channels, 1000)
+    assert got.shape == (n, channels)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))                 # bit-exact floats
+    assert s.readSamplesFloat(np.zeros(channels * 4, np.float32)) == 0               # stream.d:498
+    s.cleanUp()
+
+
+def test_flac_declared_length_zero_reads_nothing(gpu):
+    """STREAMINFO total = 0: _lengthInFrames = 0 and stream.d:498 returns 0 at position 0."""
+    pcm = make_pcm(512, 2, 16, 4)
+    frames, subframes, res, _ = enc.encode(pcm, 16, 256)
+    data = fb.write_file(frames, subframes, res, 44100, 16, total_samples=0)
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    assert not s.isError() and s.getLengthInFrames() == 0
+    assert s.readSamplesFloat(np.zeros(64, np.float32)) == 0
+
+
+def test_qoa_stream(gpu):
+    data, want = qoa_file(5120 * 3 + 77, 2, 32000, 5)
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    assert not s.isError(), s.errorMessage()
+    assert s.getFormat() == afgpu.FORMAT_QOA and s.getNumChannels() == 2
+    assert s.getSamplerate() == 32000.0 and s.getLengthInFrames() == 5120 * 3 + 77
+    got = read_all(s, 2, 4099)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_batch_decode_mixed_formats_and_bad_files(gpu):
+    files, wants = [], []
+    for i in range(6):
+        pcm = make_pcm(3000 + 517 * i, 1 + i % 2, 16, 30 + i)
+        d, _ = fb.encode_file(pcm, 16, 1024, sample_rate=44100)
+        files.append(d)
+        wants.append(flac_expected(d)[1])
+    for i in range(3):
+        d, w = qoa_file(6000 + 1000 * i, 1 + i % 2, 44100, 40 + i)
+        files.append(d)
+        wants.append(w)
+    files.insert(4, b"\x00" * 100)                 # junk in the middle must not poison the batch
+    wants.insert(4, None)
+    files.append(b"")
+    wants.append(None)
+    out = afgpu.batch_decode(files, n_threads=3)
+    assert len(out) == len(files)
+    for item, want, blob in zip(out, wants, files):
+        if want is None:
+            assert item["status"] != 0 and item["pcm"] is None
+            assert item["message"] == "Cannot decode stream: unrecognized encoding."
+            continue
+        assert item["status"] == 0 and item["message"] is None
+        assert item["format"] == (afgpu.FORMAT_FLAC if blob[:4] == b"fLaC" else afgpu.FORMAT_QOA)
+        assert item["frames"] == len(want) and item["channels"] == want.shape[1]
+        assert np.array_equal(item["pcm"].view(np.uint32), want.view(np.uint32))
+    assert afgpu.batch_decode([]) == []
