@@ -13,11 +13,15 @@
 //     spread over the lanes) and the post-rotation run wave-parallel;
 //   * the post-filter advances min(T-2, 64) samples per step (everything a step reads is
 //     older than the step);
-//   * the de-emphasis recurrence is evaluated redundantly by all lanes (its rounding order
-//     cannot be re-associated); each lane keeps the samples it owns for the coalesced store.
+//   * the de-emphasis recurrence (rounding order cannot be re-associated) is a second kernel
+//     over the output plane, one lane per channel sequence (celt_deemph_kernel).
 // Parallelism therefore comes from the number of channel sequences in the batch.
 #include "afg_common.h"
 #include "celt_tables.h"
+
+#ifndef AFG_CELT_ABL
+#define AFG_CELT_ABL 0      // development ablations (tools/build_variant.sh): 1 no de-emphasis, 2 no post-filter, 3 no iMDCT
+#endif
 
 #include <cmath>
 #include <mutex>
@@ -229,7 +233,6 @@ __global__ __launch_bounds__(64) void celt_transform_kernel(
     float *st = states ? states + (size_t)chan * AFG_CELT_STATE_FLOATS : nullptr;
 
     PfState pf;
-    float deemph = 0.0f;
     pf.period = pf.period_old = 0;
     pf.g[0] = pf.g[1] = pf.g[2] = pf.g_old[0] = pf.g_old[1] = pf.g_old[2] = 0.0f;
     for (int i = lane; i < 2048; i += 64) buf[i] = st ? st[i] : 0.0f;
@@ -238,7 +241,6 @@ __global__ __launch_bounds__(64) void celt_transform_kernel(
         pf.g[0] = st[2049]; pf.g[1] = st[2050]; pf.g[2] = st[2051];
         pf.period_old = __float_as_int(st[2052]);
         pf.g_old[0] = st[2053]; pf.g_old[1] = st[2054]; pf.g_old[2] = st[2055];
-        deemph = st[2056];
     }
     __syncthreads();
 
@@ -251,6 +253,11 @@ __global__ __launch_bounds__(64) void celt_transform_kernel(
         // iMDCT and overlap-add, dopus.d:3684-3690
         for (int j = 0; j < blocks; j++) {
             float *dst = buf + 1024 + j * blocksize;
+#if AFG_CELT_ABL == 3
+            for (int i = lane; i < blocksize; i += 64) dst[60 + i] = src[i * blocks + j];
+            __syncthreads();
+            continue;
+#endif
             imdct_half_wave(dst + 60, tmp, src + j, blocks, fr.imdct_scale, N, tables, tb);
             if (lane < 60) {                                            // vector_fmul_window, dopus.d:230-243
                 const int k = lane;
@@ -265,14 +272,18 @@ __global__ __launch_bounds__(64) void celt_transform_kernel(
         // celt_postfilter, dopus.d:3357-3378
         {
             const int len = frame_size;
+#if AFG_CELT_ABL != 2
             pf_transition(buf + 1024, pf);
+#endif
             pf.period_old = pf.period;
             pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             pf.period = fr.pf_period_new;
             pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
             if (len > 120) {
+#if AFG_CELT_ABL != 2
                 pf_transition(buf + 1024 + 120, pf);
                 pf_apply(buf + 1024 + 240, len - 240, pf);
+#endif
                 pf.period_old = pf.period;
                 pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             }
@@ -287,22 +298,12 @@ __global__ __launch_bounds__(64) void celt_transform_kernel(
             }
         }
 
-        // de-emphasis and output scaling, dopus.d:3695-3701: serial, evaluated by every lane
+        // the post-filtered frame leaves for the output plane as is; the de-emphasis recurrence runs over it in
+        // place in celt_deemph_kernel (one lane per channel sequence instead of 64 redundant lanes)
         {
-            float m = deemph;
             const float *x = buf + 1024 - frame_size;
             float *o = out + fr.out_off;
-            for (int j0 = 0; j0 < frame_size; j0 += 64) {
-                float keep = 0.0f;
-                const int nj = min(64, frame_size - j0);
-                for (int jj = 0; jj < nj; jj++) {
-                    const float t = x[j0 + jj] + m;
-                    m = t * 0.85000610f;
-                    keep = (jj == lane) ? t : keep;
-                }
-                if (lane < nj) o[(size_t)(j0 + lane) * fr.out_stride] = keep * (1.0f / 32768.0f);   // tmp / 32768. (exact)
-            }
-            deemph = m;
+            for (int j = lane; j < frame_size; j += 64) o[(size_t)j * fr.out_stride] = x[j];
         }
         __syncthreads();
     }
@@ -315,9 +316,170 @@ __global__ __launch_bounds__(64) void celt_transform_kernel(
             st[2049] = pf.g[0]; st[2050] = pf.g[1]; st[2051] = pf.g[2];
             st[2052] = __int_as_float(pf.period_old);
             st[2053] = pf.g_old[0]; st[2054] = pf.g_old[1]; st[2055] = pf.g_old[2];
-            st[2056] = deemph;
         }
     }
+}
+
+// De-emphasis and output scaling (dopus.d:3695-3701) over the planes celt_transform_kernel wrote:
+//   tmp = x[j] + m;  m = tmp * 0.85000610f;  out[j] = tmp / 32768
+// a one-pole IIR across the whole channel sequence whose float rounding order cannot be re-associated, so the
+// time axis is serial and the parallel axis is the channel sequence: one lane per sequence, 32 sequences per
+// wavefront.  Memory is touched in whole rows: a step takes 40 samples of every sequence (40 divides every CELT
+// frame size) as 16-byte loads along the interleaved rows, transposes them through LDS (de-interleaving stereo
+// rows), runs the 32 chains, and goes back the same way; two steps are kept in flight in registers.  Layouts
+// the row scheme does not cover (stride > 2, unaligned or ragged rows) take the per-lane strided path.
+#ifndef AFG_CELT_DE_SEQ
+#define AFG_CELT_DE_SEQ 32
+#endif
+#ifndef AFG_CELT_DE_DEPTH
+#define AFG_CELT_DE_DEPTH 4
+#endif
+constexpr int kDeSeq = AFG_CELT_DE_SEQ;                      // channel sequences per wavefront
+constexpr int kDeDepth = AFG_CELT_DE_DEPTH;                  // steps kept in flight
+constexpr int kDeGroup = 40;
+constexpr int kDePitch = kDeGroup + 4;                       // floats; rows stay 16-byte aligned
+constexpr int kDeQuads = kDeSeq * kDeGroup / 4;              // float4 per step
+constexpr int kDeLoads = (kDeQuads + 63) / 64;               // float4 per lane per step
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int STRIDE>
+__device__ __forceinline__ void deemph_rows(float *xs, float *__restrict__ out, bool have, uint64_t off, int n, float &m)
+{
+    constexpr int F = 10 * STRIDE;                           // float4 per row per step
+    const int lane = threadIdx.x;
+    float *ptr[kDeLoads];
+    int lds_at[kDeLoads];
+    bool valid[kDeLoads];
+#pragma unroll
+    for (int i = 0; i < kDeLoads; i++) {
+        const int idx = lane + 64 * i;
+        const int row = (idx * (STRIDE == 1 ? 6554 : 3277)) >> 16, q = idx - row * F;     // idx / F, idx % F
+        const int lead = row * STRIDE;                       // first chain lane of the row
+        const uint32_t lo = __shfl((uint32_t)off, lead), hi = __shfl((uint32_t)(off >> 32), lead);
+        valid[i] = idx < kDeQuads && __shfl((int)have, lead) != 0;
+        ptr[i] = out + (((uint64_t)hi << 32) | lo) + 4 * q;
+        lds_at[i] = STRIDE == 1 ? row * kDePitch + 4 * q : (2 * row) * kDePitch + 2 * q;
+    }
+    f32x4 ring[kDeDepth][kDeLoads];
+    const int groups = n / kDeGroup;
+    auto load = [&](f32x4 (&b)[kDeLoads], int g) {
+#pragma unroll
+        for (int i = 0; i < kDeLoads; i++)
+            if (valid[i]) b[i] = __builtin_nontemporal_load((const f32x4 *)(ptr[i] + (size_t)g * (kDeGroup * STRIDE)));
+    };
+    auto step = [&](f32x4 (&b)[kDeLoads], int g, int g_next) {
+#pragma unroll
+        for (int i = 0; i < kDeLoads; i++) {
+            if (kDeQuads % 64 != 0 && lane + 64 * i >= kDeQuads) continue;
+            if (STRIDE == 1) {
+                *(f32x4 *)(xs + lds_at[i]) = b[i];
+            } else {                                         // (L,R,L,R) -> two samples of each channel's row
+                *(f32x2 *)(xs + lds_at[i]) = f32x2{ b[i].x, b[i].z };
+                *(f32x2 *)(xs + lds_at[i] + kDePitch) = f32x2{ b[i].y, b[i].w };
+            }
+        }
+        if (g_next < groups) load(b, g_next);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kDeSeq && have) {
+            f32x4 *row = (f32x4 *)(xs + lane * kDePitch);
+            f32x4 v[kDeGroup / 4];
+#pragma unroll
+            for (int k = 0; k < kDeGroup / 4; k++) v[k] = row[k];
+#pragma unroll
+            for (int k = 0; k < kDeGroup / 4; k++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float t = v[k][e] + m;
+                    m = t * 0.85000610f;
+                    v[k][e] = t * (1.0f / 32768.0f);                                // tmp / 32768. (exact)
+                }
+                row[k] = v[k];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < kDeLoads; i++) {
+            f32x4 o;
+            if (kDeQuads % 64 != 0 && lane + 64 * i >= kDeQuads) continue;
+            if (STRIDE == 1) {
+                o = *(const f32x4 *)(xs + lds_at[i]);
+            } else {
+                const f32x2 l = *(const f32x2 *)(xs + lds_at[i]), r = *(const f32x2 *)(xs + lds_at[i] + kDePitch);
+                o = f32x4{ l.x, r.x, l.y, r.y };
+            }
+            if (valid[i]) *(f32x4 *)(ptr[i] + (size_t)g * (kDeGroup * STRIDE)) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+#pragma unroll
+    for (int d = 0; d < kDeDepth; d++)
+        if (d < groups) load(ring[d], d);
+    for (int g = 0; g < groups; g += kDeDepth) {
+#pragma unroll
+        for (int d = 0; d < kDeDepth; d++)
+            if (g + d < groups) step(ring[d], g + d, g + d + kDeDepth);
+    }
+}
+
+__global__ __launch_bounds__(64) void celt_deemph_kernel(
+    const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs, float *__restrict__ out,
+    float *__restrict__ states, uint32_t n_chan)
+{
+    __shared__ __attribute__((aligned(16))) float xs[kDeSeq * kDePitch];
+    const int lane = threadIdx.x;
+    const uint32_t chan = blockIdx.x * (uint32_t)kDeSeq + (uint32_t)lane;
+    const bool mine = lane < kDeSeq && chan < n_chan;
+    float *st = (states && mine) ? states + (size_t)chan * AFG_CELT_STATE_FLOATS : nullptr;
+    float m = st ? st[2056] : 0.0f;
+    uint64_t r = mine ? rec_base[chan] : 0;
+    const uint64_t r_end = mine ? rec_base[chan + 1] : 0;
+    while (__any(r < r_end)) {
+        const bool have = r < r_end;
+        int n = 0, stride = 0;
+        uint64_t off = 0;
+        if (have) {
+            const afg_celt_frame *fr = recs + r;
+            n = fr->frame_size; stride = (int)fr->out_stride; off = fr->out_off;
+            r++;
+        }
+        // can this step of the 32 sequences be walked as rows?
+        const int n0 = __builtin_amdgcn_readfirstlane(n), s0 = __builtin_amdgcn_readfirstlane(stride);
+        bool bad = false;
+        if (lane < kDeSeq) {
+            if (have) bad = n != n0 || stride != s0;
+            if (s0 == 2) {
+                const bool p_have = __shfl_xor((int)have, 1) != 0;
+                const uint32_t plo = __shfl_xor((uint32_t)off, 1), phi = __shfl_xor((uint32_t)(off >> 32), 1);
+                const uint64_t p_off = ((uint64_t)phi << 32) | plo;
+                if (have != p_have) bad = true;
+                else if (have) bad = bad || ((lane & 1) ? off != p_off + 1 : (off & 3) != 0);
+            } else if (have) {
+                bad = bad || (off & 3) != 0;
+            }
+        }
+        const bool rows = (s0 == 1 || s0 == 2) && n0 > 0 && n0 % kDeGroup == 0 && !__any(bad);
+        if (rows) {
+            if (s0 == 2) deemph_rows<2>(xs, out, have, off, n0, m);
+            else deemph_rows<1>(xs, out, have, off, n0, m);
+        } else if (have) {
+            float *o = out + off;
+            for (int j0 = 0; j0 < n; j0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = j0 + k < n ? o[(size_t)(j0 + k) * stride] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (j0 + k < n) {
+                        const float t = x[k] + m;
+                        m = t * 0.85000610f;
+                        o[(size_t)(j0 + k) * stride] = t * (1.0f / 32768.0f);
+                    }
+                }
+            }
+        }
+    }
+    if (st) st[2056] = m;
 }
 
 // ---- host: tables exactly as ff_imdct15_init (dopus.d:1489-1499), in x87 long double like D's real ----
@@ -387,6 +549,9 @@ extern "C" int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_bas
     if (int rc = ensure_tables(&d_tables, &tb)) return rc;
     hipLaunchKernelGGL(celt_transform_kernel, dim3(n_chan), dim3(64), 0, (hipStream_t)hip_stream,
                        d_rec_base, d_recs, d_coeffs, d_out, d_states, d_tables, tb);
+    AFG_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(celt_deemph_kernel, dim3((n_chan + kDeSeq - 1) / kDeSeq), dim3(64), 0, (hipStream_t)hip_stream,
+                       d_rec_base, d_recs, d_out, d_states, n_chan);
     AFG_HIP_CHECK(hipGetLastError());
     return AFG_OK;
 }

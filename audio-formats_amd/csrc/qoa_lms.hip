@@ -18,6 +18,7 @@ constexpr int kSliceLen = 20;
 constexpr int kFramesPerWave = 32;
 constexpr int kStepSlices = 8;                       // slices fetched per channel per refill
 constexpr int kInRow = kStepSlices * 2 + 1;          // 64-bit words per tile row (+1 pad)
+constexpr int kStoreIters = kFramesPerWave * kSliceLen / 64;   // float2 stores per lane per staged step
 
 __device__ const short k_dequant[16 * 8] = {
     1, -1, 3, -3, 5, -5, 7, -7,  5, -5, 18, -18, 32, -32, 49, -49,
@@ -73,6 +74,19 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
         max_samples = b > max_samples ? b : max_samples;
     }
     const int max_slices = (max_samples + kSliceLen - 1) / kSliceLen;
+
+    // store plan of the all-stereo case: float2 slot (lane + 64*it) of a staged step is sample pair k of frame
+    // row r; its output offset and the number of samples left from k are fixed for the whole frame
+    const bool all_stereo = __ballot(C != 2 && me.samples != 0) == 0;
+    uint64_t st_off[kStoreIters];
+    int st_lim[kStoreIters];
+#pragma unroll
+    for (int it = 0; it < kStoreIters; it++) {
+        const int idx2 = lane + 64 * it, r = idx2 / kSliceLen, k = idx2 - r * kSliceLen;
+        const RowInfo m = rows[r];
+        st_off[it] = m.out_off + 2 * k;
+        st_lim[it] = (int)m.samples - k;
+    }
 
     for (int pair = 0; pair < max_pairs; pair++) {
         const int ch = 2 * pair + slot;
@@ -130,6 +144,24 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
                 // stage [frame][sample][slot]
 #pragma unroll
                 for (int k = 0; k < kSliceLen; k++) stage[(fr * kSliceLen + k) * 2 + slot] = outv[k];
+                if (all_stereo) {
+                    // every frame of this wavefront is stereo: the staged step is 32 rows of 20 (L,R) pairs, each
+                    // row contiguous in the output; ten 8-byte stores per lane through the offsets set up above
+                    // (one wavefront per workgroup: its LDS accesses complete in order, no barrier needed)
+                    __builtin_amdgcn_wave_barrier();
+                    const int first = sidx * kSliceLen;
+#pragma unroll
+                    for (int it = 0; it < kStoreIters; it++) {
+                        const float2 v = ((const float2 *)stage)[lane + 64 * it];
+                        if (first < st_lim[it]) {
+                            const uint64_t o = st_off[it] + (uint64_t)first * 2;
+                            if (out_i16) *(short2 *)(out_i16 + o) = make_short2((short)v.x, (short)v.y);
+                            if (out_f32) *(float2 *)(out_f32 + o) = make_float2(v.x * (1.0f / 32767), v.y * (1.0f / 32767));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
                 __syncthreads();
                 // store: frame rows of 20 samples x (1|2) slots
                 for (int idx = lane; idx < kFramesPerWave * kSliceLen * 2; idx += 64) {

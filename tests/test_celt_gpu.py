@@ -62,3 +62,31 @@ def test_celt_chunked_with_state_equals_whole(gpu):
         m = ~np.isnan(got)
         out[m] = got[m]
     assert check(out, want) == 0
+
+
+def test_celt_many_streams_row_path(gpu):
+    """37 stereo + 5 mono streams of equal frame size: the de-emphasis pass walks whole rows (several
+    wavefronts, a partly filled last one, a mono/stereo boundary inside a wavefront)."""
+    rec_base, recs, coeffs, total = synthetic.celt_batch(21, [3] * 42, [2] * 37 + [1] * 5, p_postfilter=0.5)
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    assert check(got, want) == 0
+
+
+def test_celt_padded_output_stride(gpu):
+    """out_stride 3 (stereo written into a 3-channel plane) and an unaligned mono row: per-lane path."""
+    rec_base, recs, coeffs, total = synthetic.celt_batch(22, [4, 4], [2, 1])
+    stereo = recs["out_stride"] == 2
+    recs["out_off"][stereo] = (recs["out_off"][stereo] // 2) * 3 + recs["out_off"][stereo] % 2
+    recs["out_stride"][stereo] = 3
+    base = int(recs["out_off"][stereo].max()) + 3 * 960
+    mono = ~stereo
+    recs["out_off"][mono] = recs["out_off"][mono] - recs["out_off"][mono].min() + base + 1       # odd offset
+    total = int(recs["out_off"][mono].max()) + 960
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    written = np.zeros(total, bool)
+    for r in recs:
+        written[int(r["out_off"]) + np.arange(int(r["frame_size"])) * int(r["out_stride"])] = True
+    assert not np.isnan(got[written]).any() and np.isnan(got[~written]).all()
+    assert np.array_equal(got[written].view(np.uint32), want[written].view(np.uint32))
