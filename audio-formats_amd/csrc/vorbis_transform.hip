@@ -361,7 +361,42 @@ constexpr int kNL = 2048;
 constexpr int kUFloats = kNL / 2 + kNL / 16;       // 1152: padded complex buffer
 constexpr int kWaveLds = kUFloats + kNL / 2;        // + buf2 = 2176 floats >= n
 
-struct alignas(8) f2 { float x, y; };
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Packed fp32 (v_pk_mul_f32 / v_pk_add_f32): one instruction works on a register pair -- a complex
+// value.  op_sel / op_sel_hi pick which half of each source feeds the low / high result, neg_lo /
+// neg_hi flip the sign of a source half; every product and sum is rounded exactly as the scalar
+// expression it replaces (a*(-b) == -(a*b), a + (-b) == a - b), so results stay bit-identical to the
+// reference's expression trees.  The compiler folds whole-pair swizzles and negations by itself;
+// mixed-sign forms are spelled out here.
+#define AFG_PK(name, op, mods)                                                              \
+    __device__ __forceinline__ f2 name(f2 a, f2 b)                                          \
+    {                                                                                       \
+        f2 r;                                                                               \
+        asm(op " %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b));                             \
+        return r;                                                                           \
+    }
+AFG_PK(pk_mul_ll_hl, "v_pk_mul_f32", "op_sel:[0,0] op_sel_hi:[1,0]")                        // ( a.x*b.x ,  a.y*b.x)
+AFG_PK(pk_mul_xneg, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]")            // (-a.y*b.y ,  a.x*b.y)
+AFG_PK(pk_mul_lh_ll, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[0,0]")                        // ( a.x*b.y ,  a.x*b.x)
+AFG_PK(pk_mul_ll_lnh, "v_pk_mul_f32", "op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]")          // ( a.x*b.x , -a.x*b.y)
+AFG_PK(pk_mul_nhh_nhl, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]")   // (-a.y*b.y , -a.y*b.x)
+AFG_PK(pk_mul_nhl_hh, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0]")          // (-a.y*b.x ,  a.y*b.y)
+AFG_PK(pk_mul_hl_ll, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,0]")                        // ( a.y*b.x ,  a.x*b.x)
+AFG_PK(pk_mul_nlh_hh, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[1,0]")          // (-a.x*b.y ,  a.y*b.y)
+AFG_PK(pk_mul_lh_hh, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,1]")                        // ( a.x*b.y ,  a.y*b.y)
+AFG_PK(pk_mul_hl_nll, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]")          // ( a.y*b.x , -a.x*b.x)
+AFG_PK(pk_mul_lh_nll, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[1,0]")          // ( a.x*b.y , -a.x*b.x)
+AFG_PK(pk_mul_nhl_nhh, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]")   // (-a.y*b.x , -a.y*b.y)
+AFG_PK(pk_add_swap, "v_pk_add_f32", "op_sel:[1,1] op_sel_hi:[0,0]")                         // ( a.y+b.y ,  a.x+b.x)
+AFG_PK(pk_add_lh_hnl, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")          // ( a.x+b.y ,  a.y-b.x)
+AFG_PK(pk_add_hnl_lh, "v_pk_add_f32", "op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1]")          // ( a.y-b.x ,  a.x+b.y)
+AFG_PK(pk_add_hnh_nll, "v_pk_add_f32", "op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]")   // ( a.y-b.y , -a.x+b.x)
+AFG_PK(pk_add_lnh_hl, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")          // ( a.x-b.y ,  a.y+b.x)
+AFG_PK(pk_add_lnl_hh, "v_pk_add_f32", "op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[0,1]")          // ( a.x-b.x ,  a.y+b.y)
+AFG_PK(pk_add_ll_hnh, "v_pk_add_f32", "op_sel:[0,0] op_sel_hi:[1,1] neg_hi:[0,1]")          // ( a.x+b.x ,  a.y-b.y)
+AFG_PK(pk_add_lnl_nhh, "v_pk_add_f32", "op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]")   // ( a.x-b.x , -a.y+b.y)
+#undef AFG_PK
 
 __device__ __forceinline__ int pad_e(int m) { return m + (m >> 3); }
 
@@ -387,12 +422,9 @@ __device__ __forceinline__ const T *fresh(const T *p)
 
 __device__ __forceinline__ void bfly2(f2 &p, f2 &q, f2 c)
 {
-    const float d0 = p.x - q.x;
-    const float d1 = p.y - q.y;
-    p.x = p.x + q.x;
-    p.y = p.y + q.y;
-    q.x = d0 * c.x - d1 * c.y;
-    q.y = d1 * c.x + d0 * c.y;
+    const f2 d = p - q;
+    p = p + q;
+    q = pk_mul_ll_hl(d, c) + pk_mul_xneg(d, c);       // (d.x*c.x - d.y*c.y, d.y*c.x + d.x*c.y)
 }
 
 // issue the loads of one channel spectrum (n = 2048): 4 x 16 bytes per lane
@@ -447,16 +479,14 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int q = lane + 64 * r, qm = n8 - 1 - q;
-        const float4 x = xin[r];
+        const f2 xa = f2{ xin[r].x, xin[r].y }, xb = f2{ xin[r].z, xin[r].w };
         const f2 a0 = A2p[q];                       // A[2q], A[2q+1]
         const f2 a1 = A2p[n8 + qm];                 // A[n4+2q'], A[n4+2q'+1]
-        f2 d;
-        d.y = (x.x * a0.x - x.z * a0.y);
-        d.x = (x.x * a0.y + x.z * a0.x);
+        // d.x = x.x*a0.y + x.z*a0.x, d.y = x.x*a0.x - x.z*a0.y
+        const f2 d = pk_mul_lh_ll(xa, a0) + pk_mul_ll_lnh(xb, a0);
         V[n4 - 1 - q] = d;                          // buf2[n2-2-2q], [n2-1-2q]
-        f2 g;
-        g.y = (-x.w * a1.x - -x.y * a1.y);
-        g.x = (-x.w * a1.y + -x.y * a1.x);
+        // g.x = -x.w*a1.y + -x.y*a1.x, g.y = -x.w*a1.x - -x.y*a1.y
+        const f2 g = pk_mul_nhh_nhl(xb, a1) + pk_mul_nhl_hh(xa, a1);
         V[q] = g;                                   // buf2[n4-2-2q'] = buf2[2q]
     }
     __builtin_amdgcn_wave_barrier();
@@ -469,13 +499,10 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         const f2 e0 = V[n8 + it];                   // v[n4+o], v[n4+o+1], o = 2 it
         const f2 e1 = V[it];
         const f2 aa = tw.p1[r];                     // A[n2-4-2o], A[n2-3-2o]
-        const float v41_21 = e0.y - e1.y;
-        const float v40_20 = e0.x - e1.x;
-        f2 hi, lo;
-        hi.x = e0.y + e1.y;                         // d0[1]
-        hi.y = e0.x + e1.x;                         // d0[0]
-        lo.x = v41_21 * aa.x - v40_20 * aa.y;       // d1[1]
-        lo.y = v40_20 * aa.x + v41_21 * aa.y;       // d1[0]
+        const f2 df = e0 - e1;                      // (v40_20, v41_21)
+        const f2 hi = pk_add_swap(e0, e1);          // (d0[1], d0[0])
+        // lo.x = v41_21*aa.x - v40_20*aa.y (d1[1]), lo.y = v40_20*aa.x + v41_21*aa.y (d1[0])
+        const f2 lo = pk_mul_hl_ll(df, aa) + pk_mul_nlh_hh(df, aa);
         U[pad_e(n8 - 1 - it)] = hi;
         U[pad_e(n4 - 1 - it)] = lo;
     }
@@ -535,61 +562,40 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     // zz[i] = z[-i]
     {
         const float A2 = A[n >> 3];
+        const f2 A2p2 = f2{ A2, A2 };
         const int b9 = 9 * lane;                    // pad_e(8 lane)
-        float zz[16];
+        f2 t[8];                                    // t[k] = (zz[2k], zz[2k+1]), zz[i] = z[-i]
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const f2 t = U[b9 + k];
-            zz[2 * k] = t.x;
-            zz[2 * k + 1] = t.y;
+        for (int k = 0; k < 8; k++) t[k] = U[b9 + k];
+        {
+            const f2 K = t[0] - t[4];               // (k00, k11)
+            const f2 L = t[1] - t[5];               // (l00, l11)
+            t[0] = t[0] + t[4];
+            t[1] = t[1] + t[5];
+            t[4] = K;                                                   // zz[8] = k00, zz[9] = k11
+            t[5] = pk_add_lh_hnl(L, L) * A2p2;                          // ((l00+l11)*A2, (l11-l00)*A2)
         }
-        float k00, k11, l00, l11;
-        k00 = zz[0] - zz[8];
-        k11 = zz[1] - zz[9];
-        l00 = zz[2] - zz[10];
-        l11 = zz[3] - zz[11];
-        zz[0] = zz[0] + zz[8];
-        zz[1] = zz[1] + zz[9];
-        zz[2] = zz[2] + zz[10];
-        zz[3] = zz[3] + zz[11];
-        zz[8] = k00;
-        zz[9] = k11;
-        zz[10] = (l00 + l11) * A2;
-        zz[11] = (l11 - l00) * A2;
-
-        k00 = zz[4] - zz[12];
-        k11 = zz[5] - zz[13];
-        l00 = zz[6] - zz[14];
-        l11 = zz[7] - zz[15];
-        zz[4] = zz[4] + zz[12];
-        zz[5] = zz[5] + zz[13];
-        zz[6] = zz[6] + zz[14];
-        zz[7] = zz[7] + zz[15];
-        zz[12] = k11;
-        zz[13] = -k00;
-        zz[14] = (l11 - l00) * A2;
-        zz[15] = (l00 + l11) * -A2;
-#pragma unroll
-        for (int h = 0; h < 16; h += 8) {           // iter_54 (:1866-1896) on z and z-8
-            const float i00 = zz[h + 0] - zz[h + 4];
-            const float y0 = zz[h + 0] + zz[h + 4];
-            const float y2 = zz[h + 2] + zz[h + 6];
-            const float i22 = zz[h + 2] - zz[h + 6];
-            zz[h + 0] = y0 + y2;
-            zz[h + 2] = y0 - y2;
-            const float i33 = zz[h + 3] - zz[h + 7];
-            zz[h + 4] = i00 + i33;
-            zz[h + 6] = i00 - i33;
-            const float i11 = zz[h + 1] - zz[h + 5];
-            const float y1 = zz[h + 1] + zz[h + 5];
-            const float y3 = zz[h + 3] + zz[h + 7];
-            zz[h + 1] = y1 + y3;
-            zz[h + 3] = y1 - y3;
-            zz[h + 5] = i11 - i22;
-            zz[h + 7] = i11 + i22;
+        {
+            const f2 L = t[3] - t[7];               // (l00, l11)
+            const f2 k6 = pk_add_hnh_nll(t[2], t[6]);                   // (k11, -k00) = (zz5-zz13, zz12-zz4)
+            t[2] = t[2] + t[6];
+            t[3] = t[3] + t[7];
+            t[6] = k6;
+            t[7] = pk_add_hnl_lh(L, L) * f2{ A2, -A2 };                 // ((l11-l00)*A2, (l00+l11)*-A2)
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) U[b9 + k] = f2{ zz[2 * k], zz[2 * k + 1] };
+        for (int h = 0; h < 8; h += 4) {            // iter_54 (:1866-1896) on z and z-8
+            const f2 y02 = t[h] + t[h + 2];         // (y0, y1)
+            const f2 i01 = t[h] - t[h + 2];         // (i00, i11)
+            const f2 y23 = t[h + 1] + t[h + 3];     // (y2, y3)
+            const f2 i23 = t[h + 1] - t[h + 3];     // (i22, i33)
+            t[h] = y02 + y23;
+            t[h + 1] = y02 - y23;
+            t[h + 2] = pk_add_lh_hnl(i01, i23);     // (i00 + i33, i11 - i22)
+            t[h + 3] = pk_add_lnh_hl(i01, i23);     // (i00 - i33, i11 + i22)
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) U[b9 + k] = t[k];
     }
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
@@ -626,34 +632,31 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         for (int r = 0; r < 4; r++) {
             const int sidx = lane + 64 * r;
             const f2 cc = C2[sidx];
-            const float a02 = dn[r].x - en[r].x;
-            const float a11 = dn[r].y + en[r].y;
-            const float b0 = cc.y * a02 + cc.x * a11;
-            const float b1 = cc.y * a11 - cc.x * a02;
-            const float b2 = dn[r].x + en[r].x;
-            const float b3 = dn[r].y - en[r].y;
-            const f2 dnew = f2{ b2 + b0, b3 + b1 };
-            const f2 enew = f2{ b2 - b0, b1 - b3 };
-            // step 8 for x = sidx (pair v2[n4-1-x] = enew) and x = n4-1-sidx (pair v2[sidx] = dnew)
+            const f2 aa = pk_add_lnl_hh(dn[r], en[r]);                  // (a02, a11)
+            const f2 bs = pk_add_ll_hnh(dn[r], en[r]);                  // (b2, b3)
+            // b0 = cc.y*a02 + cc.x*a11, b1 = cc.y*a11 - cc.x*a02
+            const f2 bq = pk_mul_lh_hh(aa, cc) + pk_mul_hl_nll(aa, cc);
+            const f2 dnew = bs + bq;                                    // (b2 + b0, b3 + b1)
+            const f2 enew = pk_add_lnl_nhh(bs, bq);                     // (b2 - b0, b1 - b3)
+            // step 8 for x = sidx (pair v2[n4-1-x] = enew) and x = n4-1-sidx (pair v2[sidx] = dnew):
+            //   pa = e.x*bb.y - e.y*bb.x, pb = -e.x*bb.x - e.y*bb.y
             {
                 const int x = sidx;
                 const f2 bb = B2[n4 - 1 - x];
-                const float pa = enew.x * bb.y - enew.y * bb.x;
-                const float pb = -enew.x * bb.x - enew.y * bb.y;
-                smem[x] = pa;
-                smem[n2 - 1 - x] = -pa;
-                smem[n2 + x] = pb;
-                smem[n - 1 - x] = pb;
+                const f2 pp = pk_mul_lh_nll(enew, bb) + pk_mul_nhl_nhh(enew, bb);
+                smem[x] = pp.x;
+                smem[n2 - 1 - x] = -pp.x;
+                smem[n2 + x] = pp.y;
+                smem[n - 1 - x] = pp.y;
             }
             {
                 const int x = n4 - 1 - sidx;
                 const f2 bb = B2[sidx];
-                const float pa = dnew.x * bb.y - dnew.y * bb.x;
-                const float pb = -dnew.x * bb.x - dnew.y * bb.y;
-                smem[x] = pa;
-                smem[n2 - 1 - x] = -pa;
-                smem[n2 + x] = pb;
-                smem[n - 1 - x] = pb;
+                const f2 pp = pk_mul_lh_nll(dnew, bb) + pk_mul_nhl_nhh(dnew, bb);
+                smem[x] = pp.x;
+                smem[n2 - 1 - x] = -pp.x;
+                smem[n2 + x] = pp.y;
+                smem[n - 1 - x] = pp.y;
             }
         }
     }
@@ -664,6 +667,16 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 #ifndef AFG_VORBIS_MIN_WAVES
 #define AFG_VORBIS_MIN_WAVES 2
 #endif
+// Make the prefetched spectrum resident *here*: the wait this forces only covers loads that were
+// issued a whole transform ago.  (Loads and stores share one in-order counter on gfx9-class hardware;
+// waiting for a load that was issued after a batch of PCM stores would wait for those stores too.)
+__device__ __forceinline__ void settle(float4 (&x)[4])
+{
+    asm volatile("" : "+v"(x[0].x), "+v"(x[0].y), "+v"(x[0].z), "+v"(x[0].w), "+v"(x[1].x), "+v"(x[1].y), "+v"(x[1].z),
+                 "+v"(x[1].w), "+v"(x[2].x), "+v"(x[2].y), "+v"(x[2].z), "+v"(x[2].w), "+v"(x[3].x), "+v"(x[3].y),
+                 "+v"(x[3].z), "+v"(x[3].w) : : "memory");
+}
+
 template <int C>                                     // channels: 1 or 2 on this path
 __device__ __forceinline__ void vorbis_wave_body(
     float *smem, const float *ltab, const VorbisSeg &seg, const VorbisStream &st,
@@ -681,60 +694,97 @@ __device__ __forceinline__ void vorbis_wave_body(
     const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
     const int p_end = (int)(seg.p0 + seg.count);
 
-    // spectrum of the first transform
-    float4 xin[4];
-    {
-        const uint64_t gp = st.pkt_base + (uint64_t)p_first;
-        if (pflags[gp] & AFG_VORBIS_LONG) load_spectrum(xin, spec + spec_off[gp]);
-    }
+    // flags of packets [fbase, fbase + 64), one per lane: the packet loop reads them with a lane read
+    // instead of a (vector-memory) byte load per packet
+    int fbase = 0;
+    unsigned fl_reg = 0;
+    uint64_t so_reg = 0, oo_reg = 0;                  // spectrum / output offsets of the same packets
+    auto refill = [&](int from) {
+        fbase = from;
+        const int q = from + lane;
+        const bool in = q < p_end;
+        fl_reg = in ? (unsigned)pflags[st.pkt_base + (uint64_t)q] : 0u;
+        so_reg = in ? spec_off[st.pkt_base + (uint64_t)q] : 0;
+        oo_reg = in ? out_off[st.pkt_base + (uint64_t)q] : 0;
+    };
+    auto flags_of = [&](int p) -> unsigned { return (unsigned)__builtin_amdgcn_readlane((int)fl_reg, p - fbase); };
+    auto lane64 = [&](uint64_t v, int p) -> uint64_t {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, p - fbase);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), p - fbase);
+        return ((uint64_t)hi << 32) | lo;
+    };
+    refill(p_first);
+
+    // The spectrum of transform k+1 sits in xin while transform k runs from xcur; the loads of k+2 are
+    // issued after the PCM stores of k (see settle()).
+    float4 xin[4], xcur[4];
+    auto issue = [&](int p, int c) {
+        if (p < p_end && (flags_of(p) & AFG_VORBIS_LONG))
+            load_spectrum(xin, spec + lane64(so_reg, p) + c * (kNL / 2));
+    };
+    issue(p_first, 0);
+    settle(xin);
+#pragma unroll
+    for (int r = 0; r < 4; r++) xcur[r] = xin[r];
+    if (C == 2) issue(p_first, 1);
+    else issue(p_first + 1, 0);
 
     for (int p = p_first; p < p_end; p++) {
-        const uint64_t gp = st.pkt_base + (uint64_t)p;
-        const unsigned fl = pflags[gp];
+        if (p + 2 - fbase >= 64) refill(p);
+        const unsigned fl = flags_of(p);
         int n, left, right, right_end;
         window_bounds(bs0, bs1, fl, n, left, right, right_end);
         const int n2 = n >> 1;
         const int which = (fl & AFG_VORBIS_LONG) ? 1 : 0;
         const float *T = tables + st.tab[which];
         const float *A = T, *B = T + n2, *Ct = T + n;
-        const float *src = spec + spec_off[gp];
+        const float *src = spec + lane64(so_reg, p);
         const bool emit = (p >= (int)seg.p0) && previous_length > 0;
         const int pn = previous_length;
         const float *w = (pn * 2 == kNL) ? ltab + kNL + kNL / 4                                 // get_window(pn), :2245-2251
                                          : tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);
         const int nout = right - left;
-        float *o = out + out_off[gp];
+        float *o = out + lane64(oo_reg, p);
 
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            {
-                if (which) {
-                    float4 xcur[4];
+            if (which) {
+                imdct_2048_wave(xcur, smem, tw, ltab, ltab + kNL / 2, ltab + kNL);   // :2526-2527, tables in LDS
+            } else {
+                for (int k = lane; k < n2; k += 64) smem[k] = src[c * n2 + k];
+                __builtin_amdgcn_wave_barrier();
+                inverse_mdct_lds<64>(smem, smem + n, n, 31 - __clz(n), A, B, Ct);
+            }
+            settle(xin);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) xcur[r] = xin[r];
-                    // next transform's spectrum: other channel of this packet, or channel 0 of the next
-                    {
-                        const bool more_here = (c + 1 < C);
-                        const int pnx = more_here ? p : p + 1;
-                        if (pnx < p_end) {
-                            const uint64_t gq = st.pkt_base + (uint64_t)pnx;
-                            if (pflags[gq] & AFG_VORBIS_LONG)
-                                load_spectrum(xin, spec + spec_off[gq] + (more_here ? (c + 1) * (kNL / 2) : 0));
-                        }
-                    }
-                    imdct_2048_wave(xcur, smem, tw, ltab, ltab + kNL / 2, ltab + kNL);   // :2526-2527, tables in LDS
-                } else {
-                    for (int k = lane; k < n2; k += 64) smem[k] = src[c * n2 + k];
-                    __builtin_amdgcn_wave_barrier();
-                    inverse_mdct_lds<64>(smem, smem + n, n, 31 - __clz(n), A, B, Ct);
-                    // the following transform (if long) was not prefetched while this one ran
-                    if (c + 1 == C && p + 1 < p_end) {
-                        const uint64_t gq = st.pkt_base + (uint64_t)(p + 1);
-                        if (pflags[gq] & AFG_VORBIS_LONG) load_spectrum(xin, spec + spec_off[gq]);
-                    }
+            for (int r = 0; r < 4; r++) xcur[r] = xin[r];
+            // vorbis_finish_frame (:2606-2657) + interleave (:3927-3952) for this channel: each
+            // channel stores its own 4-byte column of the interleaved frames (merged in L2)
+            if (which && pn * 2 == kNL && nout == kNL / 2 && right_end - right == kNL / 2) {
+                // long block between long blocks (the common case): fixed trip counts, so all LDS reads of the
+                // window / overlap step are in flight together instead of one dependent round trip per 64 samples
+                const float *pw = prevw + c * 1024;
+                float cur[16], nxt[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    cur[i] = smem[left + lane + 64 * i];
+                    nxt[i] = smem[right + lane + 64 * i];
                 }
-                // vorbis_finish_frame (:2606-2657) + interleave (:3927-3952) for this channel: each
-                // channel stores its own 4-byte column of the interleaved frames (merged in L2)
+                if (emit) {
+                    float pv[16], wa[16], wb[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        pv[i] = pw[lane + 64 * i];
+                        wa[i] = w[lane + 64 * i];
+                        wb[i] = w[1023 - lane - 64 * i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        o[(lane + 64 * i) * C + c] = cur[i] * wa[i] + pv[i] * wb[i];       // :2624-2626
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) prevw[c * 1024 + lane + 64 * i] = nxt[i];      // :2641-2643
+            } else {
                 if (emit) {
                     const float *wt = w;
                     const float *pw = prevw + c * 1024;
@@ -745,8 +795,11 @@ __device__ __forceinline__ void vorbis_wave_body(
                 }
                 for (int k = lane; k < right_end - right; k += 64)
                     prevw[c * 1024 + k] = smem[right + k];                                     // :2641-2643
-                __builtin_amdgcn_wave_barrier();
             }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            if (C == 2) issue(p + 1, c);
+            else issue(p + 2, 0);
         }
         previous_length = right_end - right;
     }
@@ -766,9 +819,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void vorbis_wave_kernel(
     float *ltab = lds;                                                   // one copy per workgroup
     for (int i = threadIdx.x; i < kTabFloats; i += 64 * kWavesPerGroup) ltab[i] = tables[tab2048 + i];
     __syncthreads();                                                     // the only block-level barrier
-    const uint32_t sidx = blockIdx.x * kWavesPerGroup + (threadIdx.x >> 6);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: segment and
+    const uint32_t sidx = blockIdx.x * kWavesPerGroup + wave;                                  // stream records load as SMEM
     if (sidx >= n_segs) return;
-    float *smem = lds + kTabFloats + (threadIdx.x >> 6) * kWaveStride;
+    float *smem = lds + kTabFloats + wave * kWaveStride;
     const VorbisSeg seg = segs[sidx];
     const VorbisStream st = streams[seg.stream];
     if (st.nch == 1) vorbis_wave_body<1>(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
