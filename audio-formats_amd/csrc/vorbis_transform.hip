@@ -32,7 +32,7 @@ struct VorbisSeg {
     uint32_t stream;
     uint32_t p0;       // first packet (stream-relative)
     uint32_t count;
-    uint32_t pad;
+    uint32_t pad;      // wave path: channel walked by this wavefront
 };
 
 struct VorbisStream {
@@ -442,32 +442,55 @@ __device__ __forceinline__ void load_spectrum(float4 (&x)[4], const float *__res
 // inverse_mdct for n = 2048 (stb_vorbis2.d:1941-2242); result in smem[0..2048)
 // Twiddles of the passes whose lane -> table index mapping is strided (they would hit a few LDS
 // banks only): they do not depend on the packet, so each lane keeps its own in registers.
-struct LaneTwiddles {
-    f2 p1[4];       // step 2:        A[n2-4-2o], o = 2 (lane + 64 r)
-    f2 pa[3];       // stages 0, 1:   A[j << 3], A[(j+64) << 3], A[j << 4]
-    f2 pb[7];       // stages 2..4:   A[(jp+8k) << 5] k<4, A[(jp+8k) << 6] k<2, A[jp << 7]
-};
-
-__device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &t, const float *A)
+#ifndef AFG_VORBIS_TW_REGS
+#define AFG_VORBIS_TW_REGS 1
+#endif
+constexpr int kLaneTw = 14;                          // lane-constant twiddles per lane
+constexpr int kTabBase = kNL / 2 + kNL / 2 + kNL / 4 + kNL / 2;      // A B C window of n = 2048 (floats)
+constexpr int kTabFloats = kTabBase + (AFG_VORBIS_TW_REGS ? 0 : kLaneTw * 64 * 2);   // + the lane-major twiddle copy
+// which A entry lane `lane` needs as its i-th lane-constant twiddle (complex index into A)
+__device__ __forceinline__ int lane_twiddle_index(int i, int lane)
 {
     constexpr int n4 = kNL / 4;
-    const int lane = threadIdx.x & 63;
-    const f2 *A2p = (const f2 *)A;
-#pragma unroll
-    for (int r = 0; r < 4; r++) t.p1[r] = A2p[n4 - 2 - 2 * (lane + 64 * r)];
-    t.pa[0] = A2p[4 * lane];
-    t.pa[1] = A2p[4 * (lane + 64)];
-    t.pa[2] = A2p[8 * lane];
     const int jp = lane & 7;
-#pragma unroll
-    for (int k = 0; k < 4; k++) t.pb[k] = A2p[16 * (jp + 8 * k)];
-#pragma unroll
-    for (int k = 0; k < 2; k++) t.pb[4 + k] = A2p[32 * (jp + 8 * k)];
-    t.pb[6] = A2p[64 * jp];
+    if (i < 4) return n4 - 2 - 2 * (lane + 64 * i);             // step 2:      A[n2-4-2o], o = 2 (lane + 64 r)
+    if (i == 4) return 4 * lane;                                // stages 0, 1: A[j << 3]
+    if (i == 5) return 4 * (lane + 64);                         //              A[(j+64) << 3]
+    if (i == 6) return 8 * lane;                                //              A[j << 4]
+    if (i < 11) return 16 * (jp + 8 * (i - 7));                 // stages 2..4: A[(jp+8k) << 5], k < 4
+    if (i < 13) return 32 * (jp + 8 * (i - 11));                //              A[(jp+8k) << 6], k < 2
+    return 64 * jp;                                             //              A[jp << 7]
 }
 
+#if AFG_VORBIS_TW_REGS
+struct LaneTwiddles {                                // kept in registers
+    f2 v[kLaneTw];
+    __device__ __forceinline__ f2 p1(int r) const { return v[r]; }
+    __device__ __forceinline__ f2 pa(int i) const { return v[4 + i]; }
+    __device__ __forceinline__ f2 pb(int k) const { return v[7 + k]; }
+};
+__device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &t, const float *A, const float *)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < kLaneTw; i++) t.v[i] = ((const f2 *)A)[lane_twiddle_index(i, lane)];
+}
+#else
+struct LaneTwiddles {                                // lane-major copy in LDS: [i][lane], conflict-free 8-byte reads
+    const f2 *t;
+    __device__ __forceinline__ f2 p1(int r) const { return t[r * 64]; }
+    __device__ __forceinline__ f2 pa(int i) const { return t[(4 + i) * 64]; }
+    __device__ __forceinline__ f2 pb(int k) const { return t[(7 + k) * 64]; }
+};
+__device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &t, const float *, const float *lane_major)
+{
+    t.t = (const f2 *)lane_major + (threadIdx.x & 63);
+}
+#endif
+
+template <typename AfterStep0>
 __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *smem, const LaneTwiddles &tw,
-                                                const float *A, const float *B, const float *C)
+                                                const float *A, const float *B, const float *C, AfterStep0 after_step0)
 {
     constexpr int n = kNL, n2 = n / 2, n4 = n / 4, n8 = n / 8;
     int lane = fresh_lane();
@@ -490,6 +513,7 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         V[q] = g;                                   // buf2[n4-2-2q'] = buf2[2q]
     }
     __builtin_amdgcn_wave_barrier();
+    after_step0();                                  // the spectrum registers are free from here on
     lane = fresh_lane();
 
     // step 2 (:2006-2040): half-iteration `it` makes points n4-1-it and n8-1-it
@@ -498,7 +522,7 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         const int it = lane + 64 * r;
         const f2 e0 = V[n8 + it];                   // v[n4+o], v[n4+o+1], o = 2 it
         const f2 e1 = V[it];
-        const f2 aa = tw.p1[r];                     // A[n2-4-2o], A[n2-3-2o]
+        const f2 aa = tw.p1(r);                     // A[n2-4-2o], A[n2-3-2o]
         const f2 df = e0 - e1;                      // (v40_20, v41_21)
         const f2 hi = pk_add_swap(e0, e1);          // (d0[1], d0[0])
         // lo.x = v41_21*aa.x - v40_20*aa.y (d1[1]), lo.y = v40_20*aa.x + v41_21*aa.y (d1[0])
@@ -512,9 +536,9 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     // stages l = 0, 1 (:2053-2060): point sets {base + j + 64 r}, lane j, both halves
     {
             const int j = lane;
-        const f2 w00 = tw.pa[0];                    // A[(j) << 3]
-        const f2 w01 = tw.pa[1];                    // A[(j+64) << 3]
-        const f2 w1 = tw.pa[2];                     // A[j << 4]
+        const f2 w00 = tw.pa(0);                    // A[(j) << 3]
+        const f2 w01 = tw.pa(1);                    // A[(j+64) << 3]
+        const f2 w1 = tw.pa(2);                     // A[j << 4]
 #pragma unroll
         for (int hb = 0; hb < 2; hb++) {
             const int base = hb * (n4 / 2) + j;
@@ -540,15 +564,15 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 #pragma unroll
         for (int k = 0; k < 8; k++) e[k] = U[pad_e(base + 8 * k)];
 #pragma unroll
-        for (int k = 0; k < 4; k++) bfly2(e[k], e[k + 4], tw.pb[k]);                    // A[b << 5]
+        for (int k = 0; k < 4; k++) bfly2(e[k], e[k + 4], tw.pb(k));                    // A[b << 5]
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const f2 w = tw.pb[4 + k];                                                    // A[b << 6]
+            const f2 w = tw.pb(4 + k);                                                    // A[b << 6]
             bfly2(e[k], e[k + 2], w);
             bfly2(e[k + 4], e[k + 6], w);
         }
         {
-            const f2 w = tw.pb[6];                                                        // A[b << 7]
+            const f2 w = tw.pb(6);                                                        // A[b << 7]
 #pragma unroll
             for (int k = 0; k < 8; k += 2) bfly2(e[k], e[k + 1], w);
         }
@@ -594,21 +618,16 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
             t[h + 2] = pk_add_lh_hnl(i01, i23);     // (i00 + i33, i11 - i22)
             t[h + 3] = pk_add_lnh_hl(i01, i23);     // (i00 - i33, i11 + i22)
         }
+        // steps 4-6 (:2096-2124) folded into the store: entry e of the bit-reverse table takes points
+        // 511-2*brev8(e) -> v2[511-e] and 510-2*brev8(e) -> v2[255-e].  Point 8*lane+k is 511-(8J+kk) with
+        // J = 63-lane, kk = 7-k, i.e. e = brev2(kk>>1)*64 + brev6(J): a per-k constant minus a per-lane one.
+        f2 *const Vr = V - (int)(__brev((unsigned)(63 - lane)) >> 26);
 #pragma unroll
-        for (int k = 0; k < 8; k++) U[b9 + k] = t[k];
-    }
-    __builtin_amdgcn_wave_barrier();
-    lane = fresh_lane();
-
-    // steps 4-6 (:2096-2124): entry e takes points 511-2*brev8(e) and 510-2*brev8(e)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int e = lane + 64 * r;
-        const int br = (int)(__brev((unsigned)e) >> 24);
-        const f2 pa = U[pad_e(n4 - 1 - 2 * br)];
-        const f2 pb = U[pad_e(n4 - 2 - 2 * br)];
-        V[n4 - 1 - e] = pa;                         // (v[n2-2-2e], v[n2-1-2e]) = (u[k4+1], u[k4])
-        V[n8 - 1 - e] = pb;                         // (v[n4-2-2e], v[n4-1-2e]) = (u[k4+3], u[k4+2])
+        for (int k = 0; k < 8; k++) {
+            constexpr int rev2[4] = { 0, 2, 1, 3 };
+            const int kk = 7 - k;
+            Vr[((kk & 1) ? n8 - 1 : n4 - 1) - 64 * rev2[kk >> 1]] = t[k];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
@@ -677,7 +696,8 @@ __device__ __forceinline__ void settle(float4 (&x)[4])
                  "+v"(x[3].z), "+v"(x[3].w) : : "memory");
 }
 
-template <int C>                                     // channels: 1 or 2 on this path
+// One wavefront walks ONE channel of a segment (the channels of a stream are independent up to the
+// interleave of the output, which is a strided store): half the registers of a two-channel walk.
 __device__ __forceinline__ void vorbis_wave_body(
     float *smem, const float *ltab, const VorbisSeg &seg, const VorbisStream &st,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
@@ -686,13 +706,20 @@ __device__ __forceinline__ void vorbis_wave_body(
 {
     const int lane = threadIdx.x & 63;
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
+    const int C = (int)st.nch, c = (int)seg.pad;      // channels of the stream, channel of this wavefront
 
-    float *const prevw = smem + kWaveLds;             // previous_window: C x 1024 floats behind the transform area
     LaneTwiddles tw;
-    load_lane_twiddles(tw, ltab);
+    load_lane_twiddles(tw, ltab, ltab + kTabBase);
     int previous_length = 0;
     const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
     const int p_end = (int)(seg.p0 + seg.count);
+    const float *const lwin = ltab + kNL + kNL / 4;   // window of n = 2048 (LDS)
+
+    // previous_window (:2641-2643) lives in registers: sample lane + 64 i of channel c in pv[i]
+    // (its length is 64, 128 or 1024 on this path: right_end - right of a 256- or 2048-sample block)
+    float pv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) pv[i] = 0.0f;
 
     // flags of packets [fbase, fbase + 64), one per lane: the packet loop reads them with a lane read
     // instead of a (vector-memory) byte load per packet
@@ -715,22 +742,17 @@ __device__ __forceinline__ void vorbis_wave_body(
     };
     refill(p_first);
 
-    // The spectrum of transform k+1 sits in xin while transform k runs from xcur; the loads of k+2 are
-    // issued after the PCM stores of k (see settle()).
-    float4 xin[4], xcur[4];
-    auto issue = [&](int p, int c) {
+    // One spectrum is in flight: step 0 of transform k empties xin, the loads of transform k+1 follow at once
+    // and are waited for (settle) just before the PCM stores of transform k enter the queue.
+    float4 xin[4];
+    auto issue = [&](int p) {
         if (p < p_end && (flags_of(p) & AFG_VORBIS_LONG))
             load_spectrum(xin, spec + lane64(so_reg, p) + c * (kNL / 2));
     };
-    issue(p_first, 0);
-    settle(xin);
-#pragma unroll
-    for (int r = 0; r < 4; r++) xcur[r] = xin[r];
-    if (C == 2) issue(p_first, 1);
-    else issue(p_first + 1, 0);
+    issue(p_first);
 
     for (int p = p_first; p < p_end; p++) {
-        if (p + 2 - fbase >= 64) refill(p);
+        if (p + 1 - fbase >= 64) refill(p);
         const unsigned fl = flags_of(p);
         int n, left, right, right_end;
         window_bounds(bs0, bs1, fl, n, left, right, right_end);
@@ -741,75 +763,60 @@ __device__ __forceinline__ void vorbis_wave_body(
         const float *src = spec + lane64(so_reg, p);
         const bool emit = (p >= (int)seg.p0) && previous_length > 0;
         const int pn = previous_length;
-        const float *w = (pn * 2 == kNL) ? ltab + kNL + kNL / 4                                 // get_window(pn), :2245-2251
-                                         : tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);
-        const int nout = right - left;
+        const int nout = right - left, plen = right_end - right;
         float *o = out + lane64(oo_reg, p);
 
-#pragma unroll
-        for (int c = 0; c < C; c++) {
+        {
+            auto next = [&]() { issue(p + 1); };
             if (which) {
-                imdct_2048_wave(xcur, smem, tw, ltab, ltab + kNL / 2, ltab + kNL);   // :2526-2527, tables in LDS
+                imdct_2048_wave(xin, smem, tw, ltab, ltab + kNL / 2, ltab + kNL, next);   // :2526-2527, tables in LDS
             } else {
                 for (int k = lane; k < n2; k += 64) smem[k] = src[c * n2 + k];
                 __builtin_amdgcn_wave_barrier();
                 inverse_mdct_lds<64>(smem, smem + n, n, 31 - __clz(n), A, B, Ct);
+                next();
             }
             settle(xin);
-#pragma unroll
-            for (int r = 0; r < 4; r++) xcur[r] = xin[r];
             // vorbis_finish_frame (:2606-2657) + interleave (:3927-3952) for this channel: each
             // channel stores its own 4-byte column of the interleaved frames (merged in L2)
-            if (which && pn * 2 == kNL && nout == kNL / 2 && right_end - right == kNL / 2) {
-                // long block between long blocks (the common case): fixed trip counts, so all LDS reads of the
-                // window / overlap step are in flight together instead of one dependent round trip per 64 samples
-                const float *pw = prevw + c * 1024;
-                float cur[16], nxt[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    cur[i] = smem[left + lane + 64 * i];
-                    nxt[i] = smem[right + lane + 64 * i];
-                }
-                if (emit) {
-                    float pv[16], wa[16], wb[16];
+            if (emit) {
+                const int nwin = pn < nout ? pn : nout;
+                if (pn * 2 == kNL) {                               // get_window(pn), :2245-2251: the long window (LDS)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        pv[i] = pw[lane + 64 * i];
-                        wa[i] = w[lane + 64 * i];
-                        wb[i] = w[1023 - lane - 64 * i];
+                        const int jj = lane + 64 * i;
+                        if (jj < nwin) o[jj * C + c] = smem[left + jj] * lwin[jj] + pv[i] * lwin[1023 - jj];   // :2624-2626
                     }
+                } else {
+                    const float *wt = tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);
 #pragma unroll
-                    for (int i = 0; i < 16; i++)
-                        o[(lane + 64 * i) * C + c] = cur[i] * wa[i] + pv[i] * wb[i];       // :2624-2626
+                    for (int i = 0; i < 2; i++) {                  // pn is 64 or 128 here
+                        const int jj = lane + 64 * i;
+                        if (jj < nwin) o[jj * C + c] = smem[left + jj] * wt[jj] + pv[i] * wt[pn - 1 - jj];
+                    }
                 }
-#pragma unroll
-                for (int i = 0; i < 16; i++) prevw[c * 1024 + lane + 64 * i] = nxt[i];      // :2641-2643
-            } else {
-                if (emit) {
-                    const float *wt = w;
-                    const float *pw = prevw + c * 1024;
-                    const int nwin = pn < nout ? pn : nout;
-                    for (int jj = lane; jj < nwin; jj += 64)
-                        o[jj * C + c] = smem[left + jj] * wt[jj] + pw[jj] * wt[pn - 1 - jj];   // :2624-2626
-                    for (int jj = nwin + lane; jj < nout; jj += 64) o[jj * C + c] = smem[left + jj];
-                }
-                for (int k = lane; k < right_end - right; k += 64)
-                    prevw[c * 1024 + k] = smem[right + k];                                     // :2641-2643
+                for (int jj = nwin + lane; jj < nout; jj += 64) o[jj * C + c] = smem[left + jj];
             }
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if (64 * i < plen) pv[i] = smem[right + lane + 64 * i];                 // :2641-2643
             __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-            if (C == 2) issue(p + 1, c);
-            else issue(p + 2, 0);
         }
-        previous_length = right_end - right;
+        previous_length = plen;
     }
 }
 
-constexpr int kWavesPerGroup = 8;
-constexpr int kWaveStride = kWaveLds + 2 * 1024;      // transform area + previous_window of two channels
-constexpr int kTabFloats = kNL / 2 + kNL / 2 + kNL / 4 + kNL / 2;     // A B C window of n = 2048
+#ifndef AFG_VORBIS_GROUP_WAVES
+#define AFG_VORBIS_GROUP_WAVES 2
+#endif
+constexpr int kWavesPerGroup = AFG_VORBIS_GROUP_WAVES;
+constexpr int kWaveStride = kWaveLds;                 // transform area only: previous_window is in registers
 
-__global__ __launch_bounds__(64 * kWavesPerGroup) void vorbis_wave_kernel(
+#ifndef AFG_VORBIS_WAVES_PER_EU
+#define AFG_VORBIS_WAVES_PER_EU 2
+#endif
+__global__ __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(AFG_VORBIS_WAVES_PER_EU, AFG_VORBIS_WAVES_PER_EU)))
+void vorbis_wave_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
     const uint64_t *__restrict__ out_off, const float *tables, uint32_t tab2048,
@@ -817,7 +824,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void vorbis_wave_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *ltab = lds;                                                   // one copy per workgroup
-    for (int i = threadIdx.x; i < kTabFloats; i += 64 * kWavesPerGroup) ltab[i] = tables[tab2048 + i];
+    for (int i = threadIdx.x; i < kTabBase; i += 64 * kWavesPerGroup) ltab[i] = tables[tab2048 + i];
+    for (int i = threadIdx.x; i < (AFG_VORBIS_TW_REGS ? 0 : kLaneTw * 64); i += 64 * kWavesPerGroup)
+        ((f2 *)(ltab + kTabBase))[i] = ((const f2 *)(tables + tab2048))[lane_twiddle_index(i >> 6, i & 63)];
     __syncthreads();                                                     // the only block-level barrier
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: segment and
     const uint32_t sidx = blockIdx.x * kWavesPerGroup + wave;                                  // stream records load as SMEM
@@ -825,8 +834,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void vorbis_wave_kernel(
     float *smem = lds + kTabFloats + wave * kWaveStride;
     const VorbisSeg seg = segs[sidx];
     const VorbisStream st = streams[seg.stream];
-    if (st.nch == 1) vorbis_wave_body<1>(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
-    else vorbis_wave_body<2>(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
+    vorbis_wave_body(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
 }
 
 int ilog_host(int n)       // stb_vorbis2.d:634-650
@@ -964,7 +972,10 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
         }
         for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
             uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
-            (fast ? wave_segs : segs).push_back(VorbisSeg{ s, p0, cnt, 0 });
+            if (fast)
+                for (uint32_t c = 0; c < channels[s]; c++) wave_segs.push_back(VorbisSeg{ s, p0, cnt, c });   // one per channel
+            else
+                segs.push_back(VorbisSeg{ s, p0, cnt, 0 });
         }
     }
     if (lds > 160 * 1024) {
