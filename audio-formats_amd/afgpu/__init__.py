@@ -52,6 +52,7 @@ ABI_SYMBOLS = [
     "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse",
     "afg_batch_decode", "afg_batch_free",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
+    "afg_copy_probe_hip",
 ]
 
 
@@ -155,6 +156,7 @@ def lib():
     L.afg_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
     L.afg_memcpy_d2h.argtypes = [vp, vp, C.c_size_t, vp]
     L.afg_stream_synchronize.argtypes = [vp]
+    L.afg_copy_probe_hip.argtypes = [vp, vp, C.c_size_t, vp]
     _lib = L
     return L
 
@@ -393,6 +395,11 @@ def batch_decode(files, n_threads=0):
         return out
     finally:
         lib().afg_batch_free(C.byref(res))
+
+
+def copy_probe(d_dst, d_src, nbytes, stream=None):
+    """Enqueue the streaming copy used to measure the practical HBM copy ceiling (afg_copy_probe_hip)."""
+    check(lib().afg_copy_probe_hip(_ptr(d_dst), _ptr(d_src), int(nbytes), _stream(stream)))
 
 
 def device_count():

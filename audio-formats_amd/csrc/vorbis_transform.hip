@@ -19,6 +19,7 @@
 //     rows; twiddle/window tables (host-computed exactly as :851-881) are
 //     shared by all workgroups and served from L2.
 #include "afg_common.h"
+#include "afg_pk.h"
 
 #include <cmath>
 #include <map>
@@ -361,42 +362,7 @@ constexpr int kNL = 2048;
 constexpr int kUFloats = kNL / 2 + kNL / 16;       // 1152: padded complex buffer
 constexpr int kWaveLds = kUFloats + kNL / 2;        // + buf2 = 2176 floats >= n
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// Packed fp32 (v_pk_mul_f32 / v_pk_add_f32): one instruction works on a register pair -- a complex
-// value.  op_sel / op_sel_hi pick which half of each source feeds the low / high result, neg_lo /
-// neg_hi flip the sign of a source half; every product and sum is rounded exactly as the scalar
-// expression it replaces (a*(-b) == -(a*b), a + (-b) == a - b), so results stay bit-identical to the
-// reference's expression trees.  The compiler folds whole-pair swizzles and negations by itself;
-// mixed-sign forms are spelled out here.
-#define AFG_PK(name, op, mods)                                                              \
-    __device__ __forceinline__ f2 name(f2 a, f2 b)                                          \
-    {                                                                                       \
-        f2 r;                                                                               \
-        asm(op " %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b));                             \
-        return r;                                                                           \
-    }
-AFG_PK(pk_mul_ll_hl, "v_pk_mul_f32", "op_sel:[0,0] op_sel_hi:[1,0]")                        // ( a.x*b.x ,  a.y*b.x)
-AFG_PK(pk_mul_xneg, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]")            // (-a.y*b.y ,  a.x*b.y)
-AFG_PK(pk_mul_lh_ll, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[0,0]")                        // ( a.x*b.y ,  a.x*b.x)
-AFG_PK(pk_mul_ll_lnh, "v_pk_mul_f32", "op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]")          // ( a.x*b.x , -a.x*b.y)
-AFG_PK(pk_mul_nhh_nhl, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]")   // (-a.y*b.y , -a.y*b.x)
-AFG_PK(pk_mul_nhl_hh, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0]")          // (-a.y*b.x ,  a.y*b.y)
-AFG_PK(pk_mul_hl_ll, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,0]")                        // ( a.y*b.x ,  a.x*b.x)
-AFG_PK(pk_mul_nlh_hh, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[1,0]")          // (-a.x*b.y ,  a.y*b.y)
-AFG_PK(pk_mul_lh_hh, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,1]")                        // ( a.x*b.y ,  a.y*b.y)
-AFG_PK(pk_mul_hl_nll, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]")          // ( a.y*b.x , -a.x*b.x)
-AFG_PK(pk_mul_lh_nll, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[1,0]")          // ( a.x*b.y , -a.x*b.x)
-AFG_PK(pk_mul_nhl_nhh, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]")   // (-a.y*b.x , -a.y*b.y)
-AFG_PK(pk_add_swap, "v_pk_add_f32", "op_sel:[1,1] op_sel_hi:[0,0]")                         // ( a.y+b.y ,  a.x+b.x)
-AFG_PK(pk_add_lh_hnl, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")          // ( a.x+b.y ,  a.y-b.x)
-AFG_PK(pk_add_hnl_lh, "v_pk_add_f32", "op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1]")          // ( a.y-b.x ,  a.x+b.y)
-AFG_PK(pk_add_hnh_nll, "v_pk_add_f32", "op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]")   // ( a.y-b.y , -a.x+b.x)
-AFG_PK(pk_add_lnh_hl, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")          // ( a.x-b.y ,  a.y+b.x)
-AFG_PK(pk_add_lnl_hh, "v_pk_add_f32", "op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[0,1]")          // ( a.x-b.x ,  a.y+b.y)
-AFG_PK(pk_add_ll_hnh, "v_pk_add_f32", "op_sel:[0,0] op_sel_hi:[1,1] neg_hi:[0,1]")          // ( a.x+b.x ,  a.y-b.y)
-AFG_PK(pk_add_lnl_nhh, "v_pk_add_f32", "op_sel:[0,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]")   // ( a.x-b.x , -a.y+b.y)
-#undef AFG_PK
+// f2 and the packed-arithmetic helpers: afg_pk.h
 
 __device__ __forceinline__ int pad_e(int m) { return m + (m >> 3); }
 

@@ -137,15 +137,16 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
 
-    # device-to-device copy of the same byte volume (spectrum plane -> PCM plane): the practical HBM ceiling
-    # of this box for a read-N/write-N stream, reported next to the 8 TB/s spec the roofline is priced against
+    # device-to-device copy of the same byte volume (spectrum plane -> PCM plane) with the library's streaming
+    # copy kernel: the copy rate this box sustains for a read-N/write-N stream, reported next to the 8 TB/s spec
+    # the roofline is priced against (hipMemcpy / torch copy_ reach only ~4.6-4.9 TB/s on the same buffers)
     copy_ms = []
     if rank == 0:
         scratch = torch.empty_like(coef)
         for i in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            scratch.copy_(coef)
+            afgpu.copy_probe(scratch, coef, coef.numel() * 4)
             e1.record(stream)
             torch.cuda.synchronize()
             if i:

@@ -128,3 +128,94 @@ int afg_device_free(void* d_ptr);
 int afg_memcpy_h2d(void* d_dst, const(void)* src, size_t bytes, void* hip_stream);
 int afg_memcpy_d2h(void* dst, const(void)* d_src, size_t bytes, void* hip_stream);
 int afg_stream_synchronize(void* hip_stream);
+int afg_copy_probe_hip(void* d_dst, const(void)* d_src, size_t bytes, void* hip_stream);
+
+// ---- outer surface: the reading half of AudioStream (stream.d:102-637) ----------------------------
+enum afg_format : int   // AudioFileFormat, stream.d:36-47 (same order)
+{
+    wav = 0, mp3 = 1, flac = 2, ogg = 3, opus = 4, qoa = 5, mod = 6, xm = 7, unknown = 8,
+}
+enum long AFG_UNKNOWN_LENGTH = -1;   // audiostreamUnknownLength, stream.d:90
+
+struct afg_stream;
+afg_stream* afg_open_from_memory(const(ubyte)* data, size_t length);
+int afg_is_error(const(afg_stream)* s);
+const(char)* afg_error_message(const(afg_stream)* s);
+int afg_get_format(const(afg_stream)* s);
+int afg_get_num_channels(const(afg_stream)* s);
+long afg_get_length_in_frames(const(afg_stream)* s);
+float afg_get_samplerate(const(afg_stream)* s);
+int afg_read_samples_float(afg_stream* s, float* outData, int frames);
+void afg_close(afg_stream* s);
+
+struct afg_flac_parsed
+{
+    uint sample_rate, channels, bps, max_block;
+    ulong total_samples;
+    ulong n_frames, n_subframes, n_res, out_samples;
+    afg_flac_frame* frames;
+    afg_flac_subframe* subframes;
+    int* res;
+    void* owner;
+}
+int afg_flac_parse(const(ubyte)* data, size_t length, afg_flac_parsed* parsed);
+void afg_flac_parsed_free(afg_flac_parsed* parsed);
+int afg_qoa_parse(const(ubyte)* data, size_t length, uint* channels, uint* samplerate, uint* samples,
+                  afg_qoa_frame* frames, size_t frame_cap, size_t* n_frames);
+
+struct afg_batch_item
+{
+    int status;
+    const(char)* message;
+    int format;
+    int channels;
+    float samplerate;
+    long frames;
+    float* pcm;
+}
+struct afg_batch_result
+{
+    int n_files;
+    afg_batch_item* items;
+    void* owner;
+}
+int afg_batch_decode(const(ubyte*)* data, const(size_t)* length, int n_files, int n_threads, afg_batch_result* result);
+void afg_batch_free(afg_batch_result* result);
+
+/// Drop-in for the decoding use of `AudioStream` (stream.d:102): same member names and error-state contract
+/// (never throws, `isError` + `errorMessage`), backed by the device library.  Not thread-safe per instance,
+/// like the original (stream.d:31-33).
+struct GpuAudioStream
+{
+nothrow @nogc:
+    private afg_stream* _h;
+
+    @disable this(this);
+    ~this() { cleanUp(); }
+
+    void openFromMemory(const(ubyte)[] inputData)
+    {
+        cleanUp();
+        _h = afg_open_from_memory(inputData.ptr, inputData.length);
+    }
+    void cleanUp() { if (_h !is null) { afg_close(_h); _h = null; } }
+
+    bool isError() { return afg_is_error(_h) != 0; }
+    bool isValid() { return !isError(); }
+    const(char)[] errorMessage()
+    {
+        import core.stdc.string : strlen;
+        const(char)* m = afg_error_message(_h);
+        return m is null ? null : m[0 .. strlen(m)];
+    }
+    afg_format getFormat() { return cast(afg_format) afg_get_format(_h); }
+    int getNumChannels() { return afg_get_num_channels(_h); }
+    long getLengthInFrames() { return afg_get_length_in_frames(_h); }
+    float getSamplerate() { return afg_get_samplerate(_h); }
+    int readSamplesFloat(float* outData, int frames) { return afg_read_samples_float(_h, outData, frames); }
+    int readSamplesFloat(float[] outData)
+    {
+        const int ch = getNumChannels();
+        return ch > 0 ? readSamplesFloat(outData.ptr, cast(int)(outData.length / ch)) : 0;
+    }
+}

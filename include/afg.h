@@ -288,6 +288,9 @@ int afg_device_free(void *d_ptr);
 int afg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *hip_stream);
 int afg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *hip_stream);
 int afg_stream_synchronize(void *hip_stream);
+/* Streaming device-to-device copy (16-byte aligned) used by bench.py to measure the copy rate this device
+ * actually sustains, the practical ceiling the HBM-bound kernels are compared with next to the 8 TB/s spec. */
+int afg_copy_probe_hip(void *d_dst, const void *d_src, size_t bytes, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,35 @@ def bench_celt(dev, streams, frames_per_stream, steps, warmup):
             "bitwise_mismatches": int((got.view(np.uint32) != want.view(np.uint32)).sum())}
 
 
+def bench_flac_e2e(files, frames_per_file, threads):
+    """End to end through afg_batch_decode: file bytes in host memory -> host parse (threads) -> H2D -> restore
+    kernel -> D2H -> interleaved floats in host memory.  One encoded file replicated `files` times."""
+    import time
+    import afgpu
+    import flac_bitstream as fb
+    rng = np.random.default_rng(3)
+    n = 4096 * frames_per_file
+    t = np.arange(n)
+    pcm = np.stack([9000 * np.sin(0.01 * t) + 800 * rng.standard_normal(n),
+                    7000 * np.sin(0.013 * t + 1) + 800 * rng.standard_normal(n)], 1).round().astype(np.int64)
+    data, _ = fb.encode_file(pcm, 16, 4096, orders=(8, 12), use_fixed_every=1000)
+    blobs = [data] * files
+    afgpu.batch_decode(blobs[:2], threads)            # warm up (device init, tables)
+    t0 = time.perf_counter()
+    out = afgpu.batch_decode(blobs, threads)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(files):
+        afgpu.flac_parse(data)                        # host parse alone, one thread (includes the numpy copies)
+    dt_parse = time.perf_counter() - t0
+    ok = all(o["status"] == 0 and o["frames"] == n for o in out)
+    samples = 2 * n * files
+    return {"workload": f"{files} x FLAC 16-bit stereo, {frames_per_file} frames of 4096 ({len(data)} bytes each)",
+            "threads": threads, "all_ok": ok, "seconds": dt, "samples_per_s_end_to_end": samples / dt,
+            "compressed_MBps": len(data) * files / dt / 1e6,
+            "host_parse_one_thread_samples_per_s": samples / dt_parse}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--codec", default="all")
@@ -147,6 +176,8 @@ def main():
     ap.add_argument("--flac-files", type=int, default=4096)
     ap.add_argument("--flac-frames", type=int, default=323)
     ap.add_argument("--flac-float", action="store_true")
+    ap.add_argument("--e2e-files", type=int, default=2048)
+    ap.add_argument("--e2e-threads", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     res = {}
@@ -159,6 +190,8 @@ def main():
     if args.codec in ("all", "qoa"):
         torch.cuda.empty_cache()
         res["qoa"] = bench_qoa(dev, 4096, 4.0, args.steps, args.warmup)
+    if args.codec == "flac_e2e":
+        res["flac_e2e"] = bench_flac_e2e(args.e2e_files, 8, args.e2e_threads)
     if args.codec in ("all", "celt"):
         torch.cuda.empty_cache()
         res["celt"] = bench_celt(dev, 8192, 200, args.steps, args.warmup)
