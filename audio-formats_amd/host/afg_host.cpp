@@ -365,7 +365,7 @@ bool qoa_parse(const uint8_t *d, size_t n, QoaInfo &qi, std::vector<afg_qoa_fram
 }
 
 // ---------------------------------------------------------------------------------------------
-// a decoded file
+// decoded files: one result plane for a whole batch
 // ---------------------------------------------------------------------------------------------
 struct Decoded {
     int status = AFG_OK;
@@ -375,7 +375,7 @@ struct Decoded {
     float samplerate = 0;
     int64_t frames = 0;                 // frames actually decoded
     int64_t declared_frames = AFG_UNKNOWN_LENGTH;
-    std::vector<float> pcm;
+    size_t pcm_off = 0;                 // float offset of this file's interleaved PCM in the result plane
 };
 
 struct Parsed {
@@ -405,96 +405,140 @@ struct DeviceBuf {
     }
 };
 
-// Run the device stage for a set of parsed files (all FLAC records in one launch, all QOA frames
-// in another) and fill their PCM.
-int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, std::vector<Decoded> &out)
+// page-locked host memory: H2D / D2H run at PCIe rate without a staging copy
+struct PinnedBuf {
+    void *p = nullptr;
+    ~PinnedBuf() { release(); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; afg::set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return AFG_ERR_OOM; }
+        return AFG_OK;
+    }
+};
+
+template <typename F>
+void parallel_for(size_t n, unsigned threads, F fn)
+{
+    if (n == 0) return;
+    threads = (unsigned)std::min<size_t>(std::max(1u, threads), n);
+    std::atomic<size_t> next{ 0 };
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) return;
+            fn(i);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+}
+
+struct BatchOut {
+    std::vector<Decoded> files;
+    PinnedBuf plane;                    // all PCM of the batch, FLAC files first then QOA files
+    size_t plane_floats = 0;
+};
+
+// Device stage for a set of parsed files: every FLAC record of the batch in one launch, every QOA frame
+// in another; inputs are gathered (by `threads` host threads) into one page-locked buffer per kind and
+// the results come back as one plane.
+int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out)
 {
     const size_t nf = parsed.size();
-    out.assign(nf, Decoded());
-    // ---- FLAC: concatenate records ----
-    std::vector<afg_flac_frame> frames;
-    std::vector<afg_flac_subframe> subs;
-    size_t res_total = 0, out_total = 0;
-    for (size_t i = 0; i < nf; i++)
-        if (parsed[i].format == AFG_FORMAT_FLAC) { res_total += parsed[i].flac.res.size(); out_total += parsed[i].flac.out_samples; }
-    std::vector<size_t> flac_out_base(nf, 0);
-    if (out_total) {
-        DeviceBuf d_res, d_frames, d_subs, d_out;
-        std::vector<int32_t> res;
-        res.reserve(res_total);
-        size_t ob = 0;
-        for (size_t i = 0; i < nf; i++) {
-            Parsed &p = parsed[i];
-            if (p.format != AFG_FORMAT_FLAC) continue;
-            flac_out_base[i] = ob;
-            const size_t rb = res.size(), sb = subs.size();
-            for (afg_flac_frame f : p.flac.frames) {
-                f.in_off += rb; f.out_off += ob; f.sf_index += (uint32_t)sb;
-                frames.push_back(f);
-            }
-            subs.insert(subs.end(), p.flac.subframes.begin(), p.flac.subframes.end());
-            res.insert(res.end(), p.flac.res.begin(), p.flac.res.end());
-            ob += p.flac.out_samples;
-        }
-        int rc;
-        if ((rc = d_res.alloc(res.size() * 4)) || (rc = d_frames.alloc(frames.size() * sizeof(afg_flac_frame))) ||
-            (rc = d_subs.alloc(subs.size() * sizeof(afg_flac_subframe))) || (rc = d_out.alloc(out_total * 4)))
-            return rc;
-        AFG_HIP_CHECK(hipMemcpy(d_res.p, res.data(), res.size() * 4, hipMemcpyHostToDevice));
-        AFG_HIP_CHECK(hipMemcpy(d_frames.p, frames.data(), frames.size() * sizeof(afg_flac_frame), hipMemcpyHostToDevice));
-        AFG_HIP_CHECK(hipMemcpy(d_subs.p, subs.data(), subs.size() * sizeof(afg_flac_subframe), hipMemcpyHostToDevice));
-        rc = afg_flac_transform_hip(frames.size(), (const afg_flac_frame *)d_frames.p, (const afg_flac_subframe *)d_subs.p,
-                                    (const int32_t *)d_res.p, nullptr, (float *)d_out.p, nullptr);
-        if (rc) return rc;
-        AFG_HIP_CHECK(hipDeviceSynchronize());
-        for (size_t i = 0; i < nf; i++) {
-            Parsed &p = parsed[i];
-            if (p.format != AFG_FORMAT_FLAC) continue;
-            Decoded &dcd = out[i];
-            dcd.pcm.resize(p.flac.out_samples);
-            AFG_HIP_CHECK(hipMemcpy(dcd.pcm.data(), (const float *)d_out.p + flac_out_base[i], p.flac.out_samples * 4, hipMemcpyDeviceToHost));
-        }
-    }
-    // ---- QOA ----
-    {
-        std::vector<afg_qoa_frame> qf;
-        size_t bytes_total = 0, qout = 0;
-        std::vector<size_t> byte_base(nf, 0), out_base(nf, 0);
-        for (size_t i = 0; i < nf; i++) {
-            Parsed &p = parsed[i];
-            if (p.format != AFG_FORMAT_QOA) continue;
-            byte_base[i] = bytes_total;
-            out_base[i] = qout;
-            for (afg_qoa_frame f : p.qoa) { f.byte_off += bytes_total; f.out_off += qout; qf.push_back(f); }
-            bytes_total += (len[i] + 7) & ~(size_t)7;
-            qout += p.qoa.back().out_off + (size_t)p.qoa.back().samples * p.qoa.back().channels;
-        }
-        if (!qf.empty()) {
-            DeviceBuf d_bytes, d_fr, d_out;
-            int rc;
-            if ((rc = d_bytes.alloc(bytes_total)) || (rc = d_fr.alloc(qf.size() * sizeof(afg_qoa_frame))) || (rc = d_out.alloc(qout * 4)))
-                return rc;
-            for (size_t i = 0; i < nf; i++)
-                if (parsed[i].format == AFG_FORMAT_QOA)
-                    AFG_HIP_CHECK(hipMemcpy((uint8_t *)d_bytes.p + byte_base[i], data[i], len[i], hipMemcpyHostToDevice));
-            AFG_HIP_CHECK(hipMemcpy(d_fr.p, qf.data(), qf.size() * sizeof(afg_qoa_frame), hipMemcpyHostToDevice));
-            rc = afg_qoa_transform_hip(qf.size(), (const afg_qoa_frame *)d_fr.p, (const uint8_t *)d_bytes.p, nullptr,
-                                       (float *)d_out.p, nullptr);
-            if (rc) return rc;
-            AFG_HIP_CHECK(hipDeviceSynchronize());
-            for (size_t i = 0; i < nf; i++) {
-                Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_QOA) continue;
-                const size_t cnt = p.qoa.back().out_off + (size_t)p.qoa.back().samples * p.qoa.back().channels;
-                out[i].pcm.resize(cnt);
-                AFG_HIP_CHECK(hipMemcpy(out[i].pcm.data(), (const float *)d_out.p + out_base[i], cnt * 4, hipMemcpyDeviceToHost));
-            }
-        }
-    }
-    // ---- per-file metadata ----
+    out.files.assign(nf, Decoded());
+    // ---- layout ----
+    std::vector<size_t> res_base(nf, 0), fr_base(nf, 0), sf_base(nf, 0), qbyte_base(nf, 0), qfr_base(nf, 0);
+    size_t res_total = 0, fr_total = 0, sf_total = 0, flac_out = 0, qbytes = 0, qframes = 0, qoa_out = 0;
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
-        Decoded &dcd = out[i];
+        if (p.format != AFG_FORMAT_FLAC) continue;
+        res_base[i] = res_total; fr_base[i] = fr_total; sf_base[i] = sf_total;
+        out.files[i].pcm_off = flac_out;
+        res_total += p.flac.res.size(); fr_total += p.flac.frames.size(); sf_total += p.flac.subframes.size();
+        flac_out += p.flac.out_samples;
+    }
+    for (size_t i = 0; i < nf; i++) {
+        Parsed &p = parsed[i];
+        if (p.format != AFG_FORMAT_QOA) continue;
+        qbyte_base[i] = qbytes; qfr_base[i] = qframes;
+        out.files[i].pcm_off = flac_out + qoa_out;
+        qbytes += (len[i] + 15) & ~(size_t)15;
+        qframes += p.qoa.size();
+        qoa_out += p.qoa.back().out_off + (size_t)p.qoa.back().samples * p.qoa.back().channels;
+    }
+    out.plane_floats = flac_out + qoa_out;
+    if (out.plane_floats == 0) goto metadata;
+    {
+        if (int rc = out.plane.alloc(out.plane_floats * sizeof(float))) return rc;
+        DeviceBuf d_out;
+        if (int rc = d_out.alloc(out.plane_floats * sizeof(float))) return rc;
+        hipStream_t stream = nullptr;
+        // ---- FLAC ----
+        if (flac_out) {
+            const size_t rec_bytes = fr_total * sizeof(afg_flac_frame) + sf_total * sizeof(afg_flac_subframe);
+            const size_t rec_pad = (rec_bytes + 15) & ~(size_t)15;
+            PinnedBuf h_in;
+            DeviceBuf d_in;
+            if (int rc = h_in.alloc(rec_pad + res_total * 4)) return rc;
+            if (int rc = d_in.alloc(rec_pad + res_total * 4)) return rc;
+            afg_flac_frame *hf = (afg_flac_frame *)h_in.p;
+            afg_flac_subframe *hs = (afg_flac_subframe *)(hf + fr_total);
+            int32_t *hr = (int32_t *)((uint8_t *)h_in.p + rec_pad);
+            parallel_for(nf, threads, [&](size_t i) {
+                Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_FLAC) return;
+                for (size_t k = 0; k < p.flac.frames.size(); k++) {
+                    afg_flac_frame f = p.flac.frames[k];
+                    f.in_off += res_base[i]; f.out_off += out.files[i].pcm_off; f.sf_index += (uint32_t)sf_base[i];
+                    hf[fr_base[i] + k] = f;
+                }
+                std::memcpy(hs + sf_base[i], p.flac.subframes.data(), p.flac.subframes.size() * sizeof(afg_flac_subframe));
+                std::memcpy(hr + res_base[i], p.flac.res.data(), p.flac.res.size() * 4);
+                std::vector<int32_t>().swap(p.flac.res);               // the residual plane is the big one: drop it early
+            });
+            AFG_HIP_CHECK(hipMemcpyAsync(d_in.p, h_in.p, rec_pad + res_total * 4, hipMemcpyHostToDevice, stream));
+            const afg_flac_frame *df = (const afg_flac_frame *)d_in.p;
+            const afg_flac_subframe *ds = (const afg_flac_subframe *)(df + fr_total);
+            const int32_t *dr = (const int32_t *)((const uint8_t *)d_in.p + rec_pad);
+            if (int rc = afg_flac_transform_hip(fr_total, df, ds, dr, nullptr, (float *)d_out.p, stream)) return rc;
+            AFG_HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        // ---- QOA ----
+        if (qoa_out) {
+            const size_t rec_pad = (qframes * sizeof(afg_qoa_frame) + 15) & ~(size_t)15;
+            PinnedBuf h_in;
+            DeviceBuf d_in;
+            if (int rc = h_in.alloc(rec_pad + qbytes)) return rc;
+            if (int rc = d_in.alloc(rec_pad + qbytes)) return rc;
+            afg_qoa_frame *hq = (afg_qoa_frame *)h_in.p;
+            uint8_t *hb = (uint8_t *)h_in.p + rec_pad;
+            parallel_for(nf, threads, [&](size_t i) {
+                Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_QOA) return;
+                for (size_t k = 0; k < p.qoa.size(); k++) {
+                    afg_qoa_frame f = p.qoa[k];
+                    f.byte_off += qbyte_base[i]; f.out_off += out.files[i].pcm_off;
+                    hq[qfr_base[i] + k] = f;
+                }
+                std::memcpy(hb + qbyte_base[i], data[i], len[i]);
+            });
+            AFG_HIP_CHECK(hipMemcpyAsync(d_in.p, h_in.p, rec_pad + qbytes, hipMemcpyHostToDevice, stream));
+            if (int rc = afg_qoa_transform_hip(qframes, (const afg_qoa_frame *)d_in.p, (const uint8_t *)d_in.p + rec_pad, nullptr,
+                                               (float *)d_out.p, stream))
+                return rc;
+            AFG_HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        AFG_HIP_CHECK(hipMemcpyAsync(out.plane.p, d_out.p, out.plane_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+        AFG_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+metadata:
+    for (size_t i = 0; i < nf; i++) {
+        Parsed &p = parsed[i];
+        Decoded &dcd = out.files[i];
         dcd.format = p.format;
         if (p.format == AFG_FORMAT_FLAC) {
             dcd.channels = (int)p.fi.channels;
@@ -504,7 +548,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         } else if (p.format == AFG_FORMAT_QOA) {
             dcd.channels = (int)p.qi.channels;
             dcd.samplerate = (float)p.qi.samplerate;
-            dcd.frames = (int64_t)(dcd.pcm.size() / p.qi.channels);
+            dcd.frames = (int64_t)(p.qoa.back().out_off / p.qi.channels) + p.qoa.back().samples;
             dcd.declared_frames = (int64_t)p.qi.samples;
         } else {
             dcd.status = AFG_ERR_UNSUPPORTED;
@@ -519,6 +563,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
 struct afg_stream {
     const char *error = kErrorNotInitialized;      // stream.d:1379
     Decoded d;
+    std::vector<float> pcm;
     int64_t position = 0;
 };
 
@@ -533,11 +578,12 @@ afg_stream *afg_open_from_memory(const uint8_t *data, size_t length)
     parse_file(data, length, parsed[0]);
     if (parsed[0].format == AFG_FORMAT_UNKNOWN) { s->error = kErrorUnknownFormat; return s; }
     if (afg::require_device() != AFG_OK) { s->error = kErrorDecoderInitializationFailed; return s; }
-    std::vector<Decoded> out;
+    BatchOut out;
     const uint8_t *dp[1] = { data };
     const size_t lp[1] = { length };
-    if (decode_parsed(parsed, dp, lp, out) != AFG_OK) { s->error = kErrorDecodingError; return s; }
-    s->d = std::move(out[0]);
+    if (decode_parsed(parsed, dp, lp, 1, out) != AFG_OK) { s->error = kErrorDecodingError; return s; }
+    s->d = out.files[0];
+    if (out.plane_floats) s->pcm.assign((const float *)out.plane.p, (const float *)out.plane.p + out.plane_floats);
     s->error = s->d.status == AFG_OK ? nullptr : kErrorDecodingError;
     return s;
 }
@@ -561,7 +607,7 @@ int afg_read_samples_float(afg_stream *s, float *out, int frames)
     // declares 0 samples therefore reads nothing); the check is made on entry only, like the reference's.
     if (s->d.format == AFG_FORMAT_FLAC && s->position == s->d.declared_frames) return 0;
     const int64_t n = std::max<int64_t>(0, std::min<int64_t>(s->d.frames - s->position, frames));
-    if (out && n) std::memcpy(out, s->d.pcm.data() + s->position * s->d.channels, (size_t)n * s->d.channels * sizeof(float));
+    if (out && n) std::memcpy(out, s->pcm.data() + s->position * s->d.channels, (size_t)n * s->d.channels * sizeof(float));
     s->position += n;
     return (int)n;
 }
@@ -635,36 +681,26 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
     if (n_files == 0) return AFG_OK;
     if (int rc = afg::require_device()) return rc;
     std::vector<Parsed> parsed((size_t)n_files);
-    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
-    nt = std::min<unsigned>(nt, (unsigned)n_files);
-    std::atomic<int> next{ 0 };
-    auto work = [&]() {
-        for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= n_files) return;
-            if (data[i] && length[i]) parse_file(data[i], length[i], parsed[(size_t)i]);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
+    const unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    parallel_for((size_t)n_files, nt, [&](size_t i) {
+        if (data[i] && length[i]) parse_file(data[i], length[i], parsed[i]);
+    });
 
-    auto *owner = new (std::nothrow) std::vector<Decoded>;
+    BatchOut *owner = new (std::nothrow) BatchOut;
     if (!owner) return AFG_ERR_OOM;
-    int rc = decode_parsed(parsed, data, length, *owner);
+    int rc = decode_parsed(parsed, data, length, nt, *owner);
     if (rc) { delete owner; return rc; }
     afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));
     if (!items) { delete owner; return AFG_ERR_OOM; }
     for (int i = 0; i < n_files; i++) {
-        Decoded &d = (*owner)[(size_t)i];
+        const Decoded &d = owner->files[(size_t)i];
         items[i].status = d.status;
         items[i].message = d.message;
         items[i].format = d.format;
         items[i].channels = d.channels;
         items[i].samplerate = d.samplerate;
         items[i].frames = d.frames;
-        items[i].pcm = d.pcm.empty() ? nullptr : d.pcm.data();
+        items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)owner->plane.p + d.pcm_off : nullptr;
     }
     out->n_files = n_files;
     out->items = items;
@@ -676,7 +712,7 @@ void afg_batch_free(afg_batch_result *r)
 {
     if (!r) return;
     std::free(r->items);
-    delete (std::vector<Decoded> *)r->owner;
+    delete (BatchOut *)r->owner;
     r->items = nullptr; r->owner = nullptr; r->n_files = 0;
 }
 
