@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "afg_celt_transform_hip",
     "afg_open_from_memory", "afg_is_error", "afg_error_message", "afg_get_format", "afg_get_num_channels",
     "afg_get_length_in_frames", "afg_get_samplerate", "afg_read_samples_float", "afg_close",
-    "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse",
+    "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse", "afg_mp3_parse", "afg_mp3_parsed_free",
     "afg_batch_decode", "afg_batch_free",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
     "afg_copy_probe_hip",
@@ -71,6 +71,14 @@ class FlacParsed(C.Structure):
                 ("total_samples", C.c_uint64), ("n_frames", C.c_uint64), ("n_subframes", C.c_uint64),
                 ("n_res", C.c_uint64), ("out_samples", C.c_uint64), ("frames", C.c_void_p),
                 ("subframes", C.c_void_p), ("res", C.c_void_p), ("owner", C.c_void_p)]
+
+
+class Mp3Parsed(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("hz", C.c_int32), ("tagged", C.c_int32), ("start_delay", C.c_int32),
+                ("detected_samples", C.c_uint64), ("declared_samples", C.c_uint64), ("pcm_samples", C.c_uint64),
+                ("n_runs", C.c_uint64), ("n_blocks", C.c_uint64), ("n_copies", C.c_uint64),
+                ("run_granules", C.c_void_p), ("coef", C.c_void_p), ("flags", C.c_void_p), ("copies", C.c_void_p),
+                ("owner", C.c_void_p)]
 
 
 class BatchItem(C.Structure):
@@ -146,6 +154,9 @@ def lib():
     L.afg_flac_parse.argtypes = [vp, C.c_size_t, C.POINTER(FlacParsed)]
     L.afg_flac_parsed_free.argtypes = [C.POINTER(FlacParsed)]
     L.afg_flac_parsed_free.restype = None
+    L.afg_mp3_parse.argtypes = [vp, C.c_size_t, C.POINTER(Mp3Parsed)]
+    L.afg_mp3_parsed_free.argtypes = [C.POINTER(Mp3Parsed)]
+    L.afg_mp3_parsed_free.restype = None
     L.afg_qoa_parse.argtypes = [vp, C.c_size_t, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, C.c_size_t,
                                 C.POINTER(C.c_size_t)]
     L.afg_batch_decode.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(BatchResult)]
@@ -317,6 +328,26 @@ def flac_parse(file_bytes):
                 view(out.subframes, out.n_subframes, FLAC_SUBFRAME_DTYPE), view(out.res, out.n_res, np.int32))
     finally:
         lib().afg_flac_parsed_free(C.byref(out))
+
+
+def mp3_parse(file_bytes):
+    """Host front-end only (afg_mp3_parse): (info dict, run_granules, coef [blocks, 576], flags, copies [n, 2])."""
+    buf = bytes(file_bytes)
+    out = Mp3Parsed()
+    check(lib().afg_mp3_parse(buf, len(buf), C.byref(out)))
+    try:
+        def view(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype)
+            raw = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(raw, dtype=dtype, count=count).copy()
+        info = {k: int(getattr(out, k)) for k in ("channels", "hz", "tagged", "start_delay", "detected_samples",
+                                                  "declared_samples", "pcm_samples")}
+        return (info, view(out.run_granules, out.n_runs, np.uint32),
+                view(out.coef, out.n_blocks * 576, np.float32).reshape(-1, 576), view(out.flags, out.n_blocks, np.uint32),
+                view(out.copies, out.n_copies * 2, np.uint64).reshape(-1, 2))
+    finally:
+        lib().afg_mp3_parsed_free(C.byref(out))
 
 
 def qoa_parse(file_bytes):

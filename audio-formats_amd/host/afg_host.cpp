@@ -10,6 +10,7 @@
 // getters, :429-637 readSamplesFloat): parse the file into transform-stage records, restore the
 // samples on the device, serve interleaved floats.
 #include "../csrc/afg_common.h"
+#include "afg_mp3_front.h"
 
 #include <algorithm>
 #include <atomic>
@@ -384,14 +385,18 @@ struct Parsed {
     FlacRecords flac;
     QoaInfo qi;
     std::vector<afg_qoa_frame> qoa;
+    afg_mp3::File mp3;
 };
 
-// startDecoding's probe order for the formats handled here (stream.d:1586-1838): FLAC, then QOA
+// startDecoding's probe order for the formats handled here (stream.d:1586-1838): FLAC, QOA, then MP3 (whose
+// detection is the weakest: a frame-sync search, which is why the reference tries it after the containers)
 void parse_file(const uint8_t *d, size_t n, Parsed &p)
 {
     if (flac_parse(d, n, p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
     p.flac = FlacRecords();
     if (qoa_parse(d, n, p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
+    if (afg_mp3::looks_like_mp3(d, n) && afg_mp3::parse_file(d, n, p.mp3)) { p.format = AFG_FORMAT_MP3; return; }
+    p.mp3 = afg_mp3::File();
 }
 
 struct DeviceBuf {
@@ -470,7 +475,18 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         qframes += p.qoa.size();
         qoa_out += p.qoa.back().out_off + (size_t)p.qoa.back().samples * p.qoa.back().channels;
     }
-    out.plane_floats = flac_out + qoa_out;
+    std::vector<size_t> mp3_blk_base(nf, 0);
+    size_t mp3_blocks = 0, mp3_out = 0, mp3_runs = 0;
+    for (size_t i = 0; i < nf; i++) {
+        Parsed &p = parsed[i];
+        if (p.format != AFG_FORMAT_MP3) continue;
+        mp3_blk_base[i] = mp3_blocks;
+        out.files[i].pcm_off = flac_out + qoa_out + mp3_out;
+        mp3_blocks += p.mp3.flags.size();
+        mp3_out += (size_t)p.mp3.pcm_samples;
+        mp3_runs += p.mp3.run_granules.size();
+    }
+    out.plane_floats = flac_out + qoa_out + mp3_out;
     if (out.plane_floats == 0) goto metadata;
     {
         if (int rc = out.plane.alloc(out.plane_floats * sizeof(float))) return rc;
@@ -532,8 +548,61 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 return rc;
             AFG_HIP_CHECK(hipStreamSynchronize(stream));
         }
-        AFG_HIP_CHECK(hipMemcpyAsync(out.plane.p, d_out.p, out.plane_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
-        AFG_HIP_CHECK(hipStreamSynchronize(stream));
+        if (flac_out + qoa_out) {
+            AFG_HIP_CHECK(hipMemcpyAsync(out.plane.p, d_out.p, (flac_out + qoa_out) * sizeof(float), hipMemcpyDeviceToHost, stream));
+            AFG_HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        // ---- MP3: spectra of every decoded granule -> PCM plane -> the samples mp3dec_ex_read would deliver ----
+        if (mp3_blocks) {
+            const size_t coef_bytes = mp3_blocks * 576 * sizeof(float), flag_bytes = (mp3_blocks * 4 + 15) & ~(size_t)15;
+            PinnedBuf h_in, h_pcm;
+            DeviceBuf d_in, d_pcm;
+            if (int rc = h_in.alloc(coef_bytes + flag_bytes)) return rc;
+            if (int rc = d_in.alloc(coef_bytes + flag_bytes)) return rc;
+            if (int rc = h_pcm.alloc(coef_bytes)) return rc;
+            if (int rc = d_pcm.alloc(coef_bytes)) return rc;
+            float *hc = (float *)h_in.p;
+            uint32_t *hfl = (uint32_t *)((uint8_t *)h_in.p + coef_bytes);
+            std::vector<uint32_t> granules;
+            std::vector<uint8_t> channels;
+            granules.reserve(mp3_runs);
+            channels.reserve(mp3_runs);
+            for (size_t i = 0; i < nf; i++) {
+                if (parsed[i].format != AFG_FORMAT_MP3) continue;
+                for (uint32_t g : parsed[i].mp3.run_granules) {
+                    granules.push_back(g);
+                    channels.push_back((uint8_t)parsed[i].mp3.channels);
+                }
+            }
+            parallel_for(nf, threads, [&](size_t i) {
+                Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_MP3) return;
+                std::memcpy(hc + mp3_blk_base[i] * 576, p.mp3.coef.data(), p.mp3.coef.size() * sizeof(float));
+                std::memcpy(hfl + mp3_blk_base[i], p.mp3.flags.data(), p.mp3.flags.size() * sizeof(uint32_t));
+                std::vector<float>().swap(p.mp3.coef);
+            });
+            afg_mp3_plan *plan = nullptr;
+            if (int rc = afg_mp3_plan_create(&plan, (uint32_t)granules.size(), granules.data(), channels.data(), 0)) return rc;
+            hipError_t e = hipMemcpyAsync(d_in.p, h_in.p, coef_bytes + flag_bytes, hipMemcpyHostToDevice, stream);
+            int rc = e == hipSuccess ? afg_mp3_transform_hip(plan, (const float *)d_in.p, (const uint32_t *)((const uint8_t *)d_in.p + coef_bytes),
+                                                             (float *)d_pcm.p, nullptr, stream)
+                                     : AFG_ERR_HIP;
+            if (!rc) e = hipMemcpyAsync(h_pcm.p, d_pcm.p, coef_bytes, hipMemcpyDeviceToHost, stream);
+            if (!rc && e == hipSuccess) e = hipStreamSynchronize(stream);
+            afg_mp3_plan_destroy(plan);
+            if (rc) return rc;
+            if (e != hipSuccess) { afg::set_error("MP3 stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+            parallel_for(nf, threads, [&](size_t i) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_MP3) return;
+                const float *src = (const float *)h_pcm.p + mp3_blk_base[i] * 576;
+                float *dst = (float *)out.plane.p + out.files[i].pcm_off;
+                for (const afg_mp3::Copy &c : p.mp3.copies) {
+                    std::memcpy(dst, src + c.src, (size_t)c.count * sizeof(float));
+                    dst += c.count;
+                }
+            });
+        }
     }
 metadata:
     for (size_t i = 0; i < nf; i++) {
@@ -545,6 +614,11 @@ metadata:
             dcd.samplerate = (float)p.fi.sample_rate;
             dcd.frames = (int64_t)(p.flac.out_samples / p.fi.channels);
             dcd.declared_frames = (int64_t)p.fi.total_samples;      // totalSampleCount / channels, stream.d:1631
+        } else if (p.format == AFG_FORMAT_MP3) {
+            dcd.channels = p.mp3.channels;
+            dcd.samplerate = (float)p.mp3.hz;
+            dcd.frames = (int64_t)(p.mp3.pcm_samples / (uint64_t)p.mp3.channels);
+            dcd.declared_frames = (int64_t)(p.mp3.declared_samples / (uint64_t)p.mp3.channels);   // stream.d:1737
         } else if (p.format == AFG_FORMAT_QOA) {
             dcd.channels = (int)p.qi.channels;
             dcd.samplerate = (float)p.qi.samplerate;
@@ -653,6 +727,44 @@ void afg_flac_parsed_free(afg_flac_parsed *p)
 {
     if (!p) return;
     delete (FlacParsedOwner *)p->owner;
+    std::memset(p, 0, sizeof(*p));
+}
+
+int afg_mp3_parse(const uint8_t *data, size_t length, afg_mp3_parsed *out)
+{
+    if (!out) return AFG_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    if (!data) return AFG_ERR_INVALID;
+    auto *own = new (std::nothrow) afg_mp3::File;
+    if (!own) return AFG_ERR_OOM;
+    if (!afg_mp3::parse_file(data, length, *own)) {
+        delete own;
+        afg::set_error("afg_mp3_parse: no MPEG Layer III stream found");
+        return AFG_ERR_UNSUPPORTED;
+    }
+    static_assert(sizeof(afg_mp3::Copy) == sizeof(afg_mp3_copy), "copy plan layout");
+    out->channels = own->channels;
+    out->hz = own->hz;
+    out->tagged = own->tagged ? 1 : 0;
+    out->start_delay = own->start_delay;
+    out->detected_samples = own->detected_samples;
+    out->declared_samples = own->declared_samples;
+    out->pcm_samples = own->pcm_samples;
+    out->n_runs = own->run_granules.size();
+    out->n_blocks = own->flags.size();
+    out->n_copies = own->copies.size();
+    out->run_granules = own->run_granules.data();
+    out->coef = own->coef.data();
+    out->flags = own->flags.data();
+    out->copies = (afg_mp3_copy *)own->copies.data();
+    out->owner = own;
+    return AFG_OK;
+}
+
+void afg_mp3_parsed_free(afg_mp3_parsed *p)
+{
+    if (!p) return;
+    delete (afg_mp3::File *)p->owner;
     std::memset(p, 0, sizeof(*p));
 }
 

@@ -1,0 +1,817 @@
+// afg_mp3_front.cpp -- host front-end for MPEG-1/2/2.5 Layer III files.
+//
+// Everything the reference does ahead of the transform seam (minimp3.d:1226): frame sync
+// (minimp3.d:1436-1484), header / side info (:487-614), scalefactors (:616-719), Huffman decoding and
+// requantisation (:721-883), mid/side and intensity stereo (:885-983), short-block reorder (:985-1000),
+// the bit reservoir (:1170-1197), and the file-level drive of minimp3_ex (ID3v2 / ID3v1 / APE skipping
+// :93-142, Xing/Info tag and LAME delay/padding :144-190, :566-621, delivery order and trimming
+// :787-888).  Output: the transform-stage records of include/afg.h (576 floats + one flag word per
+// granule-channel) and a copy plan that turns the device's PCM plane into what mp3dec_ex_read returns.
+//
+// Organisation (not the reference's): the main-data stream of a file is treated as one byte queue that
+// frames append to and granules consume from; a granule's spectrum is decoded by spectral-line index
+// against precomputed band boundaries with two-level lookup tables for the code books
+// (mp3_front_tables.h, generated); every float is produced by the reference's expression trees, so the
+// records are bit-identical to the oracle's.  Layer I / II frames are not handled (the stream ends there).
+#include "afg_mp3_front.h"
+
+#include "mp3_front_tables.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace afg_mp3 {
+namespace {
+
+inline float bits_f32(unsigned b)
+{
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
+// ---- frame header ------------------------------------------------------------------------------
+struct Header {
+    const uint8_t *h;
+    bool mpeg1() const { return (h[1] & 0x08) != 0; }
+    bool mpeg25() const { return (h[1] & 0x10) == 0; }
+    int layer_code() const { return (h[1] >> 1) & 3; }              // 1 = Layer III
+    bool crc() const { return (h[1] & 1) == 0; }
+    int bitrate_index() const { return h[2] >> 4; }
+    int rate_index() const { return (h[2] >> 2) & 3; }
+    bool padding() const { return (h[2] & 2) != 0; }
+    bool mono() const { return (h[3] & 0xC0) == 0xC0; }
+    bool ms_stereo() const { return (h[3] & 0xE0) == 0x60; }       // joint stereo with the M/S bit
+    bool ms_bit() const { return (h[3] & 0x20) != 0; }
+    bool intensity() const { return (h[3] & 0x10) != 0; }
+    bool free_format() const { return (h[2] & 0xF0) == 0; }
+    bool layer1() const { return (h[1] & 6) == 6; }
+    bool valid() const
+    {
+        return h[0] == 0xff && ((h[1] & 0xF0) == 0xf0 || (h[1] & 0xFE) == 0xe2) && layer_code() != 0 &&
+               bitrate_index() != 15 && rate_index() != 3;
+    }
+    bool same_stream(const uint8_t *o) const                          // hdr_compare, minimp3.d:222-228
+    {
+        const Header b{ o };
+        return b.valid() && ((h[1] ^ o[1]) & 0xFE) == 0 && ((h[2] ^ o[2]) & 0x0C) == 0 && free_format() == b.free_format();
+    }
+    unsigned kbps() const { return 2u * k_halfrate[mpeg1() ? 1 : 0][layer_code() - 1][bitrate_index()]; }
+    unsigned hz() const
+    {
+        static const unsigned base[3] = { 44100, 48000, 32000 };
+        return base[rate_index()] >> (mpeg1() ? 0 : 1) >> (mpeg25() ? 1 : 0);
+    }
+    unsigned samples() const { return layer1() ? 384u : (1152u >> (((h[1] & 14) == 2) ? 1 : 0)); }
+    int bytes(int free_format_size) const
+    {
+        int n = (int)(samples() * kbps() * 125 / hz());
+        if (layer1()) n &= ~3;
+        return n ? n : free_format_size;
+    }
+    int pad_bytes() const { return padding() ? (layer1() ? 4 : 1) : 0; }
+    int band_table() const                                            // index into the sfb tables, minimp3.d:534
+    {
+        int i = rate_index() + (((h[1] >> 3) & 1) + ((h[1] >> 4) & 1)) * 3;
+        return i - (i != 0);
+    }
+    bool low_rate_25() const { return rate_index() + (((h[1] >> 3) & 1) + ((h[1] >> 4) & 1)) * 3 == 2; }   // :1218
+};
+
+constexpr int kMaxFreeFormat = 2304, kSyncMatches = 10, kReservoir = 511;
+
+bool confirm_sync(const uint8_t *p, int avail, int frame_bytes)       // mp3d_match_frame
+{
+    const Header first{ p };
+    int at = 0;
+    for (int n = 0; n < kSyncMatches; n++) {
+        const Header cur{ p + at };
+        at += cur.bytes(frame_bytes) + cur.pad_bytes();
+        if (at + 4 > avail) return n > 0;
+        if (!first.same_stream(p + at)) return false;
+    }
+    return true;
+}
+
+// mp3d_find_frame: offset of the next frame in [p, p + avail) (avail if none), its size in *size
+int next_frame(const uint8_t *p, int avail, int *free_bytes, int *size)
+{
+    for (int i = 0; i < avail - 4; i++, p++) {
+        const Header hd{ p };
+        if (!hd.valid()) continue;
+        int fb = hd.bytes(*free_bytes);
+        int total = fb + hd.pad_bytes();
+        for (int k = 4; !fb && k < kMaxFreeFormat && i + 2 * k < avail - 4; k++) {
+            if (!hd.same_stream(p + k)) continue;
+            const int cand = k - hd.pad_bytes();
+            const int nxt = cand + Header{ p + k }.pad_bytes();
+            if (i + k + nxt + 4 > avail || !hd.same_stream(p + k + nxt)) continue;
+            total = k;
+            fb = cand;
+            *free_bytes = cand;
+        }
+        if ((fb && i + total <= avail && confirm_sync(p, avail - i, fb)) || (!i && total == avail)) {
+            *size = total;
+            return i;
+        }
+        *free_bytes = 0;
+    }
+    *size = 0;
+    return avail;
+}
+
+// ---- bits ----------------------------------------------------------------------------------------
+// Side info / scalefactor reader with the reference's overrun rule (a read past the end yields 0 and
+// still advances, minimp3.d:192-207).
+struct Bits {
+    const uint8_t *p;
+    int pos, limit;
+    Bits(const uint8_t *d, int bytes) : p(d), pos(0), limit(bytes * 8) {}
+    uint32_t get(int n)
+    {
+        const int at = pos;
+        pos += n;
+        if (pos > limit || n == 0) return 0;
+        uint64_t w = 0;
+        const uint8_t *q = p + (at >> 3);
+        for (int i = 0; i < 5; i++) w = (w << 8) | q[i];            // callers keep 8 readable bytes behind the data
+        return (uint32_t)((w >> (40 - (at & 7) - n)) & ((1ull << n) - 1));
+    }
+};
+
+// Spectrum reader: a 64-bit window kept at >= 32 valid bits.
+struct Window {
+    const uint8_t *base, *next;
+    uint64_t w;
+    int have;                 // valid bits in w (left-aligned)
+    int consumed;             // bits consumed since `base`
+    Window(const uint8_t *d, int bitpos) : base(d), next(d + (bitpos >> 3)), w(0), have(0), consumed(bitpos & ~7)
+    {
+        fill();
+        drop(bitpos & 7);
+    }
+    void fill()
+    {
+        while (have <= 56) {
+            w |= (uint64_t)*next++ << (56 - have);
+            have += 8;
+        }
+    }
+    uint32_t peek(int n) const { return n ? (uint32_t)(w >> (64 - n)) : 0; }
+    void drop(int n)
+    {
+        w <<= n;
+        have -= n;
+        consumed += n;
+    }
+    bool top() const { return (int64_t)w < 0; }
+};
+
+struct Granule {                       // side info of one granule-channel
+    const uint8_t *bands;              // widths, 0-terminated
+    int part23, big_values, sf_compress, global_gain, block_type, mixed;
+    int n_long, n_short;
+    int table[3], region[3], sub_gain[3];
+    int preflag, sf_scale, count1_table, scfsi;
+};
+
+// L3_read_side_info; returns main_data_begin or -1
+int read_side_info(Bits &b, Granule *g, const Header &hd)
+{
+    const int bt = hd.band_table();
+    int n = hd.mono() ? 1 : 2, begin;
+    unsigned scfsi = 0;
+    int sum = 0;
+    if (hd.mpeg1()) {
+        n *= 2;
+        begin = (int)b.get(9);
+        scfsi = b.get(7 + n);
+    } else {
+        begin = (int)(b.get(8 + n) >> n);
+    }
+    for (int k = 0; k < n; k++, g++) {
+        if (hd.mono()) scfsi <<= 4;
+        g->part23 = (int)b.get(12);
+        sum += g->part23;
+        g->big_values = (int)b.get(9);
+        if (g->big_values > 288) return -1;
+        g->global_gain = (int)b.get(8);
+        g->sf_compress = (int)b.get(hd.mpeg1() ? 4 : 9);
+        g->bands = k_sfb_long[bt];
+        g->n_long = 22;
+        g->n_short = 0;
+        unsigned tables;
+        if (b.get(1)) {
+            g->block_type = (int)b.get(2);
+            if (!g->block_type) return -1;
+            g->mixed = (int)b.get(1);
+            g->region[0] = 7;
+            g->region[1] = 255;
+            if (g->block_type == 2) {
+                scfsi &= 0x0F0F;
+                if (!g->mixed) {
+                    g->region[0] = 8;
+                    g->bands = k_sfb_short[bt];
+                    g->n_long = 0;
+                    g->n_short = 39;
+                } else {
+                    g->bands = k_sfb_mixed[bt];
+                    g->n_long = hd.mpeg1() ? 8 : 6;
+                    g->n_short = 30;
+                }
+            }
+            tables = b.get(10) << 5;
+            for (int i = 0; i < 3; i++) g->sub_gain[i] = (int)b.get(3);
+        } else {
+            g->block_type = 0;
+            g->mixed = 0;
+            tables = b.get(15);
+            g->region[0] = (int)b.get(4);
+            g->region[1] = (int)b.get(3);
+            g->region[2] = 255;
+        }
+        g->table[0] = (int)(tables >> 10);
+        g->table[1] = (int)((tables >> 5) & 31);
+        g->table[2] = (int)(tables & 31);
+        g->preflag = hd.mpeg1() ? (int)b.get(1) : (g->sf_compress >= 500);
+        g->sf_scale = (int)b.get(1);
+        g->count1_table = (int)b.get(1);
+        g->scfsi = (int)((scfsi >> 12) & 15);
+        scfsi <<= 4;
+    }
+    if (sum + b.pos > b.limit + begin * 8) return -1;
+    return begin;
+}
+
+// L3_ldexp_q2: y * 2^(-exp/4) built from quarter-octave steps (float products in this order)
+float scale_q2(float y, int exp_q2)
+{
+    int e;
+    do {
+        e = std::min(30 * 4, exp_q2);
+        y *= bits_f32(k_expfrac_bits[e & 3]) * (float)(1 << 30 >> (e >> 2));
+    } while ((exp_q2 -= e) > 0);
+    return y;
+}
+
+// L3_pow_43
+float pow43(int x)
+{
+    if (x < 129) return bits_f32(k_pow43_bits[16 + x]);
+    int mult = 256;
+    if (x < 1024) {
+        mult = 16;
+        x <<= 3;
+    }
+    const int sign = 2 * x & 64;
+    const float frac = (float)((x & 63) - sign) / (float)((x & ~63) + sign);
+    return bits_f32(k_pow43_bits[16 + ((x + sign) >> 6)]) * (1.0f + frac * ((4.0f / 3) + frac * (2.0f / 9))) * (float)mult;
+}
+
+constexpr int kMaxScf = 255 - 4 - 210, kMaxScfi = (kMaxScf + 3) & ~3;
+
+// L3_decode_scalefactors: band scales `scale[0 .. n_long + n_short)`, intensity positions in ist[]
+void band_scales(const Header &hd, uint8_t *ist, Bits &b, const Granule &g, float *scale, int ch)
+{
+    const uint8_t *parts = k_scf_partitions[(g.n_short ? 1 : 0) + (g.n_long ? 0 : 1)];
+    uint8_t width[4], iscf[40];
+    int scfsi = g.scfsi;
+    const int shift = g.sf_scale + 1;
+    if (hd.mpeg1()) {
+        const int part = k_scfc_decode[g.sf_compress];
+        width[0] = width[1] = (uint8_t)(part >> 2);
+        width[2] = width[3] = (uint8_t)(part & 3);
+    } else {
+        const int ist_ch = (hd.intensity() && ch) ? 1 : 0;
+        int sfc = g.sf_compress >> ist_ch, k = ist_ch * 12, prod;
+        for (; sfc >= 0; sfc -= prod, k += 4) {
+            prod = 1;
+            for (int i = 3; i >= 0; i--) {
+                width[i] = (uint8_t)(sfc / prod % k_scf_mod[k + i]);
+                prod *= k_scf_mod[k + i];
+            }
+        }
+        parts += k;
+        scfsi = -16;
+    }
+    {   // L3_read_scalefactors
+        uint8_t *s = iscf, *ip = ist;
+        for (int i = 0; i < 4 && parts[i]; i++, scfsi *= 2) {
+            const int cnt = parts[i];
+            if (scfsi & 8) {
+                std::memcpy(s, ip, (size_t)cnt);
+            } else if (!width[i]) {
+                std::memset(s, 0, (size_t)cnt);
+                std::memset(ip, 0, (size_t)cnt);
+            } else {
+                const int none = (scfsi < 0) ? (1 << width[i]) - 1 : -1;
+                for (int k = 0; k < cnt; k++) {
+                    const int v = (int)b.get(width[i]);
+                    ip[k] = (uint8_t)(v == none ? -1 : v);
+                    s[k] = (uint8_t)v;
+                }
+            }
+            ip += cnt;
+            s += cnt;
+        }
+        s[0] = s[1] = s[2] = 0;
+    }
+    if (g.n_short) {
+        const int sh = 3 - shift;
+        for (int i = 0; i < g.n_short; i += 3)
+            for (int w = 0; w < 3; w++) iscf[g.n_long + i + w] = (uint8_t)(iscf[g.n_long + i + w] + (g.sub_gain[w] << sh));
+    } else if (g.preflag) {
+        for (int i = 0; i < 10; i++) iscf[11 + i] = (uint8_t)(iscf[11 + i] + k_preamp[i]);
+    }
+    const int gain_exp = g.global_gain - 4 - 210 - (hd.ms_stereo() ? 2 : 0);
+    const float gain = scale_q2((float)(1 << (kMaxScfi / 4)), kMaxScfi - gain_exp);
+    for (int i = 0; i < g.n_long + g.n_short; i++) scale[i] = scale_q2(gain, iscf[i] << shift);
+}
+
+// L3_huffman by spectral line: big-value pairs of the three regions, then count1 quads up to the end of
+// part2_3 (a quad that ends past it is discarded) or the end of the band table.
+void spectrum(float *line, const uint8_t *main_data, int *bitpos, const Granule &g, const float *scale, int limit)
+{
+    int ends[41], nb = 0, acc = 0;
+    for (; g.bands[nb]; nb++) ends[nb] = (acc += g.bands[nb]);
+    const int total = acc;                                  // 576 for every table
+    Window win(main_data, *bitpos);
+    int i = 0, band = 0;
+    const int big_end = std::min(2 * g.big_values, total);
+    int first_band = 0;
+    for (int r = 0; r < 3 && i < big_end; r++) {
+        const int last_band = std::min(first_band + g.region[r], nb - 1);      // a region spans region[r] + 1 bands
+        const int stop = std::min(ends[last_band], big_end);
+        first_band = last_band + 1;
+        const int t = g.table[r], book = k_book_of_table[t], extra = k_linbits[t];
+        const unsigned *lut = k_huff_lut + k_huff_lut_base[book];
+        while (i < stop) {
+            while (i >= ends[band]) band++;
+            const float one = scale[band];
+            int xy = 0;
+            if (book) {
+                unsigned e = lut[win.peek(AFG_MP3_HUFF_L1)];
+                if (e & 0x80000000u) {
+                    const int sub = (int)((e >> 24) & 0x7f);
+                    e = lut[(e & 0xffffff) + ((win.peek(AFG_MP3_HUFF_L1 + sub)) & ((1u << sub) - 1))];
+                }
+                win.drop((int)(e >> 8));
+                xy = (int)(e & 0xff);
+            }
+            for (int j = 0; j < 2; j++, xy >>= 4) {
+                int v = xy & 15;
+                if (extra && v == 15) {
+                    v += (int)win.peek(extra);
+                    win.drop(extra);
+                    win.fill();
+                    line[i + j] = one * pow43(v) * (win.top() ? -1 : 1);
+                } else {
+                    line[i + j] = bits_f32(k_pow43_bits[16 + v - (win.top() ? 16 : 0)]) * one;
+                }
+                if (v) win.drop(1);
+            }
+            win.fill();
+            i += 2;
+        }
+        if (i >= big_end) break;
+    }
+    // count1 region.  The reference tracks "pairs left in the current band" starting from wherever the
+    // big values stopped; by line index that is simply the band containing the line.
+    const unsigned char *c1 = k_count1_lut + (g.count1_table ? 64 : 0);
+    i = big_end;
+    // when the big values overshoot a band the reference keeps counting from its own pair counter; for a
+    // well-formed granule 2*big_values lands on a pair boundary inside a band, handled here by index
+    for (;; i += 4) {
+        const unsigned e = c1[win.peek(6)];
+        win.drop((int)(e >> 4));
+        if (win.consumed > limit) break;
+        if (i >= total) break;
+        while (band < nb && i >= ends[band]) band++;
+        if (band >= nb) break;
+        float one = scale[band];
+        if (e & 8) { line[i] = win.top() ? -one : one; win.drop(1); }
+        if (e & 4) { line[i + 1] = win.top() ? -one : one; win.drop(1); }
+        if (i + 2 >= total) break;
+        int b2 = band;
+        while (b2 < nb && i + 2 >= ends[b2]) b2++;
+        if (b2 >= nb) break;
+        one = scale[b2];
+        if (e & 2) { line[i + 2] = win.top() ? -one : one; win.drop(1); }
+        if (e & 1) { line[i + 3] = win.top() ? -one : one; win.drop(1); }
+        win.fill();
+    }
+    *bitpos = limit;
+}
+
+void mid_side(float *l, int n)
+{
+    float *r = l + 576;
+    for (int i = 0; i < n; i++) {
+        const float a = l[i], b = r[i];
+        l[i] = a + b;
+        r[i] = a - b;
+    }
+}
+
+// L3_intensity_stereo + L3_stereo_process
+void intensity(float *left, uint8_t *ist, const Granule *g, const Header &hd)
+{
+    const int nb = g->n_long + g->n_short, blocks = g->n_short ? 3 : 1;
+    int top[3] = { -1, -1, -1 };
+    {   // last band of the right channel with energy, per window
+        const float *r = left + 576;
+        for (int b = 0; b < nb; b++) {
+            for (int k = 0; k < g->bands[b]; k += 2)
+                if (r[k] != 0 || r[k + 1] != 0) { top[b % 3] = b; break; }
+            r += g->bands[b];
+        }
+    }
+    if (g->n_long) top[0] = top[1] = top[2] = std::max(std::max(top[0], top[1]), top[2]);
+    for (int i = 0; i < blocks; i++) {
+        const int itop = nb - blocks + i, prev = itop - blocks;
+        ist[itop] = (uint8_t)(top[i] >= prev ? (hd.mpeg1() ? 3 : 0) : ist[prev]);
+    }
+    const int lsf_shift = g[1].sf_compress & 1;
+    const unsigned max_pos = hd.mpeg1() ? 7 : 64;
+    float *l = left;
+    for (int b = 0; g->bands[b]; b++) {
+        const unsigned ipos = ist[b];
+        const int n = g->bands[b];
+        if (b > top[b % 3] && ipos < max_pos) {
+            const float s = hd.ms_bit() ? 1.41421356f : 1;
+            float kl, kr;
+            if (hd.mpeg1()) {
+                kl = bits_f32(k_pan_bits[2 * ipos]);
+                kr = bits_f32(k_pan_bits[2 * ipos + 1]);
+            } else {
+                kl = 1;
+                kr = scale_q2(1, (int)((ipos + 1) >> 1 << lsf_shift));
+                if (ipos & 1) {
+                    kl = kr;
+                    kr = 1;
+                }
+            }
+            const float fl = kl * s, fr = kr * s;
+            for (int i = 0; i < n; i++) {
+                l[i + 576] = l[i] * fr;
+                l[i] = l[i] * fl;
+            }
+        } else if (hd.ms_bit()) {
+            mid_side(l, n);
+        }
+        l += n;
+    }
+}
+
+// L3_reorder: [band][window][line] -> [band][line][window]
+void interleave_windows(float *x, const uint8_t *bands)
+{
+    float tmp[576];
+    float *d = tmp;
+    const float *s = x;
+    for (int len; (len = *bands) != 0; bands += 3, s += 3 * len)
+        for (int i = 0; i < len; i++) {
+            *d++ = s[i];
+            *d++ = s[len + i];
+            *d++ = s[2 * len + i];
+        }
+    std::memcpy(x, tmp, (size_t)(d - tmp) * sizeof(float));
+}
+
+// ---- ID3 / APE --------------------------------------------------------------------------------------
+size_t id3v2_size(const uint8_t *p, size_t n)
+{
+    if (n >= 10 && !std::memcmp(p, "ID3", 3) && !((p[5] & 15) || (p[6] & 0x80) || (p[7] & 0x80) || (p[8] & 0x80) || (p[9] & 0x80))) {
+        size_t sz = (size_t)(((p[6] & 0x7f) << 21) | ((p[7] & 0x7f) << 14) | ((p[8] & 0x7f) << 7) | (p[9] & 0x7f)) + 10;
+        if (p[5] & 16) sz += 10;
+        return sz;
+    }
+    return 0;
+}
+void trim_trailing_tags(const uint8_t *p, size_t *n)
+{
+    size_t m = *n;
+    if (m >= 128 && !std::memcmp(p + m - 128, "TAG", 3)) {
+        m -= 128;
+        if (m >= 227 && !std::memcmp(p + m - 227, "TAG+", 4)) m -= 227;
+    }
+    if (m > 32 && !std::memcmp(p + m - 32, "APETAGEX", 8)) {
+        m -= 32;
+        const uint8_t *t = p + m + 12;
+        const uint32_t sz = ((uint32_t)t[3] << 24) | ((uint32_t)t[2] << 16) | ((uint32_t)t[1] << 8) | t[0];
+        if (m >= sz) m -= sz;
+    }
+    *n = m;
+}
+
+// mp3dec_check_vbrtag: 1 tag with frame count, -1 tag without, 0 none
+int info_tag(const uint8_t *frame, int size, uint32_t *frames, int *delay, int *padding)
+{
+    const Header hd{ frame };
+    Bits b(frame + 4, size - 4);
+    if (hd.crc()) b.get(16);
+    Granule g[4];
+    if (read_side_info(b, g, hd) < 0) return 0;
+    const uint8_t *t = frame + 4 + b.pos / 8;
+    if (std::memcmp(t, "Xing", 4) && std::memcmp(t, "Info", 4)) return 0;
+    const int fl = t[7];
+    if (!(fl & 1)) return -1;
+    t += 8;
+    *frames = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+    t += 4;
+    if (fl & 2) t += 4;
+    if (fl & 4) t += 100;
+    if (fl & 8) t += 4;
+    *delay = *padding = 0;
+    if (*t) {
+        t += 21;
+        if (t - frame + 14 >= size) return 0;
+        *delay = ((t[0] << 4) | (t[1] >> 4)) + 529;
+        *padding = (((t[1] & 0xF) << 8) | t[2]) - 529;
+    }
+    return 1;
+}
+
+// ---- one file --------------------------------------------------------------------------------------
+struct Decoder {                           // what persists between frames on the host side
+    uint8_t header[4] = { 0, 0, 0, 0 };
+    int free_bytes = 0;
+    std::vector<uint8_t> reservoir;        // unread main data of earlier frames (<= 511 bytes)
+    void reset()
+    {
+        header[0] = 0;
+        free_bytes = 0;
+        reservoir.clear();
+    }
+};
+
+struct FrameResult {
+    int consumed = 0;          // bytes to advance
+    int samples = 0;           // per channel, 0 = nothing decoded
+    int channels = 0, hz = 0, layer = 0;
+    bool stop = false;         // Layer I/II or allocation trouble
+};
+
+// mp3dec_decode_frame up to the seam; records go to `out` when given (the open scan passes nullptr)
+FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fresh_state)
+{
+    FrameResult r;
+    int at = 0, size = 0;
+    const Header kept{ d.header };
+    if (avail > 4 && d.header[0] == 0xff && kept.same_stream(p)) {
+        const Header hd{ p };
+        size = hd.bytes(d.free_bytes) + hd.pad_bytes();
+        if (size != avail && (size + 4 > avail || !hd.same_stream(p + size))) size = 0;
+    }
+    if (!size) {
+        d.reset();                                         // memset(dec, 0): transform state and reservoir start over
+        *fresh_state = true;
+        at = next_frame(p, avail, &d.free_bytes, &size);
+        if (!size || at + size > avail) {
+            r.consumed = at;
+            return r;
+        }
+    }
+    const uint8_t *fp = p + at;
+    const Header hd{ fp };
+    std::memcpy(d.header, fp, 4);
+    r.consumed = at + size;
+    r.channels = hd.mono() ? 1 : 2;
+    r.hz = (int)hd.hz();
+    r.layer = 4 - hd.layer_code();
+    if (r.layer != 3) {
+        r.stop = true;
+        return r;
+    }
+    // side info; the frame body is copied so that short frames can be read with slack behind them
+    uint8_t body[kMaxFreeFormat + 16];
+    const int body_bytes = std::min(size - 4, kMaxFreeFormat);
+    std::memcpy(body, fp + 4, (size_t)body_bytes);
+    std::memset(body + body_bytes, 0, 16);
+    Bits sb(body, body_bytes);
+    if (hd.crc()) sb.get(16);
+    Granule gi[4];
+    const int begin = read_side_info(sb, gi, hd);
+    if (begin < 0 || sb.pos > sb.limit) {
+        d.header[0] = 0;                                   // mp3dec_init: the next call resynchronises
+        return r;
+    }
+    // main data = the last `begin` bytes of the reservoir + this frame's payload
+    const int payload = (sb.limit - sb.pos) / 8;
+    const int have = std::min((int)d.reservoir.size(), begin);
+    std::vector<uint8_t> md((size_t)have + (size_t)payload + 16, 0);
+    std::memcpy(md.data(), d.reservoir.data() + (d.reservoir.size() - (size_t)have), (size_t)have);
+    std::memcpy(md.data() + have, body + sb.pos / 8, (size_t)payload);
+    const bool ok = (int)d.reservoir.size() >= begin;
+    const int md_bytes = have + payload;
+    int bitpos = 0;
+    if (ok) {
+        const int ngr = hd.mpeg1() ? 2 : 1, nch = r.channels;
+        for (int gr = 0; gr < ngr; gr++) {
+            float x[2][576];
+            std::memset(x, 0, sizeof(x));
+            uint8_t ist[2][40];
+            float scale[40];
+            const Granule *g = gi + gr * nch;
+            for (int ch = 0; ch < nch; ch++) {
+                const int limit = bitpos + g[ch].part23;
+                Bits sfb(md.data(), md_bytes);
+                sfb.pos = bitpos;
+                band_scales(hd, ist[ch], sfb, g[ch], scale, ch);
+                bitpos = sfb.pos;
+                spectrum(x[ch], md.data(), &bitpos, g[ch], scale, limit);
+            }
+            if (hd.intensity()) intensity(x[0], ist[1], g, hd);
+            else if (hd.ms_stereo()) mid_side(x[0], 576);
+            uint32_t fl[2] = { 0, 0 };
+            for (int ch = 0; ch < nch; ch++) {
+                int aa = 31;
+                const int n_long_bands = (g[ch].mixed ? 2 : 0) << (hd.low_rate_25() ? 1 : 0);
+                if (g[ch].n_short) {
+                    aa = n_long_bands - 1;
+                    interleave_windows(x[ch] + n_long_bands * 18, g[ch].bands + g[ch].n_long);
+                }
+                fl[ch] = AFG_MP3_FLAGS(g[ch].block_type, n_long_bands, aa);
+            }
+            if (out) {
+                if (*fresh_state || out->run_granules.empty()) {
+                    out->run_granules.push_back(0);
+                    *fresh_state = false;
+                }
+                out->run_granules.back()++;
+                for (int ch = 0; ch < nch; ch++) {
+                    out->coef.insert(out->coef.end(), x[ch], x[ch] + 576);
+                    out->flags.push_back(fl[ch]);
+                }
+            } else {
+                *fresh_state = false;
+            }
+        }
+        r.samples = (int)hd.samples();
+    }
+    {   // L3_save_reservoir: unread main data, at most 511 bytes
+        int pos = (bitpos + 7) / 8, remains = md_bytes - pos;
+        if (!ok) {                                         // nothing was consumed: everything stays
+            pos = 0;
+            remains = md_bytes;
+        }
+        if (remains > kReservoir) {
+            pos += remains - kReservoir;
+            remains = kReservoir;
+        }
+        std::vector<uint8_t> keep;
+        if (remains > 0) keep.assign(md.begin() + pos, md.begin() + pos + remains);
+        d.reservoir.swap(keep);
+    }
+    return r;
+}
+
+}  // namespace
+
+bool looks_like_mp3(const uint8_t *data, size_t size)
+{
+    if (!data || size < 10) return false;
+    if (!std::memcmp(data, "RIFF", 4) || !std::memcmp(data, "RF64", 4) || !std::memcmp(data, "OggS", 4) ||
+        !std::memcmp(data, "fLaC", 4) || !std::memcmp(data, "qoaf", 4))
+        return false;                                      // formats the reference probes before MP3 (stream.d:1586-1706)
+    size_t n = size;
+    const size_t id3 = id3v2_size(data, n);
+    if (id3 >= n) return false;
+    const uint8_t *p = data + id3;
+    n -= id3;
+    trim_trailing_tags(p, &n);
+    int fb = 0, sz = 0;
+    next_frame(p, (int)std::min<size_t>(n, 0x7fffffff), &fb, &sz);
+    return sz != 0;
+}
+
+// mp3dec_ex_open (index scan or Xing/Info tag) followed by mp3dec_ex_read to the end of the stream
+bool parse_file(const uint8_t *data, size_t size, File &f)
+{
+    f = File();
+    if (!data || size < 10) return false;
+    const uint8_t *buf = data;
+    size_t n = size;
+    {
+        size_t id3 = id3v2_size(buf, n);
+        if (id3) {
+            id3 = std::min(id3, n);
+            buf += id3;
+            n -= id3;
+        }
+        trim_trailing_tags(buf, &n);
+    }
+    if (!n) return false;
+    // keep 16 readable bytes behind the data for the windowed readers
+    std::vector<uint8_t> padded(n + 16, 0);
+    std::memcpy(padded.data(), buf, n);
+    buf = padded.data();
+
+    Decoder dec;
+    uint64_t start = 0, declared = 0, detected = 0;
+    int to_skip = 0, counted = 0, probe = 0;
+    bool have = false, tagged = false;
+    int ch0 = 0, hz0 = 0, layer0 = 0;
+    {
+        const uint8_t *p = buf;
+        size_t left = n;
+        for (;;) {
+            int fb = 0, sz = 0;
+            const int i = next_frame(p, (int)std::min<size_t>(left, 0x7fffffff), &fb, &sz);
+            p += i;
+            left -= (size_t)i;
+            if (i && !sz) continue;
+            if (!sz) break;
+            const Header hd{ p };
+            const int nch = hd.mono() ? 1 : 2;
+            const uint64_t off = (uint64_t)(p - buf);
+            if (!have) {
+                have = true;
+                ch0 = nch;
+                hz0 = (int)hd.hz();
+                layer0 = 4 - hd.layer_code();
+                start = off;
+                if (layer0 == 3) {
+                    uint32_t frames = 0;
+                    int delay = 0, padding = 0;
+                    const int t = info_tag(p, sz, &frames, &delay, &padding);
+                    if (t) start = off + (uint64_t)sz;
+                    if (t > 0) {
+                        padding *= nch;
+                        to_skip = delay * nch;
+                        declared = (uint64_t)hd.samples() * (uint64_t)nch * frames;
+                        if (declared >= (uint64_t)to_skip) declared -= (uint64_t)to_skip;
+                        if (padding > 0 && declared >= (uint64_t)padding) declared -= (uint64_t)padding;
+                        detected = declared;
+                        tagged = true;
+                        break;
+                    }
+                    if (t < 0) {
+                        p += sz;
+                        left -= (size_t)sz;
+                        continue;
+                    }
+                }
+            }
+            counted++;
+            if (!probe && counted < 256) {                 // early frames may lack their reservoir: count what decodes
+                bool fresh = false;
+                const FrameResult fr = frame(dec, p, (int)std::min<size_t>(left, 0x7fffffff), nullptr, &fresh);
+                probe = fr.stop ? 0 : fr.samples;
+                declared += (uint64_t)probe * (uint64_t)nch;
+            } else {
+                declared += (uint64_t)hd.samples() * (uint64_t)nch;
+            }
+            p += sz;
+            left -= (size_t)sz;
+        }
+    }
+    if (!have || layer0 != 3) return false;
+    f.channels = ch0;
+    f.hz = hz0;
+    f.tagged = tagged;
+    f.start_delay = to_skip;
+    f.detected_samples = detected;
+    f.declared_samples = declared;
+
+    dec.reset();
+    bool fresh = true;
+    uint64_t off = start, cur = 0;
+    for (;;) {
+        if (detected && cur >= detected) break;
+        const uint64_t left = n - off;
+        if (!left) break;
+        const uint64_t blocks_before = f.flags.size();
+        const std::vector<uint32_t> runs_before = f.run_granules;
+        const FrameResult fr = frame(dec, buf + off, (int)std::min<uint64_t>(left, 0x7fffffff), &f, &fresh);
+        if (fr.stop || fr.hz != hz0 || fr.layer != layer0 || fr.channels != ch0) {
+            // MP3D_E_DECODE (minimp3_ex.d:851-857; also what "no further frame" turns into, since the frame info
+            // stays zero then): the stream ends here; records of this frame are dropped
+            f.flags.resize(blocks_before);
+            f.coef.resize(blocks_before * 576);
+            f.run_granules = runs_before;
+            break;
+        }
+        if (fr.samples) {
+            const int total = fr.samples * fr.channels;
+            int used = 0;
+            if (to_skip) {
+                used = std::min(total, to_skip);
+                to_skip -= used;
+            }
+            uint64_t take = (uint64_t)(total - used);
+            if (detected && cur + take >= detected) take = detected - cur;
+            if (take) f.copies.push_back(Copy{ blocks_before * 576 + (uint64_t)used, take });
+            cur += take;
+        } else if (to_skip) {
+            const int fs = (int)Header{ buf + off }.samples() * fr.channels;
+            to_skip -= std::min(fs, to_skip);
+        }
+        off += (uint64_t)fr.consumed;
+    }
+    f.pcm_samples = cur;
+    // trailing granules that no copy refers to are still part of their run (the device needs whole runs)
+    return true;
+}
+
+}  // namespace afg_mp3

@@ -207,9 +207,9 @@ int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const af
 
 /* ========================================================================== *
  *  Outer surface: the AudioStream subset (stream.d:102-637) over the host front-ends
- *  that exist so far -- FLAC (native container, drflac.d:680-1695, :1887-2153) and QOA
- *  (qoa.d:413-486, :703-851).  Other formats report "unrecognized encoding" until their
- *  host parsers land (MP3, Vorbis, Opus: SURVEY 8f).  The host parses the whole file into
+ *  that exist so far -- FLAC (native container, drflac.d:680-1695, :1887-2153), QOA
+ *  (qoa.d:413-486, :703-851) and MP3 Layer III (minimp3.d, minimp3_ex.d).  Other formats report
+ *  "unrecognized encoding" until their host parsers land (Vorbis, Opus: SURVEY 8f).  The host parses the whole file into
  *  transform-stage records, the device restores the samples, the stream serves them.
  * ========================================================================== */
 
@@ -256,6 +256,28 @@ void afg_flac_parsed_free(afg_flac_parsed *parsed);
 /* frames may be NULL (count only); at most frame_cap records are written, *n_frames gets the total. */
 int  afg_qoa_parse(const uint8_t *data, size_t length, uint32_t *channels, uint32_t *samplerate,
                    uint32_t *samples, afg_qoa_frame *frames, size_t frame_cap, size_t *n_frames);
+
+/* MP3 (MPEG-1/2/2.5 Layer III) front-end on its own: frame sync, side info, scalefactors, Huffman +
+ * requantisation, stereo processing, reorder and bit reservoir (minimp3.d:487-1000, :1170-1230, :1436-1581)
+ * driven the way minimp3_ex does it (ID3/APE skipping, Xing/Info tag, delay/padding: minimp3_ex.d:93-190,
+ * :566-639, :787-888).  Result: the records afg_mp3_transform_hip consumes -- one plan stream per run of
+ * continuous decoder state -- and the copy plan that turns its PCM plane into what mp3dec_ex_read delivers. */
+typedef struct afg_mp3_copy { uint64_t src_float, count; } afg_mp3_copy;
+typedef struct afg_mp3_parsed {
+    int32_t  channels, hz, tagged, start_delay;
+    uint64_t detected_samples;     /* 0: delivery runs to the end of the data */
+    uint64_t declared_samples;     /* mp3dec_ex_t.samples; AudioStream length = this / channels (stream.d:1737) */
+    uint64_t pcm_samples;          /* floats the copy plan delivers */
+    uint64_t n_runs, n_blocks, n_copies;
+    uint32_t *run_granules;        /* [n_runs] granules per plan stream, all with `channels` channels */
+    float    *coef;                /* n_blocks * 576 */
+    uint32_t *flags;               /* n_blocks, AFG_MP3_FLAGS */
+    afg_mp3_copy *copies;
+    void     *owner;               /* internal */
+} afg_mp3_parsed;
+
+int  afg_mp3_parse(const uint8_t *data, size_t length, afg_mp3_parsed *out);   /* AFG_ERR_UNSUPPORTED: no Layer III stream */
+void afg_mp3_parsed_free(afg_mp3_parsed *parsed);
 
 /* Batch decode (no reference counterpart: the throughput path).  Files are parsed by n_threads
  * host threads (0 = hardware concurrency), restored on the current device in one launch per

@@ -22,6 +22,7 @@
 #define AFG_ORACLE_H
 
 #include <stddef.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -67,6 +68,27 @@ void afgo_mp3_granule(afgo_mp3_state *st, float *coef, const uint32_t *flags, in
 void afgo_mp3_transform(uint32_t n_streams, const uint32_t *ngr, const uint8_t *nch,
                         const float *coef, const uint32_t *flags, float *pcm,
                         afgo_mp3_state *states);
+
+/* MP3 front-end + file drive (mp3_frontend.c): everything minimp3 / minimp3_ex do ahead of the transform
+ * seam, for whole files in memory.  The transform-stage records of every decoded granule are kept so
+ * that the product's parser can be compared record by record. */
+typedef struct afgo_mp3_file {
+    int channels, hz;
+    int vbr_tag_found;
+    int start_delay;                /* samples (channels included) skipped at the start, minimp3_ex.d:594 */
+    uint64_t detected_samples;      /* 0 = read to the end of the data, minimp3_ex.d:600 */
+    uint64_t samples;               /* mp3dec_ex_t.samples: what AudioStream divides by the channel count */
+    uint32_t n_streams;             /* runs of granules with continuous decoder state (a resync resets it) */
+    uint32_t *stream_granules;      /* [n_streams] */
+    uint64_t n_blocks;              /* gr-ch blocks in coef / flags, order [granule][channel] */
+    float *coef;
+    uint32_t *flags;
+    uint64_t pcm_samples;           /* what mp3dec_ex_read delivers until it returns 0 */
+    float *pcm;
+} afgo_mp3_file;
+
+int afgo_mp3_decode_file(const uint8_t *data, size_t size, afgo_mp3_file *out);   /* 0 ok, -1 not Layer III, -2 memory */
+void afgo_mp3_file_free(afgo_mp3_file *f);
 
 /* --------------------------------------------------------------- Vorbis -- */
 

@@ -184,6 +184,41 @@ def vorbis_transform(npkt, nch, bs0, bs1, pflags, spec_off, out_off, spec, out_t
     return out
 
 
+class _Mp3File(C.Structure):
+    _fields_ = [("channels", C.c_int), ("hz", C.c_int), ("vbr_tag_found", C.c_int), ("start_delay", C.c_int),
+                ("detected_samples", C.c_uint64), ("samples", C.c_uint64), ("n_streams", C.c_uint32),
+                ("stream_granules", C.POINTER(C.c_uint32)), ("n_blocks", C.c_uint64), ("coef", C.POINTER(C.c_float)),
+                ("flags", C.POINTER(C.c_uint32)), ("pcm_samples", C.c_uint64), ("pcm", C.POINTER(C.c_float))]
+
+
+def mp3_decode_file(data):
+    """Oracle front-end + transform over a whole file in memory.  Returns None if no Layer III stream is found,
+    else a dict: channels, hz, tagged, start_delay, detected_samples, declared_samples, runs, coef, flags, pcm."""
+    buf = bytes(data)
+    f = _Mp3File()
+    fn = lib().afgo_mp3_decode_file
+    fn.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_Mp3File)]
+    rc = fn(buf, len(buf), C.byref(f))
+    if rc != 0:
+        return None
+    try:
+        def arr(ptr, n, shape=None):
+            a = np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+            return a.reshape(shape) if shape else a
+        nb = int(f.n_blocks)
+        return {"channels": f.channels, "hz": f.hz, "tagged": f.vbr_tag_found, "start_delay": f.start_delay,
+                "detected_samples": int(f.detected_samples), "declared_samples": int(f.samples),
+                "runs": arr(f.stream_granules, int(f.n_streams)).astype(np.uint32) if f.n_streams else np.zeros(0, np.uint32),
+                "coef": arr(f.coef, nb * 576, (-1, 576)) if nb else np.zeros((0, 576), np.float32),
+                "flags": arr(f.flags, nb).astype(np.uint32) if nb else np.zeros(0, np.uint32),
+                "pcm": arr(f.pcm, int(f.pcm_samples))}
+    finally:
+        free = lib().afgo_mp3_file_free
+        free.argtypes = [C.POINTER(_Mp3File)]
+        free.restype = None
+        free(C.byref(f))
+
+
 # --------------------------------------------------------------- FLAC ------
 def flac_transform(frames, subframes, res, out_total, want_float=False):
     frames = np.ascontiguousarray(frames, FLAC_FRAME_DTYPE)

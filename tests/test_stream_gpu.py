@@ -108,3 +108,48 @@ def test_batch_decode_mixed_formats_and_bad_files(gpu):
         assert item["frames"] == len(want) and item["channels"] == want.shape[1]
         assert np.array_equal(item["pcm"].view(np.uint32), want.view(np.uint32))
     assert afgpu.batch_decode([]) == []
+
+
+# ---- MP3: file bytes -> host front-end -> device transform -> what mp3dec_ex_read delivers --------------------
+import os  # noqa: E402
+
+MP3_FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "mathjax_invalid_keypress.mp3")
+
+
+def test_mp3_stream(gpu):
+    data = open(MP3_FIXTURE, "rb").read()
+    want = oraclelib.mp3_decode_file(data)
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    assert not s.isError(), s.errorMessage()
+    assert s.getFormat() == afgpu.FORMAT_MP3 and s.getNumChannels() == 2 and s.getSamplerate() == 44100.0
+    assert s.getLengthInFrames() == want["declared_samples"] // 2 == 23087            # stream.d:1737
+    got = read_all(s, 2, 777)
+    assert got.shape == (23087, 2)
+    assert np.array_equal(got.view(np.uint32), want["pcm"].reshape(-1, 2).view(np.uint32))      # bit-exact
+    assert s.readSamplesFloat(np.zeros(8, np.float32)) == 0
+
+
+def test_mp3_variants_in_a_batch(gpu):
+    d = open(MP3_FIXTURE, "rb").read()
+    body = d[45:]
+    files = [d, body[209:], bytes(300) + body, d[:5000], d + b"TAG" + bytes(125)]
+    rng = np.random.default_rng(11)
+    for _ in range(6):                                   # damaged copies: resynchronisation splits them into several runs
+        v = bytearray(d)
+        pos = int(rng.integers(600, len(v) - 2500))
+        del v[pos:pos + int(rng.integers(1, 200))]
+        files.append(bytes(v))
+    pcm = make_pcm(3000, 2, 16, 5)
+    flac, _ = fb.encode_file(pcm, 16, 1024)
+    files.insert(3, flac)                                # formats can be mixed freely
+    out = afgpu.batch_decode(files, n_threads=4)
+    for blob, item in zip(files, out):
+        if blob[:4] == b"fLaC":
+            assert item["format"] == afgpu.FORMAT_FLAC and item["frames"] == 3000
+            continue
+        want = oraclelib.mp3_decode_file(blob)
+        assert item["status"] == 0 and item["format"] == afgpu.FORMAT_MP3
+        assert item["frames"] * item["channels"] == len(want["pcm"])
+        if item["frames"]:
+            assert np.array_equal(item["pcm"].reshape(-1).view(np.uint32), want["pcm"].view(np.uint32))
