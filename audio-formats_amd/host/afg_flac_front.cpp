@@ -1,0 +1,340 @@
+// afg_flac_front.cpp -- host front-ends for native FLAC files and QOA files.
+//
+//   FLAC  container + frame/subframe headers + Rice residuals   (reference drflac.d:680-1695,
+//         :1887-2153; the prediction half of drflac.d:1235 is NOT done here: residuals and
+//         subframe parameters become afg_flac_subframe / afg_flac_frame records)
+//   QOA   file/frame headers only (reference qoa.d:413-486): the device reads the raw bytes
+#include "afg_flac_front.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace afg_front {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// MSB-first bit reader over memory (the role of drflac_bs, drflac.d:680-1002)
+// ---------------------------------------------------------------------------------------------
+struct BitReader {
+    const uint8_t *p;
+    size_t nbits, pos = 0;
+    bool fail = false;
+    BitReader(const uint8_t *data, size_t bytes) : p(data), nbits(bytes * 8) {}
+    uint32_t bit()
+    {
+        if (pos >= nbits) { fail = true; return 0; }
+        uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1u;
+        pos++;
+        return b;
+    }
+    uint64_t bits(unsigned n)      // n <= 57
+    {
+        if (n == 0) return 0;
+        if (pos + n > nbits) { fail = true; pos = nbits; return 0; }
+        uint64_t v = 0;
+        size_t byte = pos >> 3;
+        unsigned have = 0;
+        uint64_t acc = 0;
+        unsigned skip = (unsigned)(pos & 7);
+        while (have < n + skip) { acc = (acc << 8) | p[byte++]; have += 8; }
+        v = (acc >> (have - n - skip)) & ((n == 64) ? ~0ull : ((1ull << n) - 1));
+        pos += n;
+        return v;
+    }
+    int64_t sbits(unsigned n)      // two's complement, drflac__read_int32 (drflac.d:858-870)
+    {
+        uint64_t v = bits(n);
+        if (n == 0) return 0;
+        uint64_t sign = 1ull << (n - 1);
+        return (int64_t)((v ^ sign)) - (int64_t)sign;
+    }
+    bool unary(uint32_t &zeros)    // counts zeros up to and including the terminating one
+    {
+        zeros = 0;
+        for (;;) {
+            if (pos >= nbits) { fail = true; return false; }
+            unsigned skip = (unsigned)(pos & 7);
+            uint32_t byte = (uint32_t)(p[pos >> 3] << skip) & 0xffu;
+            if (byte) {
+                unsigned lz = (unsigned)__builtin_clz(byte) - 24;
+                zeros += lz;
+                pos += lz + 1;
+                return true;
+            }
+            zeros += 8 - skip;
+            pos += 8 - skip;
+        }
+    }
+    void align() { pos = (pos + 7) & ~(size_t)7; }
+    size_t byte_pos() const { return pos >> 3; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// FLAC: native container -> records
+// ---------------------------------------------------------------------------------------------
+
+// STREAMINFO + metadata walk, drflac.d:1901-1931, :1933-2118 (ID3-prefixed FLAC is not supported by
+// the reference either, drflac.d:12-13)
+bool flac_open(const uint8_t *d, size_t n, FlacInfo &fi)
+{
+    if (n < 4 + 4 + 34 || d[0] != 'f' || d[1] != 'L' || d[2] != 'a' || d[3] != 'C') return false;
+    size_t pos = 4;
+    bool got = false;
+    for (;;) {
+        if (pos + 4 > n) return false;
+        const bool last = (d[pos] & 0x80) != 0;
+        const unsigned type = d[pos] & 0x7f;
+        const size_t len = ((size_t)d[pos + 1] << 16) | ((size_t)d[pos + 2] << 8) | d[pos + 3];
+        pos += 4;
+        if (pos + len > n) return false;
+        if (type == 0) {
+            if (len < 34) return false;
+            BitReader br(d + pos, len);
+            br.bits(16);                               // min block size
+            fi.max_block = (uint32_t)br.bits(16);
+            br.bits(24); br.bits(24);                  // min/max frame size
+            fi.sample_rate = (uint32_t)br.bits(20);
+            fi.channels = (uint32_t)br.bits(3) + 1;
+            fi.bps = (uint32_t)br.bits(5) + 1;
+            fi.total_samples = br.bits(36);
+            got = true;
+        }
+        pos += len;
+        if (last) break;
+    }
+    fi.first_frame = pos;
+    return got && fi.sample_rate != 0 && fi.bps >= 4;
+}
+
+
+// drflac__read_utf8_coded_number, drflac.d:1005-1043
+bool read_utf8(BitReader &br, uint64_t &out)
+{
+    uint32_t b0 = (uint32_t)br.bits(8);
+    if (br.fail) return false;
+    int extra;
+    if ((b0 & 0x80) == 0) { out = b0; return true; }
+    else if ((b0 & 0xE0) == 0xC0) { extra = 1; out = b0 & 0x1F; }
+    else if ((b0 & 0xF0) == 0xE0) { extra = 2; out = b0 & 0x0F; }
+    else if ((b0 & 0xF8) == 0xF0) { extra = 3; out = b0 & 0x07; }
+    else if ((b0 & 0xFC) == 0xF8) { extra = 4; out = b0 & 0x03; }
+    else if ((b0 & 0xFE) == 0xFC) { extra = 5; out = b0 & 0x01; }
+    else if (b0 == 0xFE) { extra = 6; out = 0; }
+    else return false;
+    for (int i = 0; i < extra; i++) {
+        uint32_t b = (uint32_t)br.bits(8);
+        if (br.fail || (b & 0xC0) != 0x80) return false;
+        out = (out << 6) | (b & 0x3F);
+    }
+    return true;
+}
+
+// residual of one subframe into dst[order .. block_size), drflac.d:1279-1328 (+ Rice :1166-1224)
+bool flac_residual(BitReader &br, uint32_t block_size, uint32_t order, int32_t *dst)
+{
+    const unsigned method = (unsigned)br.bits(2);
+    if (method > 1) return false;                                  // :1287
+    const unsigned part_order = (unsigned)br.bits(4);
+    const uint32_t nparts = 1u << part_order;
+    if ((block_size >> part_order) < order && part_order) return false;
+    uint32_t i = order;
+    for (uint32_t part = 0; part < nparts; part++) {
+        uint32_t count = block_size >> part_order;
+        if (part == 0) {
+            if (count < order) return false;
+            count -= order;                                        // :1295
+        }
+        unsigned k = (unsigned)br.bits(method == 0 ? 4 : 5);
+        // The reference tests the parameter against 16 / 32 (drflac.d:1301, :1304), values a 4- / 5-bit
+        // field never takes, so its unencoded-partition branch (:1313-1321) is dead and the FLAC escape
+        // codes 15 / 31 are decoded as plain Rice parameters.  Results must be identical to the
+        // reference's, so the same happens here (DESIGN.md "FLAC front-end"); flip kSpecEscape to get
+        // the format's own behaviour.
+        constexpr bool kSpecEscape = false;
+        const bool escape = kSpecEscape && ((method == 0 && k == 15) || (method == 1 && k == 31));
+        if (br.fail) return false;
+        if (!escape) {
+            for (uint32_t j = 0; j < count; j++) {
+                uint32_t q;
+                if (!br.unary(q)) return false;
+                uint32_t v = (q << k) | (uint32_t)br.bits(k);
+                dst[i++] = (int32_t)((v >> 1) ^ (~(v & 1) + 1));   // zig-zag, :1224
+            }
+        } else {
+            const unsigned raw = (unsigned)br.bits(5);
+            for (uint32_t j = 0; j < count; j++) dst[i++] = (int32_t)br.sbits(raw);
+        }
+        if (br.fail) return false;
+    }
+    return i == block_size;
+}
+
+const int16_t kFixedCoef[5][4] = { { 0, 0, 0, 0 }, { 1, 0, 0, 0 }, { 2, -1, 0, 0 }, { 3, -3, 1, 0 }, { 4, -6, 4, -1 } };   // :1397-1403
+
+// one frame: header (drflac.d:1444-1528), subframes (:1530-1599), padding + CRC-16 (:1673)
+bool flac_frame(BitReader &br, const FlacInfo &fi, FlacRecords &rec)
+{
+    static const uint32_t bpsTable[8] = { 0, 8, 12, 255, 16, 20, 24, 255 };
+    if (br.bits(14) != 0x3FFE || br.fail) return false;
+    br.bits(1);
+    br.bits(1);                                                    // blocking strategy: number is skipped either way
+    const unsigned bsCode = (unsigned)br.bits(4), srCode = (unsigned)br.bits(4);
+    const unsigned asg = (unsigned)br.bits(4), bpsCode = (unsigned)br.bits(3);
+    br.bits(1);
+    uint64_t number;
+    if (!read_utf8(br, number)) return false;
+    uint32_t bs;
+    if (bsCode == 0) return false;                                 // reserved (undefined shift in the reference)
+    else if (bsCode == 1) bs = 192;
+    else if (bsCode <= 5) bs = 576u << (bsCode - 2);
+    else if (bsCode == 6) bs = (uint32_t)br.bits(8) + 1;
+    else if (bsCode == 7) bs = (uint32_t)br.bits(16) + 1;
+    else bs = 256u << (bsCode - 8);
+    if (srCode == 12) br.bits(8);
+    else if (srCode == 13 || srCode == 14) br.bits(16);
+    else if (srCode == 15) return false;
+    uint32_t bps = bpsTable[bpsCode];
+    if (bps == 255) return false;                                  // reserved
+    if (bps == 0) bps = fi.bps;
+    br.bits(8);                                                    // CRC-8 (stored, unused: :1450)
+    if (br.fail) return false;
+    uint32_t C;
+    if (asg <= 7) C = asg + 1;
+    else if (asg <= 10) C = 2;
+    else return false;
+    if (C != fi.channels || bs == 0 || bs > 65535) return false;
+
+    afg_flac_frame fr;
+    std::memset(&fr, 0, sizeof(fr));
+    fr.in_off = rec.res.size();
+    fr.out_off = rec.out_samples;
+    fr.block_size = bs;
+    fr.sf_index = (uint32_t)rec.subframes.size();
+    fr.channels = (uint8_t)C;
+    fr.assignment = (uint8_t)(asg <= 7 ? AFG_FLAC_INDEPENDENT : asg);
+    fr.bps = (uint8_t)fi.bps;                                      // drflac_read_s32 shifts by 32 - STREAMINFO bps (:2883)
+    rec.res.resize(rec.res.size() + (size_t)bs * C);
+    for (uint32_t c = 0; c < C; c++) {
+        int32_t *dst = rec.res.data() + fr.in_off + (size_t)c * bs;
+        afg_flac_subframe sf;
+        std::memset(&sf, 0, sizeof(sf));
+        const unsigned hdr = (unsigned)br.bits(8);                 // :1530-1569
+        if (br.fail || (hdr & 0x80)) return false;
+        const unsigned type = (hdr & 0x7E) >> 1;
+        unsigned wasted = 0;
+        if (hdr & 1) {
+            uint32_t z;
+            if (!br.unary(z)) return false;
+            wasted = z + 1;
+        }
+        unsigned sbps = bps;                                       // side channels carry one extra bit, :1578-1585
+        if ((asg == AFG_FLAC_LEFT_SIDE || asg == AFG_FLAC_MID_SIDE) && c == 1) sbps++;
+        else if (asg == AFG_FLAC_RIGHT_SIDE && c == 0) sbps++;
+        if (wasted >= sbps) return false;
+        sbps -= wasted;
+        sf.wasted = (uint8_t)wasted;
+        sf.use64 = sbps > 16;                                      // :1308
+        if (type == 0) {                                           // constant, :1375-1385
+            const int32_t v = (int32_t)br.sbits(sbps);
+            std::fill(dst, dst + bs, v);
+        } else if (type == 1) {                                    // verbatim, :1387-1394
+            for (uint32_t i = 0; i < bs; i++) dst[i] = (int32_t)br.sbits(sbps);
+        } else if (type & 0x20) {                                  // LPC, :1417-1441
+            const unsigned order = (type & 0x1F) + 1;
+            if (order > bs) return false;
+            for (unsigned i = 0; i < order; i++) dst[i] = (int32_t)br.sbits(sbps);
+            const unsigned prec = (unsigned)br.bits(4);
+            if (prec == 15) return false;
+            const int shift = (int)br.sbits(5);
+            if (shift < 0) return false;                           // undefined in the reference: rejected
+            for (unsigned i = 0; i < order; i++) sf.coef[i] = (int16_t)br.sbits(prec + 1);
+            sf.order = (uint8_t)order;
+            sf.shift = (uint8_t)shift;
+            if (!flac_residual(br, bs, order, dst)) return false;
+        } else if (type & 0x08) {                                  // fixed, :1396-1415
+            const unsigned order = type & 0x07;
+            if (order > 4 || order > bs) return false;
+            for (unsigned i = 0; i < order; i++) dst[i] = (int32_t)br.sbits(sbps);
+            for (unsigned i = 0; i < order; i++) sf.coef[i] = kFixedCoef[order][i];
+            sf.order = (uint8_t)order;
+            sf.shift = 0;
+            if (!flac_residual(br, bs, order, dst)) return false;
+        } else {
+            return false;                                          // reserved
+        }
+        if (br.fail) return false;
+        rec.subframes.push_back(sf);
+    }
+    br.align();
+    br.bits(16);                                                   // CRC-16, not verified (drflac.d:108, :1673)
+    if (br.fail) return false;
+    rec.frames.push_back(fr);
+    rec.out_samples += (uint64_t)bs * C;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// QOA: locate frames (qoa.d:413-486); everything else happens on the device
+// ---------------------------------------------------------------------------------------------
+
+uint64_t be64(const uint8_t *p)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) v = (v << 8) | p[i];
+    return v;
+}
+
+}  // namespace
+
+// whole file -> records; stops at the first frame that does not parse (the reference's read loop
+// does the same: drflac.d:2860)
+bool flac_parse(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec)
+{
+    if (!flac_open(d, n, fi)) return false;
+    BitReader br(d + fi.first_frame, n - fi.first_frame);
+    while (br.byte_pos() + 2 < n - fi.first_frame) {
+        const size_t keep_f = rec.frames.size(), keep_s = rec.subframes.size(), keep_r = rec.res.size();
+        if (!flac_frame(br, fi, rec)) {
+            rec.frames.resize(keep_f);
+            rec.subframes.resize(keep_s);
+            rec.res.resize(keep_r);
+            break;
+        }
+    }
+    return true;
+}
+
+bool qoa_parse(const uint8_t *d, size_t n, QoaInfo &qi, std::vector<afg_qoa_frame> &frames)
+{
+    if (n < 16) return false;                                      // QOA_MIN_FILESIZE
+    const uint64_t fh = be64(d);
+    if ((fh >> 32) != 0x716f6166u) return false;                   // 'qoaf'
+    qi.samples = (uint32_t)(fh & 0xffffffffu);
+    if (!qi.samples) return false;
+    const uint64_t first = be64(d + 8);
+    qi.channels = (uint32_t)((first >> 56) & 0xff);
+    qi.samplerate = (uint32_t)((first >> 32) & 0xffffff);
+    if (qi.channels == 0 || qi.channels > 8 || qi.samplerate == 0) return false;
+    size_t pos = 8;
+    uint64_t out = 0;
+    while (pos + 8 + 16 * (size_t)qi.channels <= n) {
+        const uint64_t h = be64(d + pos);
+        const uint32_t ch = (uint32_t)((h >> 56) & 0xff), sr = (uint32_t)((h >> 32) & 0xffffff);
+        const uint32_t smp = (uint32_t)((h >> 16) & 0xffff), fsz = (uint32_t)(h & 0xffff);
+        if (fsz < 8 + 16 * ch || pos + fsz > n) break;
+        const uint32_t slices = (fsz - 8 - 16 * ch) / 8;
+        if (ch != qi.channels || sr != qi.samplerate || smp * ch > slices * 20 || smp == 0) break;   // qoa.d:478-486
+        afg_qoa_frame fr;
+        std::memset(&fr, 0, sizeof(fr));
+        fr.byte_off = pos;
+        fr.out_off = out;
+        fr.samples = (uint16_t)smp;
+        fr.channels = (uint8_t)ch;
+        frames.push_back(fr);
+        out += (uint64_t)smp * ch;
+        pos += fsz;
+    }
+    return !frames.empty();
+}
+
+}  // namespace afg_front

@@ -463,10 +463,20 @@ void intensity(float *left, uint8_t *ist, const Granule *g, const Header &hd)
     }
 }
 
-// L3_reorder: [band][window][line] -> [band][line][window]
+// L3_reorder: [band][window][line] -> [band][line][window].  For MPEG-2.5 at 8 kHz a mixed block starts its
+// short part at line 72 (4 subbands, minimp3.d:1218) while the band table's short part starts at line 48, so the
+// reference walks 24 lines past the channel's 576 (minimp3.d:1223): into the next channel's spectrum for channel 0,
+// into the scalefactor array behind grbuf for channel 1.  The work area below has the same layout so that even
+// this corner gives the reference's numbers.
+struct Work {
+    float x[2][576];
+    float scale[40];                   // directly behind the spectra, as mp3dec_scratch_t.scf (minimp3.d:179-181)
+    float slack[24];
+};
+
 void interleave_windows(float *x, const uint8_t *bands)
 {
-    float tmp[576];
+    float tmp[640];
     float *d = tmp;
     const float *s = x;
     for (int len; (len = *bands) != 0; bands += 3, s += 3 * len)
@@ -599,19 +609,23 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
     // main data = the last `begin` bytes of the reservoir + this frame's payload
     const int payload = (sb.limit - sb.pos) / 8;
     const int have = std::min((int)d.reservoir.size(), begin);
-    std::vector<uint8_t> md((size_t)have + (size_t)payload + 16, 0);
-    std::memcpy(md.data(), d.reservoir.data() + (d.reservoir.size() - (size_t)have), (size_t)have);
+    // (a damaged granule can claim far more big values than it has bits for: the spectrum reader may run up to
+    // 288 pairs x 47 bits past the data; it finds zeros there)
+    std::vector<uint8_t> md((size_t)have + (size_t)payload + 2048, 0);
+    if (have) std::memcpy(md.data(), d.reservoir.data() + (d.reservoir.size() - (size_t)have), (size_t)have);
     std::memcpy(md.data() + have, body + sb.pos / 8, (size_t)payload);
     const bool ok = (int)d.reservoir.size() >= begin;
     const int md_bytes = have + payload;
     int bitpos = 0;
     if (ok) {
         const int ngr = hd.mpeg1() ? 2 : 1, nch = r.channels;
+        Work wk;
+        std::memset(&wk, 0, sizeof(wk));
+        float (&x)[2][576] = wk.x;
+        float *scale = wk.scale;
         for (int gr = 0; gr < ngr; gr++) {
-            float x[2][576];
-            std::memset(x, 0, sizeof(x));
+            std::memset(x, 0, sizeof(wk.x));
             uint8_t ist[2][40];
-            float scale[40];
             const Granule *g = gi + gr * nch;
             for (int ch = 0; ch < nch; ch++) {
                 const int limit = bitpos + g[ch].part23;

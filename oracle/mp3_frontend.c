@@ -442,7 +442,7 @@ typedef struct {
 
 typedef struct {
     bs_t bs;
-    uint8_t maindata[MAX_BITRESERVOIR_BYTES + MAX_L3_FRAME_PAYLOAD_BYTES + 8];
+    uint8_t maindata[MAX_BITRESERVOIR_BYTES + MAX_L3_FRAME_PAYLOAD_BYTES + 2048];   /* zeroed slack: a damaged granule may read far past its data */
     gr_info_t gr_info[4];
     float grbuf[2][576];
     float scf[40];
