@@ -15,8 +15,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -52,6 +54,8 @@ struct Parsed {
     QoaInfo qi;
     std::vector<afg_qoa_frame> qoa;
     afg_mp3::File mp3;
+    const float *mp3_coef() const { return mp3.ext_coef ? mp3.ext_coef : mp3.coef.data(); }
+    const uint32_t *mp3_flags() const { return mp3.ext_flags ? mp3.ext_flags : mp3.flags.data(); }
 };
 
 // startDecoding's probe order for the formats handled here (stream.d:1586-1838): FLAC, QOA, then MP3 (whose
@@ -89,6 +93,70 @@ struct PinnedBuf {
     }
 };
 
+// Staging buffers (gathered inputs, the raw MP3 PCM plane) are reused across calls: pinning memory costs about as
+// much as moving it.  The pool keeps the few largest buffers it has seen, bounded in count and bytes.
+class StagingPool {
+public:
+    struct Lease {
+        StagingPool *pool = nullptr;
+        void *p = nullptr;
+        size_t cap = 0;
+        Lease() = default;
+        Lease(const Lease &) = delete;
+        Lease &operator=(const Lease &) = delete;
+        ~Lease() { if (pool && p) pool->give_back(p, cap); }
+    };
+    int take(size_t bytes, Lease &out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].second >= bytes && (best == free_.size() || free_[i].second < free_[best].second)) best = i;
+            if (best != free_.size()) {
+                out.pool = this; out.p = free_[best].first; out.cap = free_[best].second;
+                held_ -= out.cap;
+                free_.erase(free_.begin() + (long)best);
+                return AFG_OK;
+            }
+        }
+        void *p = nullptr;
+        const size_t cap = bytes ? bytes : 1;
+        hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+        if (e != hipSuccess) { afg::set_error("hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); return AFG_ERR_OOM; }
+        out.pool = this; out.p = p; out.cap = cap;
+        return AFG_OK;
+    }
+private:
+    void give_back(void *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (free_.size() < 8 && held_ + cap <= ((size_t)16 << 30)) {
+            free_.emplace_back(p, cap);
+            held_ += cap;
+        } else {
+            (void)hipHostFree(p);
+        }
+    }
+    std::mutex mu_;
+    std::vector<std::pair<void *, size_t>> free_;
+    size_t held_ = 0;
+};
+StagingPool g_staging;
+
+// AFG_TRACE=1: wall-clock of the host stages on stderr (development aid)
+struct StageTimer {
+    bool on = std::getenv("AFG_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[afg] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 template <typename F>
 void parallel_for(size_t n, unsigned threads, F fn)
 {
@@ -110,8 +178,8 @@ void parallel_for(size_t n, unsigned threads, F fn)
 
 struct BatchOut {
     std::vector<Decoded> files;
-    PinnedBuf plane;                    // all PCM of the batch, FLAC files first then QOA files
-    size_t plane_floats = 0;
+    StagingPool::Lease plane;           // all PCM of the batch: FLAC files, then QOA files, then MP3 files; page-locked,
+    size_t plane_floats = 0;            // returned to the pool by afg_batch_free / afg_close
 };
 
 // Device stage for a set of parsed files: every FLAC record of the batch in one launch, every QOA frame
@@ -121,6 +189,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
 {
     const size_t nf = parsed.size();
     out.files.assign(nf, Decoded());
+    StageTimer tm;
     // ---- layout ----
     std::vector<size_t> res_base(nf, 0), fr_base(nf, 0), sf_base(nf, 0), qbyte_base(nf, 0), qfr_base(nf, 0);
     size_t res_total = 0, fr_total = 0, sf_total = 0, flac_out = 0, qbytes = 0, qframes = 0, qoa_out = 0;
@@ -148,14 +217,15 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         if (p.format != AFG_FORMAT_MP3) continue;
         mp3_blk_base[i] = mp3_blocks;
         out.files[i].pcm_off = flac_out + qoa_out + mp3_out;
-        mp3_blocks += p.mp3.flags.size();
+        mp3_blocks += p.mp3.blocks();
         mp3_out += (size_t)p.mp3.pcm_samples;
         mp3_runs += p.mp3.run_granules.size();
     }
     out.plane_floats = flac_out + qoa_out + mp3_out;
     if (out.plane_floats == 0) goto metadata;
     {
-        if (int rc = out.plane.alloc(out.plane_floats * sizeof(float))) return rc;
+        if (int rc = g_staging.take(out.plane_floats * sizeof(float), out.plane)) return rc;
+        tm.lap("layout + plane alloc");
         DeviceBuf d_out;
         if (int rc = d_out.alloc(out.plane_floats * sizeof(float))) return rc;
         hipStream_t stream = nullptr;
@@ -163,9 +233,9 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         if (flac_out) {
             const size_t rec_bytes = fr_total * sizeof(afg_flac_frame) + sf_total * sizeof(afg_flac_subframe);
             const size_t rec_pad = (rec_bytes + 15) & ~(size_t)15;
-            PinnedBuf h_in;
+            StagingPool::Lease h_in;
             DeviceBuf d_in;
-            if (int rc = h_in.alloc(rec_pad + res_total * 4)) return rc;
+            if (int rc = g_staging.take(rec_pad + res_total * 4, h_in)) return rc;
             if (int rc = d_in.alloc(rec_pad + res_total * 4)) return rc;
             afg_flac_frame *hf = (afg_flac_frame *)h_in.p;
             afg_flac_subframe *hs = (afg_flac_subframe *)(hf + fr_total);
@@ -192,9 +262,9 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         // ---- QOA ----
         if (qoa_out) {
             const size_t rec_pad = (qframes * sizeof(afg_qoa_frame) + 15) & ~(size_t)15;
-            PinnedBuf h_in;
+            StagingPool::Lease h_in;
             DeviceBuf d_in;
-            if (int rc = h_in.alloc(rec_pad + qbytes)) return rc;
+            if (int rc = g_staging.take(rec_pad + qbytes, h_in)) return rc;
             if (int rc = d_in.alloc(rec_pad + qbytes)) return rc;
             afg_qoa_frame *hq = (afg_qoa_frame *)h_in.p;
             uint8_t *hb = (uint8_t *)h_in.p + rec_pad;
@@ -218,56 +288,66 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             AFG_HIP_CHECK(hipMemcpyAsync(out.plane.p, d_out.p, (flac_out + qoa_out) * sizeof(float), hipMemcpyDeviceToHost, stream));
             AFG_HIP_CHECK(hipStreamSynchronize(stream));
         }
+        tm.lap("flac+qoa stages");
         // ---- MP3: spectra of every decoded granule -> PCM plane -> the samples mp3dec_ex_read would deliver ----
         if (mp3_blocks) {
             const size_t coef_bytes = mp3_blocks * 576 * sizeof(float), flag_bytes = (mp3_blocks * 4 + 15) & ~(size_t)15;
-            PinnedBuf h_in, h_pcm;
             DeviceBuf d_in, d_pcm;
-            if (int rc = h_in.alloc(coef_bytes + flag_bytes)) return rc;
             if (int rc = d_in.alloc(coef_bytes + flag_bytes)) return rc;
-            if (int rc = h_pcm.alloc(coef_bytes)) return rc;
             if (int rc = d_pcm.alloc(coef_bytes)) return rc;
-            float *hc = (float *)h_in.p;
-            uint32_t *hfl = (uint32_t *)((uint8_t *)h_in.p + coef_bytes);
-            std::vector<uint32_t> granules;
+            std::vector<uint32_t> granules, hfl(mp3_blocks);
             std::vector<uint8_t> channels;
             granules.reserve(mp3_runs);
             channels.reserve(mp3_runs);
-            for (size_t i = 0; i < nf; i++) {
-                if (parsed[i].format != AFG_FORMAT_MP3) continue;
-                for (uint32_t g : parsed[i].mp3.run_granules) {
+            hipError_t e = hipSuccess;
+            for (size_t i = 0; i < nf && e == hipSuccess; i++) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_MP3) continue;
+                for (uint32_t g : p.mp3.run_granules) {
                     granules.push_back(g);
-                    channels.push_back((uint8_t)parsed[i].mp3.channels);
+                    channels.push_back((uint8_t)p.mp3.channels);
                 }
+                const size_t nb = p.mp3.blocks();
+                if (!nb) continue;
+                std::memcpy(hfl.data() + mp3_blk_base[i], p.mp3_flags(), nb * sizeof(uint32_t));
+                // the batch path parsed this file straight into page-locked staging: one asynchronous copy per file
+                // into the packed device plane (a file parsed on its own comes from ordinary memory)
+                e = hipMemcpyAsync((float *)d_in.p + mp3_blk_base[i] * 576, p.mp3_coef(), nb * 576 * sizeof(float),
+                                   hipMemcpyHostToDevice, stream);
             }
-            parallel_for(nf, threads, [&](size_t i) {
-                Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_MP3) return;
-                std::memcpy(hc + mp3_blk_base[i] * 576, p.mp3.coef.data(), p.mp3.coef.size() * sizeof(float));
-                std::memcpy(hfl + mp3_blk_base[i], p.mp3.flags.data(), p.mp3.flags.size() * sizeof(uint32_t));
-                std::vector<float>().swap(p.mp3.coef);
-            });
+            if (e == hipSuccess)
+                e = hipMemcpyAsync((uint8_t *)d_in.p + coef_bytes, hfl.data(), mp3_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);        // hfl is pageable: settle before it goes away
+            if (e != hipSuccess) { afg::set_error("MP3 upload failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+            tm.lap("mp3 upload");
             afg_mp3_plan *plan = nullptr;
             if (int rc = afg_mp3_plan_create(&plan, (uint32_t)granules.size(), granules.data(), channels.data(), 0)) return rc;
-            hipError_t e = hipMemcpyAsync(d_in.p, h_in.p, coef_bytes + flag_bytes, hipMemcpyHostToDevice, stream);
             int rc = e == hipSuccess ? afg_mp3_transform_hip(plan, (const float *)d_in.p, (const uint32_t *)((const uint8_t *)d_in.p + coef_bytes),
                                                              (float *)d_pcm.p, nullptr, stream)
                                      : AFG_ERR_HIP;
-            if (!rc) e = hipMemcpyAsync(h_pcm.p, d_pcm.p, coef_bytes, hipMemcpyDeviceToHost, stream);
+            // delivery: the copy plan of each file, merged into maximal contiguous pieces (one per undamaged file),
+            // straight from the device PCM plane into the page-locked result plane
+            for (size_t i = 0; i < nf && !rc && e == hipSuccess; i++) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_MP3) continue;
+                const float *src = (const float *)d_pcm.p + mp3_blk_base[i] * 576;
+                float *dst = (float *)out.plane.p + out.files[i].pcm_off;
+                const std::vector<afg_mp3::Copy> &cp = p.mp3.copies;
+                for (size_t k = 0; k < cp.size() && e == hipSuccess;) {
+                    uint64_t from = cp[k].src, cnt = cp[k].count;
+                    size_t j = k + 1;
+                    while (j < cp.size() && cp[j].src == from + cnt) cnt += cp[j++].count;
+                    e = hipMemcpyAsync(dst, src + from, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, stream);
+                    dst += cnt;
+                    k = j;
+                }
+            }
             if (!rc && e == hipSuccess) e = hipStreamSynchronize(stream);
             afg_mp3_plan_destroy(plan);
+            tm.lap("mp3 plan+h2d+kernel+d2h");
             if (rc) return rc;
             if (e != hipSuccess) { afg::set_error("MP3 stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
-            parallel_for(nf, threads, [&](size_t i) {
-                const Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_MP3) return;
-                const float *src = (const float *)h_pcm.p + mp3_blk_base[i] * 576;
-                float *dst = (float *)out.plane.p + out.files[i].pcm_off;
-                for (const afg_mp3::Copy &c : p.mp3.copies) {
-                    std::memcpy(dst, src + c.src, (size_t)c.count * sizeof(float));
-                    dst += c.count;
-                }
-            });
+            tm.lap("mp3 delivery copies");
         }
     }
 metadata:
@@ -417,7 +497,7 @@ int afg_mp3_parse(const uint8_t *data, size_t length, afg_mp3_parsed *out)
     out->declared_samples = own->declared_samples;
     out->pcm_samples = own->pcm_samples;
     out->n_runs = own->run_granules.size();
-    out->n_blocks = own->flags.size();
+    out->n_blocks = own->blocks();
     out->n_copies = own->copies.size();
     out->run_granules = own->run_granules.data();
     out->coef = own->coef.data();
@@ -458,15 +538,41 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
     out->n_files = 0; out->items = nullptr; out->owner = nullptr;
     if (n_files == 0) return AFG_OK;
     if (int rc = afg::require_device()) return rc;
+    StageTimer tm;
     std::vector<Parsed> parsed((size_t)n_files);
     const unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    // pass 1: containers with a signature are parsed at once; MP3 candidates only get an upper bound of their
+    // record count, so that pass 2 can parse them straight into one page-locked staging buffer
+    std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0);
     parallel_for((size_t)n_files, nt, [&](size_t i) {
-        if (data[i] && length[i]) parse_file(data[i], length[i], parsed[i]);
+        if (!data[i] || !length[i]) return;
+        Parsed &p = parsed[i];
+        if (flac_parse(data[i], length[i], p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
+        p.flac = FlacRecords();
+        if (qoa_parse(data[i], length[i], p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
+        if (afg_mp3::looks_like_mp3(data[i], length[i])) bound[i] = afg_mp3::max_blocks(data[i], length[i]);
     });
-
+    size_t total_bound = 0;
+    for (size_t i = 0; i < (size_t)n_files; i++) { base[i] = total_bound; total_bound += bound[i]; }
+    StagingPool::Lease mp3_stage;
+    if (total_bound) {
+        if (int rc = g_staging.take(total_bound * (576 * sizeof(float) + sizeof(uint32_t)), mp3_stage)) return rc;
+        float *coef0 = (float *)mp3_stage.p;
+        uint32_t *flags0 = (uint32_t *)(coef0 + total_bound * 576);
+        parallel_for((size_t)n_files, nt, [&](size_t i) {
+            if (!bound[i]) return;
+            Parsed &p = parsed[i];
+            bool ok = afg_mp3::parse_file_into(data[i], length[i], p.mp3, coef0 + base[i] * 576, flags0 + base[i], bound[i]);
+            if (ok && p.mp3.overflow) ok = afg_mp3::parse_file(data[i], length[i], p.mp3);     // cannot happen; be safe
+            if (ok) p.format = AFG_FORMAT_MP3;
+            else p.mp3 = afg_mp3::File();
+        });
+    }
+    tm.lap("parse (all threads)");
     BatchOut *owner = new (std::nothrow) BatchOut;
     if (!owner) return AFG_ERR_OOM;
     int rc = decode_parsed(parsed, data, length, nt, *owner);
+    tm.lap("decode_parsed total");
     if (rc) { delete owner; return rc; }
     afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));
     if (!items) { delete owner; return AFG_ERR_OOM; }

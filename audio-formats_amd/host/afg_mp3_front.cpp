@@ -653,10 +653,7 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
                     *fresh_state = false;
                 }
                 out->run_granules.back()++;
-                for (int ch = 0; ch < nch; ch++) {
-                    out->coef.insert(out->coef.end(), x[ch], x[ch] + 576);
-                    out->flags.push_back(fl[ch]);
-                }
+                for (int ch = 0; ch < nch; ch++) out->push(x[ch], fl[ch]);
             } else {
                 *fresh_state = false;
             }
@@ -699,10 +696,40 @@ bool looks_like_mp3(const uint8_t *data, size_t size)
     return sz != 0;
 }
 
+size_t max_blocks(const uint8_t *data, size_t size)
+{
+    if (!data || size < 10) return 0;
+    const uint8_t *buf = data;
+    size_t n = size;
+    size_t id3 = id3v2_size(buf, n);
+    if (id3) {
+        id3 = std::min(id3, n);
+        buf += id3;
+        n -= id3;
+    }
+    trim_trailing_tags(buf, &n);
+    // every frame the decoder can accept starts at a position that holds a valid header, and frames do not
+    // overlap: the blocks of ALL such positions bound the result (false positives are ~1 per 3 KB of noise)
+    size_t blocks = 0;
+    for (size_t at = 0; at + 4 <= n; at++) {
+        if (buf[at] != 0xff) continue;
+        const Header hd{ buf + at };
+        if (hd.valid()) blocks += (size_t)(hd.mpeg1() ? 2 : 1) * (hd.mono() ? 1 : 2);
+    }
+    return blocks + 8;
+}
+
+bool parse_file_into(const uint8_t *data, size_t size, File &f, float *coef, uint32_t *flags, size_t cap);
+
 // mp3dec_ex_open (index scan or Xing/Info tag) followed by mp3dec_ex_read to the end of the stream
-bool parse_file(const uint8_t *data, size_t size, File &f)
+bool parse_file(const uint8_t *data, size_t size, File &f) { return parse_file_into(data, size, f, nullptr, nullptr, 0); }
+
+bool parse_file_into(const uint8_t *data, size_t size, File &f, float *coef_dst, uint32_t *flags_dst, size_t cap)
 {
     f = File();
+    f.ext_coef = coef_dst;
+    f.ext_flags = flags_dst;
+    f.ext_cap = cap;
     if (!data || size < 10) return false;
     const uint8_t *buf = data;
     size_t n = size;
@@ -795,14 +822,13 @@ bool parse_file(const uint8_t *data, size_t size, File &f)
         if (detected && cur >= detected) break;
         const uint64_t left = n - off;
         if (!left) break;
-        const uint64_t blocks_before = f.flags.size();
+        const uint64_t blocks_before = f.blocks();
         const std::vector<uint32_t> runs_before = f.run_granules;
         const FrameResult fr = frame(dec, buf + off, (int)std::min<uint64_t>(left, 0x7fffffff), &f, &fresh);
         if (fr.stop || fr.hz != hz0 || fr.layer != layer0 || fr.channels != ch0) {
             // MP3D_E_DECODE (minimp3_ex.d:851-857; also what "no further frame" turns into, since the frame info
             // stays zero then): the stream ends here; records of this frame are dropped
-            f.flags.resize(blocks_before);
-            f.coef.resize(blocks_before * 576);
+            f.truncate(blocks_before);
             f.run_granules = runs_before;
             break;
         }

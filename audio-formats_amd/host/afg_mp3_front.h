@@ -23,9 +23,42 @@ struct File {
     std::vector<float> coef;             // 576 floats per granule-channel, order [granule][channel]
     std::vector<uint32_t> flags;         // AFG_MP3_FLAGS per granule-channel
     std::vector<Copy> copies;
+
+    // Optional caller-provided record storage (the batch path parses straight into its page-locked staging
+    // buffer).  When set, coef / flags above stay empty; `overflow` reports that `ext_cap` blocks were not enough.
+    float *ext_coef = nullptr;
+    uint32_t *ext_flags = nullptr;
+    size_t ext_cap = 0, n_blocks = 0;
+    bool overflow = false;
+
+    size_t blocks() const { return n_blocks; }
+    void push(const float *x, uint32_t fl)
+    {
+        if (ext_coef) {
+            if (n_blocks >= ext_cap) { overflow = true; return; }
+            for (int i = 0; i < 576; i++) ext_coef[n_blocks * 576 + i] = x[i];
+            ext_flags[n_blocks] = fl;
+        } else {
+            coef.insert(coef.end(), x, x + 576);
+            flags.push_back(fl);
+        }
+        n_blocks++;
+    }
+    void truncate(size_t nb)
+    {
+        n_blocks = nb;
+        if (!ext_coef) {
+            coef.resize(nb * 576);
+            flags.resize(nb);
+        }
+    }
 };
 
 bool looks_like_mp3(const uint8_t *data, size_t size);
 bool parse_file(const uint8_t *data, size_t size, File &out);      // false: no Layer III stream found
+// as above into caller-provided storage of `cap` blocks (out.overflow set if that was too small)
+bool parse_file_into(const uint8_t *data, size_t size, File &out, float *coef, uint32_t *flags, size_t cap);
+// an upper bound for the number of granule-channel blocks parse_file will produce (frame-header walk only)
+size_t max_blocks(const uint8_t *data, size_t size);
 
 }  // namespace afg_mp3
