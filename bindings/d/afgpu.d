@@ -163,6 +163,21 @@ void afg_flac_parsed_free(afg_flac_parsed* parsed);
 int afg_qoa_parse(const(ubyte)* data, size_t length, uint* channels, uint* samplerate, uint* samples,
                   afg_qoa_frame* frames, size_t frame_cap, size_t* n_frames);
 
+struct afg_mp3_copy { ulong src_float, count; }
+struct afg_mp3_parsed
+{
+    int channels, hz, tagged, start_delay;
+    ulong detected_samples, declared_samples, pcm_samples;
+    ulong n_runs, n_blocks, n_copies;
+    uint* run_granules;
+    float* coef;
+    uint* flags;
+    afg_mp3_copy* copies;
+    void* owner;
+}
+int afg_mp3_parse(const(ubyte)* data, size_t length, afg_mp3_parsed* parsed);
+void afg_mp3_parsed_free(afg_mp3_parsed* parsed);
+
 struct afg_batch_item
 {
     int status;
