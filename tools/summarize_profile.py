@@ -20,7 +20,7 @@ def main(tag):
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     g = os.path.join(ROOT, "gpurun_out")
-    stats = glob.glob(os.path.join(g, f"{tag}_stats", "*", "*kernel_stats.csv"))
+    stats = glob.glob(os.path.join(g, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as fh:
@@ -31,7 +31,7 @@ def main(tag):
                                    r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]]) + "\n")
     pmc = {}
     for sub, ctr in ((f"{tag}_fetch", "FETCH_SIZE"), (f"{tag}_write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(g, sub, "*", "*counter_collection.csv"))
+        files = glob.glob(os.path.join(g, sub, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             continue
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
