@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "afg_celt_transform_hip",
     "afg_open_from_memory", "afg_is_error", "afg_error_message", "afg_get_format", "afg_get_num_channels",
     "afg_get_length_in_frames", "afg_get_samplerate", "afg_read_samples_float", "afg_close",
-    "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse", "afg_mp3_parse", "afg_mp3_parsed_free",
+    "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse", "afg_mp3_parse", "afg_mp3_parsed_free", "afg_vorbis_parse", "afg_vorbis_parsed_free",
     "afg_batch_decode", "afg_batch_free",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
     "afg_copy_probe_hip",
@@ -79,6 +79,13 @@ class Mp3Parsed(C.Structure):
                 ("n_runs", C.c_uint64), ("n_blocks", C.c_uint64), ("n_copies", C.c_uint64),
                 ("run_granules", C.c_void_p), ("coef", C.c_void_p), ("flags", C.c_void_p), ("copies", C.c_void_p),
                 ("owner", C.c_void_p)]
+
+
+class VorbisParsed(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("blocksize0", C.c_int32), ("blocksize1", C.c_int32), ("sample_rate", C.c_uint32),
+                ("total_samples", C.c_uint32), ("n_packets", C.c_uint64), ("spec_floats", C.c_uint64),
+                ("pcm_frames", C.c_uint64), ("pflags", C.c_void_p), ("spec", C.c_void_p), ("take_from", C.c_void_p),
+                ("take_count", C.c_void_p), ("owner", C.c_void_p)]
 
 
 class BatchItem(C.Structure):
@@ -157,6 +164,9 @@ def lib():
     L.afg_mp3_parse.argtypes = [vp, C.c_size_t, C.POINTER(Mp3Parsed)]
     L.afg_mp3_parsed_free.argtypes = [C.POINTER(Mp3Parsed)]
     L.afg_mp3_parsed_free.restype = None
+    L.afg_vorbis_parse.argtypes = [vp, C.c_size_t, C.POINTER(VorbisParsed)]
+    L.afg_vorbis_parsed_free.argtypes = [C.POINTER(VorbisParsed)]
+    L.afg_vorbis_parsed_free.restype = None
     L.afg_qoa_parse.argtypes = [vp, C.c_size_t, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, C.c_size_t,
                                 C.POINTER(C.c_size_t)]
     L.afg_batch_decode.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(BatchResult)]
@@ -348,6 +358,27 @@ def mp3_parse(file_bytes):
                 view(out.copies, out.n_copies * 2, np.uint64).reshape(-1, 2))
     finally:
         lib().afg_mp3_parsed_free(C.byref(out))
+
+
+def vorbis_parse(file_bytes):
+    """Host front-end only (afg_vorbis_parse): dict with channels, sample_rate, blocksize0/1, total_samples, pflags,
+    spec, take_from, take_count, pcm_frames (numpy copies)."""
+    buf = bytes(file_bytes)
+    out = VorbisParsed()
+    check(lib().afg_vorbis_parse(buf, len(buf), C.byref(out)))
+    try:
+        def view(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype)
+            raw = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(raw, dtype=dtype, count=count).copy()
+        n = int(out.n_packets)
+        return {"channels": out.channels, "sample_rate": out.sample_rate, "blocksize0": out.blocksize0,
+                "blocksize1": out.blocksize1, "total_samples": int(out.total_samples), "pcm_frames": int(out.pcm_frames),
+                "pflags": view(out.pflags, n, np.uint8), "spec": view(out.spec, int(out.spec_floats), np.float32),
+                "take_from": view(out.take_from, n, np.int32), "take_count": view(out.take_count, n, np.int32)}
+    finally:
+        lib().afg_vorbis_parsed_free(C.byref(out))
 
 
 def qoa_parse(file_bytes):

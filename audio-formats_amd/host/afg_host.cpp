@@ -12,6 +12,7 @@
 #include "../csrc/afg_common.h"
 #include "afg_flac_front.h"
 #include "afg_mp3_front.h"
+#include "afg_vorbis_front.h"
 
 #include <algorithm>
 #include <atomic>
@@ -54,17 +55,29 @@ struct Parsed {
     QoaInfo qi;
     std::vector<afg_qoa_frame> qoa;
     afg_mp3::File mp3;
+    afg_vorbis::File ogg;
     const float *mp3_coef() const { return mp3.ext_coef ? mp3.ext_coef : mp3.coef.data(); }
     const uint32_t *mp3_flags() const { return mp3.ext_flags ? mp3.ext_flags : mp3.flags.data(); }
 };
 
-// startDecoding's probe order for the formats handled here (stream.d:1586-1838): FLAC, QOA, then MP3 (whose
+// startDecoding's probe order for the formats handled here (stream.d:1586-1838): FLAC, QOA, OGG, then MP3 (whose
 // detection is the weakest: a frame-sync search, which is why the reference tries it after the containers)
+void parse_file_unguarded(const uint8_t *d, size_t n, Parsed &p);
 void parse_file(const uint8_t *d, size_t n, Parsed &p)
+{
+    try {
+        parse_file_unguarded(d, n, p);
+    } catch (...) {                                        // out of memory inside a parser: the file is simply not decodable
+        p = Parsed();
+    }
+}
+void parse_file_unguarded(const uint8_t *d, size_t n, Parsed &p)
 {
     if (flac_parse(d, n, p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
     p.flac = FlacRecords();
     if (qoa_parse(d, n, p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
+    if (afg_vorbis::parse_file(d, n, p.ogg)) { p.format = AFG_FORMAT_OGG; return; }
+    p.ogg = afg_vorbis::File();
     if (afg_mp3::looks_like_mp3(d, n) && afg_mp3::parse_file(d, n, p.mp3)) { p.format = AFG_FORMAT_MP3; return; }
     p.mp3 = afg_mp3::File();
 }
@@ -221,7 +234,16 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         mp3_out += (size_t)p.mp3.pcm_samples;
         mp3_runs += p.mp3.run_granules.size();
     }
-    out.plane_floats = flac_out + qoa_out + mp3_out;
+    size_t ogg_out = 0, ogg_packets = 0, ogg_spec = 0;
+    for (size_t i = 0; i < nf; i++) {
+        Parsed &p = parsed[i];
+        if (p.format != AFG_FORMAT_OGG) continue;
+        out.files[i].pcm_off = flac_out + qoa_out + mp3_out + ogg_out;
+        ogg_out += (size_t)p.ogg.pcm_frames * (size_t)p.ogg.channels;
+        ogg_packets += p.ogg.pflags.size();
+        ogg_spec += p.ogg.spec.size();
+    }
+    out.plane_floats = flac_out + qoa_out + mp3_out + ogg_out;
     if (out.plane_floats == 0) goto metadata;
     {
         if (int rc = g_staging.take(out.plane_floats * sizeof(float), out.plane)) return rc;
@@ -349,6 +371,67 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             if (e != hipSuccess) { afg::set_error("MP3 stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
             tm.lap("mp3 delivery copies");
         }
+        // ---- Vorbis: one plan stream per file; delivery = the pull API's share of every packet's output ----
+        if (ogg_packets) {
+            std::vector<uint32_t> npk;
+            std::vector<uint8_t> chans, pflags;
+            std::vector<uint16_t> b0, b1;
+            pflags.reserve(ogg_packets);
+            for (size_t i = 0; i < nf; i++) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_OGG || p.ogg.pflags.empty()) continue;
+                npk.push_back((uint32_t)p.ogg.pflags.size());
+                chans.push_back((uint8_t)p.ogg.channels);
+                b0.push_back((uint16_t)p.ogg.blocksize0);
+                b1.push_back((uint16_t)p.ogg.blocksize1);
+                pflags.insert(pflags.end(), p.ogg.pflags.begin(), p.ogg.pflags.end());
+            }
+            afg_vorbis_plan *plan = nullptr;
+            if (int rc = afg_vorbis_plan_create(&plan, (uint32_t)npk.size(), npk.data(), chans.data(), b0.data(), b1.data(),
+                                                pflags.data(), 0))
+                return rc;
+            struct PlanGuard { afg_vorbis_plan *p; ~PlanGuard() { afg_vorbis_plan_destroy(p); } } guard{ plan };
+            if (afg_vorbis_plan_spec_floats(plan) != ogg_spec) {
+                afg::set_error("Vorbis stage: spectrum layout mismatch (%llu vs %zu floats)",
+                               (unsigned long long)afg_vorbis_plan_spec_floats(plan), ogg_spec);
+                return AFG_ERR_INVALID;
+            }
+            const size_t out_floats = (size_t)afg_vorbis_plan_out_floats(plan);
+            std::vector<uint64_t> out_off(ogg_packets);
+            if (int rc = afg_vorbis_plan_offsets(plan, nullptr, out_off.data())) return rc;
+            DeviceBuf d_spec, d_pcm;
+            if (int rc = d_spec.alloc(ogg_spec * sizeof(float))) return rc;
+            if (int rc = d_pcm.alloc(out_floats * sizeof(float))) return rc;
+            size_t at = 0;
+            for (size_t i = 0; i < nf; i++) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_OGG || p.ogg.spec.empty()) continue;
+                AFG_HIP_CHECK(hipMemcpyAsync((float *)d_spec.p + at, p.ogg.spec.data(), p.ogg.spec.size() * sizeof(float),
+                                             hipMemcpyHostToDevice, stream));
+                at += p.ogg.spec.size();
+            }
+            if (int rc = afg_vorbis_transform_hip(plan, (const float *)d_spec.p, (float *)d_pcm.p, stream)) return rc;
+            size_t pk = 0;
+            for (size_t i = 0; i < nf; i++) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_OGG) continue;
+                float *dst = (float *)out.plane.p + out.files[i].pcm_off;
+                const size_t n = p.ogg.pflags.size(), C = (size_t)p.ogg.channels;
+                for (size_t k = 0; k < n;) {
+                    if (p.ogg.take_count[k] <= 0) { k++; continue; }
+                    uint64_t from = out_off[pk + k] + (uint64_t)p.ogg.take_from[k] * C, cnt = (uint64_t)p.ogg.take_count[k] * C;
+                    size_t j = k + 1;
+                    while (j < n && p.ogg.take_count[j] > 0 && out_off[pk + j] + (uint64_t)p.ogg.take_from[j] * C == from + cnt)
+                        cnt += (uint64_t)p.ogg.take_count[j++] * C;
+                    AFG_HIP_CHECK(hipMemcpyAsync(dst, (const float *)d_pcm.p + from, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, stream));
+                    dst += cnt;
+                    k = j;
+                }
+                pk += n;
+            }
+            AFG_HIP_CHECK(hipStreamSynchronize(stream));
+            tm.lap("vorbis stage");
+        }
     }
 metadata:
     for (size_t i = 0; i < nf; i++) {
@@ -365,6 +448,11 @@ metadata:
             dcd.samplerate = (float)p.mp3.hz;
             dcd.frames = (int64_t)(p.mp3.pcm_samples / (uint64_t)p.mp3.channels);
             dcd.declared_frames = (int64_t)(p.mp3.declared_samples / (uint64_t)p.mp3.channels);   // stream.d:1737
+        } else if (p.format == AFG_FORMAT_OGG) {
+            dcd.channels = p.ogg.channels;
+            dcd.samplerate = (float)p.ogg.sample_rate;
+            dcd.frames = (int64_t)p.ogg.pcm_frames;
+            dcd.declared_frames = (int64_t)p.ogg.total_samples;    // stb_vorbis_stream_length_in_samples, stream.d:1696
         } else if (p.format == AFG_FORMAT_QOA) {
             dcd.channels = (int)p.qi.channels;
             dcd.samplerate = (float)p.qi.samplerate;
@@ -394,17 +482,21 @@ afg_stream *afg_open_from_memory(const uint8_t *data, size_t length)
     afg_stream *s = new (std::nothrow) afg_stream;
     if (!s) return nullptr;
     if (!data || length == 0) { s->error = kErrorUnknownFormat; return s; }
-    std::vector<Parsed> parsed(1);
-    parse_file(data, length, parsed[0]);
-    if (parsed[0].format == AFG_FORMAT_UNKNOWN) { s->error = kErrorUnknownFormat; return s; }
-    if (afg::require_device() != AFG_OK) { s->error = kErrorDecoderInitializationFailed; return s; }
-    BatchOut out;
-    const uint8_t *dp[1] = { data };
-    const size_t lp[1] = { length };
-    if (decode_parsed(parsed, dp, lp, 1, out) != AFG_OK) { s->error = kErrorDecodingError; return s; }
-    s->d = out.files[0];
-    if (out.plane_floats) s->pcm.assign((const float *)out.plane.p, (const float *)out.plane.p + out.plane_floats);
-    s->error = s->d.status == AFG_OK ? nullptr : kErrorDecodingError;
+    try {
+        std::vector<Parsed> parsed(1);
+        parse_file(data, length, parsed[0]);
+        if (parsed[0].format == AFG_FORMAT_UNKNOWN) { s->error = kErrorUnknownFormat; return s; }
+        if (afg::require_device() != AFG_OK) { s->error = kErrorDecoderInitializationFailed; return s; }
+        BatchOut out;
+        const uint8_t *dp[1] = { data };
+        const size_t lp[1] = { length };
+        if (decode_parsed(parsed, dp, lp, 1, out) != AFG_OK) { s->error = kErrorDecodingError; return s; }
+        s->d = out.files[0];
+        if (out.plane_floats) s->pcm.assign((const float *)out.plane.p, (const float *)out.plane.p + out.plane_floats);
+        s->error = s->d.status == AFG_OK ? nullptr : kErrorDecodingError;
+    } catch (...) {
+        s->error = kErrorDecoderInitializationFailed;      // out of memory while decoding
+    }
     return s;
 }
 
@@ -442,31 +534,36 @@ struct FlacParsedOwner {
 
 int afg_flac_parse(const uint8_t *data, size_t length, afg_flac_parsed *out)
 {
-    if (!out) return AFG_ERR_INVALID;
-    std::memset(out, 0, sizeof(*out));
-    if (!data) return AFG_ERR_INVALID;
-    auto *own = new (std::nothrow) FlacParsedOwner;
-    if (!own) return AFG_ERR_OOM;
-    FlacInfo fi;
-    if (!flac_parse(data, length, fi, own->rec)) {
-        delete own;
-        afg::set_error("afg_flac_parse: not a native FLAC stream");
-        return AFG_ERR_UNSUPPORTED;
+    try {
+        if (!out) return AFG_ERR_INVALID;
+        std::memset(out, 0, sizeof(*out));
+        if (!data) return AFG_ERR_INVALID;
+        auto *own = new (std::nothrow) FlacParsedOwner;
+        if (!own) return AFG_ERR_OOM;
+        FlacInfo fi;
+        if (!flac_parse(data, length, fi, own->rec)) {
+            delete own;
+            afg::set_error("afg_flac_parse: not a native FLAC stream");
+            return AFG_ERR_UNSUPPORTED;
+        }
+        out->sample_rate = fi.sample_rate;
+        out->channels = fi.channels;
+        out->bps = fi.bps;
+        out->max_block = fi.max_block;
+        out->total_samples = fi.total_samples;
+        out->n_frames = own->rec.frames.size();
+        out->n_subframes = own->rec.subframes.size();
+        out->n_res = own->rec.res.size();
+        out->out_samples = own->rec.out_samples;
+        out->frames = own->rec.frames.data();
+        out->subframes = own->rec.subframes.data();
+        out->res = own->rec.res.data();
+        out->owner = own;
+        return AFG_OK;
+    } catch (...) {
+        afg::set_error("out of host memory");
+        return AFG_ERR_OOM;
     }
-    out->sample_rate = fi.sample_rate;
-    out->channels = fi.channels;
-    out->bps = fi.bps;
-    out->max_block = fi.max_block;
-    out->total_samples = fi.total_samples;
-    out->n_frames = own->rec.frames.size();
-    out->n_subframes = own->rec.subframes.size();
-    out->n_res = own->rec.res.size();
-    out->out_samples = own->rec.out_samples;
-    out->frames = own->rec.frames.data();
-    out->subframes = own->rec.subframes.data();
-    out->res = own->rec.res.data();
-    out->owner = own;
-    return AFG_OK;
 }
 
 void afg_flac_parsed_free(afg_flac_parsed *p)
@@ -478,39 +575,84 @@ void afg_flac_parsed_free(afg_flac_parsed *p)
 
 int afg_mp3_parse(const uint8_t *data, size_t length, afg_mp3_parsed *out)
 {
-    if (!out) return AFG_ERR_INVALID;
-    std::memset(out, 0, sizeof(*out));
-    if (!data) return AFG_ERR_INVALID;
-    auto *own = new (std::nothrow) afg_mp3::File;
-    if (!own) return AFG_ERR_OOM;
-    if (!afg_mp3::parse_file(data, length, *own)) {
-        delete own;
-        afg::set_error("afg_mp3_parse: no MPEG Layer III stream found");
-        return AFG_ERR_UNSUPPORTED;
+    try {
+        if (!out) return AFG_ERR_INVALID;
+        std::memset(out, 0, sizeof(*out));
+        if (!data) return AFG_ERR_INVALID;
+        auto *own = new (std::nothrow) afg_mp3::File;
+        if (!own) return AFG_ERR_OOM;
+        if (!afg_mp3::parse_file(data, length, *own)) {
+            delete own;
+            afg::set_error("afg_mp3_parse: no MPEG Layer III stream found");
+            return AFG_ERR_UNSUPPORTED;
+        }
+        static_assert(sizeof(afg_mp3::Copy) == sizeof(afg_mp3_copy), "copy plan layout");
+        out->channels = own->channels;
+        out->hz = own->hz;
+        out->tagged = own->tagged ? 1 : 0;
+        out->start_delay = own->start_delay;
+        out->detected_samples = own->detected_samples;
+        out->declared_samples = own->declared_samples;
+        out->pcm_samples = own->pcm_samples;
+        out->n_runs = own->run_granules.size();
+        out->n_blocks = own->blocks();
+        out->n_copies = own->copies.size();
+        out->run_granules = own->run_granules.data();
+        out->coef = own->coef.data();
+        out->flags = own->flags.data();
+        out->copies = (afg_mp3_copy *)own->copies.data();
+        out->owner = own;
+        return AFG_OK;
+    } catch (...) {
+        afg::set_error("out of host memory");
+        return AFG_ERR_OOM;
     }
-    static_assert(sizeof(afg_mp3::Copy) == sizeof(afg_mp3_copy), "copy plan layout");
-    out->channels = own->channels;
-    out->hz = own->hz;
-    out->tagged = own->tagged ? 1 : 0;
-    out->start_delay = own->start_delay;
-    out->detected_samples = own->detected_samples;
-    out->declared_samples = own->declared_samples;
-    out->pcm_samples = own->pcm_samples;
-    out->n_runs = own->run_granules.size();
-    out->n_blocks = own->blocks();
-    out->n_copies = own->copies.size();
-    out->run_granules = own->run_granules.data();
-    out->coef = own->coef.data();
-    out->flags = own->flags.data();
-    out->copies = (afg_mp3_copy *)own->copies.data();
-    out->owner = own;
-    return AFG_OK;
 }
 
 void afg_mp3_parsed_free(afg_mp3_parsed *p)
 {
     if (!p) return;
     delete (afg_mp3::File *)p->owner;
+    std::memset(p, 0, sizeof(*p));
+}
+
+int afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out)
+{
+    try {
+        if (!out) return AFG_ERR_INVALID;
+        std::memset(out, 0, sizeof(*out));
+        if (!data) return AFG_ERR_INVALID;
+        auto *own = new (std::nothrow) afg_vorbis::File;
+        if (!own) return AFG_ERR_OOM;
+        if (!afg_vorbis::parse_file(data, length, *own)) {
+            delete own;
+            afg::set_error("afg_vorbis_parse: not an Ogg Vorbis I stream");
+            return AFG_ERR_UNSUPPORTED;
+        }
+        out->channels = own->channels;
+        out->blocksize0 = own->blocksize0;
+        out->blocksize1 = own->blocksize1;
+        out->sample_rate = own->sample_rate;
+        out->total_samples = own->total_samples;
+        out->n_packets = own->pflags.size();
+        out->spec_floats = own->spec.size();
+        out->pcm_frames = own->pcm_frames;
+        out->pflags = own->pflags.data();
+        out->spec = own->spec.data();
+        out->take_from = own->take_from.data();
+        out->take_count = own->take_count.data();
+        out->owner = own;
+        return AFG_OK;
+    } catch (...) {
+        afg::set_error("out of host memory");
+        return AFG_ERR_OOM;
+    }
+}
+
+void afg_vorbis_parsed_free(afg_vorbis_parsed *p)
+{
+    if (!p) return;
+    delete (afg_vorbis::File *)p->owner;
     std::memset(p, 0, sizeof(*p));
 }
 
@@ -534,62 +676,74 @@ int afg_qoa_parse(const uint8_t *data, size_t length, uint32_t *channels, uint32
 
 int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_files, int n_threads, afg_batch_result *out)
 {
-    if (!out || n_files < 0 || (n_files && (!data || !length))) return AFG_ERR_INVALID;
-    out->n_files = 0; out->items = nullptr; out->owner = nullptr;
-    if (n_files == 0) return AFG_OK;
-    if (int rc = afg::require_device()) return rc;
-    StageTimer tm;
-    std::vector<Parsed> parsed((size_t)n_files);
-    const unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
-    // pass 1: containers with a signature are parsed at once; MP3 candidates only get an upper bound of their
-    // record count, so that pass 2 can parse them straight into one page-locked staging buffer
-    std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0);
-    parallel_for((size_t)n_files, nt, [&](size_t i) {
-        if (!data[i] || !length[i]) return;
-        Parsed &p = parsed[i];
-        if (flac_parse(data[i], length[i], p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
-        p.flac = FlacRecords();
-        if (qoa_parse(data[i], length[i], p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
-        if (afg_mp3::looks_like_mp3(data[i], length[i])) bound[i] = afg_mp3::max_blocks(data[i], length[i]);
-    });
-    size_t total_bound = 0;
-    for (size_t i = 0; i < (size_t)n_files; i++) { base[i] = total_bound; total_bound += bound[i]; }
-    StagingPool::Lease mp3_stage;
-    if (total_bound) {
-        if (int rc = g_staging.take(total_bound * (576 * sizeof(float) + sizeof(uint32_t)), mp3_stage)) return rc;
-        float *coef0 = (float *)mp3_stage.p;
-        uint32_t *flags0 = (uint32_t *)(coef0 + total_bound * 576);
+    try {
+        if (!out || n_files < 0 || (n_files && (!data || !length))) return AFG_ERR_INVALID;
+        out->n_files = 0; out->items = nullptr; out->owner = nullptr;
+        if (n_files == 0) return AFG_OK;
+        if (int rc = afg::require_device()) return rc;
+        StageTimer tm;
+        std::vector<Parsed> parsed((size_t)n_files);
+        const unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+        // pass 1: containers with a signature are parsed at once; MP3 candidates only get an upper bound of their
+        // record count, so that pass 2 can parse them straight into one page-locked staging buffer
+        std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0);
         parallel_for((size_t)n_files, nt, [&](size_t i) {
-            if (!bound[i]) return;
+            if (!data[i] || !length[i]) return;
             Parsed &p = parsed[i];
-            bool ok = afg_mp3::parse_file_into(data[i], length[i], p.mp3, coef0 + base[i] * 576, flags0 + base[i], bound[i]);
-            if (ok && p.mp3.overflow) ok = afg_mp3::parse_file(data[i], length[i], p.mp3);     // cannot happen; be safe
-            if (ok) p.format = AFG_FORMAT_MP3;
-            else p.mp3 = afg_mp3::File();
+            try {
+            if (flac_parse(data[i], length[i], p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
+            p.flac = FlacRecords();
+            if (qoa_parse(data[i], length[i], p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
+            if (afg_vorbis::parse_file(data[i], length[i], p.ogg)) { p.format = AFG_FORMAT_OGG; return; }
+            p.ogg = afg_vorbis::File();
+            if (afg_mp3::looks_like_mp3(data[i], length[i])) bound[i] = afg_mp3::max_blocks(data[i], length[i]);
+            } catch (...) { p = Parsed(); }
         });
+        size_t total_bound = 0;
+        for (size_t i = 0; i < (size_t)n_files; i++) { base[i] = total_bound; total_bound += bound[i]; }
+        StagingPool::Lease mp3_stage;
+        if (total_bound) {
+            if (int rc = g_staging.take(total_bound * (576 * sizeof(float) + sizeof(uint32_t)), mp3_stage)) return rc;
+            float *coef0 = (float *)mp3_stage.p;
+            uint32_t *flags0 = (uint32_t *)(coef0 + total_bound * 576);
+            parallel_for((size_t)n_files, nt, [&](size_t i) {
+                if (!bound[i]) return;
+                Parsed &p = parsed[i];
+                bool ok = false;
+                try {
+                    ok = afg_mp3::parse_file_into(data[i], length[i], p.mp3, coef0 + base[i] * 576, flags0 + base[i], bound[i]);
+                    if (ok && p.mp3.overflow) ok = afg_mp3::parse_file(data[i], length[i], p.mp3);     // cannot happen; be safe
+                } catch (...) { ok = false; }
+                if (ok) p.format = AFG_FORMAT_MP3;
+                else p.mp3 = afg_mp3::File();
+            });
+        }
+        tm.lap("parse (all threads)");
+        BatchOut *owner = new (std::nothrow) BatchOut;
+        if (!owner) return AFG_ERR_OOM;
+        int rc = decode_parsed(parsed, data, length, nt, *owner);
+        tm.lap("decode_parsed total");
+        if (rc) { delete owner; return rc; }
+        afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));
+        if (!items) { delete owner; return AFG_ERR_OOM; }
+        for (int i = 0; i < n_files; i++) {
+            const Decoded &d = owner->files[(size_t)i];
+            items[i].status = d.status;
+            items[i].message = d.message;
+            items[i].format = d.format;
+            items[i].channels = d.channels;
+            items[i].samplerate = d.samplerate;
+            items[i].frames = d.frames;
+            items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)owner->plane.p + d.pcm_off : nullptr;
+        }
+        out->n_files = n_files;
+        out->items = items;
+        out->owner = owner;
+        return AFG_OK;
+    } catch (...) {
+        afg::set_error("out of host memory");
+        return AFG_ERR_OOM;
     }
-    tm.lap("parse (all threads)");
-    BatchOut *owner = new (std::nothrow) BatchOut;
-    if (!owner) return AFG_ERR_OOM;
-    int rc = decode_parsed(parsed, data, length, nt, *owner);
-    tm.lap("decode_parsed total");
-    if (rc) { delete owner; return rc; }
-    afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));
-    if (!items) { delete owner; return AFG_ERR_OOM; }
-    for (int i = 0; i < n_files; i++) {
-        const Decoded &d = owner->files[(size_t)i];
-        items[i].status = d.status;
-        items[i].message = d.message;
-        items[i].format = d.format;
-        items[i].channels = d.channels;
-        items[i].samplerate = d.samplerate;
-        items[i].frames = d.frames;
-        items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)owner->plane.p + d.pcm_off : nullptr;
-    }
-    out->n_files = n_files;
-    out->items = items;
-    out->owner = owner;
-    return AFG_OK;
 }
 
 void afg_batch_free(afg_batch_result *r)

@@ -1,0 +1,23 @@
+// afg_vorbis_front.h -- host front-end for Ogg Vorbis I files (see afg_vorbis_front.cpp).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/afg.h"
+
+namespace afg_vorbis {
+
+struct File {
+    int channels = 0, blocksize0 = 0, blocksize1 = 0;
+    uint32_t sample_rate = 0;
+    uint32_t total_samples = 0;            // stb_vorbis_stream_length_in_samples: granule of the last page, 0 = unknown
+    std::vector<uint8_t> pflags;           // one per decoded audio packet (AFG_VORBIS_LONG | PREV | NEXT)
+    std::vector<float> spec;               // per packet [channel][n/2]: floor-multiplied, uncoupled spectra
+    std::vector<int32_t> take_from, take_count;   // frames of packet p's (right_start - left_start) output that are delivered
+    uint64_t pcm_frames = 0;               // sum of take_count
+};
+
+bool parse_file(const uint8_t *data, size_t size, File &out);      // false: not an Ogg Vorbis I stream the reference accepts
+
+}  // namespace afg_vorbis

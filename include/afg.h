@@ -208,8 +208,8 @@ int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const af
 /* ========================================================================== *
  *  Outer surface: the AudioStream subset (stream.d:102-637) over the host front-ends
  *  that exist so far -- FLAC (native container, drflac.d:680-1695, :1887-2153), QOA
- *  (qoa.d:413-486, :703-851) and MP3 Layer III (minimp3.d, minimp3_ex.d).  Other formats report
- *  "unrecognized encoding" until their host parsers land (Vorbis, Opus: SURVEY 8f).  The host parses the whole file into
+ *  (qoa.d:413-486, :703-851), MP3 Layer III (minimp3.d, minimp3_ex.d) and Ogg Vorbis (stb_vorbis2.d).
+ *  Other formats report "unrecognized encoding" (Opus, WAV, MOD, XM).  The host parses the whole file into
  *  transform-stage records, the device restores the samples, the stream serves them.
  * ========================================================================== */
 
@@ -278,6 +278,25 @@ typedef struct afg_mp3_parsed {
 
 int  afg_mp3_parse(const uint8_t *data, size_t length, afg_mp3_parsed *out);   /* AFG_ERR_UNSUPPORTED: no Layer III stream */
 void afg_mp3_parsed_free(afg_mp3_parsed *parsed);
+
+/* Ogg Vorbis I front-end on its own: Ogg pages and lacing, the three header packets (code books, floor 1,
+ * residues 0/1/2, mappings, modes: stb_vorbis2.d:2669-3266) and every audio packet up to the transform seam
+ * (floor decode, residue decode, inverse coupling, floor curve: :2354-2523), plus what the pull API delivers of
+ * each packet's output (first frame primed only, last-page truncation: :2531-2596, :2606-2657) and the stream
+ * length (:3797-3868).  Result: the inputs of afg_vorbis_plan_create / afg_vorbis_transform_hip for one stream. */
+typedef struct afg_vorbis_parsed {
+    int32_t  channels, blocksize0, blocksize1;
+    uint32_t sample_rate;
+    uint32_t total_samples;        /* 0 = unknown */
+    uint64_t n_packets, spec_floats, pcm_frames;
+    uint8_t *pflags;               /* [n_packets] */
+    float   *spec;                 /* per packet [channel][n/2] */
+    int32_t *take_from, *take_count;   /* frames [take_from, take_from + take_count) of packet p's output are delivered */
+    void    *owner;                /* internal */
+} afg_vorbis_parsed;
+
+int  afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out);   /* AFG_ERR_UNSUPPORTED: not Ogg Vorbis */
+void afg_vorbis_parsed_free(afg_vorbis_parsed *parsed);
 
 /* Batch decode (no reference counterpart: the throughput path).  Files are parsed by n_threads
  * host threads (0 = hardware concurrency), restored on the current device in one launch per

@@ -143,6 +143,26 @@ uint64_t afgo_vorbis_layout(uint32_t npkt, int nch, int blocksize0, int blocksiz
                             const uint8_t *pflags, uint64_t spec_base, uint64_t out_base,
                             uint64_t *spec_off, uint64_t *out_off, uint64_t *spec_total);
 
+/* Ogg Vorbis front-end (vorbis_frontend.c): Ogg pages, the three header packets, and every audio packet up to
+ * the transform seam, for a whole file in memory; `take_*` is what the pull API delivers of each packet's
+ * (right_start - left_start) output frames. */
+typedef struct afgo_vorbis_file {
+    int channels;
+    unsigned sample_rate;
+    int blocksize0, blocksize1;
+    uint32_t total_samples;          /* stb_vorbis_stream_length_in_samples (0 = unknown) */
+    uint32_t n_packets;              /* decoded audio packets, the discarded first one included */
+    uint8_t *pflags;                 /* AFG_VORBIS_LONG | PREV | NEXT */
+    uint64_t spec_floats;
+    float *spec;                     /* per packet [channel][n/2], after floor multiply and inverse coupling */
+    int32_t *take_from, *take_count; /* delivered frames of packet p: [take_from, take_from + take_count) */
+    uint64_t pcm_frames;             /* sum of take_count */
+} afgo_vorbis_file;
+
+int afgo_vorbis_decode_file(const uint8_t *data, size_t size, afgo_vorbis_file *out);   /* 0 ok, -1 not Ogg Vorbis */
+int afgo_vorbis_decode_file_ex(const uint8_t *data, size_t size, afgo_vorbis_file *out, int seek_clears_eof);
+void afgo_vorbis_file_free(afgo_vorbis_file *f);
+
 /* ----------------------------------------------------------------- FLAC -- */
 
 /* drflac.d:1060-1140 */

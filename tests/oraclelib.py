@@ -219,6 +219,52 @@ def mp3_decode_file(data):
         free(C.byref(f))
 
 
+class _VorbisFile(C.Structure):
+    _fields_ = [("channels", C.c_int), ("sample_rate", C.c_uint), ("blocksize0", C.c_int), ("blocksize1", C.c_int),
+                ("total_samples", C.c_uint32), ("n_packets", C.c_uint32), ("pflags", C.POINTER(C.c_uint8)),
+                ("spec_floats", C.c_uint64), ("spec", C.POINTER(C.c_float)), ("take_from", C.POINTER(C.c_int32)),
+                ("take_count", C.POINTER(C.c_int32)), ("pcm_frames", C.c_uint64)]
+
+
+def vorbis_decode_file(data, seek_clears_eof=False):
+    """Oracle Ogg Vorbis front-end over a whole file in memory (records up to the transform seam + delivery plan).
+    None if the data is not an Ogg Vorbis stream the reference accepts.  seek_clears_eof=True: upstream stb_vorbis'
+    seek (see afgo_vorbis_decode_file_ex)."""
+    buf = bytes(data)
+    f = _VorbisFile()
+    fn = lib().afgo_vorbis_decode_file_ex
+    fn.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_VorbisFile), C.c_int]
+    if fn(buf, len(buf), C.byref(f), int(seek_clears_eof)) != 0:
+        return None
+    try:
+        n = int(f.n_packets)
+
+        def arr(ptr, cnt, dtype):
+            return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dtype) if cnt else np.zeros(0, dtype)
+        return {"channels": f.channels, "sample_rate": f.sample_rate, "blocksize0": f.blocksize0, "blocksize1": f.blocksize1,
+                "total_samples": int(f.total_samples), "pflags": arr(f.pflags, n, np.uint8),
+                "spec": arr(f.spec, int(f.spec_floats), np.float32), "take_from": arr(f.take_from, n, np.int32),
+                "take_count": arr(f.take_count, n, np.int32), "pcm_frames": int(f.pcm_frames)}
+    finally:
+        free = lib().afgo_vorbis_file_free
+        free.argtypes = [C.POINTER(_VorbisFile)]
+        free.restype = None
+        free(C.byref(f))
+
+
+def vorbis_file_pcm(rec):
+    """records of vorbis_decode_file -> transform oracle -> the frames the pull API delivers ([frames, channels])."""
+    n, ch = len(rec["pflags"]), rec["channels"]
+    if n == 0:
+        return np.zeros((0, ch), np.float32)
+    so, oo, _, total = vorbis_layout(np.array([n], np.uint32), [ch], [rec["blocksize0"]], [rec["blocksize1"]], rec["pflags"])
+    out = vorbis_transform(np.array([n], np.uint32), np.array([ch], np.uint8), np.array([rec["blocksize0"]], np.uint16),
+                           np.array([rec["blocksize1"]], np.uint16), rec["pflags"], so, oo, rec["spec"], total)
+    parts = [out[int(oo[p]) + int(rec["take_from"][p]) * ch: int(oo[p]) + (int(rec["take_from"][p]) + int(rec["take_count"][p])) * ch]
+             for p in range(n) if rec["take_count"][p] > 0]
+    return (np.concatenate(parts) if parts else np.zeros(0, np.float32)).reshape(-1, ch)
+
+
 # --------------------------------------------------------------- FLAC ------
 def flac_transform(frames, subframes, res, out_total, want_float=False):
     frames = np.ascontiguousarray(frames, FLAC_FRAME_DTYPE)

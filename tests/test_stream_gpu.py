@@ -153,3 +153,42 @@ def test_mp3_variants_in_a_batch(gpu):
         assert item["frames"] * item["channels"] == len(want["pcm"])
         if item["frames"]:
             assert np.array_equal(item["pcm"].reshape(-1).view(np.uint32), want["pcm"].view(np.uint32))
+
+
+# ---- Ogg Vorbis ---------------------------------------------------------------------------------------------
+OGG_FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "mathjax_invalid_keypress.ogg")
+
+
+def test_ogg_stream(gpu):
+    data = open(OGG_FIXTURE, "rb").read()
+    want = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(data))
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    assert not s.isError(), s.errorMessage()
+    assert s.getFormat() == afgpu.FORMAT_OGG and s.getNumChannels() == 2 and s.getSamplerate() == 44100.0
+    assert s.getLengthInFrames() == 22050                                            # stream.d:1696
+    got = read_all(s, 2, 1000)
+    assert got.shape == want.shape == (22050, 2)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))                 # bit-exact
+
+
+def test_all_formats_in_one_batch(gpu):
+    ogg = open(OGG_FIXTURE, "rb").read()
+    mp3 = open(MP3_FIXTURE, "rb").read()
+    flac, _ = fb.encode_file(make_pcm(5000, 2, 16, 8), 16, 1024)
+    qoa, qoa_want = qoa_file(7000, 2, 44100, 9)
+    cut = ogg[:len(ogg) - 300]                                                       # a cut Ogg file still yields its head
+    files = [ogg, mp3, flac, qoa, cut, ogg, b"junk" * 100]
+    out = afgpu.batch_decode(files, n_threads=4)
+    assert [o["format"] for o in out[:6]] == [afgpu.FORMAT_OGG, afgpu.FORMAT_MP3, afgpu.FORMAT_FLAC, afgpu.FORMAT_QOA,
+                                              afgpu.FORMAT_OGG, afgpu.FORMAT_OGG]
+    assert out[6]["status"] != 0
+    want_ogg = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(ogg))
+    for k in (0, 5):
+        assert np.array_equal(out[k]["pcm"].view(np.uint32), want_ogg.view(np.uint32))
+    want_cut = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(cut, seek_clears_eof=True))
+    assert out[4]["frames"] == len(want_cut) > 5000
+    assert np.array_equal(out[4]["pcm"].view(np.uint32), want_cut.view(np.uint32))
+    assert np.array_equal(out[1]["pcm"].reshape(-1).view(np.uint32), oraclelib.mp3_decode_file(mp3)["pcm"].view(np.uint32))
+    assert np.array_equal(out[3]["pcm"].view(np.uint32), qoa_want.view(np.uint32))
+    assert out[2]["frames"] == 5000

@@ -1,0 +1,87 @@
+"""Ogg Vorbis host front-end (no device): the product parser (afg_vorbis_parse) against the oracle restatement of
+stb_vorbis on a real file and on damaged variants, and the real file against the MP3 encoding of the same sound.
+
+Reference behaviour followed: stb_vorbis2.d:984-1152 (pages, packets), :2669-3266 (setup), :2300-2597 (packet decode
+and sample bookkeeping), :2606-2657 (finish_frame), :3797-3868 (stream length)."""
+import os
+
+import numpy as np
+import pytest
+
+import afgpu
+import oraclelib
+
+HERE = os.path.dirname(__file__)
+OGG = os.path.join(HERE, "golden", "mathjax_invalid_keypress.ogg")
+MP3 = os.path.join(HERE, "golden", "mathjax_invalid_keypress.mp3")
+
+
+def same_records(data, upstream_seek=False):
+    want = oraclelib.vorbis_decode_file(data, seek_clears_eof=upstream_seek)
+    if want is None:
+        with pytest.raises(afgpu.AfgError):
+            afgpu.vorbis_parse(data)
+        return None, None
+    got = afgpu.vorbis_parse(data)
+    for k in ("channels", "sample_rate", "blocksize0", "blocksize1", "total_samples", "pcm_frames"):
+        assert got[k] == want[k], k
+    for k in ("pflags", "take_from", "take_count"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    assert got["spec"].shape == want["spec"].shape
+    assert np.array_equal(got["spec"].view(np.uint32), want["spec"].view(np.uint32))      # bit-exact spectra
+    return got, want
+
+
+def test_real_file():
+    got, want = same_records(open(OGG, "rb").read())
+    assert (got["channels"], got["sample_rate"], got["blocksize0"], got["blocksize1"]) == (2, 44100, 256, 2048)
+    assert got["total_samples"] == 22050 == got["pcm_frames"]          # the last page's granule position truncates the tail
+    assert got["take_count"][0] == 0                                     # the first frame only primes the overlap (:2659)
+    assert set(got["pflags"]) >= {0, 7}                                  # short and long blocks
+    pcm = oraclelib.vorbis_file_pcm(got)
+    assert pcm.shape == (22050, 2) and np.isfinite(pcm).all() and 0.3 < np.abs(pcm).max() < 1.0
+
+
+def test_two_codecs_agree_on_the_sound():
+    """The same earcon ships as MP3 and as Ogg Vorbis: two unrelated bitstreams, two unrelated front-ends, two
+    transform oracles -- the decoded waveforms must be the same sound (what no single-codec self-check can show)."""
+    v = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(open(OGG, "rb").read()))
+    m = oraclelib.mp3_decode_file(open(MP3, "rb").read())["pcm"].reshape(-1, 2)
+    n = min(len(v), len(m))
+    for c in range(2):
+        a, b = v[:n, c].astype(np.float64), m[:n, c].astype(np.float64)
+        assert np.corrcoef(a, b)[0, 1] > 0.9999                          # sample-aligned (both trim their codec delay)
+        assert np.sqrt(np.mean((a - b) ** 2)) < 0.1 * np.sqrt(np.mean(b ** 2))
+
+
+def test_truncation_and_damage_agree_with_the_oracle():
+    d = open(OGG, "rb").read()
+    audio_page = 58 + 27 + 17 + 3877                                     # start of the third page
+    # A cut file has no page with the last-page flag: the stream-length scan runs into the end of the data.  The
+    # reference's seek (unlike upstream stb_vorbis') does not reset the eof flag afterwards, so its decoder stops
+    # after the frame it primed at open time: nothing is delivered.  The product keeps decoding what is there, like
+    # upstream; both behaviours are pinned here.
+    for cut in (len(d) - 1, len(d) - 200, audio_page + 27 + 26 + 700, audio_page + 30, audio_page, audio_page - 5, 3000, 58, 40):
+        same_records(d[:cut], upstream_seek=True)
+        ref = oraclelib.vorbis_decode_file(d[:cut])
+        assert ref is None or ref["pcm_frames"] == 0
+    rng = np.random.default_rng(3)
+    body0 = audio_page + 27 + 26
+    agree = 0
+    for trial in range(40):
+        v = bytearray(d)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(body0, len(v)))
+            v[pos] ^= 1 << int(rng.integers(0, 8))                       # audio payload damage (page CRCs are not checked
+        same_records(bytes(v), upstream_seek=True)                       # while decoding, :1019); the length scan does
+        agree += 1                                                       # check them, fails, and trips the same eof quirk
+    assert agree == 40
+
+
+def test_not_vorbis():
+    d = open(OGG, "rb").read()
+    for blob in (b"", b"OggS" + bytes(100), d[:58] + bytes(200), bytes(5000), open(MP3, "rb").read(),
+                 d[:28] + b"\x01OpusHead" + d[37:]):
+        with pytest.raises(afgpu.AfgError):
+            afgpu.vorbis_parse(blob)
+        assert oraclelib.vorbis_decode_file(blob) is None

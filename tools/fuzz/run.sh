@@ -9,7 +9,9 @@ n=${1:-2000}
 cd "$root/audio-formats_amd/host"
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I. "$root/tools/fuzz/fuzz_mp3.cpp" afg_mp3_front.cpp -o "$out/fuzz_mp3"
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I. "$root/tools/fuzz/fuzz_flac.cpp" afg_flac_front.cpp -o "$out/fuzz_flac"
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I. "$root/tools/fuzz/fuzz_vorbis.cpp" afg_vorbis_front.cpp -o "$out/fuzz_vorbis"
 for seed in 1 2 3; do "$out/fuzz_mp3" "$root/tests/golden/mathjax_invalid_keypress.mp3" $seed "$n"; done
+for seed in 1 2 3; do "$out/fuzz_vorbis" "$root/tests/golden/mathjax_invalid_keypress.ogg" $seed "$n"; done
 cd "$root/tests" && python3 - "$out" <<'PY'
 import sys
 sys.path.insert(0, "../audio-formats_amd")
