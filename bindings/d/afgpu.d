@@ -178,6 +178,20 @@ struct afg_mp3_parsed
 int afg_mp3_parse(const(ubyte)* data, size_t length, afg_mp3_parsed* parsed);
 void afg_mp3_parsed_free(afg_mp3_parsed* parsed);
 
+struct afg_vorbis_parsed
+{
+    int channels, blocksize0, blocksize1;
+    uint sample_rate, total_samples;
+    ulong n_packets, spec_floats, pcm_frames;
+    ubyte* pflags;
+    float* spec;
+    int* take_from;
+    int* take_count;
+    void* owner;
+}
+int afg_vorbis_parse(const(ubyte)* data, size_t length, afg_vorbis_parsed* parsed);
+void afg_vorbis_parsed_free(afg_vorbis_parsed* parsed);
+
 struct afg_batch_item
 {
     int status;
