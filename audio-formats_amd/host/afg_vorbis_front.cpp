@@ -173,6 +173,13 @@ struct Book {
     struct Node { int32_t child[2]; };
     std::vector<Node> tree;                   // child: >= 0 node index, < 0: -(symbol + 1); INT32_MIN-ish 0x7fffffff: none
     bool usable = false;
+    // A book whose length list is sparse and stays sparse (fewer than entries/4 words in use, :2838) is handled by the
+    // reference through its *sorted* word list: vector look-ups are indexed by a word's rank in that list -- the
+    // left-to-right position of its leaf -- not by its entry number.  For lookup type 1 the expansion is made in that
+    // order too (consistent); for lookup type 2 the table is still laid out by entry, so such a book reads the
+    // vector of a different entry (:1344-1444 with :2987-2997).  The same happens here.
+    std::vector<int32_t> rank;                // empty: index by symbol
+    int vec(int sym) const { return rank.empty() ? sym : rank[(size_t)sym]; }
 };
 constexpr int kFast = 10;
 constexpr int32_t kNone = 0x7fffffff;
@@ -216,6 +223,16 @@ struct Builder {
         return ok;
     }
 };
+
+void leaf_order(const Book &b, int32_t node, std::vector<int32_t> &order)
+{
+    for (int v = 0; v < 2; v++) {
+        const int32_t c = b.tree[(size_t)node].child[v];
+        if (c == kNone) continue;
+        if (c < 0) order.push_back(-(c + 1));
+        else leaf_order(b, c, order);
+    }
+}
 
 bool build_decoder(Book &b)
 {
@@ -356,6 +373,15 @@ bool read_setup(Bits &br, Setup &st)
             }
         }
         if (!build_decoder(b)) return false;
+        int in_use = 0;
+        for (uint8_t l : b.len) in_use += l != 255;
+        const bool stays_sparse = sparse && in_use < (b.entries >> 2);
+        std::vector<int32_t> order;                          // symbols by leaf position
+        if (stays_sparse) {
+            leaf_order(b, 0, order);
+            b.rank.assign((size_t)b.entries, 0);
+            for (size_t k = 0; k < order.size(); k++) b.rank[(size_t)order[k]] = (int32_t)k;
+        }
         b.lookup = (int)br.get(4);
         if (b.lookup > 2) return false;
         if (b.lookup > 0) {
@@ -383,13 +409,14 @@ bool read_setup(Bits &br, Setup &st)
             b.mult.assign((size_t)b.entries * (size_t)b.dim, 0.0f);
             float last = 0;                                  // carried across entries when sequence_p is set: :2974, :2994
             if (b.lookup == 1) {
-                for (int j = 0; j < b.entries; j++) {
-                    if (sparse && b.len[(size_t)j] == 255) continue;     // the reference expands used entries only
+                const int count = stays_sparse ? (int)order.size() : b.entries;
+                for (int jj = 0; jj < count; jj++) {
+                    const int j = stays_sparse ? order[(size_t)jj] : jj;      // entry whose vector goes to slot jj
                     uint32_t div = 1;
                     for (int k = 0; k < b.dim; k++) {
                         const uint32_t off = ((uint32_t)j / div) % nvals;
                         const float val = raw[off] * delta + b.minimum + last;
-                        b.mult[(size_t)j * (size_t)b.dim + (size_t)k] = val;
+                        b.mult[(size_t)jj * (size_t)b.dim + (size_t)k] = val;
                         if (b.sequence) last = val;
                         if (k + 1 < b.dim) {
                             if (div > 0xffffffffu / nvals) return false;
@@ -555,7 +582,7 @@ bool add_vector(Bits &br, const Book &b, float *out, int len)
     const int z = symbol(br, b);
     if (z < 0) return false;
     len = std::min(len, b.dim);
-    const float *m = b.mult.data() + (size_t)z * (size_t)b.dim;
+    const float *m = b.mult.data() + (size_t)b.vec(z) * (size_t)b.dim;
     if (b.sequence) {
         float last = 0;
         for (int i = 0; i < len; i++) {
@@ -574,7 +601,7 @@ bool add_vector_strided(Bits &br, const Book &b, float *out, int len, int step) 
     const int z = symbol(br, b);
     if (z < 0) return false;
     len = std::min(len, b.dim);
-    const float *m = b.mult.data() + (size_t)z * (size_t)b.dim;
+    const float *m = b.mult.data() + (size_t)b.vec(z) * (size_t)b.dim;
     float last = 0;
     for (int i = 0; i < len; i++) {
         const float val = m[i] + last;
@@ -609,7 +636,9 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
     const int n = st.bs[mode.blockflag], n2 = n >> 1, C = st.channels;
     n_out = n;
     const Mapping &map = st.mappings[(size_t)mode.mapping];
-    sc.spec.assign((size_t)C * (size_t)n2, 0.0f);
+    // a channel owns n floats although its spectrum is n/2: a type-2 residue on a single channel is bounded by 2 * n/2
+    // (:1594) and may write into the upper half, as it does in the reference's blocksize-sized channel buffers
+    sc.spec.assign((size_t)C * (size_t)n, 0.0f);
     sc.y.assign((size_t)C * 256, 0);
     bool zero[256], really_zero[256];
 
@@ -672,7 +701,7 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
         for (int j = 0; j < C; j++)
             if (map.mux[j] == sm) {
                 skip[ch] = zero[j];
-                buf[ch] = zero[j] ? nullptr : sc.spec.data() + (size_t)j * (size_t)n2;
+                buf[ch] = zero[j] ? nullptr : sc.spec.data() + (size_t)j * (size_t)n;
                 ch++;
             }
         const Residue &r = st.residues[map.residue_of[sm]];
@@ -714,7 +743,7 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
                                 const int zz = symbol(br, bk);
                                 if (zz < 0) { done = true; break; }
                                 if (ci + pi * ch + eff > n2 * ch) eff = n2 * ch - (pi * ch - ci);
-                                const float *m = bk.mult.data() + (size_t)zz * (size_t)bk.dim;
+                                const float *m = bk.mult.data() + (size_t)bk.vec(zz) * (size_t)bk.dim;
                                 for (int e = 0; e < eff; e++) {
                                     const float val = m[e] + last;
                                     if (buf[ci]) buf[ci][pi] += val;
@@ -777,7 +806,7 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
 
     // inverse coupling (:2493-2514)
     for (int i = map.coupling - 1; i >= 0; --i) {
-        float *m = sc.spec.data() + (size_t)map.mag[i] * (size_t)n2, *a = sc.spec.data() + (size_t)map.ang[i] * (size_t)n2;
+        float *m = sc.spec.data() + (size_t)map.mag[i] * (size_t)n, *a = sc.spec.data() + (size_t)map.ang[i] * (size_t)n;
         for (int j = 0; j < n2; j++) {
             float a2, m2;
             if (m[j] > 0) {
@@ -793,7 +822,7 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
     }
     // floor curves (:2255-2284)
     for (int i = 0; i < C; i++) {
-        float *t = sc.spec.data() + (size_t)i * (size_t)n2;
+        float *t = sc.spec.data() + (size_t)i * (size_t)n;
         if (really_zero[i]) { std::fill(t, t + n2, 0.0f); continue; }
         const Floor1 &g = st.floors[map.floor_of[map.mux[i]]];
         const int16_t *Y = sc.y.data() + (size_t)i * 256;
@@ -931,7 +960,7 @@ bool parse_file(const uint8_t *data, size_t size, File &f)
     Scratch sc;
     bool first = true, loc_valid = false;
     uint32_t cur_loc = 0;
-    int deferred = 0;
+    int deferred = 0, prev_overlap = 0;
     for (size_t k = 3; k < dm.packets.size(); k++) {
         const Packet &pk = dm.packets[k];
         unsigned flags = 0;
@@ -952,6 +981,13 @@ bool parse_file(const uint8_t *data, size_t size, File &f)
         } else {
             right_start = n2;
             right_end = n;
+        }
+        {   // The transform stage overlaps a block's left window with the previous block's right window: they must have
+            // the same length, which is what consistent prev/next window flags guarantee.  A stream that breaks this
+            // (the reference mixes windows of different lengths then, :2618-2627) ends at that packet here.
+            const int left_end = ((flags & AFG_VORBIS_LONG) && !(flags & AFG_VORBIS_PREV)) ? (n + f.blocksize0) >> 2 : n2;
+            if (prev_overlap && prev_overlap != left_end - left_start) break;
+            prev_overlap = right_end - right_start;
         }
         int left = left_start, len = right_end;
         bool len_set = false;
@@ -987,7 +1023,8 @@ bool parse_file(const uint8_t *data, size_t size, File &f)
         if (!len_set && loc_valid) cur_loc += (uint32_t)(right_start - left);
         // record
         f.pflags.push_back((uint8_t)flags);
-        f.spec.insert(f.spec.end(), sc.spec.begin(), sc.spec.end());
+        for (int c = 0; c < f.channels; c++)
+            f.spec.insert(f.spec.end(), sc.spec.begin() + (size_t)c * (size_t)n, sc.spec.begin() + (size_t)c * (size_t)n + (size_t)n2);
         int r = std::min(right_start, len);
         int count = first ? 0 : std::max(0, r - left);
         f.take_from.push_back(first ? 0 : left - left_start);

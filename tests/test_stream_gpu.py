@@ -186,9 +186,32 @@ def test_all_formats_in_one_batch(gpu):
     want_ogg = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(ogg))
     for k in (0, 5):
         assert np.array_equal(out[k]["pcm"].view(np.uint32), want_ogg.view(np.uint32))
-    want_cut = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(cut, seek_clears_eof=True))
+    from test_vorbis_frontend import cut_at_window_break
+    want_cut = oraclelib.vorbis_file_pcm(cut_at_window_break(oraclelib.vorbis_decode_file(cut, seek_clears_eof=True)))
     assert out[4]["frames"] == len(want_cut) > 5000
     assert np.array_equal(out[4]["pcm"].view(np.uint32), want_cut.view(np.uint32))
     assert np.array_equal(out[1]["pcm"].reshape(-1).view(np.uint32), oraclelib.mp3_decode_file(mp3)["pcm"].view(np.uint32))
     assert np.array_equal(out[3]["pcm"].view(np.uint32), qoa_want.view(np.uint32))
     assert out[2]["frames"] == 5000
+
+
+def test_synthetic_vorbis_streams_end_to_end(gpu):
+    """Generated streams (tests/vorbis_bitstream.py) through the whole path: mono .. 6 channels, several block-size
+    pairs (wave kernel and general kernel), all residue types."""
+    import vorbis_bitstream as vb
+    files, wants = [], []
+    for k, (ch, bs) in enumerate([(1, (256, 2048)), (2, (256, 2048)), (2, (512, 512)), (3, (256, 1024)), (6, (1024, 4096)),
+                                  (2, (2048, 8192))]):
+        d = vb.make_file(900 + k, channels=ch, bs=bs, n_packets=16, residue_types=[(0, 1), (1, 2), (2, 0)][k % 3])
+        rec = oraclelib.vorbis_decode_file(d)
+        assert rec is not None and len(rec["pflags"]) >= 10
+        files.append(d)
+        wants.append(oraclelib.vorbis_file_pcm(rec))
+    out = afgpu.batch_decode(files, n_threads=2)
+    for item, want in zip(out, wants):
+        assert item["status"] == 0 and item["format"] == afgpu.FORMAT_OGG
+        assert item["frames"] == len(want) and item["channels"] == want.shape[1]
+        if len(want):
+            rms = float(np.sqrt(np.mean((item["pcm"].astype(np.float64) - want) ** 2)))
+            assert rms <= 1e-5 * max(1.0, float(np.abs(want).max()))             # north-star tolerance on this scale
+            assert np.array_equal(item["pcm"].view(np.uint32), want.view(np.uint32))
