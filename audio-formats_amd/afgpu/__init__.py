@@ -49,6 +49,7 @@ ABI_SYMBOLS = [
     "afg_celt_transform_hip",
     "afg_open_from_memory", "afg_is_error", "afg_error_message", "afg_get_format", "afg_get_num_channels",
     "afg_get_length_in_frames", "afg_get_samplerate", "afg_read_samples_float", "afg_close",
+    "afg_can_seek", "afg_seek_position", "afg_tell_position",
     "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse", "afg_mp3_parse", "afg_mp3_parsed_free", "afg_vorbis_parse", "afg_vorbis_parsed_free",
     "afg_batch_decode", "afg_batch_free",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
@@ -157,6 +158,9 @@ def lib():
     L.afg_get_samplerate.restype = C.c_float
     L.afg_read_samples_float.argtypes = [vp, vp, C.c_int]
     L.afg_close.argtypes = [vp]
+    L.afg_can_seek.argtypes = [vp]
+    L.afg_seek_position.argtypes = [vp, C.c_int]
+    L.afg_tell_position.argtypes = [vp]
     L.afg_close.restype = None
     L.afg_flac_parse.argtypes = [vp, C.c_size_t, C.POINTER(FlacParsed)]
     L.afg_flac_parsed_free.argtypes = [C.POINTER(FlacParsed)]
@@ -429,6 +433,15 @@ class AudioStream:
 
     def getSamplerate(self):
         return float(lib().afg_get_samplerate(self._h))
+
+    def canSeek(self):
+        return bool(lib().afg_can_seek(self._h))
+
+    def seekPosition(self, frame):
+        return bool(lib().afg_seek_position(self._h, int(frame)))
+
+    def tellPosition(self):
+        return int(lib().afg_tell_position(self._h))
 
     def readSamplesFloat(self, out):
         """out: float32 numpy array whose size is a multiple of the channel count; returns frames read."""

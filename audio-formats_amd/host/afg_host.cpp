@@ -524,6 +524,21 @@ int afg_read_samples_float(afg_stream *s, float *out, int frames)
     return (int)n;
 }
 
+int afg_can_seek(const afg_stream *s) { return s && !s->error; }
+
+int afg_seek_position(afg_stream *s, int frame)
+{
+    if (!s || s->error) return 0;
+    // the reference bounds a seek by the declared length (stream.d:1104, :1113, :1137); what can actually be served is
+    // bounded by what was decoded
+    const int64_t limit = std::max<int64_t>(s->d.declared_frames, 0);
+    if (frame < 0 || frame > limit) return 0;
+    s->position = std::min<int64_t>(frame, s->d.frames);
+    return 1;
+}
+
+int afg_tell_position(const afg_stream *s) { return (s && !s->error) ? (int)s->position : -1; }
+
 void afg_close(afg_stream *s) { delete s; }
 
 namespace {

@@ -146,6 +146,9 @@ int afg_get_num_channels(const(afg_stream)* s);
 long afg_get_length_in_frames(const(afg_stream)* s);
 float afg_get_samplerate(const(afg_stream)* s);
 int afg_read_samples_float(afg_stream* s, float* outData, int frames);
+int afg_can_seek(const(afg_stream)* s);
+int afg_seek_position(afg_stream* s, int frame);
+int afg_tell_position(const(afg_stream)* s);
 void afg_close(afg_stream* s);
 
 struct afg_flac_parsed
@@ -241,6 +244,9 @@ nothrow @nogc:
     int getNumChannels() { return afg_get_num_channels(_h); }
     long getLengthInFrames() { return afg_get_length_in_frames(_h); }
     float getSamplerate() { return afg_get_samplerate(_h); }
+    bool canSeek() { return afg_can_seek(_h) != 0; }
+    bool seekPosition(int frame) { return afg_seek_position(_h, frame) != 0; }
+    int tellPosition() { return afg_tell_position(_h); }
     int readSamplesFloat(float* outData, int frames) { return afg_read_samples_float(_h, outData, frames); }
     int readSamplesFloat(float[] outData)
     {

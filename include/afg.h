@@ -234,6 +234,11 @@ int64_t     afg_get_length_in_frames(const afg_stream *s);     /* AFG_UNKNOWN_LE
 float       afg_get_samplerate(const afg_stream *s);
 /* readSamplesFloat (stream.d:429-637): interleaved, returns frames read (< frames: end or error). */
 int         afg_read_samples_float(afg_stream *s, float *out, int frames);
+/* canSeek / seekPosition / tellPosition (stream.d:352-369, :1095-1189, :1208-1261): positions are frames; a seek outside
+ * [0, length] fails and leaves the position alone (the invariants of examples/transcode's additionalTests). */
+int         afg_can_seek(const afg_stream *s);
+int         afg_seek_position(afg_stream *s, int frame);     /* 1 = done, 0 = refused */
+int         afg_tell_position(const afg_stream *s);          /* -1 on an invalid stream */
 void        afg_close(afg_stream *s);
 
 /* Host front-ends on their own (no device needed): what the stream and batch entry points run

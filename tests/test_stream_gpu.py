@@ -215,3 +215,30 @@ def test_synthetic_vorbis_streams_end_to_end(gpu):
             rms = float(np.sqrt(np.mean((item["pcm"].astype(np.float64) - want) ** 2)))
             assert rms <= 1e-5 * max(1.0, float(np.abs(want).max()))             # north-star tolerance on this scale
             assert np.array_equal(item["pcm"].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("which", ["flac", "qoa", "mp3", "ogg"])
+def test_seek_and_tell_invariants(gpu, which):
+    """the checks of the reference's examples/transcode additionalTests (main.d:93-160)"""
+    if which == "flac":
+        data, _ = fb.encode_file(make_pcm(5000, 2, 16, 3), 16, 1024)
+    elif which == "qoa":
+        data, _ = qoa_file(6000, 2, 44100, 3)
+    else:
+        data = open(MP3_FIXTURE if which == "mp3" else OGG_FIXTURE, "rb").read()
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    assert not s.isError() and s.canSeek()
+    ch, n = s.getNumChannels(), s.getLengthInFrames()
+    whole = read_all(s, ch, 4096)
+    assert len(whole) == n
+    assert s.seekPosition(0) and s.tellPosition() == 0
+    assert not s.seekPosition(n + 1) and s.tellPosition() == 0           # past the end: refused, a no-op
+    assert not s.seekPosition(-1) and s.tellPosition() == 0
+    assert s.seekPosition(n // 2) and s.tellPosition() == n // 2
+    buf = np.zeros(64 * ch, np.float32)
+    assert s.readSamplesFloat(buf) == 64 and s.tellPosition() == n // 2 + 64
+    assert np.array_equal(buf.reshape(-1, ch), whole[n // 2:n // 2 + 64])   # sample-accurate
+    assert s.seekPosition(n - 1) and s.tellPosition() == n - 1
+    assert s.readSamplesFloat(np.zeros(16 * ch, np.float32)) == 1        # exactly one frame is left
+    assert s.seekPosition(n) and s.readSamplesFloat(np.zeros(16 * ch, np.float32)) == 0
