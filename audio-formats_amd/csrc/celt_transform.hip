@@ -20,9 +20,10 @@
 #include "celt_tables.h"
 
 #ifndef AFG_CELT_ABL
-#define AFG_CELT_ABL 0      // development ablations (tools/build_variant.sh): 1 no de-emphasis, 2 no post-filter, 3 no iMDCT
+#define AFG_CELT_ABL 0      // development ablations (tools/build_variant.sh): 2 no post-filter, 5 no steady-state comb filter
 #endif
 
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -30,6 +31,8 @@
 namespace {
 
 struct alignas(8) cpx { float re, im; };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct CeltTables {          // float offsets into one device table
     uint32_t twiddle[4];     // twiddle_exptab of N = 3..6 (len4 complex each)
@@ -103,215 +106,437 @@ __device__ __forceinline__ void fft15(cpx *out, const cpx *in, int stride, const
     }
 }
 
-// imdct15_half (dopus.d:1611-1637) of one block; dst = buf + 1024 + j*blocksize + 60
-__device__ void imdct_half_wave(float *dst, cpx *tmp, const float *__restrict__ src, int stride, float scale,
-                                int N, const float *__restrict__ tables, const CeltTables &tb)
-{
-    const int lane = threadIdx.x;
-    const int len2 = 15 << N, len4 = len2 >> 1, len8 = len4 >> 1, fft_n = N - 1;
-    const cpx *tw = (const cpx *)(tables + tb.twiddle[N - 3]);
-    cpx *z = (cpx *)dst;
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel A: iMDCT + the in-frame overlap windows, fully parallel over frame records.
+//
+// A 32-lane half of a wavefront owns one record (all its blocks at once); the two halves take the two channels of a
+// stereo frame when the records pair up (same geometry, interleaved output), so the 32 15-point base transforms
+// of a 960-sample frame fill the wavefront and the PCM leaves as whole interleaved rows.
+//   * lane (block j, base transform a): loads its 15 strided inputs straight from HBM, pre-rotates them
+//     (dopus.d:1619-1625) and runs fft15 (:1552-1581) in registers;
+//   * the radix-2 levels of fft_calc (:1596-1606) run as fused radix-8 / radix-4 register passes over LDS;
+//   * post-rotation (:1629-1636) in place, then vector_fmul_window (:230-243) of blocks j >= 1.
+// A frame's iMDCT output covers frame positions [60, F + 60): [60, F) goes to the frame's own output slots, the
+// last 60 values -- the overlap the NEXT frame's first window consumes (dst[0..60) of :3688) -- to slots [0, 60)
+// of the next record of the sequence (or to the state blob after the last one).  The first window of every frame
+// (block 0) is applied by kernel B, which walks the sequence in order.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kTailSlot = 1084;          // state words [1084, 1144): kernel A's hand-over of the last frame's overlap
 
-    for (int i = lane; i < len4; i += 64) {                              // pre-rotation
-        const cpx t = { src[(size_t)(len2 - 1 - 2 * i) * stride], src[(size_t)(2 * i) * stride] };
-        tmp[i] = cmul(t, tw[i]);
-    }
-    __syncthreads();
-    {                                                                    // base transforms: lane = 15-point block
-        const int nblk = 1 << fft_n;
-        if (lane < nblk) {
-            const int a = (int)(__brev((unsigned)lane) >> (32 - fft_n)) & (nblk - 1);   // fft_n == 0 -> shift 32: masked
-            fft15(z + 15 * lane, tmp + (fft_n ? a : 0), nblk, (const cpx *)(tables + tb.exptab[0]));
-        }
-    }
-    __syncthreads();
-    for (int L = 1; L <= fft_n; L++) {                                   // radix-2 levels, dopus.d:1596-1606
-        const cpx *ex = (const cpx *)(tables + tb.exptab[L]);
-        const int h = 15 << (L - 1);
-        for (int idx = lane; idx < len4 / 2; idx += 64) {
-            const int q15 = idx / 15, r15 = idx - 15 * q15;
-            const int blk = q15 >> (L - 1);
-            const int k = (q15 & ((1 << (L - 1)) - 1)) * 15 + r15;
-            cpx *lo = z + blk * 2 * h + k, *hi = lo + h;
-            const cpx t = cmul(*hi, ex[k]);
-            const cpx l0 = *lo;
-            hi->re = l0.re - t.re;
-            hi->im = l0.im - t.im;
-            lo->re = l0.re + t.re;
-            lo->im = l0.im + t.im;
-        }
-        __syncthreads();
-    }
-    for (int i = lane; i < len8; i += 64) {                              // post-rotation
-        const cpx za = z[len8 - i - 1], zb = z[len8 + i];
-        const cpx ta = tw[len8 - i - 1], tb2 = tw[len8 + i];
-        // CMUL3(r0, i1, za.im, za.re, ta.im, ta.re);  CMUL3(r1, i0, zb.im, zb.re, tb.im, tb.re)
-        const float r0 = za.im * ta.im - za.re * ta.re;
-        const float i1 = za.im * ta.re + za.re * ta.im;
-        const float r1 = zb.im * tb2.im - zb.re * tb2.re;
-        const float i0 = zb.im * tb2.re + zb.re * tb2.im;
-        z[len8 - i - 1].re = scale * r0;
-        z[len8 - i - 1].im = scale * i0;
-        z[len8 + i].re = scale * r1;
-        z[len8 + i].im = scale * i1;
-    }
-    __syncthreads();
+__device__ __forceinline__ bool celt_pair_ok(const afg_celt_frame &even, const afg_celt_frame &odd)
+{
+    return even.out_stride == 2 && odd.out_stride == 2 && odd.out_off == even.out_off + 1 && (even.out_off & 1) == 0 &&
+           even.frame_size == odd.frame_size && even.blocks == odd.blocks;
 }
 
+template <int G>
+__device__ __forceinline__ void radix_pass(cpx *z, int l, int nb15, int L0, const float *__restrict__ tables,
+                                           const CeltTables &tb, bool act)
+{
+    const int ngrp = nb15 >> G;                              // groups of 2^G base transforms (1..8)
+    const int lg = 31 - __clz(ngrp);
+    const int o = l & (ngrp - 1), rstep = 32 >> lg;
+    const int low = o & ((1 << (L0 - 1)) - 1);
+    const int base15 = ((o >> (L0 - 1)) << (L0 - 1 + G)) | low;
+    for (int r = l >> lg; r < 15; r += rstep) {
+        if (!act) continue;
+        cpx v[1 << G];
+#pragma unroll
+        for (int q = 0; q < (1 << G); q++) v[q] = z[15 * (base15 | (q << (L0 - 1))) + r];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const cpx *ex = (const cpx *)(tables + tb.exptab[L0 + g]);
+#pragma unroll
+            for (int q = 0; q < (1 << G); q++) {
+                if (q & (1 << g)) continue;
+                const int k = (low | ((q & ((1 << g) - 1)) << (L0 - 1))) * 15 + r;
+                const cpx t = cmul(v[q | (1 << g)], ex[k]);
+                const cpx l0 = v[q];
+                v[q | (1 << g)].re = l0.re - t.re;
+                v[q | (1 << g)].im = l0.im - t.im;
+                v[q].re = l0.re + t.re;
+                v[q].im = l0.im + t.im;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < (1 << G); q++) z[15 * (base15 | (q << (L0 - 1))) + r] = v[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kAWaves = 4;               // wavefronts per workgroup of kernel A (they share the LDS copy of the tables)
+constexpr int kTabFloatsMax = 3712;      // >= the whole table (ensure_tables): 3698 floats
+
+struct ARec {                            // what a half-wave needs of its record (and of the sequence around it)
+    afg_celt_frame fr;
+    bool paired;
+};
+
+__global__ __launch_bounds__(64 * kAWaves) void celt_imdct_kernel(
+    const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs,
+    const float *__restrict__ coeffs, float *__restrict__ out, float *__restrict__ states,
+    const float *__restrict__ tables, CeltTables tb, uint32_t tab_floats, uint32_t n_chan, uint32_t per_pair)
+{
+    __shared__ __attribute__((aligned(16))) float ltab[kTabFloatsMax];
+    __shared__ __attribute__((aligned(16))) float lwin[120];
+    __shared__ __attribute__((aligned(16))) cpx zbuf[kAWaves][2][480];
+    for (uint32_t i = threadIdx.x; i < tab_floats; i += 64 * kAWaves) ltab[i] = tables[i];
+    if (threadIdx.x < 120) lwin[threadIdx.x] = d_celt_window[threadIdx.x];
+    __syncthreads();
+
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, l = lane & 31;
+    // channel pair (2c, 2c+1); its records are split into per_pair contiguous chunks, one per wavefront
+    const uint32_t wid = blockIdx.x * kAWaves + wv;
+    const uint32_t pair = wid / per_pair, k0 = wid % per_pair;
+    const uint32_t c0 = 2 * pair, c1 = c0 + 1;
+    if (c0 >= n_chan) return;
+    const uint64_t base0 = rec_base[c0], cnt0 = rec_base[c0 + 1] - base0;
+    uint64_t base1 = 0, cnt1 = 0;
+    if (c1 < n_chan) { base1 = rec_base[c1]; cnt1 = rec_base[c1 + 1] - base1; }
+    const uint64_t cmax = cnt0 > cnt1 ? cnt0 : cnt1;
+    const uint64_t chunk = (cmax + per_pair - 1) / per_pair;
+    const uint64_t q_lo = (uint64_t)k0 * chunk, q_hi = q_lo + chunk < cmax ? q_lo + chunk : cmax;
+    cpx *z = zbuf[wv][h];
+    float *Y = (float *)z;                                   // block outputs, frame position p = 60 + index
+    const float *Y0 = (const float *)zbuf[wv][0], *Y1 = (const float *)zbuf[wv][1];
+
+    // one pass of the transform over the record this half-wave holds in `fr` (act = lane has a record)
+    auto transform = [&](const afg_celt_frame &fr, bool act, bool paired, uint64_t out_even, uint32_t my_chan,
+                         uint64_t my_base, uint64_t my_cnt, uint64_t q) {
+        const int F = fr.frame_size, B = fr.blocks, bs = F / B;
+        const int N = 31 - __clz(bs / 15), fft_n = N - 1, nblk = 1 << fft_n;
+        const int len2 = bs, len4 = len2 >> 1, len8 = len4 >> 1, nb15 = F / 30;
+        const cpx *tw = (const cpx *)(ltab + tb.twiddle[N - 3]);
+        const float *src = coeffs + fr.coef_off;
+
+        // pre-rotation + 15-point base transforms, in registers
+        if (act && l < nb15) {
+            const int j = l >> fft_n, an = l & (nblk - 1);
+            const int a = (int)(__brev((unsigned)an) >> (32 - fft_n));
+            float xa[15], xb[15];
+#pragma unroll
+            for (int k = 0; k < 15; k++) {
+                const int i = a + nblk * k;
+                xa[k] = __builtin_nontemporal_load(src + (size_t)(len2 - 1 - 2 * i) * B + j);
+                xb[k] = __builtin_nontemporal_load(src + (size_t)(2 * i) * B + j);
+            }
+            cpx x[15];
+#pragma unroll
+            for (int k = 0; k < 15; k++) x[k] = cmul(cpx{ xa[k], xb[k] }, tw[a + nblk * k]);
+            cpx y[15];
+            fft15(y, x, 1, (const cpx *)(ltab + tb.exptab[0]));
+#pragma unroll
+            for (int m = 0; m < 15; m++) z[15 * l + m] = y[m];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // radix-2 levels 1..fft_n
+        if (fft_n == 5) { radix_pass<3>(z, l, nb15, 1, ltab, tb, act); radix_pass<2>(z, l, nb15, 4, ltab, tb, act); }
+        else if (fft_n == 4) { radix_pass<2>(z, l, nb15, 1, ltab, tb, act); radix_pass<2>(z, l, nb15, 3, ltab, tb, act); }
+        else if (fft_n == 3) radix_pass<3>(z, l, nb15, 1, ltab, tb, act);
+        else radix_pass<2>(z, l, nb15, 1, ltab, tb, act);
+        // post-rotation, in place: block j's len2 floats are frame positions 60 + j*bs + [0, len2)
+        if (act) {
+            const float scale = fr.imdct_scale;
+            for (int t = l; t < F / 4; t += 32) {
+                const int j = t / len8, i = t - j * len8;
+                cpx *zj = z + j * len4;
+                const cpx za = zj[len8 - i - 1], zb = zj[len8 + i];
+                const cpx ta = tw[len8 - i - 1], tb2 = tw[len8 + i];
+                const float r0 = za.im * ta.im - za.re * ta.re;
+                const float i1 = za.im * ta.re + za.re * ta.im;
+                const float r1 = zb.im * tb2.im - zb.re * tb2.re;
+                const float i0 = zb.im * tb2.re + zb.re * tb2.im;
+                zj[len8 - i - 1] = cpx{ scale * r0, scale * i0 };
+                zj[len8 + i] = cpx{ scale * r1, scale * i1 };
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // vector_fmul_window of blocks 1..B-1 (frame positions [j*bs, j*bs + 120) = Y[j*bs - 60 ...])
+        if (act) {
+            for (int t = l; t < (B - 1) * 60; t += 32) {
+                const int j = 1 + t / 60, k = t - (j - 1) * 60;
+                float *d = Y + j * bs - 60;
+                const float s0 = d[k], s1 = d[119 - k];
+                const float wi = lwin[k], wj = lwin[119 - k];
+                d[k] = s0 * wj - s1 * wi;
+                d[119 - k] = s0 * wi + s1 * wj;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // frame positions [60, F) -> this frame's slots
+        if (paired) {
+            f32x2 *o = (f32x2 *)(out + out_even);
+            for (int p = 60 + lane; p < F; p += 64) o[p] = f32x2{ Y0[p - 60], Y1[p - 60] };
+        } else if (act) {
+            float *o = out + fr.out_off;
+            for (int p = 60 + l; p < F; p += 32) o[(size_t)p * fr.out_stride] = Y[p - 60];
+        }
+        // frame positions [F, F + 60) -> the next frame's slots [0, 60), or the state blob
+        if (act) {
+            float *o = nullptr;
+            size_t stride = 1;
+            if (q + 1 < my_cnt) {
+                const afg_celt_frame *nx = recs + my_base + q + 1;
+                o = out + nx->out_off;
+                stride = nx->out_stride;
+            } else if (states) {
+                o = states + (size_t)my_chan * AFG_CELT_STATE_FLOATS + kTailSlot;
+            }
+            if (o)
+                for (int k = l; k < 60; k += 32) o[(size_t)k * stride] = Y[F - 60 + k];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (uint64_t q = q_lo; q < q_hi; q++) {
+        const bool have0 = q < cnt0, have1 = q < cnt1;
+        afg_celt_frame f0 = {}, f1 = {};
+        if (have0) f0 = recs[base0 + q];
+        if (have1) f1 = recs[base1 + q];
+        const bool paired = have0 && have1 && celt_pair_ok(f0, f1);
+        if (paired) {
+            transform(h ? f1 : f0, true, true, f0.out_off, h ? c1 : c0, h ? base1 : base0, h ? cnt1 : cnt0, q);
+        } else {
+            if (have0) transform(f0, h == 0, false, 0, c0, base0, cnt0, q);
+            if (have1) transform(f1, h == 0, false, 0, c1, base1, cnt1, q);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel B: first overlap window of every frame + celt_postfilter (dopus.d:3281-3378), in place on the output
+// plane.  The comb filter feeds on its own output, so a channel sequence is walked in order; one wavefront takes
+// the two channels of a stereo stream (32 lanes each) when all their records pair up, else one sequence.  History
+// lives in a 2048-sample LDS ring per channel (the reference's CeltFrame.buf without the memmove, :3370).
+// ---------------------------------------------------------------------------------------------------------------
 struct PfState {
     int period, period_old;
     float g[3], g_old[3];
 };
 
-// celt_postfilter_apply_transition (dopus.d:3281-3324) on data[0..120)
-__device__ void pf_transition(float *data, const PfState &pf)
+constexpr int kRing = 2048;
+
+// celt_postfilter_apply_transition (dopus.d:3281-3324) on ring positions [n0, n0 + 120)
+__device__ __forceinline__ void pf_transition(float *ring, const float *win2, int n0, const PfState &pf, int l, bool lane_on)
 {
-    if (pf.g[0] == 0.0f && pf.g_old[0] == 0.0f) return;
-    const int lane = threadIdx.x;
+    const bool go = lane_on && !(pf.g[0] == 0.0f && pf.g_old[0] == 0.0f);
+    if (!__any(go)) return;
     const int T0 = pf.period_old, T1 = pf.period;
     // a filter whose gains are all zero contributes exact zeros whatever it reads (its period may
     // still be 0 on a fresh decoder): only live filters bound the parallel step
     const bool live0 = pf.g_old[0] != 0.0f || pf.g_old[1] != 0.0f || pf.g_old[2] != 0.0f;
     const bool live1 = pf.g[0] != 0.0f || pf.g[1] != 0.0f || pf.g[2] != 0.0f;
-    int step = 64;
-    if (live0) step = min(step, T0 - 2);
-    if (live1) step = min(step, T1 - 2);
+    int step = 32;
+    if (go && live0) step = min(step, T0 - 2);
+    if (go && live1) step = min(step, T1 - 2);
     step = max(step, 1);
+    step = min(__shfl(step, 0), __shfl(step, 32));
     for (int i0 = 0; i0 < 120; i0 += step) {
-        const int i = i0 + lane;
+        const int i = i0 + l;
         float v = 0.0f;
-        const bool on = lane < step && i < 120;
+        const bool on = go && l < step && i < 120;
         if (on) {
-            const float w = d_celt_window2[i];
-            const float x0 = data[i - T1 + 2], x1 = data[i - T1 + 1], x2 = data[i - T1], x3 = data[i - T1 - 1],
-                        x4 = data[i - T1 - 2];
-            const double acc = (1.0 - w) * pf.g_old[0] * data[i - T0] +
-                               (1.0 - w) * pf.g_old[1] * (data[i - T0 - 1] + data[i - T0 + 1]) +
-                               (1.0 - w) * pf.g_old[2] * (data[i - T0 - 2] + data[i - T0 + 2]) +
+            const float w = win2[i];
+#define RD(x) ring[(n0 + (x)) & (kRing - 1)]
+            const float x0 = RD(i - T1 + 2), x1 = RD(i - T1 + 1), x2 = RD(i - T1), x3 = RD(i - T1 - 1),
+                        x4 = RD(i - T1 - 2);
+            const double acc = (1.0 - w) * pf.g_old[0] * RD(i - T0) +
+                               (1.0 - w) * pf.g_old[1] * (RD(i - T0 - 1) + RD(i - T0 + 1)) +
+                               (1.0 - w) * pf.g_old[2] * (RD(i - T0 - 2) + RD(i - T0 + 2)) +
                                w * pf.g[0] * x2 +
                                w * pf.g[1] * (x1 + x3) +
                                w * pf.g[2] * (x0 + x4);
-            v = (float)(data[i] + acc);
+            v = (float)(RD(i) + acc);
         }
-        __syncthreads();
-        if (on) data[i] = v;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        if (on) RD(i) = v;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// celt_postfilter_apply (dopus.d:3326-3355)
-__device__ void pf_apply(float *data, int len, const PfState &pf)
+// celt_postfilter_apply (dopus.d:3326-3355) on ring positions [n0, n0 + len)
+__device__ __forceinline__ void pf_apply(float *ring, int n0, int len, const PfState &pf, int l, bool lane_on)
 {
-    if (pf.g[0] == 0.0f || len <= 0) return;
-    const int lane = threadIdx.x;
+    const bool go = lane_on && pf.g[0] != 0.0f && len > 0;
+    if (!__any(go)) return;
     const int T = pf.period;
-    const int step = max(min(T - 2, 64), 1);
+    int step = go ? max(min(T - 2, 32), 1) : 32;
+    step = min(__shfl(step, 0), __shfl(step, 32));
     for (int i0 = 0; i0 < len; i0 += step) {
-        const int i = i0 + lane;
+        const int i = i0 + l;
         float v = 0.0f;
-        const bool on = lane < step && i < len;
+        const bool on = go && l < step && i < len;
         if (on) {
-            const float x0 = data[i - T + 2], x1 = data[i - T + 1], x2 = data[i - T], x3 = data[i - T - 1],
-                        x4 = data[i - T - 2];
-            v = data[i] + (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
+            const float x0 = RD(i - T + 2), x1 = RD(i - T + 1), x2 = RD(i - T), x3 = RD(i - T - 1), x4 = RD(i - T - 2);
+            v = RD(i) + (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
         }
-        __syncthreads();
-        if (on) data[i] = v;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        if (on) RD(i) = v;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-__global__ __launch_bounds__(64) void celt_transform_kernel(
-    const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs,
-    const float *__restrict__ coeffs, float *__restrict__ out, float *__restrict__ states,
-    const float *__restrict__ tables, CeltTables tb)
+__global__ __launch_bounds__(64) void celt_postfilter_kernel(
+    const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs, float *__restrict__ out,
+    float *__restrict__ states, uint32_t n_chan)
 {
-    __shared__ __attribute__((aligned(16))) float buf[2048];
-    __shared__ __attribute__((aligned(16))) cpx tmp[480];
-    const int lane = threadIdx.x;
-    const uint32_t chan = blockIdx.x;
-    float *st = states ? states + (size_t)chan * AFG_CELT_STATE_FLOATS : nullptr;
+    __shared__ __attribute__((aligned(16))) float rings[2][kRing];
+    __shared__ float win2[120];
+    const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
+    const uint32_t chan = blockIdx.x, pchan = chan ^ 1u;
+    const uint64_t base = rec_base[chan], cnt = rec_base[chan + 1] - base;
+    if (cnt == 0) return;
+
+    // do all records of this sequence and its neighbour pair up?
+    bool paired = false;
+    uint64_t pbase = 0;
+    if (pchan < n_chan) {
+        pbase = rec_base[pchan];
+        if (rec_base[pchan + 1] - pbase == cnt) {
+            bool bad = false;
+            for (uint64_t q = lane; q < cnt; q += 64) {
+                const afg_celt_frame a = recs[base + q], b = recs[pbase + q];
+                bad = bad || !((chan & 1u) ? celt_pair_ok(b, a) : celt_pair_ok(a, b));
+            }
+            paired = !__any(bad);
+        }
+    }
+    if (paired && (chan & 1u)) return;
+    const bool lane_on = paired || h == 0;
+    const uint32_t my_chan = (paired && h == 1) ? pchan : chan;
+    const uint64_t my_base = (paired && h == 1) ? pbase : base;
+    float *st = states ? states + (size_t)my_chan * AFG_CELT_STATE_FLOATS : nullptr;
+    float *ring = rings[h];
 
     PfState pf;
     pf.period = pf.period_old = 0;
     pf.g[0] = pf.g[1] = pf.g[2] = pf.g_old[0] = pf.g_old[1] = pf.g_old[2] = 0.0f;
-    for (int i = lane; i < 2048; i += 64) buf[i] = st ? st[i] : 0.0f;
-    if (st) {
-        pf.period = __float_as_int(st[2048]);
-        pf.g[0] = st[2049]; pf.g[1] = st[2050]; pf.g[2] = st[2051];
-        pf.period_old = __float_as_int(st[2052]);
-        pf.g_old[0] = st[2053]; pf.g_old[1] = st[2054]; pf.g_old[2] = st[2055];
-    }
-    __syncthreads();
-
-    for (uint64_t r = rec_base[chan]; r < rec_base[chan + 1]; r++) {
-        const afg_celt_frame fr = recs[r];
-        const int frame_size = fr.frame_size, blocks = fr.blocks, blocksize = frame_size / blocks;
-        const int N = 31 - __clz(blocksize / 15);
-        const float *src = coeffs + fr.coef_off;
-
-        // iMDCT and overlap-add, dopus.d:3684-3690
-        for (int j = 0; j < blocks; j++) {
-            float *dst = buf + 1024 + j * blocksize;
-#if AFG_CELT_ABL == 3
-            for (int i = lane; i < blocksize; i += 64) dst[60 + i] = src[i * blocks + j];
-            __syncthreads();
-            continue;
-#endif
-            imdct_half_wave(dst + 60, tmp, src + j, blocks, fr.imdct_scale, N, tables, tb);
-            if (lane < 60) {                                            // vector_fmul_window, dopus.d:230-243
-                const int k = lane;
-                const float s0 = dst[k], s1 = dst[119 - k];
-                const float wi = d_celt_window[k], wj = d_celt_window[119 - k];
-                dst[k] = s0 * wj - s1 * wi;
-                dst[119 - k] = s0 * wi + s1 * wj;
-            }
-            __syncthreads();
+    if (lane_on) {
+        for (int i = l; i < 1024; i += 32) ring[i] = st ? st[i] : 0.0f;
+        if (st) {
+            pf.period = __float_as_int(st[2048]);
+            pf.g[0] = st[2049]; pf.g[1] = st[2050]; pf.g[2] = st[2051];
+            pf.period_old = __float_as_int(st[2052]);
+            pf.g_old[0] = st[2053]; pf.g_old[1] = st[2054]; pf.g_old[2] = st[2055];
         }
+    }
+    int n0 = 1024;
+    for (int i = lane; i < 120; i += 64) win2[i] = d_celt_window2[i];
+    float wi[2], wj[2];                                      // block-0 window taps of this lane
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int k = min(l + 32 * u, 59);
+        wi[u] = d_celt_window[k];
+        wj[u] = d_celt_window[119 - k];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // frames are fetched one ahead into registers (15 x 64 positions cover the largest frame), records two ahead
+    f32x2 nxt[15];
+    auto fetch = [&](const afg_celt_frame &fr) {
+        const int F = __shfl((int)fr.frame_size, 0);
+        const uint64_t off = __shfl(fr.out_off, 0);
+        if (paired) {
+            const f32x2 *o = (const f32x2 *)(out + off);
+#pragma unroll
+            for (int i = 0; i < 15; i++)
+                if (lane + 64 * i < F) nxt[i] = __builtin_nontemporal_load(o + lane + 64 * i);
+        } else {
+            const float *o = out + off;
+            const size_t stride = __shfl(fr.out_stride, 0);
+#pragma unroll
+            for (int i = 0; i < 15; i++)
+                if (lane + 64 * i < F) nxt[i].x = __builtin_nontemporal_load(o + (size_t)(lane + 64 * i) * stride);
+        }
+    };
+    afg_celt_frame fr = recs[my_base], fr_next = fr;
+    if (cnt > 1) fr_next = recs[my_base + 1];
+    fetch(fr);
+
+    for (uint64_t q = 0; q < cnt; q++) {
+        const int F = __shfl((int)fr.frame_size, 0);
+        afg_celt_frame fr_next2 = fr_next;
+        if (q + 2 < cnt) fr_next2 = recs[my_base + q + 2];
+        // the frame as kernel A left it: [0, 60) previous overlap, [60, F) this frame's iMDCT
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            const int p = lane + 64 * i;
+            if (p < F) {
+                rings[0][(n0 + p) & (kRing - 1)] = nxt[i].x;
+                if (paired) rings[1][(n0 + p) & (kRing - 1)] = nxt[i].y;
+            }
+        }
+        if (q + 1 < cnt) fetch(fr_next);
+        __builtin_amdgcn_wave_barrier();
+        if (q == 0 && lane_on)                               // the overlap a fresh call starts from: state or silence
+            for (int k = l; k < 60; k += 32) RD(k) = st ? st[1024 + k] : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        // vector_fmul_window of block 0 (dopus.d:3688, :230-243)
+        if (lane_on) {
+            float a[2], b[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int k = l + 32 * u;
+                if (k < 60) {
+                    const float s0 = RD(k), s1 = RD(119 - k);
+                    a[u] = s0 * wj[u] - s1 * wi[u];
+                    b[u] = s0 * wi[u] + s1 * wj[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int k = l + 32 * u;
+                if (k < 60) { RD(k) = a[u]; RD(119 - k) = b[u]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
 
         // celt_postfilter, dopus.d:3357-3378
-        {
-            const int len = frame_size;
 #if AFG_CELT_ABL != 2
-            pf_transition(buf + 1024, pf);
+        pf_transition(ring, win2, n0, pf, l, lane_on);
+#endif
+        pf.period_old = pf.period;
+        pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
+        pf.period = fr.pf_period_new;
+        pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
+        if (F > 120) {
+#if AFG_CELT_ABL != 2
+            pf_transition(ring, win2, n0 + 120, pf, l, lane_on);
+#if AFG_CELT_ABL != 5
+            pf_apply(ring, n0 + 240, F - 240, pf, l, lane_on);
+#endif
 #endif
             pf.period_old = pf.period;
             pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
-            pf.period = fr.pf_period_new;
-            pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
-            if (len > 120) {
-#if AFG_CELT_ABL != 2
-                pf_transition(buf + 1024 + 120, pf);
-                pf_apply(buf + 1024 + 240, len - 240, pf);
-#endif
-                pf.period_old = pf.period;
-                pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
-            }
-            // memmove(buf, buf + len, 1084 floats): ascending 64-wide chunks never overlap (len >= 120)
-            for (int i0 = 0; i0 < 1024 + 60; i0 += 64) {
-                const int i = i0 + lane;
-                float v = 0.0f;
-                if (i < 1024 + 60) v = buf[i + len];
-                __syncthreads();
-                if (i < 1024 + 60) buf[i] = v;
-                __syncthreads();
-            }
         }
 
-        // the post-filtered frame leaves for the output plane as is; the de-emphasis recurrence runs over it in
-        // place in celt_deemph_kernel (one lane per channel sequence instead of 64 redundant lanes)
-        {
-            const float *x = buf + 1024 - frame_size;
-            float *o = out + fr.out_off;
-            for (int j = lane; j < frame_size; j += 64) o[(size_t)j * fr.out_stride] = x[j];
+        // Make the prefetched frame resident *here*: loads and stores share one in-order counter on this hardware,
+        // so a wait placed after the stores below would also wait for them to drain.
+#pragma unroll
+        for (int i = 0; i < 15; i++) asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y) : : "memory");
+        // the post-filtered frame goes back; the de-emphasis recurrence runs over it in celt_deemph_kernel
+        if (paired) {
+            f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
+#pragma unroll
+            for (int i = 0; i < 15; i++) {
+                const int p = lane + 64 * i;
+                if (p < F) o[p] = f32x2{ rings[0][(n0 + p) & (kRing - 1)], rings[1][(n0 + p) & (kRing - 1)] };
+            }
+        } else {
+            float *o = out + __shfl(fr.out_off, 0);
+            const size_t stride = __shfl(fr.out_stride, 0);
+            for (int p = lane; p < F; p += 64) o[(size_t)p * stride] = rings[0][(n0 + p) & (kRing - 1)];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        n0 = (n0 + F) & (kRing - 1);
+        fr = fr_next;
+        fr_next = fr_next2;
     }
 
-    if (st) {
-        __syncthreads();
-        for (int i = lane; i < 2048; i += 64) st[i] = buf[i];
-        if (lane == 0) {
+    if (st && lane_on) {
+        for (int i = l; i < 1024; i += 32) st[i] = ring[(n0 - 1024 + i) & (kRing - 1)];
+        for (int k = l; k < 60; k += 32) st[1024 + k] = st[kTailSlot + k];
+        if (l == 0) {
             st[2048] = __int_as_float(pf.period);
             st[2049] = pf.g[0]; st[2050] = pf.g[1]; st[2051] = pf.g[2];
             st[2052] = __int_as_float(pf.period_old);
@@ -319,6 +544,7 @@ __global__ __launch_bounds__(64) void celt_transform_kernel(
         }
     }
 }
+#undef RD
 
 // De-emphasis and output scaling (dopus.d:3695-3701) over the planes celt_transform_kernel wrote:
 //   tmp = x[j] + m;  m = tmp * 0.85000610f;  out[j] = tmp / 32768
@@ -340,8 +566,6 @@ constexpr int kDeGroup = 40;
 constexpr int kDePitch = kDeGroup + 4;                       // floats; rows stay 16-byte aligned
 constexpr int kDeQuads = kDeSeq * kDeGroup / 4;              // float4 per step
 constexpr int kDeLoads = (kDeQuads + 63) / 64;               // float4 per lane per step
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int STRIDE>
 __device__ __forceinline__ void deemph_rows(float *xs, float *__restrict__ out, bool have, uint64_t off, int n, float &m)
@@ -486,6 +710,7 @@ __global__ __launch_bounds__(64) void celt_deemph_kernel(
 std::mutex g_mu;
 float *g_tables[16] = {};
 CeltTables g_tb;
+uint32_t g_tab_floats = 0;
 bool g_tb_ready = false;
 
 int ensure_tables(const float **d_tables, CeltTables *tb)
@@ -526,6 +751,7 @@ int ensure_tables(const float **d_tables, CeltTables *tb)
         AFG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_celt_window2), k_celt_window2, sizeof(k_celt_window2)));
         g_tables[dev] = d;
         g_tb = c;
+        g_tab_floats = (uint32_t)t.size();
         g_tb_ready = true;
     }
     *d_tables = g_tables[dev];
@@ -547,8 +773,17 @@ extern "C" int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_bas
     const float *d_tables = nullptr;
     CeltTables tb;
     if (int rc = ensure_tables(&d_tables, &tb)) return rc;
-    hipLaunchKernelGGL(celt_transform_kernel, dim3(n_chan), dim3(64), 0, (hipStream_t)hip_stream,
-                       d_rec_base, d_recs, d_coeffs, d_out, d_states, d_tables, tb);
+    // wavefronts per channel sequence in the record-parallel kernel: enough to fill the device whatever n_chan is
+    // wavefronts per channel pair in the record-parallel kernel: enough to fill the device whatever n_chan is
+    const uint32_t pairs = (n_chan + 1) / 2;
+    const uint32_t per_pair = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, 32768 / pairs));
+    const uint64_t waves = (uint64_t)pairs * per_pair;
+    hipLaunchKernelGGL(celt_imdct_kernel, dim3((uint32_t)((waves + kAWaves - 1) / kAWaves)), dim3(64 * kAWaves), 0,
+                       (hipStream_t)hip_stream, d_rec_base, d_recs, d_coeffs, d_out, d_states, d_tables, tb,
+                       g_tab_floats, n_chan, per_pair);
+    AFG_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(celt_postfilter_kernel, dim3(n_chan), dim3(64), 0, (hipStream_t)hip_stream,
+                       d_rec_base, d_recs, d_out, d_states, n_chan);
     AFG_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(celt_deemph_kernel, dim3((n_chan + kDeSeq - 1) / kDeSeq), dim3(64), 0, (hipStream_t)hip_stream,
                        d_rec_base, d_recs, d_out, d_states, n_chan);
