@@ -164,13 +164,100 @@ __device__ __forceinline__ void radix_pass(cpx *z, int l, int nb15, int L0, cons
     __builtin_amdgcn_wave_barrier();
 }
 
+struct Geo {                             // geometry of a frame record
+    int F, B, bs, N, fft_n, nblk, len4, len8, nb15;
+};
+
+__device__ __forceinline__ Geo geo_of(const afg_celt_frame &fr)
+{
+    Geo g;
+    g.F = fr.frame_size; g.B = fr.blocks; g.bs = g.F / g.B;
+    g.N = 31 - __clz(g.bs / 15); g.fft_n = g.N - 1; g.nblk = 1 << g.fft_n;
+    g.len4 = g.bs >> 1; g.len8 = g.len4 >> 1; g.nb15 = g.F / 30;
+    return g;
+}
+
+// lane (block j, base transform a) fetches the 15 strided input pairs of its 15-point transform (dopus.d:1619-1625)
+__device__ __forceinline__ void load_inputs(float (&xa)[15], float (&xb)[15], const float *__restrict__ coeffs,
+                                            const afg_celt_frame &fr, const Geo &g, int l, bool act)
+{
+    if (act && l < g.nb15) {
+        const float *src = coeffs + fr.coef_off;
+        const int j = l >> g.fft_n, an = l & (g.nblk - 1);
+        const int a = (int)(__brev((unsigned)an) >> (32 - g.fft_n));
+#pragma unroll
+        for (int k = 0; k < 15; k++) {
+            const int i = a + g.nblk * k;
+            xa[k] = __builtin_nontemporal_load(src + (size_t)(g.bs - 1 - 2 * i) * g.B + j);
+            xb[k] = __builtin_nontemporal_load(src + (size_t)(2 * i) * g.B + j);
+        }
+    }
+}
+
+// pre-rotation + fft15 in registers, then everything up to the in-frame windows in LDS: afterwards
+// Y[i] = ((float *)z)[i] is frame position 60 + i of the frame's iMDCT output (blocks 1..B-1 windowed)
+__device__ __forceinline__ void frame_fft(cpx *z, const float (&xa)[15], const float (&xb)[15], const afg_celt_frame &fr,
+                                          const Geo &g, const float *ltab, const float *lwin, const CeltTables &tb,
+                                          int l, bool act)
+{
+    const cpx *tw = (const cpx *)(ltab + tb.twiddle[g.N - 3]);
+    if (act && l < g.nb15) {
+        const int an = l & (g.nblk - 1);
+        const int a = (int)(__brev((unsigned)an) >> (32 - g.fft_n));
+        cpx x[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) x[k] = cmul(cpx{ xa[k], xb[k] }, tw[a + g.nblk * k]);
+        cpx y[15];
+        fft15(y, x, 1, (const cpx *)(ltab + tb.exptab[0]));
+#pragma unroll
+        for (int m = 0; m < 15; m++) z[15 * l + m] = y[m];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void frame_rest(cpx *z, const afg_celt_frame &fr, const Geo &g, const float *ltab,
+                                           const float *lwin, const CeltTables &tb, int l, bool act)
+{
+    const cpx *tw = (const cpx *)(ltab + tb.twiddle[g.N - 3]);
+    float *Y = (float *)z;
+    // radix-2 levels 1..fft_n
+    if (g.fft_n == 5) { radix_pass<3>(z, l, g.nb15, 1, ltab, tb, act); radix_pass<2>(z, l, g.nb15, 4, ltab, tb, act); }
+    else if (g.fft_n == 4) { radix_pass<2>(z, l, g.nb15, 1, ltab, tb, act); radix_pass<2>(z, l, g.nb15, 3, ltab, tb, act); }
+    else if (g.fft_n == 3) radix_pass<3>(z, l, g.nb15, 1, ltab, tb, act);
+    else radix_pass<2>(z, l, g.nb15, 1, ltab, tb, act);
+    // post-rotation, in place: block j's bs floats are frame positions 60 + j*bs + [0, bs)
+    if (act) {
+        const float scale = fr.imdct_scale;
+        for (int t = l; t < g.F / 4; t += 32) {
+            const int j = t / g.len8, i = t - j * g.len8;
+            cpx *zj = z + j * g.len4;
+            const cpx za = zj[g.len8 - i - 1], zb = zj[g.len8 + i];
+            const cpx ta = tw[g.len8 - i - 1], tb2 = tw[g.len8 + i];
+            const float r0 = za.im * ta.im - za.re * ta.re;
+            const float i1 = za.im * ta.re + za.re * ta.im;
+            const float r1 = zb.im * tb2.im - zb.re * tb2.re;
+            const float i0 = zb.im * tb2.re + zb.re * tb2.im;
+            zj[g.len8 - i - 1] = cpx{ scale * r0, scale * i0 };
+            zj[g.len8 + i] = cpx{ scale * r1, scale * i1 };
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // vector_fmul_window of blocks 1..B-1 (frame positions [j*bs, j*bs + 120) = Y[j*bs - 60 ...])
+    if (act) {
+        for (int t = l; t < (g.B - 1) * 60; t += 32) {
+            const int j = 1 + t / 60, k = t - (j - 1) * 60;
+            float *d = Y + j * g.bs - 60;
+            const float s0 = d[k], s1 = d[119 - k];
+            const float wi = lwin[k], wj = lwin[119 - k];
+            d[k] = s0 * wj - s1 * wi;
+            d[119 - k] = s0 * wi + s1 * wj;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 constexpr int kAWaves = 4;               // wavefronts per workgroup of kernel A (they share the LDS copy of the tables)
 constexpr int kTabFloatsMax = 3712;      // >= the whole table (ensure_tables): 3698 floats
-
-struct ARec {                            // what a half-wave needs of its record (and of the sequence around it)
-    afg_celt_frame fr;
-    bool paired;
-};
 
 __global__ __launch_bounds__(64 * kAWaves) void celt_imdct_kernel(
     const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs,
@@ -203,66 +290,12 @@ __global__ __launch_bounds__(64 * kAWaves) void celt_imdct_kernel(
     // one pass of the transform over the record this half-wave holds in `fr` (act = lane has a record)
     auto transform = [&](const afg_celt_frame &fr, bool act, bool paired, uint64_t out_even, uint32_t my_chan,
                          uint64_t my_base, uint64_t my_cnt, uint64_t q) {
-        const int F = fr.frame_size, B = fr.blocks, bs = F / B;
-        const int N = 31 - __clz(bs / 15), fft_n = N - 1, nblk = 1 << fft_n;
-        const int len2 = bs, len4 = len2 >> 1, len8 = len4 >> 1, nb15 = F / 30;
-        const cpx *tw = (const cpx *)(ltab + tb.twiddle[N - 3]);
-        const float *src = coeffs + fr.coef_off;
-
-        // pre-rotation + 15-point base transforms, in registers
-        if (act && l < nb15) {
-            const int j = l >> fft_n, an = l & (nblk - 1);
-            const int a = (int)(__brev((unsigned)an) >> (32 - fft_n));
-            float xa[15], xb[15];
-#pragma unroll
-            for (int k = 0; k < 15; k++) {
-                const int i = a + nblk * k;
-                xa[k] = __builtin_nontemporal_load(src + (size_t)(len2 - 1 - 2 * i) * B + j);
-                xb[k] = __builtin_nontemporal_load(src + (size_t)(2 * i) * B + j);
-            }
-            cpx x[15];
-#pragma unroll
-            for (int k = 0; k < 15; k++) x[k] = cmul(cpx{ xa[k], xb[k] }, tw[a + nblk * k]);
-            cpx y[15];
-            fft15(y, x, 1, (const cpx *)(ltab + tb.exptab[0]));
-#pragma unroll
-            for (int m = 0; m < 15; m++) z[15 * l + m] = y[m];
-        }
-        __builtin_amdgcn_wave_barrier();
-        // radix-2 levels 1..fft_n
-        if (fft_n == 5) { radix_pass<3>(z, l, nb15, 1, ltab, tb, act); radix_pass<2>(z, l, nb15, 4, ltab, tb, act); }
-        else if (fft_n == 4) { radix_pass<2>(z, l, nb15, 1, ltab, tb, act); radix_pass<2>(z, l, nb15, 3, ltab, tb, act); }
-        else if (fft_n == 3) radix_pass<3>(z, l, nb15, 1, ltab, tb, act);
-        else radix_pass<2>(z, l, nb15, 1, ltab, tb, act);
-        // post-rotation, in place: block j's len2 floats are frame positions 60 + j*bs + [0, len2)
-        if (act) {
-            const float scale = fr.imdct_scale;
-            for (int t = l; t < F / 4; t += 32) {
-                const int j = t / len8, i = t - j * len8;
-                cpx *zj = z + j * len4;
-                const cpx za = zj[len8 - i - 1], zb = zj[len8 + i];
-                const cpx ta = tw[len8 - i - 1], tb2 = tw[len8 + i];
-                const float r0 = za.im * ta.im - za.re * ta.re;
-                const float i1 = za.im * ta.re + za.re * ta.im;
-                const float r1 = zb.im * tb2.im - zb.re * tb2.re;
-                const float i0 = zb.im * tb2.re + zb.re * tb2.im;
-                zj[len8 - i - 1] = cpx{ scale * r0, scale * i0 };
-                zj[len8 + i] = cpx{ scale * r1, scale * i1 };
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // vector_fmul_window of blocks 1..B-1 (frame positions [j*bs, j*bs + 120) = Y[j*bs - 60 ...])
-        if (act) {
-            for (int t = l; t < (B - 1) * 60; t += 32) {
-                const int j = 1 + t / 60, k = t - (j - 1) * 60;
-                float *d = Y + j * bs - 60;
-                const float s0 = d[k], s1 = d[119 - k];
-                const float wi = lwin[k], wj = lwin[119 - k];
-                d[k] = s0 * wj - s1 * wi;
-                d[119 - k] = s0 * wi + s1 * wj;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        const Geo g = geo_of(fr);
+        const int F = g.F;
+        float xa[15], xb[15];
+        load_inputs(xa, xb, coeffs, fr, g, l, act);
+        frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
+        frame_rest(z, fr, g, ltab, lwin, tb, l, act);
         // frame positions [60, F) -> this frame's slots
         if (paired) {
             f32x2 *o = (f32x2 *)(out + out_even);
@@ -546,6 +579,176 @@ __global__ __launch_bounds__(64) void celt_postfilter_kernel(
 }
 #undef RD
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused path for batches with enough streams to fill the device: one wavefront walks a stereo stream (or a single
+// channel sequence) frame by frame with CeltFrame.buf of both channels in LDS -- iMDCT (the code of kernel A) straight
+// into buf + 1024 + 60, every overlap window, post-filter, interleaved store, memmove (dopus.d:3370) -- so the
+// coefficients are read once and the post-filtered PCM written once.  The inputs of frame k+1 are fetched while
+// frame k is filtered and are made resident just before frame k's stores (one in-order memory counter).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSWaves = 8;                                   // wavefronts per workgroup, sharing the tables
+constexpr int kSLdsFloats = kTabFloatsMax + 240 + kSWaves * 2 * 2048;
+
+__global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
+    const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs,
+    const float *__restrict__ coeffs, float *__restrict__ out, float *__restrict__ states,
+    const float *__restrict__ tables, CeltTables tb, uint32_t tab_floats, uint32_t n_chan)
+{
+    extern __shared__ __attribute__((aligned(16))) float slds[];
+    float *ltab = slds, *lwin = slds + kTabFloatsMax, *win2 = lwin + 120;
+    for (uint32_t i = threadIdx.x; i < tab_floats; i += 64 * kSWaves) ltab[i] = tables[i];
+    if (threadIdx.x < 120) { lwin[threadIdx.x] = d_celt_window[threadIdx.x]; win2[threadIdx.x] = d_celt_window2[threadIdx.x]; }
+    __syncthreads();
+
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, l = lane & 31;
+    const uint32_t pair = blockIdx.x * kSWaves + wv;
+    const uint32_t c0 = 2 * pair, c1 = c0 + 1;
+    if (c0 >= n_chan) return;
+    float *bufs = win2 + 120 + (size_t)wv * 2 * 2048;
+    const uint64_t base0 = rec_base[c0], cnt0 = rec_base[c0 + 1] - base0;
+    uint64_t base1 = 0, cnt1 = 0;
+    if (c1 < n_chan) { base1 = rec_base[c1]; cnt1 = rec_base[c1 + 1] - base1; }
+
+    bool paired = false;                                     // do all records of the two sequences pair up?
+    if (cnt1 == cnt0 && cnt0 > 0) {
+        bool bad = false;
+        for (uint64_t q = lane; q < cnt0; q += 64) bad = bad || !celt_pair_ok(recs[base0 + q], recs[base1 + q]);
+        paired = !__any(bad);
+    }
+
+    // walks one sequence (lanes 0..31) or both sequences of a pair (lane half = channel)
+    auto walk = [&](bool both, uint32_t chan_lo, uint64_t base_lo, uint64_t cnt) {
+        const bool act = both || h == 0;
+        const uint32_t my_chan = (both && h) ? c1 : chan_lo;
+        const uint64_t my_base = (both && h) ? base1 : base_lo;
+        float *st = states ? states + (size_t)my_chan * AFG_CELT_STATE_FLOATS : nullptr;
+        float *buf = bufs + (both ? h : 0) * 2048;
+        cpx *z = (cpx *)(buf + 1024 + 60);
+        const float *b0 = bufs, *b1 = bufs + 2048;
+
+        PfState pf;
+        pf.period = pf.period_old = 0;
+        pf.g[0] = pf.g[1] = pf.g[2] = pf.g_old[0] = pf.g_old[1] = pf.g_old[2] = 0.0f;
+        if (act) {
+            for (int i = l; i < 2048; i += 32) buf[i] = st ? st[i] : 0.0f;
+            if (st) {
+                pf.period = __float_as_int(st[2048]);
+                pf.g[0] = st[2049]; pf.g[1] = st[2050]; pf.g[2] = st[2051];
+                pf.period_old = __float_as_int(st[2052]);
+                pf.g_old[0] = st[2053]; pf.g_old[1] = st[2054]; pf.g_old[2] = st[2055];
+            }
+        }
+        float wi[2], wj[2];                                  // block-0 window taps of this lane
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = min(l + 32 * u, 59);
+            wi[u] = lwin[k];
+            wj[u] = lwin[119 - k];
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        afg_celt_frame fr = recs[my_base], fr_next = fr;
+        if (cnt > 1) fr_next = recs[my_base + 1];
+        float xa[15], xb[15];
+        load_inputs(xa, xb, coeffs, fr, geo_of(fr), l, act);
+
+        for (uint64_t q = 0; q < cnt; q++) {
+            const Geo g = geo_of(fr);
+            const int F = g.F;
+            afg_celt_frame fr_next2 = fr_next;
+            if (q + 2 < cnt) fr_next2 = recs[my_base + q + 2];
+            // iMDCT and overlap-add, dopus.d:3684-3690
+            frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
+            if (q + 1 < cnt) load_inputs(xa, xb, coeffs, fr_next, geo_of(fr_next), l, act);
+            frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+            if (act) {                                       // vector_fmul_window of block 0
+                float *d = buf + 1024;
+                float a[2], b[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int k = l + 32 * u;
+                    if (k < 60) {
+                        const float s0 = d[k], s1 = d[119 - k];
+                        a[u] = s0 * wj[u] - s1 * wi[u];
+                        b[u] = s0 * wi[u] + s1 * wj[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int k = l + 32 * u;
+                    if (k < 60) { d[k] = a[u]; d[119 - k] = b[u]; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // celt_postfilter, dopus.d:3357-3378
+            pf_transition(buf, win2, 1024, pf, l, act);
+            pf.period_old = pf.period;
+            pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
+            pf.period = fr.pf_period_new;
+            pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
+            if (F > 120) {
+                pf_transition(buf, win2, 1024 + 120, pf, l, act);
+                pf_apply(buf, 1024 + 240, F - 240, pf, l, act);
+                pf.period_old = pf.period;
+                pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
+            }
+
+            // make the prefetched inputs resident before the stores enter the queue
+#pragma unroll
+            for (int i = 0; i < 15; i++) asm volatile("" : "+v"(xa[i]), "+v"(xb[i]) : : "memory");
+            // the post-filtered frame leaves; the de-emphasis recurrence runs over it in celt_deemph_kernel
+            if (both) {
+                f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
+#pragma unroll
+                for (int i = 0; i < 15; i++) {
+                    const int p = lane + 64 * i;
+                    if (p < F) o[p] = f32x2{ b0[1024 + p], b1[1024 + p] };
+                }
+            } else {
+                float *o = out + __shfl(fr.out_off, 0);
+                const size_t stride = __shfl(fr.out_stride, 0);
+                for (int p = lane; p < F; p += 64) o[(size_t)p * stride] = b0[1024 + p];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // memmove(buf, buf + F, 1084 floats) (:3370): ascending 16-byte chunks, a source chunk is always read
+            // before any chunk that overwrites it is written
+            if (act) {
+                for (int i0 = 0; i0 < 271; i0 += 32) {
+                    const int i = i0 + l;
+                    f32x4 v = {};
+                    if (i < 271) v = *(const f32x4 *)(buf + F + 4 * i);
+                    __builtin_amdgcn_wave_barrier();
+                    if (i < 271) *(f32x4 *)(buf + 4 * i) = v;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                for (int i0 = 0; i0 < 271; i0 += 32) { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_wave_barrier(); }
+            }
+            fr = fr_next;
+            fr_next = fr_next2;
+        }
+
+        if (st && act) {
+            for (int i = l; i < 2048; i += 32) st[i] = buf[i];
+            if (l == 0) {
+                st[2048] = __int_as_float(pf.period);
+                st[2049] = pf.g[0]; st[2050] = pf.g[1]; st[2051] = pf.g[2];
+                st[2052] = __int_as_float(pf.period_old);
+                st[2053] = pf.g_old[0]; st[2054] = pf.g_old[1]; st[2055] = pf.g_old[2];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    if (paired) {
+        walk(true, c0, base0, cnt0);
+    } else {
+        if (cnt0) walk(false, c0, base0, cnt0);
+        if (cnt1) walk(false, c1, base1, cnt1);
+    }
+}
+
 // De-emphasis and output scaling (dopus.d:3695-3701) over the planes celt_transform_kernel wrote:
 //   tmp = x[j] + m;  m = tmp * 0.85000610f;  out[j] = tmp / 32768
 // a one-pole IIR across the whole channel sequence whose float rounding order cannot be re-associated, so the
@@ -713,6 +916,15 @@ CeltTables g_tb;
 uint32_t g_tab_floats = 0;
 bool g_tb_ready = false;
 
+// AFG_CELT_PATH=stream|split overrides the choice (tests exercise both paths on small batches)
+bool use_stream_path(uint32_t pairs)
+{
+    const char *e = getenv("AFG_CELT_PATH");
+    if (e && !strcmp(e, "stream")) return true;
+    if (e && !strcmp(e, "split")) return false;
+    return pairs >= 512;
+}
+
 int ensure_tables(const float **d_tables, CeltTables *tb)
 {
     int dev = 0;
@@ -774,8 +986,23 @@ extern "C" int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_bas
     CeltTables tb;
     if (int rc = ensure_tables(&d_tables, &tb)) return rc;
     // wavefronts per channel sequence in the record-parallel kernel: enough to fill the device whatever n_chan is
-    // wavefronts per channel pair in the record-parallel kernel: enough to fill the device whatever n_chan is
     const uint32_t pairs = (n_chan + 1) / 2;
+    if (use_stream_path(pairs)) {
+        // enough streams to fill the device: one pass over the coefficients, one over the PCM
+        static_assert(kSLdsFloats * sizeof(float) <= 160 * 1024, "LDS budget");
+        AFG_HIP_CHECK(hipFuncSetAttribute((const void *)celt_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(kSLdsFloats * sizeof(float))));
+        hipLaunchKernelGGL(celt_stream_kernel, dim3((pairs + kSWaves - 1) / kSWaves), dim3(64 * kSWaves),
+                           kSLdsFloats * sizeof(float), (hipStream_t)hip_stream, d_rec_base, d_recs, d_coeffs, d_out,
+                           d_states, d_tables, tb, g_tab_floats, n_chan);
+        AFG_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(celt_deemph_kernel, dim3((n_chan + kDeSeq - 1) / kDeSeq), dim3(64), 0, (hipStream_t)hip_stream,
+                           d_rec_base, d_recs, d_out, d_states, n_chan);
+        AFG_HIP_CHECK(hipGetLastError());
+        return AFG_OK;
+    }
+    // few streams: the iMDCT of all frames in parallel, then the sequential part.
+    // wavefronts per channel pair in the record-parallel kernel: enough to fill the device whatever n_chan is
     const uint32_t per_pair = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, 32768 / pairs));
     const uint64_t waves = (uint64_t)pairs * per_pair;
     hipLaunchKernelGGL(celt_imdct_kernel, dim3((uint32_t)((waves + kAWaves - 1) / kAWaves)), dim3(64 * kAWaves), 0,

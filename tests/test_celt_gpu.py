@@ -10,6 +10,14 @@ from afgpu import synthetic
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["split", "stream"])
+def celt_path(request, monkeypatch):
+    """Both device paths on every case: 'split' (record-parallel iMDCT kernel + per-stream post-filter kernel, the
+    choice for few streams) and 'stream' (one fused walk per stream, the choice for device-filling batches)."""
+    monkeypatch.setenv("AFG_CELT_PATH", request.param)
+    return request.param
+
+
 def run_gpu(gpu, rec_base, recs, coeffs, total, states=None):
     import torch
     d_out = torch.full((total,), float("nan"), dtype=torch.float32, device=gpu)
