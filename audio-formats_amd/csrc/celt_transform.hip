@@ -6,21 +6,29 @@
 // expression trees (float, with the double sub-expressions of :3313-3318); tables are built on
 // the host in x87 long double like the D source's `real` (:1489-1499).
 //
-// The comb post-filter feeds on its own output (lag >= 13 samples) and the de-emphasis is a
-// one-pole IIR across the whole stream, so a channel sequence is processed in order by ONE
-// wavefront with the 2048-sample CeltFrame.buf resident in LDS:
-//   * pre-rotation, the 15*2^n FFT (one lane per 15-point base transform, then radix-2 levels
-//     spread over the lanes) and the post-rotation run wave-parallel;
-//   * the post-filter advances min(T-2, 64) samples per step (everything a step reads is
-//     older than the step);
-//   * the de-emphasis recurrence (rounding order cannot be re-associated) is a second kernel
-//     over the output plane, one lane per channel sequence (celt_deemph_kernel).
-// Parallelism therefore comes from the number of channel sequences in the batch.
+// The iMDCT of a frame depends on no other frame; the comb post-filter feeds on its own output (lag >= 13
+// samples) and the de-emphasis is a one-pole IIR across the whole stream.  Three device paths share the code:
+//   * celt_stream_kernel (batches that fill the device): one wavefront walks a stereo stream with CeltFrame.buf
+//     of both channels in LDS -- transform, windows, post-filter, interleaved stores -- reading the coefficients
+//     once and writing the post-filtered PCM once;
+//   * celt_imdct_kernel + celt_postfilter_kernel (few streams): the transform of all records in parallel, then the
+//     sequential part in place on the output plane;
+//   * celt_deemph_kernel: the de-emphasis recurrence (rounding order cannot be re-associated), one lane per
+//     channel sequence, over the output plane.
 #include "afg_common.h"
 #include "celt_tables.h"
 
 #ifndef AFG_CELT_ABL
-#define AFG_CELT_ABL 0      // development ablations (tools/build_variant.sh): 2 no post-filter, 5 no steady-state comb filter
+#define AFG_CELT_ABL 0      // development ablations (tools/build_variant.sh): 2 no post-filter, 5 no steady-state comb filter, 6 no iMDCT, 7 no radix/post-rotation
+#endif
+
+#ifndef AFG_CELT_NT
+#define AFG_CELT_NT 1
+#endif
+#if AFG_CELT_NT
+#define AFG_CELT_LD(p) __builtin_nontemporal_load(p)
+#else
+#define AFG_CELT_LD(p) (*(p))
 #endif
 
 #include <algorithm>
@@ -123,11 +131,25 @@ __device__ __forceinline__ void fft15(cpx *out, const cpx *in, int stride, const
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kTailSlot = 1084;          // state words [1084, 1144): kernel A's hand-over of the last frame's overlap
 
+// Forces the wait for a prefetched record to this point (see the note on the in-order memory counter below).
+__device__ __forceinline__ void settle_rec(afg_celt_frame &f)
+{
+    uint32_t *w = (uint32_t *)&f;
+    static_assert(sizeof(afg_celt_frame) == 48, "record layout");
+#pragma unroll
+    for (int i = 0; i < 12; i++) asm volatile("" : "+v"(w[i]) : : "memory");
+}
+
 __device__ __forceinline__ bool celt_pair_ok(const afg_celt_frame &even, const afg_celt_frame &odd)
 {
     return even.out_stride == 2 && odd.out_stride == 2 && odd.out_off == even.out_off + 1 && (even.out_off & 1) == 0 &&
            even.frame_size == odd.frame_size && even.blocks == odd.blocks;
 }
+
+// Offsets into the table ensure_tables() builds (floats): twiddle_exptab of N = 3..6 back to back, then exptab[0]
+// (19 entries), exptab[1], ... -- computed, so that no lookup goes through memory.
+__device__ __forceinline__ int tw_off(int N) { return 120 * ((1 << (N - 3)) - 1); }
+__device__ __forceinline__ int ex_off(int i) { return i == 0 ? 1800 : 1838 + 30 * ((1 << i) - 2); }
 
 template <int G>
 __device__ __forceinline__ void radix_pass(cpx *z, int l, int nb15, int L0, const float *__restrict__ tables,
@@ -145,7 +167,7 @@ __device__ __forceinline__ void radix_pass(cpx *z, int l, int nb15, int L0, cons
         for (int q = 0; q < (1 << G); q++) v[q] = z[15 * (base15 | (q << (L0 - 1))) + r];
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const cpx *ex = (const cpx *)(tables + tb.exptab[L0 + g]);
+            const cpx *ex = (const cpx *)(tables + ex_off(L0 + g));
 #pragma unroll
             for (int q = 0; q < (1 << G); q++) {
                 if (q & (1 << g)) continue;
@@ -171,7 +193,9 @@ struct Geo {                             // geometry of a frame record
 __device__ __forceinline__ Geo geo_of(const afg_celt_frame &fr)
 {
     Geo g;
-    g.F = fr.frame_size; g.B = fr.blocks; g.bs = g.F / g.B;
+    // wave-uniform: the halves of a paired wavefront hold records of equal geometry, an unpaired one uses lanes 0..31
+    g.F = __builtin_amdgcn_readfirstlane((int)fr.frame_size); g.B = __builtin_amdgcn_readfirstlane((int)fr.blocks);
+    g.bs = g.F / g.B;
     g.N = 31 - __clz(g.bs / 15); g.fft_n = g.N - 1; g.nblk = 1 << g.fft_n;
     g.len4 = g.bs >> 1; g.len8 = g.len4 >> 1; g.nb15 = g.F / 30;
     return g;
@@ -179,18 +203,19 @@ __device__ __forceinline__ Geo geo_of(const afg_celt_frame &fr)
 
 // lane (block j, base transform a) fetches the 15 strided input pairs of its 15-point transform (dopus.d:1619-1625)
 __device__ __forceinline__ void load_inputs(float (&xa)[15], float (&xb)[15], const float *__restrict__ coeffs,
-                                            const afg_celt_frame &fr, const Geo &g, int l, bool act)
+                                            const afg_celt_frame &fr, const Geo &g, int l)
 {
-    if (act && l < g.nb15) {
-        const float *src = coeffs + fr.coef_off;
-        const int j = l >> g.fft_n, an = l & (g.nblk - 1);
-        const int a = (int)(__brev((unsigned)an) >> (32 - g.fft_n));
+    // unconditional on purpose (idle lanes repeat a neighbour's addresses): straight-line loads let the compiler
+    // count what is in flight instead of draining the queue at every merge point
+    const float *src = coeffs + fr.coef_off;
+    const int lc = l & (g.nb15 - 1);
+    const int j = lc >> g.fft_n, an = lc & (g.nblk - 1);
+    const int a = (int)(__brev((unsigned)an) >> (32 - g.fft_n));
 #pragma unroll
-        for (int k = 0; k < 15; k++) {
-            const int i = a + g.nblk * k;
-            xa[k] = __builtin_nontemporal_load(src + (size_t)(g.bs - 1 - 2 * i) * g.B + j);
-            xb[k] = __builtin_nontemporal_load(src + (size_t)(2 * i) * g.B + j);
-        }
+    for (int k = 0; k < 15; k++) {
+        const int i = a + g.nblk * k;
+        xa[k] = AFG_CELT_LD(src + (size_t)(g.bs - 1 - 2 * i) * g.B + j);
+        xb[k] = AFG_CELT_LD(src + (size_t)(2 * i) * g.B + j);
     }
 }
 
@@ -200,7 +225,7 @@ __device__ __forceinline__ void frame_fft(cpx *z, const float (&xa)[15], const f
                                           const Geo &g, const float *ltab, const float *lwin, const CeltTables &tb,
                                           int l, bool act)
 {
-    const cpx *tw = (const cpx *)(ltab + tb.twiddle[g.N - 3]);
+    const cpx *tw = (const cpx *)(ltab + tw_off(g.N));
     if (act && l < g.nb15) {
         const int an = l & (g.nblk - 1);
         const int a = (int)(__brev((unsigned)an) >> (32 - g.fft_n));
@@ -208,7 +233,7 @@ __device__ __forceinline__ void frame_fft(cpx *z, const float (&xa)[15], const f
 #pragma unroll
         for (int k = 0; k < 15; k++) x[k] = cmul(cpx{ xa[k], xb[k] }, tw[a + g.nblk * k]);
         cpx y[15];
-        fft15(y, x, 1, (const cpx *)(ltab + tb.exptab[0]));
+        fft15(y, x, 1, (const cpx *)(ltab + ex_off(0)));
 #pragma unroll
         for (int m = 0; m < 15; m++) z[15 * l + m] = y[m];
     }
@@ -218,7 +243,7 @@ __device__ __forceinline__ void frame_fft(cpx *z, const float (&xa)[15], const f
 __device__ __forceinline__ void frame_rest(cpx *z, const afg_celt_frame &fr, const Geo &g, const float *ltab,
                                            const float *lwin, const CeltTables &tb, int l, bool act)
 {
-    const cpx *tw = (const cpx *)(ltab + tb.twiddle[g.N - 3]);
+    const cpx *tw = (const cpx *)(ltab + tw_off(g.N));
     float *Y = (float *)z;
     // radix-2 levels 1..fft_n
     if (g.fft_n == 5) { radix_pass<3>(z, l, g.nb15, 1, ltab, tb, act); radix_pass<2>(z, l, g.nb15, 4, ltab, tb, act); }
@@ -228,17 +253,28 @@ __device__ __forceinline__ void frame_rest(cpx *z, const afg_celt_frame &fr, con
     // post-rotation, in place: block j's bs floats are frame positions 60 + j*bs + [0, bs)
     if (act) {
         const float scale = fr.imdct_scale;
-        for (int t = l; t < g.F / 4; t += 32) {
-            const int j = t / g.len8, i = t - j * g.len8;
-            cpx *zj = z + j * g.len4;
-            const cpx za = zj[g.len8 - i - 1], zb = zj[g.len8 + i];
-            const cpx ta = tw[g.len8 - i - 1], tb2 = tw[g.len8 + i];
-            const float r0 = za.im * ta.im - za.re * ta.re;
-            const float i1 = za.im * ta.re + za.re * ta.im;
-            const float r1 = zb.im * tb2.im - zb.re * tb2.re;
-            const float i0 = zb.im * tb2.re + zb.re * tb2.im;
-            zj[g.len8 - i - 1] = cpx{ scale * r0, scale * i0 };
-            zj[g.len8 + i] = cpx{ scale * r1, scale * i1 };
+        for (int t0 = l; t0 < g.F / 4; t0 += 128) {
+            cpx za[4], zb[4], ta[4], tc[4];
+            cpx *pa[4], *pb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = min(t0 + 32 * u, g.F / 4 - 1);
+                const int j = t / g.len8, i = t - j * g.len8;
+                cpx *zj = z + j * g.len4;
+                pa[u] = zj + g.len8 - i - 1; pb[u] = zj + g.len8 + i;
+                za[u] = *pa[u]; zb[u] = *pb[u];
+                ta[u] = tw[g.len8 - i - 1]; tc[u] = tw[g.len8 + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (t0 + 32 * u >= g.F / 4) continue;
+                const float r0 = za[u].im * ta[u].im - za[u].re * ta[u].re;
+                const float i1 = za[u].im * ta[u].re + za[u].re * ta[u].im;
+                const float r1 = zb[u].im * tc[u].im - zb[u].re * tc[u].re;
+                const float i0 = zb[u].im * tc[u].re + zb[u].re * tc[u].im;
+                *pa[u] = cpx{ scale * r0, scale * i0 };
+                *pb[u] = cpx{ scale * r1, scale * i1 };
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -293,7 +329,7 @@ __global__ __launch_bounds__(64 * kAWaves) void celt_imdct_kernel(
         const Geo g = geo_of(fr);
         const int F = g.F;
         float xa[15], xb[15];
-        load_inputs(xa, xb, coeffs, fr, g, l, act);
+        load_inputs(xa, xb, coeffs, fr, g, l);
         frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
         frame_rest(z, fr, g, ltab, lwin, tb, l, act);
         // frame positions [60, F) -> this frame's slots
@@ -393,8 +429,30 @@ __device__ __forceinline__ void pf_apply(float *ring, int n0, int len, const PfS
     const bool go = lane_on && pf.g[0] != 0.0f && len > 0;
     if (!__any(go)) return;
     const int T = pf.period;
-    int step = go ? max(min(T - 2, 32), 1) : 32;
+    // everything a step reads is at least T - 2 samples old: a lane takes samples l and l + 32 of a step when T allows
+    int step = go ? max(min(T - 2, 64), 1) : 64;
     step = min(__shfl(step, 0), __shfl(step, 32));
+    if (step > 32) {
+        for (int i0 = 0; i0 < len; i0 += step) {
+            float v[2] = { 0.0f, 0.0f };
+            bool on[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = i0 + l + 32 * u;
+                on[u] = go && l + 32 * u < step && i < len;
+                if (on[u]) {
+                    const float x0 = RD(i - T + 2), x1 = RD(i - T + 1), x2 = RD(i - T), x3 = RD(i - T - 1), x4 = RD(i - T - 2);
+                    v[u] = RD(i) + (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (on[u]) RD(i0 + l + 32 * u) = v[u];
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     for (int i0 = 0; i0 < len; i0 += step) {
         const int i = i0 + l;
         float v = 0.0f;
@@ -472,14 +530,12 @@ __global__ __launch_bounds__(64) void celt_postfilter_kernel(
         if (paired) {
             const f32x2 *o = (const f32x2 *)(out + off);
 #pragma unroll
-            for (int i = 0; i < 15; i++)
-                if (lane + 64 * i < F) nxt[i] = __builtin_nontemporal_load(o + lane + 64 * i);
+            for (int i = 0; i < 15; i++) nxt[i] = __builtin_nontemporal_load(o + min(lane + 64 * i, F - 1));
         } else {
             const float *o = out + off;
             const size_t stride = __shfl(fr.out_stride, 0);
 #pragma unroll
-            for (int i = 0; i < 15; i++)
-                if (lane + 64 * i < F) nxt[i].x = __builtin_nontemporal_load(o + (size_t)(lane + 64 * i) * stride);
+            for (int i = 0; i < 15; i++) nxt[i].x = __builtin_nontemporal_load(o + (size_t)min(lane + 64 * i, F - 1) * stride);
         }
     };
     afg_celt_frame fr = recs[my_base], fr_next = fr;
@@ -488,8 +544,7 @@ __global__ __launch_bounds__(64) void celt_postfilter_kernel(
 
     for (uint64_t q = 0; q < cnt; q++) {
         const int F = __shfl((int)fr.frame_size, 0);
-        afg_celt_frame fr_next2 = fr_next;
-        if (q + 2 < cnt) fr_next2 = recs[my_base + q + 2];
+        afg_celt_frame fr_next2 = recs[my_base + (q + 2 < cnt ? q + 2 : cnt - 1)];
         // the frame as kernel A left it: [0, 60) previous overlap, [60, F) this frame's iMDCT
 #pragma unroll
         for (int i = 0; i < 15; i++) {
@@ -499,7 +554,7 @@ __global__ __launch_bounds__(64) void celt_postfilter_kernel(
                 if (paired) rings[1][(n0 + p) & (kRing - 1)] = nxt[i].y;
             }
         }
-        if (q + 1 < cnt) fetch(fr_next);
+        fetch(fr_next);                                      // (the last frame's again at the end)
         __builtin_amdgcn_wave_barrier();
         if (q == 0 && lane_on)                               // the overlap a fresh call starts from: state or silence
             for (int k = l; k < 60; k += 32) RD(k) = st ? st[1024 + k] : 0.0f;
@@ -547,6 +602,7 @@ __global__ __launch_bounds__(64) void celt_postfilter_kernel(
         // so a wait placed after the stores below would also wait for them to drain.
 #pragma unroll
         for (int i = 0; i < 15; i++) asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y) : : "memory");
+        settle_rec(fr_next2);
         // the post-filtered frame goes back; the de-emphasis recurrence runs over it in celt_deemph_kernel
         if (paired) {
             f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
@@ -650,17 +706,22 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
         afg_celt_frame fr = recs[my_base], fr_next = fr;
         if (cnt > 1) fr_next = recs[my_base + 1];
         float xa[15], xb[15];
-        load_inputs(xa, xb, coeffs, fr, geo_of(fr), l, act);
+        load_inputs(xa, xb, coeffs, fr, geo_of(fr), l);
 
         for (uint64_t q = 0; q < cnt; q++) {
             const Geo g = geo_of(fr);
             const int F = g.F;
-            afg_celt_frame fr_next2 = fr_next;
-            if (q + 2 < cnt) fr_next2 = recs[my_base + q + 2];
+            afg_celt_frame fr_next2 = recs[my_base + (q + 2 < cnt ? q + 2 : cnt - 1)];
             // iMDCT and overlap-add, dopus.d:3684-3690
+#if AFG_CELT_ABL != 6 && AFG_CELT_ABL != 9
             frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
-            if (q + 1 < cnt) load_inputs(xa, xb, coeffs, fr_next, geo_of(fr_next), l, act);
+#endif
+#if AFG_CELT_ABL != 8 && AFG_CELT_ABL != 9
+            load_inputs(xa, xb, coeffs, fr_next, geo_of(fr_next), l);      // (the last frame's again at the end)
+#endif
+#if AFG_CELT_ABL != 6 && AFG_CELT_ABL != 7 && AFG_CELT_ABL != 9
             frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+#endif
             if (act) {                                       // vector_fmul_window of block 0
                 float *d = buf + 1024;
                 float a[2], b[2];
@@ -682,14 +743,18 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
             __builtin_amdgcn_wave_barrier();
 
             // celt_postfilter, dopus.d:3357-3378
+#if AFG_CELT_ABL != 2
             pf_transition(buf, win2, 1024, pf, l, act);
+#endif
             pf.period_old = pf.period;
             pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             pf.period = fr.pf_period_new;
             pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
             if (F > 120) {
+#if AFG_CELT_ABL != 2
                 pf_transition(buf, win2, 1024 + 120, pf, l, act);
                 pf_apply(buf, 1024 + 240, F - 240, pf, l, act);
+#endif
                 pf.period_old = pf.period;
                 pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             }
@@ -697,33 +762,35 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
             // make the prefetched inputs resident before the stores enter the queue
 #pragma unroll
             for (int i = 0; i < 15; i++) asm volatile("" : "+v"(xa[i]), "+v"(xb[i]) : : "memory");
+            settle_rec(fr_next2);
             // the post-filtered frame leaves; the de-emphasis recurrence runs over it in celt_deemph_kernel
-            if (both) {
+            if (both && F == 960) {
                 f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
+                f32x2 v[15];
 #pragma unroll
-                for (int i = 0; i < 15; i++) {
-                    const int p = lane + 64 * i;
-                    if (p < F) o[p] = f32x2{ b0[1024 + p], b1[1024 + p] };
-                }
+                for (int i = 0; i < 15; i++) v[i] = f32x2{ b0[1024 + lane + 64 * i], b1[1024 + lane + 64 * i] };
+#pragma unroll
+                for (int i = 0; i < 15; i++) o[lane + 64 * i] = v[i];
+            } else if (both) {
+                f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
+                for (int p = lane; p < F; p += 64) o[p] = f32x2{ b0[1024 + p], b1[1024 + p] };
             } else {
                 float *o = out + __shfl(fr.out_off, 0);
                 const size_t stride = __shfl(fr.out_stride, 0);
                 for (int p = lane; p < F; p += 64) o[(size_t)p * stride] = b0[1024 + p];
             }
             __builtin_amdgcn_wave_barrier();
-            // memmove(buf, buf + F, 1084 floats) (:3370): ascending 16-byte chunks, a source chunk is always read
-            // before any chunk that overwrites it is written
-            if (act) {
-                for (int i0 = 0; i0 < 271; i0 += 32) {
-                    const int i = i0 + l;
-                    f32x4 v = {};
-                    if (i < 271) v = *(const f32x4 *)(buf + F + 4 * i);
-                    __builtin_amdgcn_wave_barrier();
-                    if (i < 271) *(f32x4 *)(buf + 4 * i) = v;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            } else {
-                for (int i0 = 0; i0 < 271; i0 += 32) { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_wave_barrier(); }
+            // memmove(buf, buf + F, 1084 floats) (:3370): every read is issued before the first write
+            {
+                f32x4 mv[9];
+#pragma unroll
+                for (int u = 0; u < 9; u++)
+                    if (act && l + 32 * u < 271) mv[u] = *(const f32x4 *)(buf + F + 4 * (l + 32 * u));
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 9; u++)
+                    if (act && l + 32 * u < 271) *(f32x4 *)(buf + 4 * (l + 32 * u)) = mv[u];
+                __builtin_amdgcn_wave_barrier();
             }
             fr = fr_next;
             fr_next = fr_next2;
@@ -956,6 +1023,11 @@ int ensure_tables(const float **d_tables, CeltTables *tb)
                     t.push_back(t[c.exptab[0] + 2 * (j - 15) + 1]);
                 }
         }
+        for (int N = 3; N <= 6; N++)                                        // the device code computes these offsets
+            if (c.twiddle[N - 3] != 120u * ((1u << (N - 3)) - 1)) return AFG_ERR_INVALID;
+        for (int i = 0; i < 6; i++)
+            if (c.exptab[i] != (i == 0 ? 1800u : 1838u + 30u * ((1u << i) - 2))) return AFG_ERR_INVALID;
+        if (t.size() > (size_t)kTabFloatsMax) return AFG_ERR_INVALID;
         float *d = nullptr;
         AFG_HIP_CHECK(hipMalloc(&d, t.size() * sizeof(float)));
         AFG_HIP_CHECK(hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
