@@ -342,12 +342,32 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
     // ---- first granule's spectrum: 18 consecutive lines of this lane's subband --------
     const int g_end = (int)(seg.g0 + seg.count);
     const bool ch_on = ch < nch;
+    // Idle lanes (the second channel's half of a mono stream) repeat the first channel's addresses: every load
+    // of the loop is unconditional, so the compiler can count what is in flight instead of draining the queue.
+    const int lane_ld = ch_on ? lane : band;
     f2 pre[9];
     {
-        const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)g_first * nch) * 576) + lane * 9;
+        const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)g_first * nch) * 576) + lane_ld * 9;
 #pragma unroll
-        for (int q = 0; q < 9; q++) pre[q] = ch_on ? src[q] : f2{ 0.0f, 0.0f };
+        for (int q = 0; q < 9; q++) pre[q] = src[q];
     }
+    // flag words of 64 granules at a time sit in lane registers (lane i: granule fbase + i, one register per
+    // channel) and are read with v_readlane: no memory access on the per-granule path
+    int fbase = g_first;
+    uint32_t fl_a = 0, fl_b = 0;
+    auto refill = [&](int gb) {
+        fbase = gb;
+        const int gi = gb + lane;
+        fl_a = fl_b = 0;
+        if (gi < g_end) {
+            fl_a = flags[st.blk_base + (uint64_t)gi * nch];
+            if (nch == 2) fl_b = flags[st.blk_base + (uint64_t)gi * nch + 1];
+        }
+        asm volatile("" : "+v"(fl_a), "+v"(fl_b) : : "memory");     // waited for here, never inside the granule loop
+    };
+    refill(g_first);
+#pragma unroll
+    for (int q = 0; q < 9; q++) asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y) : : "memory");
     WAVE_SYNC();
 
     for (int g = g_first; g < g_end; g++) {
@@ -361,12 +381,14 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
             x[2 * m] = pre[m].x;
             x[2 * m + 1] = pre[m].y;
         }
-        uint32_t fl = 0;
-        if (ch_on) fl = flags[st.blk_base + (uint64_t)g * nch + ch];
+        if (g - fbase >= 64) refill(g);
+        const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane((int)fl_a, g - fbase);
+        const uint32_t fl1 = (uint32_t)__builtin_amdgcn_readlane((int)fl_b, g - fbase);
+        const uint32_t fl = ch_on ? (ch ? fl1 : fl0) : 0u;
         if (g + 1 < g_end) {
-            const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)(g + 1) * nch) * 576) + lane * 9;
+            const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)(g + 1) * nch) * 576) + lane_ld * 9;
 #pragma unroll
-            for (int q = 0; q < 9; q++) pre[q] = ch_on ? src[q] : f2{ 0.0f, 0.0f };
+            for (int q = 0; q < 9; q++) pre[q] = src[q];
         }
 
         // C. alias reduction (minimp3.d:1002-1020), IMDCT (:1152-1168), frequency inversion (:1144-1150)
@@ -505,6 +527,10 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
                 pp[16 * nch] = op16;
             }
             WAVE_SYNC();
+            // Make the prefetched spectrum resident *here*: loads and stores share one in-order counter on this
+            // hardware, so a wait placed after the stores below would also wait for them to drain.
+#pragma unroll
+            for (int q = 0; q < 9; q++) asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y) : : "memory");
             // I. 16-byte coalesced PCM stores
             float4 *dst = (float4 *)(pcm + (st.blk_base + (uint64_t)g * nch) * 576);
 #pragma unroll
