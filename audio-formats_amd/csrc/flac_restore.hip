@@ -272,6 +272,11 @@ __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, c
                                                       order1, shift1, u1, c1, h1);
             }
             __syncthreads();
+            // Make the prefetched residuals resident *here*: loads and stores share one in-order counter on this
+            // hardware, so the wait park_tile would need after the stores below would also wait for them to drain.
+#pragma unroll
+            for (int i = 0; i < kLoads; i++)
+                asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y), "+v"(nxt[i].z), "+v"(nxt[i].w) : : "memory");
             store_tile(tile, meta, row_shift, out_i32, out_f32, pair, t0);
             __syncthreads();
             if (t0 + kT < max_bs) park_tile(tile, nxt);
