@@ -699,6 +699,12 @@ __device__ __forceinline__ void vorbis_wave_body(
         fl_reg = in ? (unsigned)pflags[st.pkt_base + (uint64_t)q] : 0u;
         so_reg = in ? spec_off[st.pkt_base + (uint64_t)q] : 0;
         oo_reg = in ? out_off[st.pkt_base + (uint64_t)q] : 0;
+        // waited for here, inside the rarely taken refill: a wait at the first readlane would sit on the
+        // per-packet path and drain the previous packet's PCM stores every time
+        uint32_t s0 = (uint32_t)so_reg, s1 = (uint32_t)(so_reg >> 32), o0 = (uint32_t)oo_reg, o1 = (uint32_t)(oo_reg >> 32);
+        asm volatile("" : "+v"(fl_reg), "+v"(s0), "+v"(s1), "+v"(o0), "+v"(o1) : : "memory");
+        so_reg = ((uint64_t)s1 << 32) | s0;
+        oo_reg = ((uint64_t)o1 << 32) | o0;
     };
     auto flags_of = [&](int p) -> unsigned { return (unsigned)__builtin_amdgcn_readlane((int)fl_reg, p - fbase); };
     auto lane64 = [&](uint64_t v, int p) -> uint64_t {
