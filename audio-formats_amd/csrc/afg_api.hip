@@ -53,9 +53,10 @@ int DeviceArray::upload(const void *host, size_t nbytes)
 
 void DeviceArray::release()
 {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr && owned) (void)hipFree(ptr);
     ptr = nullptr;
     bytes = 0;
+    owned = true;
 }
 
 }  // namespace afg

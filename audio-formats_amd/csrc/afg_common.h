@@ -26,10 +26,24 @@ int require_device();
         }                                                                                \
     } while (0)
 
+// Caller-owned room for plan tables: `host` is page-locked, `dev` device memory of the same size; tables of plans
+// created with an arena are written to `host`, copied on `stream` and never allocated or waited for (the host
+// pipeline creates plans while earlier chunks are in flight: a synchronous upload would queue behind their copies).
+struct PlanArena {
+    uint8_t *host = nullptr, *dev = nullptr;
+    size_t cap = 0, used = 0;
+    hipStream_t stream = nullptr;
+};
+
+// afg_mp3_plan_create with explicit block offsets per stream (NULL: packed); see mp3_transform.hip
+int mp3_plan_create_at(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t *granules, const uint8_t *channels,
+                       const uint64_t *blk_base, uint32_t seg_granules, PlanArena *arena = nullptr);
+
 // Owns a device buffer filled from a host array at plan creation.
 struct DeviceArray {
     void *ptr = nullptr;
     size_t bytes = 0;
+    bool owned = true;                  // false: points into a PlanArena
     int upload(const void *host, size_t nbytes);
     void release();
 };

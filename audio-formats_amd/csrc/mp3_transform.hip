@@ -582,6 +582,16 @@ extern "C" {
 int afg_mp3_plan_create(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t *granules,
                         const uint8_t *channels, uint32_t seg_granules)
 {
+    return afg::mp3_plan_create_at(plan, n_streams, granules, channels, nullptr, seg_granules);
+}
+
+}  // extern "C"
+
+// Library-internal variant: stream s starts at block blk_base[s] of the planes (gaps between streams allowed);
+// NULL packs the streams back to back.  The host pipeline uses it to run the kernel on the staging layout as is.
+int afg::mp3_plan_create_at(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t *granules,
+                            const uint8_t *channels, const uint64_t *blk_base, uint32_t seg_granules, afg::PlanArena *arena)
+{
     if (!plan) return AFG_ERR_INVALID;
     *plan = nullptr;
     if (n_streams && (!granules || !channels)) {
@@ -593,18 +603,20 @@ int afg_mp3_plan_create(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t 
 
     std::vector<Mp3Stream> streams(n_streams);
     std::vector<Mp3Seg> segs;
-    uint64_t blk = 0;
+    uint64_t blk = 0, extent = 0;
     for (uint32_t s = 0; s < n_streams; s++) {
         if (channels[s] != 1 && channels[s] != 2) {
             afg::set_error("afg_mp3_plan_create: stream %u has %u channels (1 or 2 expected)", s, channels[s]);
             return AFG_ERR_INVALID;
         }
+        if (blk_base) blk = blk_base[s];
         streams[s] = Mp3Stream{ blk, granules[s], channels[s] };
         for (uint32_t g0 = 0; g0 < granules[s]; g0 += seg_granules) {
             uint32_t cnt = granules[s] - g0 < seg_granules ? granules[s] - g0 : seg_granules;
             segs.push_back(Mp3Seg{ s, g0, cnt, (g0 + cnt == granules[s]) ? 1u : 0u });
         }
         blk += (uint64_t)granules[s] * channels[s];
+        extent = blk > extent ? blk : extent;
     }
     if (segs.size() > 0x7fffffffu) {
         afg::set_error("afg_mp3_plan_create: too many segments");
@@ -614,9 +626,25 @@ int afg_mp3_plan_create(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t 
     if (!p) return AFG_ERR_OOM;
     p->n_streams = n_streams;
     p->n_segs = (uint32_t)segs.size();
-    p->blocks = blk;
-    int rc = p->d_segs.upload(segs.data(), segs.size() * sizeof(Mp3Seg));
-    if (!rc) rc = p->d_streams.upload(streams.data(), streams.size() * sizeof(Mp3Stream));
+    p->blocks = extent;
+    int rc = AFG_OK;
+    const size_t seg_bytes = segs.size() * sizeof(Mp3Seg), st_bytes = streams.size() * sizeof(Mp3Stream);
+    if (arena && arena->used + seg_bytes + st_bytes <= arena->cap) {
+        uint8_t *h = arena->host + arena->used, *d = arena->dev + arena->used;
+        std::memcpy(h, segs.data(), seg_bytes);
+        std::memcpy(h + seg_bytes, streams.data(), st_bytes);
+        hipError_t e = hipMemcpyAsync(d, h, seg_bytes + st_bytes, hipMemcpyHostToDevice, arena->stream);
+        if (e != hipSuccess) {
+            afg::set_error("plan table upload failed: %s", hipGetErrorString(e));
+            rc = AFG_ERR_HIP;
+        }
+        p->d_segs.ptr = d; p->d_segs.bytes = seg_bytes; p->d_segs.owned = false;
+        p->d_streams.ptr = d + seg_bytes; p->d_streams.bytes = st_bytes; p->d_streams.owned = false;
+        arena->used += (seg_bytes + st_bytes + 15) & ~(size_t)15;
+    } else {
+        rc = p->d_segs.upload(segs.data(), seg_bytes);
+        if (!rc) rc = p->d_streams.upload(streams.data(), st_bytes);
+    }
     if (rc) {
         afg_mp3_plan_destroy(p);
         return rc;
@@ -624,6 +652,8 @@ int afg_mp3_plan_create(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t 
     *plan = p;
     return AFG_OK;
 }
+
+extern "C" {
 
 void afg_mp3_plan_destroy(afg_mp3_plan *plan)
 {

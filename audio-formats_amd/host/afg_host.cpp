@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
@@ -46,6 +48,7 @@ struct Decoded {
     int64_t frames = 0;                 // frames actually decoded
     int64_t declared_frames = AFG_UNKNOWN_LENGTH;
     size_t pcm_off = 0;                 // float offset of this file's interleaved PCM in the result plane
+    bool in_mp3_plane = false;          // ... or in the batch's MP3 plane (staging layout, afg_batch_decode)
 };
 
 struct Parsed {
@@ -170,35 +173,194 @@ struct StageTimer {
     }
 };
 
+// Helper threads are kept between calls: the batch path runs one parallel_for per chunk of files, and creating a
+// few hundred threads each time cost more than the parsing they did.
+class HelperPool {
+public:
+    ~HelperPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    // Runs work() on the caller and on up to `helpers` pooled threads; returns when all of them are done.
+    // One job at a time: a second caller (another host thread in the library) just runs its work alone.
+    void run(unsigned helpers, const std::function<void()> &work)
+    {
+        std::unique_lock<std::mutex> job_lock(job_mu_, std::try_to_lock);
+        if (!job_lock.owns_lock() || helpers == 0) { work(); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (workers_.size() < helpers && workers_.size() < 1024) workers_.emplace_back([this] { loop(); });
+            job_ = &work; want_ = helpers; started_ = finished_ = 0; epoch_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        want_ = started_;                                    // no helper may still pick the job up
+        done_cv_.wait(lk, [&] { return finished_ == started_; });
+        job_ = nullptr;
+    }
+private:
+    void loop()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && started_ < want_); });
+            if (stop_) return;
+            seen = epoch_;
+            started_++;
+            const std::function<void()> *job = job_;
+            lk.unlock();
+            (*job)();
+            lk.lock();
+            finished_++;
+            done_cv_.notify_all();
+        }
+    }
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void()> *job_ = nullptr;
+    unsigned want_ = 0, started_ = 0, finished_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+HelperPool g_helpers;
+
 template <typename F>
 void parallel_for(size_t n, unsigned threads, F fn)
 {
     if (n == 0) return;
     threads = (unsigned)std::min<size_t>(std::max(1u, threads), n);
     std::atomic<size_t> next{ 0 };
-    auto work = [&]() {
+    const std::function<void()> work = [&]() {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= n) return;
             fn(i);
         }
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
+    g_helpers.run(threads - 1, work);
 }
 
 struct BatchOut {
     std::vector<Decoded> files;
     StagingPool::Lease plane;           // all PCM of the batch: FLAC files, then QOA files, then MP3 files; page-locked,
     size_t plane_floats = 0;            // returned to the pool by afg_batch_free / afg_close
+    StagingPool::Lease mp3_plane;       // batch path: the MP3 PCM in staging layout, served in place
 };
 
 // Device stage for a set of parsed files: every FLAC record of the batch in one launch, every QOA frame
 // in another; inputs are gathered (by `threads` host threads) into one page-locked buffer per kind and
 // the results come back as one plane.
-int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out)
+// Where the batch path parsed its MP3 files: one page-locked buffer, file i at block base[i] (gaps between files).
+// The device planes and the MP3 result plane mirror that layout, so a chunk of files moves in ONE copy each way and
+// a file's PCM is served where it lands (a per-file copy costs ~20 us of submission: 2 x 2048 of them were the whole
+// end-to-end time of a 2048-file batch).
+struct Mp3Stage {
+    const float *coef = nullptr;
+    const uint32_t *flags = nullptr;
+    size_t blocks = 0;
+    const size_t *base = nullptr;
+    float *plane = nullptr;             // host PCM plane, blocks * 576 floats (page-locked)
+};
+
+// H2D -> kernel on stream `up`, D2H on stream `down` behind an event: chunk k+1 uploads and transforms while chunk
+// k's PCM goes back (PCIe is full duplex) -- and while the host threads parse chunk k+2.
+struct Mp3Pipe {
+    const Mp3Stage *st = nullptr;
+    DeviceBuf d_in, d_pcm;
+    uint32_t *d_flags = nullptr;
+    hipStream_t up = nullptr, down = nullptr;
+    std::vector<afg_mp3_plan *> plans;
+    std::vector<hipEvent_t> events;
+    DeviceBuf d_tables;                 // plan tables: at most one 16-byte segment and stream record per block
+    StagingPool::Lease h_tables;
+    afg::PlanArena arena;
+    int rc = AFG_OK;
+    hipError_t e = hipSuccess;
+
+    int open(const Mp3Stage &stage)
+    {
+        st = &stage;
+        const size_t coef_bytes = stage.blocks * 576 * sizeof(float), flag_bytes = (stage.blocks * 4 + 15) & ~(size_t)15;
+        if (int r = d_in.alloc(coef_bytes + flag_bytes)) return r;
+        if (int r = d_pcm.alloc(coef_bytes)) return r;
+        d_flags = (uint32_t *)((uint8_t *)d_in.p + coef_bytes);
+        e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+        if (e != hipSuccess) { afg::set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+        const size_t tab_bytes = stage.blocks * 32 + 4096;
+        if (int r = d_tables.alloc(tab_bytes)) return r;
+        if (int r = g_staging.take(tab_bytes, h_tables)) return r;
+        arena.host = (uint8_t *)h_tables.p; arena.dev = (uint8_t *)d_tables.p; arena.cap = tab_bytes; arena.stream = up;
+        return AFG_OK;
+    }
+    // files [f0, f1) have been parsed into the stage: plan, upload, transform, download
+    void submit(const std::vector<Parsed> &parsed, size_t f0, size_t f1)
+    {
+        if (rc || e != hipSuccess) return;
+        std::vector<uint32_t> granules;
+        std::vector<uint8_t> channels;
+        std::vector<uint64_t> bases;
+        size_t b0 = 0, b1 = 0;
+        for (size_t i = f0; i < f1; i++) {
+            const Parsed &p = parsed[i];
+            if (p.format != AFG_FORMAT_MP3 || !p.mp3.blocks()) continue;
+            if (granules.empty()) b0 = st->base[i];
+            uint64_t at = st->base[i];
+            for (uint32_t g : p.mp3.run_granules) {
+                granules.push_back(g);
+                channels.push_back((uint8_t)p.mp3.channels);
+                bases.push_back(at);
+                at += (uint64_t)g * (uint64_t)p.mp3.channels;
+            }
+            b1 = st->base[i] + p.mp3.blocks();
+        }
+        if (granules.empty()) return;
+        afg_mp3_plan *plan = nullptr;
+        rc = afg::mp3_plan_create_at(&plan, (uint32_t)granules.size(), granules.data(), channels.data(), bases.data(), 0, &arena);
+        if (rc) return;
+        plans.push_back(plan);
+        hipEvent_t done = nullptr;
+        e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (e != hipSuccess) return;
+        events.push_back(done);
+        const size_t nb = b1 - b0;
+        e = hipMemcpyAsync((float *)d_in.p + b0 * 576, st->coef + b0 * 576, nb * 576 * sizeof(float), hipMemcpyHostToDevice, up);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_flags + b0, st->flags + b0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, up);
+        if (e != hipSuccess) return;
+        rc = afg_mp3_transform_hip(plan, (const float *)d_in.p, d_flags, (float *)d_pcm.p, nullptr, up);
+        if (rc) return;
+        e = hipEventRecord(done, up);
+        if (e == hipSuccess) e = hipStreamWaitEvent(down, done, 0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(st->plane + b0 * 576, (const float *)d_pcm.p + b0 * 576, nb * 576 * sizeof(float), hipMemcpyDeviceToHost, down);
+    }
+    int close()
+    {
+        if (up) { hipError_t e2 = hipStreamSynchronize(up); if (e == hipSuccess) e = e2; }
+        if (down) { hipError_t e2 = hipStreamSynchronize(down); if (e == hipSuccess) e = e2; }
+        for (afg_mp3_plan *p : plans) afg_mp3_plan_destroy(p);
+        for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+        plans.clear(); events.clear();
+        if (up) (void)hipStreamDestroy(up);
+        if (down) (void)hipStreamDestroy(down);
+        up = down = nullptr;
+        if (rc) return rc;
+        if (e != hipSuccess) { afg::set_error("MP3 stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+        return AFG_OK;
+    }
+    ~Mp3Pipe() { (void)close(); }
+};
+
+int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out,
+                  const Mp3Stage *stage = nullptr)
 {
     const size_t nf = parsed.size();
     out.files.assign(nf, Decoded());
@@ -224,7 +386,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         qoa_out += p.qoa.back().out_off + (size_t)p.qoa.back().samples * p.qoa.back().channels;
     }
     std::vector<size_t> mp3_blk_base(nf, 0);
-    size_t mp3_blocks = 0, mp3_out = 0, mp3_runs = 0;
+    size_t mp3_blocks = 0, mp3_out = 0;
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
         if (p.format != AFG_FORMAT_MP3) continue;
@@ -232,7 +394,18 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         out.files[i].pcm_off = flac_out + qoa_out + mp3_out;
         mp3_blocks += p.mp3.blocks();
         mp3_out += (size_t)p.mp3.pcm_samples;
-        mp3_runs += p.mp3.run_granules.size();
+    }
+    // Staged batch (afg_batch_decode): the MP3 files are already decoded, in staging layout, in stage->plane
+    const bool staged = stage && stage->blocks && mp3_blocks;
+    if (staged) {
+        mp3_out = 0;
+        for (size_t i = 0; i < nf; i++) {
+            Parsed &p = parsed[i];
+            if (p.format != AFG_FORMAT_MP3) continue;
+            const uint64_t first = p.mp3.copies.empty() ? 0 : p.mp3.copies[0].src;
+            out.files[i].pcm_off = stage->base[i] * 576 + (size_t)first;
+            out.files[i].in_mp3_plane = true;
+        }
     }
     size_t ogg_out = 0, ogg_packets = 0, ogg_spec = 0;
     for (size_t i = 0; i < nf; i++) {
@@ -242,6 +415,28 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         ogg_out += (size_t)p.ogg.pcm_frames * (size_t)p.ogg.channels;
         ogg_packets += p.ogg.pflags.size();
         ogg_spec += p.ogg.spec.size();
+    }
+    if (staged) {
+        // delivery in place: a file whose copy plan is one piece (every undamaged file) is served where it landed;
+        // the pieces of a damaged file are closed up towards its first piece (ascending, so memmove order is safe)
+        std::vector<size_t> broken;                          // files whose pieces are not already back to back
+        for (size_t i = 0; i < nf; i++) {
+            const Parsed &p = parsed[i];
+            if (p.format != AFG_FORMAT_MP3) continue;
+            for (size_t k = 1; k < p.mp3.copies.size(); k++)
+                if (p.mp3.copies[k].src != p.mp3.copies[k - 1].src + p.mp3.copies[k - 1].count) { broken.push_back(i); break; }
+        }
+        parallel_for(broken.size(), threads, [&](size_t bi) {
+            const size_t i = broken[bi];
+            const Parsed &p = parsed[i];
+            float *file_plane = stage->plane + stage->base[i] * 576;
+            float *dst = file_plane + p.mp3.copies[0].src;
+            for (const afg_mp3::Copy &c : p.mp3.copies) {
+                if (dst != file_plane + c.src) std::memmove(dst, file_plane + c.src, (size_t)c.count * sizeof(float));
+                dst += c.count;
+            }
+        });
+        tm.lap("mp3 delivery (in place)");
     }
     out.plane_floats = flac_out + qoa_out + mp3_out + ogg_out;
     if (out.plane_floats == 0) goto metadata;
@@ -312,61 +507,99 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         }
         tm.lap("flac+qoa stages");
         // ---- MP3: spectra of every decoded granule -> PCM plane -> the samples mp3dec_ex_read would deliver ----
-        if (mp3_blocks) {
+        if (mp3_blocks && !staged) {
             const size_t coef_bytes = mp3_blocks * 576 * sizeof(float), flag_bytes = (mp3_blocks * 4 + 15) & ~(size_t)15;
             DeviceBuf d_in, d_pcm;
             if (int rc = d_in.alloc(coef_bytes + flag_bytes)) return rc;
             if (int rc = d_pcm.alloc(coef_bytes)) return rc;
-            std::vector<uint32_t> granules, hfl(mp3_blocks);
-            std::vector<uint8_t> channels;
-            granules.reserve(mp3_runs);
-            channels.reserve(mp3_runs);
-            hipError_t e = hipSuccess;
-            for (size_t i = 0; i < nf && e == hipSuccess; i++) {
-                const Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_MP3) continue;
-                for (uint32_t g : p.mp3.run_granules) {
-                    granules.push_back(g);
-                    channels.push_back((uint8_t)p.mp3.channels);
+            // The files are cut into a few chunks of similar size, each with its own plan: the upload and kernel of
+            // chunk k+1 (stream `up`) run while chunk k's PCM goes back (stream `down`) -- PCIe is full duplex.
+            struct Chunk { size_t f0, f1, blk0, blocks; afg_mp3_plan *plan; hipEvent_t done; };
+            std::vector<Chunk> chunks;
+            {
+                size_t want = 8;
+                if (const char *ev = getenv("AFG_MP3_CHUNKS")) want = (size_t)std::max(1, atoi(ev));
+                const size_t target = std::max<size_t>((mp3_blocks + want - 1) / want, 8192);
+                Chunk c{ 0, 0, 0, 0, nullptr, nullptr };
+                for (size_t i = 0; i < nf; i++) {
+                    if (parsed[i].format != AFG_FORMAT_MP3) continue;
+                    if (c.blocks == 0) { c.f0 = i; c.blk0 = mp3_blk_base[i]; }
+                    c.blocks += parsed[i].mp3.blocks();
+                    c.f1 = i + 1;
+                    if (c.blocks >= target) { chunks.push_back(c); c = Chunk{ 0, 0, 0, 0, nullptr, nullptr }; }
                 }
-                const size_t nb = p.mp3.blocks();
-                if (!nb) continue;
-                std::memcpy(hfl.data() + mp3_blk_base[i], p.mp3_flags(), nb * sizeof(uint32_t));
-                // the batch path parsed this file straight into page-locked staging: one asynchronous copy per file
-                // into the packed device plane (a file parsed on its own comes from ordinary memory)
-                e = hipMemcpyAsync((float *)d_in.p + mp3_blk_base[i] * 576, p.mp3_coef(), nb * 576 * sizeof(float),
-                                   hipMemcpyHostToDevice, stream);
+                if (c.blocks) chunks.push_back(c);
             }
-            if (e == hipSuccess)
-                e = hipMemcpyAsync((uint8_t *)d_in.p + coef_bytes, hfl.data(), mp3_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);        // hfl is pageable: settle before it goes away
-            if (e != hipSuccess) { afg::set_error("MP3 upload failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
-            tm.lap("mp3 upload");
-            afg_mp3_plan *plan = nullptr;
-            if (int rc = afg_mp3_plan_create(&plan, (uint32_t)granules.size(), granules.data(), channels.data(), 0)) return rc;
-            int rc = e == hipSuccess ? afg_mp3_transform_hip(plan, (const float *)d_in.p, (const uint32_t *)((const uint8_t *)d_in.p + coef_bytes),
-                                                             (float *)d_pcm.p, nullptr, stream)
-                                     : AFG_ERR_HIP;
-            // delivery: the copy plan of each file, merged into maximal contiguous pieces (one per undamaged file),
-            // straight from the device PCM plane into the page-locked result plane
-            for (size_t i = 0; i < nf && !rc && e == hipSuccess; i++) {
-                const Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_MP3) continue;
-                const float *src = (const float *)d_pcm.p + mp3_blk_base[i] * 576;
-                float *dst = (float *)out.plane.p + out.files[i].pcm_off;
-                const std::vector<afg_mp3::Copy> &cp = p.mp3.copies;
-                for (size_t k = 0; k < cp.size() && e == hipSuccess;) {
-                    uint64_t from = cp[k].src, cnt = cp[k].count;
-                    size_t j = k + 1;
-                    while (j < cp.size() && cp[j].src == from + cnt) cnt += cp[j++].count;
-                    e = hipMemcpyAsync(dst, src + from, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, stream);
-                    dst += cnt;
-                    k = j;
+            StagingPool::Lease hfl_lease;                    // page-locked: the flag words travel asynchronously too
+            if (int rc = g_staging.take(mp3_blocks * sizeof(uint32_t), hfl_lease)) return rc;
+            uint32_t *hfl = (uint32_t *)hfl_lease.p;
+            hipStream_t up = nullptr, down = nullptr;
+            hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+            int rc = AFG_OK;
+            for (Chunk &c : chunks) {                        // plans first: their tables are uploaded synchronously
+                if (rc || e != hipSuccess) break;
+                std::vector<uint32_t> granules;
+                std::vector<uint8_t> channels;
+                for (size_t i = c.f0; i < c.f1; i++) {
+                    const Parsed &p = parsed[i];
+                    if (p.format != AFG_FORMAT_MP3) continue;
+                    for (uint32_t g : p.mp3.run_granules) {
+                        granules.push_back(g);
+                        channels.push_back((uint8_t)p.mp3.channels);
+                    }
+                    if (p.mp3.blocks()) std::memcpy(hfl + mp3_blk_base[i], p.mp3_flags(), p.mp3.blocks() * sizeof(uint32_t));
+                }
+                rc = afg_mp3_plan_create(&c.plan, (uint32_t)granules.size(), granules.data(), channels.data(), 0);
+                if (!rc) e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
+            }
+            tm.lap("mp3 plans");
+            uint32_t *d_flags = (uint32_t *)((uint8_t *)d_in.p + coef_bytes);
+            for (Chunk &c : chunks) {
+                if (rc || e != hipSuccess) break;
+                for (size_t i = c.f0; i < c.f1 && e == hipSuccess; i++) {
+                    const Parsed &p = parsed[i];
+                    if (p.format != AFG_FORMAT_MP3 || !p.mp3.blocks()) continue;
+                    // the batch path parsed this file straight into page-locked staging: one asynchronous copy per file
+                    // into the packed device plane (a file parsed on its own comes from ordinary memory)
+                    e = hipMemcpyAsync((float *)d_in.p + mp3_blk_base[i] * 576, p.mp3_coef(), p.mp3.blocks() * 576 * sizeof(float),
+                                       hipMemcpyHostToDevice, up);
+                }
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(d_flags + c.blk0, hfl + c.blk0, c.blocks * sizeof(uint32_t), hipMemcpyHostToDevice, up);
+                if (e != hipSuccess) break;
+                rc = afg_mp3_transform_hip(c.plan, (const float *)d_in.p + c.blk0 * 576, d_flags + c.blk0,
+                                           (float *)d_pcm.p + c.blk0 * 576, nullptr, up);
+                if (rc) break;
+                e = hipEventRecord(c.done, up);
+                if (e == hipSuccess) e = hipStreamWaitEvent(down, c.done, 0);
+                // delivery: the copy plan of each file, merged into maximal contiguous pieces (one per undamaged file),
+                // straight from the device PCM plane into the page-locked result plane
+                for (size_t i = c.f0; i < c.f1 && e == hipSuccess; i++) {
+                    const Parsed &p = parsed[i];
+                    if (p.format != AFG_FORMAT_MP3) continue;
+                    const float *src = (const float *)d_pcm.p + mp3_blk_base[i] * 576;
+                    float *dst = (float *)out.plane.p + out.files[i].pcm_off;
+                    const std::vector<afg_mp3::Copy> &cp = p.mp3.copies;
+                    for (size_t k = 0; k < cp.size() && e == hipSuccess;) {
+                        uint64_t from = cp[k].src, cnt = cp[k].count;
+                        size_t j = k + 1;
+                        while (j < cp.size() && cp[j].src == from + cnt) cnt += cp[j++].count;
+                        e = hipMemcpyAsync(dst, src + from, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, down);
+                        dst += cnt;
+                        k = j;
+                    }
                 }
             }
-            if (!rc && e == hipSuccess) e = hipStreamSynchronize(stream);
-            afg_mp3_plan_destroy(plan);
-            tm.lap("mp3 plan+h2d+kernel+d2h");
+            if (up) { hipError_t e2 = hipStreamSynchronize(up); if (e == hipSuccess) e = e2; }
+            if (down) { hipError_t e2 = hipStreamSynchronize(down); if (e == hipSuccess) e = e2; }
+            for (Chunk &c : chunks) {
+                if (c.plan) afg_mp3_plan_destroy(c.plan);
+                if (c.done) (void)hipEventDestroy(c.done);
+            }
+            if (up) (void)hipStreamDestroy(up);
+            if (down) (void)hipStreamDestroy(down);
+            tm.lap("mp3 h2d | kernel | d2h (chunks overlapped)");
             if (rc) return rc;
             if (e != hipSuccess) { afg::set_error("MP3 stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
             tm.lap("mp3 delivery copies");
@@ -716,31 +949,62 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
         });
         size_t total_bound = 0;
         for (size_t i = 0; i < (size_t)n_files; i++) { base[i] = total_bound; total_bound += bound[i]; }
-        StagingPool::Lease mp3_stage;
-        if (total_bound) {
-            if (int rc = g_staging.take(total_bound * (576 * sizeof(float) + sizeof(uint32_t)), mp3_stage)) return rc;
-            float *coef0 = (float *)mp3_stage.p;
-            uint32_t *flags0 = (uint32_t *)(coef0 + total_bound * 576);
-            parallel_for((size_t)n_files, nt, [&](size_t i) {
-                if (!bound[i]) return;
-                Parsed &p = parsed[i];
-                bool ok = false;
-                try {
-                    ok = afg_mp3::parse_file_into(data[i], length[i], p.mp3, coef0 + base[i] * 576, flags0 + base[i], bound[i]);
-                    if (ok && p.mp3.overflow) ok = afg_mp3::parse_file(data[i], length[i], p.mp3);     // cannot happen; be safe
-                } catch (...) { ok = false; }
-                if (ok) p.format = AFG_FORMAT_MP3;
-                else p.mp3 = afg_mp3::File();
-            });
-        }
-        tm.lap("parse (all threads)");
         BatchOut *owner = new (std::nothrow) BatchOut;
         if (!owner) return AFG_ERR_OOM;
-        int rc = decode_parsed(parsed, data, length, nt, *owner);
+        std::unique_ptr<BatchOut> guard(owner);
+        StagingPool::Lease mp3_stage;
+        Mp3Stage stage;
+        if (total_bound) {
+            if (int rc = g_staging.take(total_bound * (576 * sizeof(float) + sizeof(uint32_t)), mp3_stage)) return rc;
+            if (int rc = g_staging.take(total_bound * 576 * sizeof(float), owner->mp3_plane)) return rc;
+            float *coef0 = (float *)mp3_stage.p;
+            uint32_t *flags0 = (uint32_t *)(coef0 + total_bound * 576);
+            stage.coef = coef0; stage.flags = flags0; stage.blocks = total_bound; stage.base = base.data();
+            stage.plane = (float *)owner->mp3_plane.p;
+            Mp3Pipe pipe;
+            if (int rc = pipe.open(stage)) return rc;
+            // pass 2, chunk by chunk: all host threads parse a chunk of files, its device work is queued, and they go on
+            // with the next chunk while the copies and the kernel of this one run
+            size_t want = 8;
+            if (const char *ev = getenv("AFG_MP3_CHUNKS")) want = (size_t)std::max(1, atoi(ev));
+            const size_t target = std::max<size_t>((total_bound + want - 1) / want, 8192);
+            bool fallback = false;
+            for (size_t f0 = 0; f0 < (size_t)n_files;) {
+                size_t f1 = f0, acc = 0;
+                while (f1 < (size_t)n_files && acc < target) acc += bound[f1++];
+                std::atomic<bool> lost{ false };
+                parallel_for(f1 - f0, nt, [&](size_t k) {
+                    const size_t i = f0 + k;
+                    if (!bound[i]) return;
+                    Parsed &p = parsed[i];
+                    bool ok = false;
+                    try {
+                        ok = afg_mp3::parse_file_into(data[i], length[i], p.mp3, coef0 + base[i] * 576, flags0 + base[i], bound[i]);
+                        if (ok && p.mp3.overflow) {              // cannot happen; be safe: parse into the file's own buffers
+                            ok = afg_mp3::parse_file(data[i], length[i], p.mp3);
+                            lost = true;
+                        }
+                    } catch (...) { ok = false; }
+                    if (ok) p.format = AFG_FORMAT_MP3;
+                    else p.mp3 = afg_mp3::File();
+                });
+                if (lost) fallback = true;
+                if (!fallback) pipe.submit(parsed, f0, f1);
+                f0 = f1;
+            }
+            tm.lap("parse (all threads) | mp3 h2d | kernel | d2h");
+            const int prc = pipe.close();
+            tm.lap("mp3 pipeline drain");
+            if (prc) return prc;
+            if (fallback) stage.blocks = 0;                   // decode_parsed does those files from their own buffers
+        } else {
+            tm.lap("parse (all threads)");
+        }
+        int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr);
         tm.lap("decode_parsed total");
-        if (rc) { delete owner; return rc; }
+        if (rc) return rc;
         afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));
-        if (!items) { delete owner; return AFG_ERR_OOM; }
+        if (!items) return AFG_ERR_OOM;
         for (int i = 0; i < n_files; i++) {
             const Decoded &d = owner->files[(size_t)i];
             items[i].status = d.status;
@@ -749,11 +1013,12 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             items[i].channels = d.channels;
             items[i].samplerate = d.samplerate;
             items[i].frames = d.frames;
-            items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)owner->plane.p + d.pcm_off : nullptr;
+            const float *plane = d.in_mp3_plane ? (const float *)owner->mp3_plane.p : (const float *)owner->plane.p;
+            items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)plane + d.pcm_off : nullptr;
         }
         out->n_files = n_files;
         out->items = items;
-        out->owner = owner;
+        out->owner = guard.release();
         return AFG_OK;
     } catch (...) {
         afg::set_error("out of host memory");
