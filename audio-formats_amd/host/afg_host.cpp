@@ -457,24 +457,67 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             afg_flac_frame *hf = (afg_flac_frame *)h_in.p;
             afg_flac_subframe *hs = (afg_flac_subframe *)(hf + fr_total);
             int32_t *hr = (int32_t *)((uint8_t *)h_in.p + rec_pad);
-            parallel_for(nf, threads, [&](size_t i) {
-                Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_FLAC) return;
-                for (size_t k = 0; k < p.flac.frames.size(); k++) {
-                    afg_flac_frame f = p.flac.frames[k];
-                    f.in_off += res_base[i]; f.out_off += out.files[i].pcm_off; f.sf_index += (uint32_t)sf_base[i];
-                    hf[fr_base[i] + k] = f;
-                }
-                std::memcpy(hs + sf_base[i], p.flac.subframes.data(), p.flac.subframes.size() * sizeof(afg_flac_subframe));
-                std::memcpy(hr + res_base[i], p.flac.res.data(), p.flac.res.size() * 4);
-                std::vector<int32_t>().swap(p.flac.res);               // the residual plane is the big one: drop it early
-            });
-            AFG_HIP_CHECK(hipMemcpyAsync(d_in.p, h_in.p, rec_pad + res_total * 4, hipMemcpyHostToDevice, stream));
+            // Chunks of files: gather (host threads) -> upload + kernel on `up` -> download on `down` behind an event,
+            // so the gather of chunk k+1, the upload of chunk k and the download of chunk k-1 overlap.
             const afg_flac_frame *df = (const afg_flac_frame *)d_in.p;
             const afg_flac_subframe *ds = (const afg_flac_subframe *)(df + fr_total);
             const int32_t *dr = (const int32_t *)((const uint8_t *)d_in.p + rec_pad);
-            if (int rc = afg_flac_transform_hip(fr_total, df, ds, dr, nullptr, (float *)d_out.p, stream)) return rc;
-            AFG_HIP_CHECK(hipStreamSynchronize(stream));
+            hipStream_t up = nullptr, down = nullptr;
+            std::vector<hipEvent_t> events;
+            hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+            int rc = AFG_OK;
+            const size_t target = std::max<size_t>((res_total + 7) / 8, (size_t)4 << 20);
+            for (size_t f0 = 0; f0 < nf && !rc && e == hipSuccess;) {
+                size_t f1 = f0, acc = 0;
+                while (f1 < nf && acc < target) { if (parsed[f1].format == AFG_FORMAT_FLAC) acc += parsed[f1].flac.res.size(); f1++; }
+                size_t first = nf, last = nf;                // first / last FLAC file of the chunk
+                for (size_t i = f0; i < f1; i++)
+                    if (parsed[i].format == AFG_FORMAT_FLAC) { if (first == nf) first = i; last = i; }
+                if (first == nf) { f0 = f1; continue; }
+                parallel_for(f1 - f0, threads, [&](size_t k) {
+                    const size_t i = f0 + k;
+                    Parsed &p = parsed[i];
+                    if (p.format != AFG_FORMAT_FLAC) return;
+                    for (size_t q = 0; q < p.flac.frames.size(); q++) {
+                        afg_flac_frame f = p.flac.frames[q];
+                        f.in_off += res_base[i]; f.out_off += out.files[i].pcm_off; f.sf_index += (uint32_t)sf_base[i];
+                        hf[fr_base[i] + q] = f;
+                    }
+                    std::memcpy(hs + sf_base[i], p.flac.subframes.data(), p.flac.subframes.size() * sizeof(afg_flac_subframe));
+                    std::memcpy(hr + res_base[i], p.flac.res.data(), p.flac.res.size() * 4);
+                    std::vector<int32_t>().swap(p.flac.res);           // the residual plane is the big one: drop it early
+                });
+                const size_t fr0 = fr_base[first], fr1 = fr_base[last] + parsed[last].flac.frames.size();
+                const size_t sf0 = sf_base[first], sf1 = sf_base[last] + parsed[last].flac.subframes.size();
+                const size_t r0 = res_base[first];
+                size_t r1 = r0;
+                for (size_t q = fr0; q < fr1; q++) r1 = std::max<size_t>(r1, hf[q].in_off + (size_t)hf[q].channels * hf[q].block_size);
+                const size_t o0 = out.files[first].pcm_off, o1 = out.files[last].pcm_off + parsed[last].flac.out_samples;
+                e = hipMemcpyAsync((void *)(df + fr0), hf + fr0, (fr1 - fr0) * sizeof(afg_flac_frame), hipMemcpyHostToDevice, up);
+                if (e == hipSuccess) e = hipMemcpyAsync((void *)(ds + sf0), hs + sf0, (sf1 - sf0) * sizeof(afg_flac_subframe), hipMemcpyHostToDevice, up);
+                if (e == hipSuccess) e = hipMemcpyAsync((void *)(dr + r0), hr + r0, (r1 - r0) * 4, hipMemcpyHostToDevice, up);
+                if (e != hipSuccess) break;
+                rc = afg_flac_transform_hip(fr1 - fr0, df + fr0, ds, dr, nullptr, (float *)d_out.p, up);
+                if (rc) break;
+                hipEvent_t done = nullptr;
+                e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+                if (e != hipSuccess) break;
+                events.push_back(done);
+                e = hipEventRecord(done, up);
+                if (e == hipSuccess) e = hipStreamWaitEvent(down, done, 0);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync((float *)out.plane.p + o0, (const float *)d_out.p + o0, (o1 - o0) * sizeof(float), hipMemcpyDeviceToHost, down);
+                f0 = f1;
+            }
+            if (up) { hipError_t e2 = hipStreamSynchronize(up); if (e == hipSuccess) e = e2; }
+            if (down) { hipError_t e2 = hipStreamSynchronize(down); if (e == hipSuccess) e = e2; }
+            for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+            if (up) (void)hipStreamDestroy(up);
+            if (down) (void)hipStreamDestroy(down);
+            if (rc) return rc;
+            if (e != hipSuccess) { afg::set_error("FLAC stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+            tm.lap("flac gather | h2d | kernel | d2h (chunks overlapped)");
         }
         // ---- QOA ----
         if (qoa_out) {
@@ -501,11 +544,12 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 return rc;
             AFG_HIP_CHECK(hipStreamSynchronize(stream));
         }
-        if (flac_out + qoa_out) {
-            AFG_HIP_CHECK(hipMemcpyAsync(out.plane.p, d_out.p, (flac_out + qoa_out) * sizeof(float), hipMemcpyDeviceToHost, stream));
+        if (qoa_out) {                                       // (the FLAC part came back chunk by chunk)
+            AFG_HIP_CHECK(hipMemcpyAsync((float *)out.plane.p + flac_out, (const float *)d_out.p + flac_out, qoa_out * sizeof(float),
+                                         hipMemcpyDeviceToHost, stream));
             AFG_HIP_CHECK(hipStreamSynchronize(stream));
         }
-        tm.lap("flac+qoa stages");
+        tm.lap("qoa stage");
         // ---- MP3: spectra of every decoded granule -> PCM plane -> the samples mp3dec_ex_read would deliver ----
         if (mp3_blocks && !staged) {
             const size_t coef_bytes = mp3_blocks * 576 * sizeof(float), flag_bytes = (mp3_blocks * 4 + 15) & ~(size_t)15;
