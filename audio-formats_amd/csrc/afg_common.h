@@ -39,6 +39,11 @@ struct PlanArena {
 int mp3_plan_create_at(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t *granules, const uint8_t *channels,
                        const uint64_t *blk_base, uint32_t seg_granules, PlanArena *arena = nullptr);
 
+// afg_vorbis_plan_create with an explicit input offset per stream (NULL: packed); see vorbis_transform.hip
+int vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const uint32_t *packets, const uint8_t *channels,
+                          const uint16_t *blocksize0, const uint16_t *blocksize1, const uint8_t *pflags,
+                          const uint64_t *spec_base, uint32_t seg_packets);
+
 // Owns a device buffer filled from a host array at plan creation.
 struct DeviceArray {
     void *ptr = nullptr;

@@ -860,11 +860,18 @@ struct afg_vorbis_plan {
     afg::DeviceArray d_segs, d_wave_segs, d_streams, d_pflags, d_spec_off, d_out_off, d_tables;
 };
 
-extern "C" {
+extern "C" int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uint32_t *packets,
+                                      const uint8_t *channels, const uint16_t *blocksize0,
+                                      const uint16_t *blocksize1, const uint8_t *pflags, uint32_t seg_packets)
+{
+    return afg::vorbis_plan_create_at(plan, n_streams, packets, channels, blocksize0, blocksize1, pflags, nullptr, seg_packets);
+}
 
-int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uint32_t *packets,
-                           const uint8_t *channels, const uint16_t *blocksize0,
-                           const uint16_t *blocksize1, const uint8_t *pflags, uint32_t seg_packets)
+// Library-internal variant: the spectra of stream s start at float spec_base[s] of the input plane (gaps between
+// streams allowed; NULL packs them).  The host pipeline runs the kernel on its staging layout as is.
+int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const uint32_t *packets,
+                               const uint8_t *channels, const uint16_t *blocksize0, const uint16_t *blocksize1,
+                               const uint8_t *pflags, const uint64_t *spec_base, uint32_t seg_packets)
 {
     if (!plan) return AFG_ERR_INVALID;
     *plan = nullptr;
@@ -882,9 +889,10 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
     auto p = new (std::nothrow) afg_vorbis_plan;
     if (!p) return AFG_ERR_OOM;
 
-    uint64_t pkt = 0, so = 0, oo = 0;
+    uint64_t pkt = 0, so = 0, oo = 0, so_extent = 0;
     size_t lds = 0;
     for (uint32_t s = 0; s < n_streams; s++) {
+        if (spec_base) so = spec_base[s];
         const int bs[2] = { blocksize0[s], blocksize1[s] };
         for (int b = 0; b < 2; b++) {
             const int n = bs[b];
@@ -939,6 +947,7 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
             p->h_spec_off.push_back(so);
             p->h_out_off.push_back(oo);
             so += (uint64_t)(n / 2) * channels[s];
+            so_extent = so > so_extent ? so : so_extent;
             if (prev_len) oo += (uint64_t)(right - left) * channels[s];                // :2645-2656
             prev_len = right_end - right;
         }
@@ -960,7 +969,7 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
     p->n_wave_segs = (uint32_t)wave_segs.size();
     p->tab2048 = tab_of.count(kNL) ? tab_of[kNL] : 0;
     p->n_packets = pkt;
-    p->spec_floats = so;
+    p->spec_floats = so_extent;
     p->out_floats = oo;
     p->lds_bytes = lds;
     int rc = p->d_segs.upload(segs.data(), segs.size() * sizeof(VorbisSeg));
@@ -993,6 +1002,8 @@ int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uin
     *plan = p;
     return AFG_OK;
 }
+
+extern "C" {
 
 void afg_vorbis_plan_destroy(afg_vorbis_plan *plan)
 {

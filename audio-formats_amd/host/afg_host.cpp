@@ -270,6 +270,13 @@ struct Mp3Stage {
     float *plane = nullptr;             // host PCM plane, blocks * 576 floats (page-locked)
 };
 
+// Where the batch path parsed its Ogg Vorbis files: file i's spectra at float base[i] of one page-locked buffer
+struct OggStage {
+    const float *spec = nullptr;
+    size_t floats = 0;
+    const size_t *base = nullptr;
+};
+
 // H2D -> kernel on stream `up`, D2H on stream `down` behind an event: chunk k+1 uploads and transforms while chunk
 // k's PCM goes back (PCIe is full duplex) -- and while the host threads parse chunk k+2.
 struct Mp3Pipe {
@@ -360,7 +367,7 @@ struct Mp3Pipe {
 };
 
 int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out,
-                  const Mp3Stage *stage = nullptr)
+                  const Mp3Stage *stage = nullptr, const OggStage *ogg_stage = nullptr)
 {
     const size_t nf = parsed.size();
     out.files.assign(nf, Decoded());
@@ -407,14 +414,108 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             out.files[i].in_mp3_plane = true;
         }
     }
+    // Vorbis: chunks of files, one plan each; the Vorbis part of the result plane is the plans' output planes back to
+    // back, so a chunk's PCM comes back in one copy and a file is served where it lands (first piece onwards)
+    struct OggChunk {
+        size_t f0 = 0, f1 = 0, spec0 = 0, spec_n = 0, out0 = 0, out_n = 0;
+        afg_vorbis_plan *plan = nullptr;
+        hipEvent_t done = nullptr;
+        std::vector<size_t> spec_at;                         // per file of the chunk: float offset of its spectra in the chunk
+    };
+    struct OggChunks {
+        std::vector<OggChunk> v;
+        ~OggChunks()
+        {
+            for (OggChunk &c : v) {
+                if (c.plan) afg_vorbis_plan_destroy(c.plan);
+                if (c.done) (void)hipEventDestroy(c.done);
+            }
+        }
+    } ogg;
+    struct OggPiece { size_t file; uint64_t from, count; };  // pieces of files that are not served as one run
+    std::vector<OggPiece> ogg_pieces;
+    std::vector<size_t> ogg_broken;
     size_t ogg_out = 0, ogg_packets = 0, ogg_spec = 0;
-    for (size_t i = 0; i < nf; i++) {
-        Parsed &p = parsed[i];
-        if (p.format != AFG_FORMAT_OGG) continue;
-        out.files[i].pcm_off = flac_out + qoa_out + mp3_out + ogg_out;
-        ogg_out += (size_t)p.ogg.pcm_frames * (size_t)p.ogg.channels;
-        ogg_packets += p.ogg.pflags.size();
-        ogg_spec += p.ogg.spec.size();
+    const bool ogg_staged = ogg_stage && ogg_stage->floats;
+    {
+        size_t total = 0;
+        for (size_t i = 0; i < nf; i++)
+            if (parsed[i].format == AFG_FORMAT_OGG) { total += parsed[i].ogg.n_spec; ogg_packets += parsed[i].ogg.pflags.size(); }
+        const size_t target = std::max<size_t>((total + 7) / 8, (size_t)4 << 20);
+        for (size_t f0 = 0; f0 < nf && ogg_packets;) {
+            size_t f1 = f0, acc = 0;
+            while (f1 < nf && acc < target) { if (parsed[f1].format == AFG_FORMAT_OGG) acc += parsed[f1].ogg.n_spec; f1++; }
+            OggChunk c;
+            c.f0 = f0; c.f1 = f1; c.spec0 = ogg_spec; c.out0 = ogg_out;
+            std::vector<uint32_t> npk;
+            std::vector<uint8_t> chans, pflags;
+            std::vector<uint16_t> b0, b1;
+            std::vector<uint64_t> sbase;                     // staged: where each stream's spectra sit in the staging buffer
+            c.spec_at.assign(f1 - f0, 0);
+            size_t at = 0, span0 = 0, span1 = 0;
+            for (size_t i = f0; i < f1; i++) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_OGG) continue;
+                c.spec_at[i - f0] = at;
+                at += p.ogg.n_spec;
+                if (p.ogg.pflags.empty()) continue;
+                if (ogg_staged) {
+                    if (sbase.empty()) span0 = ogg_stage->base[i];
+                    span1 = ogg_stage->base[i] + p.ogg.n_spec;
+                    sbase.push_back(ogg_stage->base[i]);
+                }
+                npk.push_back((uint32_t)p.ogg.pflags.size());
+                chans.push_back((uint8_t)p.ogg.channels);
+                b0.push_back((uint16_t)p.ogg.blocksize0);
+                b1.push_back((uint16_t)p.ogg.blocksize1);
+                pflags.insert(pflags.end(), p.ogg.pflags.begin(), p.ogg.pflags.end());
+            }
+            f0 = f1;
+            if (npk.empty()) continue;
+            if (int rc = afg::vorbis_plan_create_at(&c.plan, (uint32_t)npk.size(), npk.data(), chans.data(), b0.data(), b1.data(),
+                                                    pflags.data(), ogg_staged ? sbase.data() : nullptr, 0))
+                return rc;
+            ogg.v.push_back(std::move(c));
+            OggChunk &k = ogg.v.back();
+            k.spec_n = (size_t)afg_vorbis_plan_spec_floats(k.plan);
+            k.out_n = (size_t)afg_vorbis_plan_out_floats(k.plan);
+            if (ogg_staged) {                                // the plan addresses the staging layout: the chunk is a span of it
+                if (k.spec_n != span1) {
+                    afg::set_error("Vorbis stage: spectrum layout mismatch (%zu vs %zu floats)", k.spec_n, span1);
+                    return AFG_ERR_INVALID;
+                }
+                k.spec0 = span0;
+                k.spec_n = span1 - span0;
+            } else if (k.spec_n != at) {
+                afg::set_error("Vorbis stage: spectrum layout mismatch (%zu vs %zu floats)", k.spec_n, at);
+                return AFG_ERR_INVALID;
+            }
+            std::vector<uint64_t> out_off(pflags.size());
+            if (int rc = afg_vorbis_plan_offsets(k.plan, nullptr, out_off.data())) return rc;
+            // delivery = the pull API's share of every packet's output: normally one run from the first packet on
+            size_t pk = 0;
+            for (size_t i = k.f0; i < k.f1; i++) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_OGG) continue;
+                const size_t n = p.ogg.pflags.size(), C = (size_t)p.ogg.channels;
+                const size_t first_piece = ogg_pieces.size();
+                for (size_t q = 0; q < n;) {
+                    if (p.ogg.take_count[q] <= 0) { q++; continue; }
+                    uint64_t from = out_off[pk + q] + (uint64_t)p.ogg.take_from[q] * C, cnt = (uint64_t)p.ogg.take_count[q] * C;
+                    size_t j = q + 1;
+                    while (j < n && p.ogg.take_count[j] > 0 && out_off[pk + j] + (uint64_t)p.ogg.take_from[j] * C == from + cnt)
+                        cnt += (uint64_t)p.ogg.take_count[j++] * C;
+                    ogg_pieces.push_back(OggPiece{ i, ogg_out + from, cnt });
+                    q = j;
+                }
+                out.files[i].pcm_off = flac_out + qoa_out + mp3_out + (ogg_pieces.size() > first_piece ? (size_t)ogg_pieces[first_piece].from : ogg_out);
+                if (ogg_pieces.size() - first_piece > 1) ogg_broken.push_back(i);
+                else if (ogg_pieces.size() > first_piece) ogg_pieces.pop_back();          // one run: nothing to move
+                pk += n;
+            }
+            if (!ogg_staged) ogg_spec += k.spec_n;
+            ogg_out += k.out_n;
+        }
     }
     if (staged) {
         // delivery in place: a file whose copy plan is one piece (every undamaged file) is served where it landed;
@@ -648,66 +749,60 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             if (e != hipSuccess) { afg::set_error("MP3 stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
             tm.lap("mp3 delivery copies");
         }
-        // ---- Vorbis: one plan stream per file; delivery = the pull API's share of every packet's output ----
-        if (ogg_packets) {
-            std::vector<uint32_t> npk;
-            std::vector<uint8_t> chans, pflags;
-            std::vector<uint16_t> b0, b1;
-            pflags.reserve(ogg_packets);
-            for (size_t i = 0; i < nf; i++) {
-                const Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_OGG || p.ogg.pflags.empty()) continue;
-                npk.push_back((uint32_t)p.ogg.pflags.size());
-                chans.push_back((uint8_t)p.ogg.channels);
-                b0.push_back((uint16_t)p.ogg.blocksize0);
-                b1.push_back((uint16_t)p.ogg.blocksize1);
-                pflags.insert(pflags.end(), p.ogg.pflags.begin(), p.ogg.pflags.end());
-            }
-            afg_vorbis_plan *plan = nullptr;
-            if (int rc = afg_vorbis_plan_create(&plan, (uint32_t)npk.size(), npk.data(), chans.data(), b0.data(), b1.data(),
-                                                pflags.data(), 0))
-                return rc;
-            struct PlanGuard { afg_vorbis_plan *p; ~PlanGuard() { afg_vorbis_plan_destroy(p); } } guard{ plan };
-            if (afg_vorbis_plan_spec_floats(plan) != ogg_spec) {
-                afg::set_error("Vorbis stage: spectrum layout mismatch (%llu vs %zu floats)",
-                               (unsigned long long)afg_vorbis_plan_spec_floats(plan), ogg_spec);
-                return AFG_ERR_INVALID;
-            }
-            const size_t out_floats = (size_t)afg_vorbis_plan_out_floats(plan);
-            std::vector<uint64_t> out_off(ogg_packets);
-            if (int rc = afg_vorbis_plan_offsets(plan, nullptr, out_off.data())) return rc;
+        // ---- Vorbis: per chunk gather (host threads) -> upload + kernel on `up` -> download on `down` ----
+        if (!ogg.v.empty()) {
+            StagingPool::Lease h_spec;
             DeviceBuf d_spec, d_pcm;
-            if (int rc = d_spec.alloc(ogg_spec * sizeof(float))) return rc;
-            if (int rc = d_pcm.alloc(out_floats * sizeof(float))) return rc;
-            size_t at = 0;
-            for (size_t i = 0; i < nf; i++) {
-                const Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_OGG || p.ogg.spec.empty()) continue;
-                AFG_HIP_CHECK(hipMemcpyAsync((float *)d_spec.p + at, p.ogg.spec.data(), p.ogg.spec.size() * sizeof(float),
-                                             hipMemcpyHostToDevice, stream));
-                at += p.ogg.spec.size();
-            }
-            if (int rc = afg_vorbis_transform_hip(plan, (const float *)d_spec.p, (float *)d_pcm.p, stream)) return rc;
-            size_t pk = 0;
-            for (size_t i = 0; i < nf; i++) {
-                const Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_OGG) continue;
-                float *dst = (float *)out.plane.p + out.files[i].pcm_off;
-                const size_t n = p.ogg.pflags.size(), C = (size_t)p.ogg.channels;
-                for (size_t k = 0; k < n;) {
-                    if (p.ogg.take_count[k] <= 0) { k++; continue; }
-                    uint64_t from = out_off[pk + k] + (uint64_t)p.ogg.take_from[k] * C, cnt = (uint64_t)p.ogg.take_count[k] * C;
-                    size_t j = k + 1;
-                    while (j < n && p.ogg.take_count[j] > 0 && out_off[pk + j] + (uint64_t)p.ogg.take_from[j] * C == from + cnt)
-                        cnt += (uint64_t)p.ogg.take_count[j++] * C;
-                    AFG_HIP_CHECK(hipMemcpyAsync(dst, (const float *)d_pcm.p + from, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, stream));
-                    dst += cnt;
-                    k = j;
+            if (!ogg_staged)
+                if (int rc = g_staging.take(ogg_spec * sizeof(float), h_spec)) return rc;
+            if (int rc = d_spec.alloc((ogg_staged ? ogg_stage->floats : ogg_spec) * sizeof(float))) return rc;
+            if (int rc = d_pcm.alloc(ogg_out * sizeof(float))) return rc;
+            float *ogg_plane = (float *)out.plane.p + flac_out + qoa_out + mp3_out;
+            hipStream_t up = nullptr, down = nullptr;
+            hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+            int rc = AFG_OK;
+            for (OggChunk &c : ogg.v) {
+                if (rc || e != hipSuccess) break;
+                const float *hs = ogg_staged ? ogg_stage->spec + c.spec0 : (const float *)h_spec.p + c.spec0;
+                if (!ogg_staged) {
+                    float *hw = (float *)h_spec.p + c.spec0;
+                    parallel_for(c.f1 - c.f0, threads, [&](size_t k) {
+                        Parsed &p = parsed[c.f0 + k];
+                        if (p.format != AFG_FORMAT_OGG || !p.ogg.n_spec) return;
+                        std::memcpy(hw + c.spec_at[k], p.ogg.spectra(), p.ogg.n_spec * sizeof(float));
+                        std::vector<float>().swap(p.ogg.spec);         // the big one: released here, by many threads
+                    });
                 }
-                pk += n;
+                e = hipMemcpyAsync((float *)d_spec.p + c.spec0, hs, c.spec_n * sizeof(float), hipMemcpyHostToDevice, up);
+                if (e != hipSuccess) break;
+                // a staged plan addresses the staging layout from float 0; a gathered one is packed from its chunk's start
+                rc = afg_vorbis_transform_hip(c.plan, (const float *)d_spec.p + (ogg_staged ? 0 : c.spec0), (float *)d_pcm.p + c.out0, up);
+                if (rc) break;
+                e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(c.done, up);
+                if (e == hipSuccess) e = hipStreamWaitEvent(down, c.done, 0);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(ogg_plane + c.out0, (const float *)d_pcm.p + c.out0, c.out_n * sizeof(float), hipMemcpyDeviceToHost, down);
             }
-            AFG_HIP_CHECK(hipStreamSynchronize(stream));
-            tm.lap("vorbis stage");
+            if (up) { hipError_t e2 = hipStreamSynchronize(up); if (e == hipSuccess) e = e2; }
+            if (down) { hipError_t e2 = hipStreamSynchronize(down); if (e == hipSuccess) e = e2; }
+            if (up) (void)hipStreamDestroy(up);
+            if (down) (void)hipStreamDestroy(down);
+            if (rc) return rc;
+            if (e != hipSuccess) { afg::set_error("Vorbis stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+            // files delivered as several runs (seek-style trims, damaged streams): close the runs up, in place
+            for (size_t bi = 0, at = 0; bi < ogg_broken.size(); bi++) {
+                const size_t i = ogg_broken[bi];
+                while (at < ogg_pieces.size() && ogg_pieces[at].file != i) at++;
+                float *dst = (float *)out.plane.p + out.files[i].pcm_off;
+                for (; at < ogg_pieces.size() && ogg_pieces[at].file == i; at++) {
+                    const float *src = ogg_plane + ogg_pieces[at].from;
+                    if (dst != src) std::memmove(dst, src, (size_t)ogg_pieces[at].count * sizeof(float));
+                    dst += ogg_pieces[at].count;
+                }
+            }
+            tm.lap("vorbis gather | h2d | kernel | d2h (chunks overlapped)");
         }
     }
 metadata:
@@ -978,7 +1073,7 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
         const unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
         // pass 1: containers with a signature are parsed at once; MP3 candidates only get an upper bound of their
         // record count, so that pass 2 can parse them straight into one page-locked staging buffer
-        std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0);
+        std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0), ogg_bound((size_t)n_files, 0), ogg_base((size_t)n_files, 0);
         parallel_for((size_t)n_files, nt, [&](size_t i) {
             if (!data[i] || !length[i]) return;
             Parsed &p = parsed[i];
@@ -986,13 +1081,39 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             if (flac_parse(data[i], length[i], p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
             p.flac = FlacRecords();
             if (qoa_parse(data[i], length[i], p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
-            if (afg_vorbis::parse_file(data[i], length[i], p.ogg)) { p.format = AFG_FORMAT_OGG; return; }
-            p.ogg = afg_vorbis::File();
+            if ((ogg_bound[i] = afg_vorbis::max_spec_floats(data[i], length[i])) != 0) return;       // parsed in pass 1b
             if (afg_mp3::looks_like_mp3(data[i], length[i])) bound[i] = afg_mp3::max_blocks(data[i], length[i]);
             } catch (...) { p = Parsed(); }
         });
-        size_t total_bound = 0;
-        for (size_t i = 0; i < (size_t)n_files; i++) { base[i] = total_bound; total_bound += bound[i]; }
+        size_t total_bound = 0, ogg_total = 0;
+        for (size_t i = 0; i < (size_t)n_files; i++) {
+            base[i] = total_bound; total_bound += bound[i];
+            ogg_base[i] = ogg_total; ogg_total += ogg_bound[i];
+        }
+        // pass 1b: Ogg Vorbis files straight into one page-locked staging buffer (no per-file megabyte vectors to
+        // fault in, gather and unmap)
+        StagingPool::Lease ogg_lease;
+        OggStage ogg_stage;
+        if (ogg_total) {
+            if (int rc = g_staging.take(ogg_total * sizeof(float), ogg_lease)) return rc;
+            float *spec0 = (float *)ogg_lease.p;
+            std::atomic<bool> lost{ false };
+            parallel_for((size_t)n_files, nt, [&](size_t i) {
+                if (!ogg_bound[i]) return;
+                Parsed &p = parsed[i];
+                bool ok = false;
+                try {
+                    ok = afg_vorbis::parse_file_into(data[i], length[i], p.ogg, spec0 + ogg_base[i], ogg_bound[i]);
+                    if (ok && p.ogg.overflow) {                  // cannot happen; be safe: the file's own buffer
+                        ok = afg_vorbis::parse_file(data[i], length[i], p.ogg);
+                        lost = true;
+                    }
+                } catch (...) { ok = false; }
+                if (ok) p.format = AFG_FORMAT_OGG;
+                else p.ogg = afg_vorbis::File();
+            });
+            if (!lost) { ogg_stage.spec = spec0; ogg_stage.floats = ogg_total; ogg_stage.base = ogg_base.data(); }
+        }
         BatchOut *owner = new (std::nothrow) BatchOut;
         if (!owner) return AFG_ERR_OOM;
         std::unique_ptr<BatchOut> guard(owner);
@@ -1044,7 +1165,7 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
         } else {
             tm.lap("parse (all threads)");
         }
-        int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr);
+        int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr, ogg_stage.floats ? &ogg_stage : nullptr);
         tm.lap("decode_parsed total");
         if (rc) return rc;
         afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));

@@ -902,11 +902,12 @@ uint32_t stream_length(const uint8_t *d, size_t n, size_t first_audio_page)
 
 }  // namespace
 
-bool parse_file(const uint8_t *data, size_t size, File &f)
+namespace {
+
+// Everything up to and including the setup header: the part of parse_file that can reject the stream.
+bool open_stream(const uint8_t *data, size_t size, File &f, Demux &dm, Setup &st)
 {
-    f = File();
     if (!data || size < 58 || std::memcmp(data, "OggS", 4)) return false;
-    Demux dm;
     demux(data, size, dm);
     if (dm.packets.size() < 3) return false;
     // identification header: alone on the first page, 30 bytes (:2678-2731)
@@ -925,7 +926,6 @@ bool parse_file(const uint8_t *data, size_t size, File &f)
         f.blocksize1 = 1 << log1;
         if (!(h[29] & 1)) return false;
     }
-    Setup st;
     st.channels = f.channels;
     st.rate = f.sample_rate;
     st.bs[0] = f.blocksize0;
@@ -955,6 +955,32 @@ bool parse_file(const uint8_t *data, size_t size, File &f)
         if (!read_setup(br, st)) return false;
         if (!p.complete) return false;
     }
+    return true;
+}
+
+}  // namespace
+
+// Upper bound of the spectrum floats parse_file_into() records, or 0 when parse_file() would reject the stream:
+// every audio packet a long block on every channel.
+size_t max_spec_floats(const uint8_t *data, size_t size)
+{
+    File f;
+    Demux dm;
+    Setup st;
+    if (!open_stream(data, size, f, dm, st)) return 0;
+    return (dm.packets.size() - 3 + 1) * (size_t)f.channels * (size_t)(f.blocksize1 / 2);
+}
+
+bool parse_file(const uint8_t *data, size_t size, File &f) { return parse_file_into(data, size, f, nullptr, 0); }
+
+bool parse_file_into(const uint8_t *data, size_t size, File &f, float *spec_dst, size_t cap)
+{
+    f = File();
+    Demux dm;
+    Setup st;
+    if (!open_stream(data, size, f, dm, st)) { f = File(); return false; }
+    f.ext_spec = spec_dst;
+    f.ext_cap = cap;
 
     // audio packets with the reference's position bookkeeping (:2531-2596)
     Scratch sc;
@@ -1023,8 +1049,15 @@ bool parse_file(const uint8_t *data, size_t size, File &f)
         if (!len_set && loc_valid) cur_loc += (uint32_t)(right_start - left);
         // record
         f.pflags.push_back((uint8_t)flags);
-        for (int c = 0; c < f.channels; c++)
-            f.spec.insert(f.spec.end(), sc.spec.begin() + (size_t)c * (size_t)n, sc.spec.begin() + (size_t)c * (size_t)n + (size_t)n2);
+        if (f.ext_spec) {
+            if (f.n_spec + (size_t)f.channels * (size_t)n2 > f.ext_cap) { f.overflow = true; break; }
+            for (int c = 0; c < f.channels; c++)
+                std::memcpy(f.ext_spec + f.n_spec + (size_t)c * (size_t)n2, sc.spec.data() + (size_t)c * (size_t)n, (size_t)n2 * sizeof(float));
+        } else {
+            for (int c = 0; c < f.channels; c++)
+                f.spec.insert(f.spec.end(), sc.spec.begin() + (size_t)c * (size_t)n, sc.spec.begin() + (size_t)c * (size_t)n + (size_t)n2);
+        }
+        f.n_spec += (size_t)f.channels * (size_t)n2;
         int r = std::min(right_start, len);
         int count = first ? 0 : std::max(0, r - left);
         f.take_from.push_back(first ? 0 : left - left_start);

@@ -14,10 +14,18 @@ struct File {
     uint32_t total_samples = 0;            // stb_vorbis_stream_length_in_samples: granule of the last page, 0 = unknown
     std::vector<uint8_t> pflags;           // one per decoded audio packet (AFG_VORBIS_LONG | PREV | NEXT)
     std::vector<float> spec;               // per packet [channel][n/2]: floor-multiplied, uncoupled spectra
+    // Optional external destination (the batch path parses straight into a page-locked staging buffer): when set,
+    // `spec` stays empty; `overflow` reports that `ext_cap` floats were not enough.
+    float *ext_spec = nullptr;
+    size_t ext_cap = 0, n_spec = 0;        // n_spec: floats recorded (either destination)
+    bool overflow = false;
+    const float *spectra() const { return ext_spec ? ext_spec : spec.data(); }
     std::vector<int32_t> take_from, take_count;   // frames of packet p's (right_start - left_start) output that are delivered
     uint64_t pcm_frames = 0;               // sum of take_count
 };
 
 bool parse_file(const uint8_t *data, size_t size, File &out);      // false: not an Ogg Vorbis I stream the reference accepts
+bool parse_file_into(const uint8_t *data, size_t size, File &out, float *spec_dst, size_t cap);
+size_t max_spec_floats(const uint8_t *data, size_t size);          // 0: parse_file would return false
 
 }  // namespace afg_vorbis

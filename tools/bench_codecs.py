@@ -198,6 +198,33 @@ def bench_mp3_e2e(files, frames_per_file, threads):
             "compressed_MBps": len(data) * files / best / 1e6}
 
 
+def bench_vorbis_e2e(files, packets, threads):
+    """End to end through afg_batch_decode for Ogg Vorbis: file bytes -> host parse (pages, code books, floor 1,
+    residues, coupling) -> H2D -> transform kernel -> D2H.  One synthetic stream (random code books) replicated."""
+    import time
+    import afgpu
+    import vorbis_bitstream as vb
+    data = vb.make_file(11, n_packets=packets, force_long_only=True, packet_bytes=(200, 600))
+    blobs = [data] * files
+    afgpu.batch_decode(blobs[:2], threads)
+    job = afgpu.BatchDecoded(blobs, threads)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        job.run()
+        best = min(best, time.perf_counter() - t0)
+    items = [dict(o) for o in job.items]
+    n = items[0]["frames"]
+    ch = items[0]["channels"]
+    finite = bool(np.isfinite(items[0]["pcm"]).all())
+    job.close()
+    ok = all(o["status"] == 0 and o["frames"] == n for o in items) and finite and n > 0
+    samples = ch * n * files
+    return {"workload": f"{files} x Ogg Vorbis stereo 2048/256, {packets} packets ({len(data)} bytes each)",
+            "threads": threads, "all_ok": ok, "seconds": best, "samples_per_s_end_to_end": samples / best,
+            "compressed_MBps": len(data) * files / best / 1e6}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--codec", default="all")
@@ -225,6 +252,8 @@ def main():
         res["qoa"] = bench_qoa(dev, 4096, 4.0, args.steps, args.warmup)
     if args.codec == "mp3_e2e":
         res["mp3_e2e"] = bench_mp3_e2e(args.e2e_files, 60, args.e2e_threads)
+    if args.codec == "vorbis_e2e":
+        res["vorbis_e2e"] = bench_vorbis_e2e(args.e2e_files, 128, args.e2e_threads)
     if args.codec == "flac_e2e":
         res["flac_e2e"] = bench_flac_e2e(args.e2e_files, 8, args.e2e_threads)
     if args.codec in ("all", "celt"):
