@@ -31,6 +31,17 @@ int main(int argc, char **argv)
         memcpy(p, v.data(), v.size());
         afg_vorbis::File out;
         if (afg_vorbis::parse_file(p, v.size(), out)) total += out.pflags.size();
+        // the batch path: bound from the headers, then decode into an exact-size external buffer (ASAN guards its end)
+        const size_t bound = afg_vorbis::max_spec_floats(p, v.size());
+        if ((bound != 0) != (out.channels != 0)) { printf("probe/parse disagree\n"); return 1; }
+        if (bound) {
+            float *dst = (float *)malloc(bound * sizeof(float));
+            afg_vorbis::File o2;
+            const bool ok = afg_vorbis::parse_file_into(p, v.size(), o2, dst, bound);
+            if (!ok || o2.overflow || o2.n_spec != out.spec.size() || o2.pflags != out.pflags ||
+                memcmp(dst, out.spec.data(), o2.n_spec * sizeof(float))) { printf("staged parse differs\n"); return 1; }
+            free(dst);
+        }
         free(p);
     }
     printf("ok blocks=%zu\n", total);
