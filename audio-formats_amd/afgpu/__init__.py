@@ -35,6 +35,10 @@ CELT_STATE_FLOATS = 2064
 QOA_FRAME_DTYPE = np.dtype([("byte_off", np.uint64), ("out_off", np.uint64), ("samples", np.uint16),
                             ("channels", np.uint8), ("pad", np.uint8, (5,))], align=True)
 assert QOA_FRAME_DTYPE.itemsize == 24
+QOA_ENC_STREAM_DTYPE = np.dtype([("pcm_off", np.uint64), ("out_off", np.uint64), ("samples", np.uint32),
+                                 ("samplerate", np.uint32), ("channels", np.uint8), ("pad", np.uint8, 7)])
+assert QOA_ENC_STREAM_DTYPE.itemsize == 32
+WAV_S8, WAV_S16LE, WAV_S24LE, WAV_FP32LE, WAV_FP64LE = range(5)
 
 # every symbol include/afg.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -54,6 +58,7 @@ ABI_SYMBOLS = [
     "afg_batch_decode", "afg_batch_free",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
     "afg_copy_probe_hip",
+    "afg_qoa_encoded_size", "afg_qoa_encode_hip", "afg_wav_encoded_size", "afg_wav_encode",
 ]
 
 
@@ -126,6 +131,13 @@ def lib():
     L.afg_last_error.restype = C.c_char_p
     L.afg_device_count.restype = C.c_int
     L.afg_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    L.afg_qoa_encoded_size.argtypes = [u32, u32]
+    L.afg_qoa_encoded_size.restype = u64
+    L.afg_qoa_encode_hip.argtypes = [u32, vp, vp, vp, vp, vp]
+    L.afg_wav_encoded_size.argtypes = [u64, u32, C.c_int]
+    L.afg_wav_encoded_size.restype = u64
+    L.afg_wav_encode.argtypes = [vp, u64, u32, u32, C.c_int, vp, u64]
+    L.afg_wav_encode.restype = u64
     L.afg_mp3_plan_create.argtypes = [C.POINTER(vp), u32, vp, vp, u32]
     L.afg_mp3_plan_destroy.argtypes = [vp]
     L.afg_mp3_plan_destroy.restype = None
@@ -316,6 +328,44 @@ def qoa_transform(n_frames, d_frames, d_bytes, d_out_i16=None, d_out_f32=None, s
     """Enqueue the QOA frame decode (afg_qoa_transform_hip)."""
     check(lib().afg_qoa_transform_hip(int(n_frames), _ptr(d_frames), _ptr(d_bytes), _ptr(d_out_i16),
                                       _ptr(d_out_f32), _stream(stream)))
+
+
+def qoa_encoded_size(samples, channels):
+    return int(lib().afg_qoa_encoded_size(int(samples), int(channels)))
+
+
+def qoa_encode(n_streams, d_streams, d_out, d_pcm_i16=None, d_pcm_f32=None, stream=None):
+    """Enqueue the QOA encoder (afg_qoa_encode_hip): d_streams is a device array of QOA_ENC_STREAM_DTYPE."""
+    check(lib().afg_qoa_encode_hip(int(n_streams), _ptr(d_streams), _ptr(d_pcm_i16), _ptr(d_pcm_f32), _ptr(d_out),
+                                   _stream(stream)))
+
+
+def qoa_encode_layout(shapes, samplerate=44100):
+    """Stream table for interleaved PCM blocks laid back to back: shapes = [(frames, channels), ...].
+    Returns (QOA_ENC_STREAM_DTYPE array, total input samples, total output bytes)."""
+    recs = np.zeros(len(shapes), QOA_ENC_STREAM_DTYPE)
+    pcm = out = 0
+    for i, (n, ch) in enumerate(shapes):
+        recs[i] = (pcm, out, n, samplerate, ch, 0)
+        pcm += n * ch
+        out += (qoa_encoded_size(n, ch) + 7) & ~7
+    return recs, pcm, out
+
+
+def wav_encode(samples, samplerate, fmt=WAV_FP32LE):
+    """Host WAV writer (afg_wav_encode): samples float32 [frames, channels] -> file bytes."""
+    x = np.ascontiguousarray(samples, np.float32)
+    if x.ndim == 1:
+        x = x[:, None]
+    frames, ch = x.shape
+    size = int(lib().afg_wav_encoded_size(frames, ch, int(fmt)))
+    if not size:
+        raise AfgError("afg_wav_encode: bad arguments")
+    out = np.zeros(size, np.uint8)
+    n = int(lib().afg_wav_encode(x.ctypes.data, frames, ch, int(samplerate), int(fmt), out.ctypes.data, size))
+    if n != size:
+        raise AfgError("afg_wav_encode failed")
+    return out.tobytes()
 
 
 def celt_transform(n_chan, d_rec_base, d_recs, d_coeffs, d_out, d_states=None, stream=None):

@@ -102,6 +102,28 @@ static assert(afg_qoa_frame.sizeof == 24);
 int afg_qoa_transform_hip(ulong n_frames, const(afg_qoa_frame)* d_frames, const(ubyte)* d_bytes,
                           short* d_out_i16, float* d_out_f32, void* hip_stream);
 
+// ---- output side: QOA encoder (replaces qoa_encode_frame, qoa.d:295-399, and QOAEncoder's framing, :538-700) and
+//      the WAV writer (WAVEncoder, wav.d:365-701; host only) ----
+struct afg_qoa_enc_stream
+{
+    ulong pcm_off;
+    ulong out_off;
+    uint samples;
+    uint samplerate;
+    ubyte channels;
+    ubyte[7] pad;
+}
+static assert(afg_qoa_enc_stream.sizeof == 32);
+
+ulong afg_qoa_encoded_size(uint samples, uint channels);
+int afg_qoa_encode_hip(uint n_streams, const(afg_qoa_enc_stream)* d_streams, const(short)* d_pcm_i16,
+                       const(float)* d_pcm_f32, ubyte* d_out, void* hip_stream);
+
+enum { AFG_WAV_S8 = 0, AFG_WAV_S16LE = 1, AFG_WAV_S24LE = 2, AFG_WAV_FP32LE = 3, AFG_WAV_FP64LE = 4 }
+ulong afg_wav_encoded_size(ulong frames, uint channels, int format);
+ulong afg_wav_encode(const(float)* samples, ulong frames, uint channels, uint samplerate, int format,
+                     ubyte* out_, ulong cap);
+
 // ---- Opus/CELT (replaces the per-channel tail of ff_celt_decode_frame, dopus.d:3680-3702) -------
 struct afg_celt_frame
 {

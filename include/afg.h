@@ -334,6 +334,44 @@ int afg_device_free(void *d_ptr);
 int afg_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *hip_stream);
 int afg_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *hip_stream);
 int afg_stream_synchronize(void *hip_stream);
+/* ========================================================================== *
+ *  Output side: what `transcode` needs after the decode.
+ *
+ *  QOA encoder: replaces qoa_encode_frame (qoa.d:295-399) and the framing of QOAEncoder (qoa.d:538-700).
+ *  The LMS state of the encoder runs through a whole stream, so a stream's channels are serial; the brute-force
+ *  search over the 16 scalefactors of every slice runs on 16 lanes.  Output bytes are the reference's.
+ * ========================================================================== */
+
+typedef struct afg_qoa_enc_stream {
+    uint64_t pcm_off;      /* index of the stream's first sample in the interleaved input plane (int16 or float) */
+    uint64_t out_off;      /* byte offset of the stream's file in the output plane (multiple of 8) */
+    uint32_t samples;      /* frames (samples per channel) */
+    uint32_t samplerate;   /* 1 .. 0xffffff (QOAEncoder.initialize rejects others, qoa.d:592) */
+    uint8_t  channels;     /* 1 .. 8 */
+    uint8_t  pad[7];
+} afg_qoa_enc_stream;      /* 32 bytes */
+
+/* Size in bytes of the QOA file for `samples` frames of `channels` channels (file header + frames). */
+uint64_t afg_qoa_encoded_size(uint32_t samples, uint32_t channels);
+
+/* Exactly one of d_pcm_i16 / d_pcm_f32 is given; floats are converted as QOAEncoder.writeSamples does
+ * (qoa.d:632-636: (int)(32768.5 + x * 32767.0) - 32768, |x| <= 1).  Descriptors must respect the ranges above. */
+int afg_qoa_encode_hip(uint32_t n_streams, const afg_qoa_enc_stream *d_streams, const int16_t *d_pcm_i16,
+                       const float *d_pcm_f32, uint8_t *d_out, void *hip_stream);
+
+/* WAV writer (wav.d:365-701, host only): 44-byte RIFF/WAVE header ('fmt ' of 16 bytes, tag 1 for PCM, 3 for IEEE
+ * float) followed by the samples; PCM conversions are the reference's (wav.d:482-527) with dither off -- the
+ * reference's TPDF dither is driven by libc rand() and is not reproducible. */
+#define AFG_WAV_S8     0
+#define AFG_WAV_S16LE  1
+#define AFG_WAV_S24LE  2
+#define AFG_WAV_FP32LE 3
+#define AFG_WAV_FP64LE 4
+uint64_t afg_wav_encoded_size(uint64_t frames, uint32_t channels, int format);          /* 0: bad arguments */
+/* Writes the whole file into `out` (capacity `cap`); returns the bytes written, 0 on bad arguments / short buffer. */
+uint64_t afg_wav_encode(const float *samples, uint64_t frames, uint32_t channels, uint32_t samplerate, int format,
+                        uint8_t *out, uint64_t cap);
+
 /* Streaming device-to-device copy (16-byte aligned) used by bench.py to measure the copy rate this device
  * actually sustains, the practical ceiling the HBM-bound kernels are compared with next to the 8 TB/s spec. */
 int afg_copy_probe_hip(void *d_dst, const void *d_src, size_t bytes, void *hip_stream);

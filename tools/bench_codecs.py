@@ -198,6 +198,31 @@ def bench_mp3_e2e(files, frames_per_file, threads):
             "compressed_MBps": len(data) * files / best / 1e6}
 
 
+def bench_qoa_encode(dev, streams, seconds, steps, warmup):
+    """QOA encoder kernel (output side): `streams` stereo streams of `seconds` at 44.1 kHz, int16 PCM resident."""
+    import afgpu
+    import oraclelib
+    n = int(seconds * 44100)
+    rng = np.random.default_rng(3)
+    t = np.arange(n)[:, None]
+    one = np.clip(8000 * np.sin(0.02 * (1 + np.arange(2))[None, :] * t) + 2000 * rng.standard_normal((n, 2)), -32768, 32767).astype(np.int16)
+    recs, n_in, n_out = afgpu.qoa_encode_layout([(n, 2)] * streams, 44100)
+    d_in = torch.from_numpy(np.tile(one.reshape(-1), streams)).to(dev)
+    d_recs = torch.from_numpy(recs.view(np.uint8).copy()).to(dev)
+    d_out = torch.zeros(n_out, dtype=torch.uint8, device=dev)
+    ms = time_launches(lambda: afgpu.qoa_encode(streams, d_recs, d_out, d_pcm_i16=d_in), steps, warmup)
+    avg = sum(ms) / len(ms) * 1e-3
+    want, _ = oraclelib.qoa_encode(one, 44100)
+    got = d_out[:len(want)].cpu().numpy()
+    import time
+    t0 = time.perf_counter()
+    oraclelib.qoa_encode(one, 44100)
+    cpu = time.perf_counter() - t0
+    return {"workload": f"{streams} x QOA encode, stereo {seconds} s", "samples_per_step": 2 * n * streams,
+            "avg_kernel_ms": avg * 1e3, "samples_per_s": 2 * n * streams / avg,
+            "oracle_one_thread_samples_per_s": 2 * n / cpu, "byte_mismatches": int((got != want).sum())}
+
+
 def bench_vorbis_e2e(files, packets, threads):
     """End to end through afg_batch_decode for Ogg Vorbis: file bytes -> host parse (pages, code books, floor 1,
     residues, coupling) -> H2D -> transform kernel -> D2H.  One synthetic stream (random code books) replicated."""
@@ -252,6 +277,8 @@ def main():
         res["qoa"] = bench_qoa(dev, 4096, 4.0, args.steps, args.warmup)
     if args.codec == "mp3_e2e":
         res["mp3_e2e"] = bench_mp3_e2e(args.e2e_files, 60, args.e2e_threads)
+    if args.codec == "qoa_enc":
+        res["qoa_enc"] = bench_qoa_encode(dev, 8192, 4.0, args.steps, args.warmup)
     if args.codec == "vorbis_e2e":
         res["vorbis_e2e"] = bench_vorbis_e2e(args.e2e_files, 128, args.e2e_threads)
     if args.codec == "flac_e2e":
