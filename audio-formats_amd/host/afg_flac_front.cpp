@@ -206,16 +206,17 @@ bool flac_frame(BitReader &br, const FlacInfo &fi, FlacRecords &rec)
 
     afg_flac_frame fr;
     std::memset(&fr, 0, sizeof(fr));
-    fr.in_off = rec.res.size();
+    fr.in_off = rec.res_size();
     fr.out_off = rec.out_samples;
     fr.block_size = bs;
     fr.sf_index = (uint32_t)rec.subframes.size();
     fr.channels = (uint8_t)C;
     fr.assignment = (uint8_t)(asg <= 7 ? AFG_FLAC_INDEPENDENT : asg);
     fr.bps = (uint8_t)fi.bps;                                      // drflac_read_s32 shifts by 32 - STREAMINFO bps (:2883)
-    rec.res.resize(rec.res.size() + (size_t)bs * C);
+    int32_t *const plane = rec.res_grow((size_t)bs * C);
+    if (!plane) return false;
     for (uint32_t c = 0; c < C; c++) {
-        int32_t *dst = rec.res.data() + fr.in_off + (size_t)c * bs;
+        int32_t *dst = plane + (size_t)c * bs;
         afg_flac_subframe sf;
         std::memset(&sf, 0, sizeof(sf));
         const unsigned hdr = (unsigned)br.bits(8);                 // :1530-1569
@@ -288,16 +289,28 @@ uint64_t be64(const uint8_t *p)
 
 // whole file -> records; stops at the first frame that does not parse (the reference's read loop
 // does the same: drflac.d:2860)
-bool flac_parse(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec)
+bool flac_parse(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec) { return flac_parse_into(d, n, fi, rec, nullptr, 0); }
+
+size_t flac_res_bound(const uint8_t *d, size_t n)
+{
+    FlacInfo fi;
+    if (!flac_open(d, n, fi) || !fi.total_samples || !fi.channels) return 0;
+    const uint64_t words = (fi.total_samples + (fi.max_block ? fi.max_block : 65535)) * fi.channels;
+    return words > ((uint64_t)1 << 40) ? 0 : (size_t)words;
+}
+
+bool flac_parse_into(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec, int32_t *res_dst, size_t cap)
 {
     if (!flac_open(d, n, fi)) return false;
+    rec.ext_res = res_dst;
+    rec.ext_cap = cap;
     BitReader br(d + fi.first_frame, n - fi.first_frame);
     while (br.byte_pos() + 2 < n - fi.first_frame) {
-        const size_t keep_f = rec.frames.size(), keep_s = rec.subframes.size(), keep_r = rec.res.size();
+        const size_t keep_f = rec.frames.size(), keep_s = rec.subframes.size(), keep_r = rec.res_size();
         if (!flac_frame(br, fi, rec)) {
             rec.frames.resize(keep_f);
             rec.subframes.resize(keep_s);
-            rec.res.resize(keep_r);
+            rec.res_truncate(keep_r);
             break;
         }
     }

@@ -19,10 +19,36 @@ struct FlacRecords {
     std::vector<afg_flac_subframe> subframes;
     std::vector<int32_t> res;
     uint64_t out_samples = 0;       // interleaved samples
+    // Optional external destination of the residual plane (the batch path parses straight into a page-locked staging
+    // buffer): when set, `res` stays empty; `overflow` reports that `ext_cap` words were not enough.
+    int32_t *ext_res = nullptr;
+    size_t ext_cap = 0, n_res = 0;
+    bool overflow = false;
+    size_t res_size() const { return ext_res ? n_res : res.size(); }
+    const int32_t *res_data() const { return ext_res ? ext_res : res.data(); }
+    int32_t *res_grow(size_t words)          // room for `words` more residuals, or nullptr (external buffer full)
+    {
+        if (ext_res) {
+            if (n_res + words > ext_cap) { overflow = true; return nullptr; }
+            int32_t *p = ext_res + n_res;
+            n_res += words;
+            return p;
+        }
+        res.resize(res.size() + words);
+        return res.data() + res.size() - words;
+    }
+    void res_truncate(size_t words)
+    {
+        if (ext_res) n_res = words;
+        else res.resize(words);
+    }
 };
 
 // whole file -> records; stops at the first frame that does not parse (drflac.d:2860).  false: not FLAC.
 bool flac_parse(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec);
+bool flac_parse_into(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec, int32_t *res_dst, size_t cap);
+// Residual words a well-formed file needs ((STREAMINFO total + one block) x channels); 0: not FLAC or length unknown.
+size_t flac_res_bound(const uint8_t *d, size_t n);
 
 struct QoaInfo {
     uint32_t channels = 0, samplerate = 0, samples = 0;

@@ -138,6 +138,7 @@ public:
         }
         void *p = nullptr;
         const size_t cap = bytes ? bytes : 1;
+        if (getenv("AFG_TRACE")) fprintf(stderr, "[afg] staging pool miss: pinning %.1f MB\n", cap / 1e6);
         hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
         if (e != hipSuccess) { afg::set_error("hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); return AFG_ERR_OOM; }
         out.pool = this; out.p = p; out.cap = cap;
@@ -147,7 +148,7 @@ private:
     void give_back(void *p, size_t cap)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        if (free_.size() < 8 && held_ + cap <= ((size_t)16 << 30)) {
+        if (free_.size() < 24 && held_ + cap <= ((size_t)24 << 30)) {
             free_.emplace_back(p, cap);
             held_ += cap;
         } else {
@@ -277,6 +278,13 @@ struct OggStage {
     const size_t *base = nullptr;
 };
 
+// Where the batch path parsed its FLAC files: file i's residual plane at word base[i] of one page-locked buffer
+struct FlacStage {
+    const int32_t *res = nullptr;
+    size_t words = 0;
+    const size_t *base = nullptr;
+};
+
 // H2D -> kernel on stream `up`, D2H on stream `down` behind an event: chunk k+1 uploads and transforms while chunk
 // k's PCM goes back (PCIe is full duplex) -- and while the host threads parse chunk k+2.
 struct Mp3Pipe {
@@ -367,7 +375,7 @@ struct Mp3Pipe {
 };
 
 int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out,
-                  const Mp3Stage *stage = nullptr, const OggStage *ogg_stage = nullptr)
+                  const Mp3Stage *stage = nullptr, const OggStage *ogg_stage = nullptr, const FlacStage *flac_stage = nullptr)
 {
     const size_t nf = parsed.size();
     out.files.assign(nf, Decoded());
@@ -375,14 +383,16 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
     // ---- layout ----
     std::vector<size_t> res_base(nf, 0), fr_base(nf, 0), sf_base(nf, 0), qbyte_base(nf, 0), qfr_base(nf, 0);
     size_t res_total = 0, fr_total = 0, sf_total = 0, flac_out = 0, qbytes = 0, qframes = 0, qoa_out = 0;
+    const bool flac_staged = flac_stage && flac_stage->words;
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
         if (p.format != AFG_FORMAT_FLAC) continue;
-        res_base[i] = res_total; fr_base[i] = fr_total; sf_base[i] = sf_total;
+        res_base[i] = flac_staged ? flac_stage->base[i] : res_total; fr_base[i] = fr_total; sf_base[i] = sf_total;
         out.files[i].pcm_off = flac_out;
-        res_total += p.flac.res.size(); fr_total += p.flac.frames.size(); sf_total += p.flac.subframes.size();
+        res_total += p.flac.res_size(); fr_total += p.flac.frames.size(); sf_total += p.flac.subframes.size();
         flac_out += p.flac.out_samples;
     }
+    if (flac_staged) res_total = flac_stage->words;          // the device plane mirrors the staging layout (gaps and all)
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
         if (p.format != AFG_FORMAT_QOA) continue;
@@ -553,11 +563,12 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             const size_t rec_pad = (rec_bytes + 15) & ~(size_t)15;
             StagingPool::Lease h_in;
             DeviceBuf d_in;
-            if (int rc = g_staging.take(rec_pad + res_total * 4, h_in)) return rc;
+            if (int rc = g_staging.take(rec_pad + (flac_staged ? 0 : res_total * 4), h_in)) return rc;
             if (int rc = d_in.alloc(rec_pad + res_total * 4)) return rc;
             afg_flac_frame *hf = (afg_flac_frame *)h_in.p;
             afg_flac_subframe *hs = (afg_flac_subframe *)(hf + fr_total);
-            int32_t *hr = (int32_t *)((uint8_t *)h_in.p + rec_pad);
+            int32_t *hr = (int32_t *)((uint8_t *)h_in.p + rec_pad);           // (not staged: the residuals are gathered here)
+            const int32_t *hres = flac_staged ? flac_stage->res : hr;
             // Chunks of files: gather (host threads) -> upload + kernel on `up` -> download on `down` behind an event,
             // so the gather of chunk k+1, the upload of chunk k and the download of chunk k-1 overlap.
             const afg_flac_frame *df = (const afg_flac_frame *)d_in.p;
@@ -571,7 +582,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             const size_t target = std::max<size_t>((res_total + 7) / 8, (size_t)4 << 20);
             for (size_t f0 = 0; f0 < nf && !rc && e == hipSuccess;) {
                 size_t f1 = f0, acc = 0;
-                while (f1 < nf && acc < target) { if (parsed[f1].format == AFG_FORMAT_FLAC) acc += parsed[f1].flac.res.size(); f1++; }
+                while (f1 < nf && acc < target) { if (parsed[f1].format == AFG_FORMAT_FLAC) acc += parsed[f1].flac.res_size(); f1++; }
                 size_t first = nf, last = nf;                // first / last FLAC file of the chunk
                 for (size_t i = f0; i < f1; i++)
                     if (parsed[i].format == AFG_FORMAT_FLAC) { if (first == nf) first = i; last = i; }
@@ -586,8 +597,10 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                         hf[fr_base[i] + q] = f;
                     }
                     std::memcpy(hs + sf_base[i], p.flac.subframes.data(), p.flac.subframes.size() * sizeof(afg_flac_subframe));
-                    std::memcpy(hr + res_base[i], p.flac.res.data(), p.flac.res.size() * 4);
-                    std::vector<int32_t>().swap(p.flac.res);           // the residual plane is the big one: drop it early
+                    if (!flac_staged) {
+                        std::memcpy(hr + res_base[i], p.flac.res_data(), p.flac.res_size() * 4);
+                        std::vector<int32_t>().swap(p.flac.res);       // the residual plane is the big one: drop it early
+                    }
                 });
                 const size_t fr0 = fr_base[first], fr1 = fr_base[last] + parsed[last].flac.frames.size();
                 const size_t sf0 = sf_base[first], sf1 = sf_base[last] + parsed[last].flac.subframes.size();
@@ -597,7 +610,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 const size_t o0 = out.files[first].pcm_off, o1 = out.files[last].pcm_off + parsed[last].flac.out_samples;
                 e = hipMemcpyAsync((void *)(df + fr0), hf + fr0, (fr1 - fr0) * sizeof(afg_flac_frame), hipMemcpyHostToDevice, up);
                 if (e == hipSuccess) e = hipMemcpyAsync((void *)(ds + sf0), hs + sf0, (sf1 - sf0) * sizeof(afg_flac_subframe), hipMemcpyHostToDevice, up);
-                if (e == hipSuccess) e = hipMemcpyAsync((void *)(dr + r0), hr + r0, (r1 - r0) * 4, hipMemcpyHostToDevice, up);
+                if (e == hipSuccess) e = hipMemcpyAsync((void *)(dr + r0), hres + r0, (r1 - r0) * 4, hipMemcpyHostToDevice, up);
                 if (e != hipSuccess) break;
                 rc = afg_flac_transform_hip(fr1 - fr0, df + fr0, ds, dr, nullptr, (float *)d_out.p, up);
                 if (rc) break;
@@ -1073,11 +1086,13 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
         const unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
         // pass 1: containers with a signature are parsed at once; MP3 candidates only get an upper bound of their
         // record count, so that pass 2 can parse them straight into one page-locked staging buffer
-        std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0), ogg_bound((size_t)n_files, 0), ogg_base((size_t)n_files, 0);
+        std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0), ogg_bound((size_t)n_files, 0), ogg_base((size_t)n_files, 0),
+            flac_bound((size_t)n_files, 0), flac_base((size_t)n_files, 0);
         parallel_for((size_t)n_files, nt, [&](size_t i) {
             if (!data[i] || !length[i]) return;
             Parsed &p = parsed[i];
             try {
+            if ((flac_bound[i] = flac_res_bound(data[i], length[i])) != 0) return;                    // parsed in pass 1b
             if (flac_parse(data[i], length[i], p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
             p.flac = FlacRecords();
             if (qoa_parse(data[i], length[i], p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
@@ -1085,10 +1100,37 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             if (afg_mp3::looks_like_mp3(data[i], length[i])) bound[i] = afg_mp3::max_blocks(data[i], length[i]);
             } catch (...) { p = Parsed(); }
         });
-        size_t total_bound = 0, ogg_total = 0;
+        tm.lap("pass 1: flac / qoa parse, ogg + mp3 bounds");
+        size_t total_bound = 0, ogg_total = 0, flac_total = 0;
         for (size_t i = 0; i < (size_t)n_files; i++) {
             base[i] = total_bound; total_bound += bound[i];
             ogg_base[i] = ogg_total; ogg_total += ogg_bound[i];
+            flac_base[i] = flac_total; flac_total += (flac_bound[i] + 3) & ~(size_t)3;        // 16-byte aligned planes
+        }
+        // pass 1b: FLAC files of known length straight into one page-locked residual buffer
+        StagingPool::Lease flac_lease;
+        FlacStage flac_stage;
+        if (flac_total) {
+            if (int rc = g_staging.take(flac_total * sizeof(int32_t), flac_lease)) return rc;
+            int32_t *res0 = (int32_t *)flac_lease.p;
+            std::atomic<bool> lost{ false };
+            parallel_for((size_t)n_files, nt, [&](size_t i) {
+                if (!flac_bound[i]) return;
+                Parsed &p = parsed[i];
+                bool ok = false;
+                try {
+                    ok = flac_parse_into(data[i], length[i], p.fi, p.flac, res0 + flac_base[i], flac_bound[i]);
+                    if (ok && p.flac.overflow) {                 // more audio than STREAMINFO declares: the file's own buffer
+                        p.flac = FlacRecords();
+                        ok = flac_parse(data[i], length[i], p.fi, p.flac);
+                        lost = true;
+                    }
+                } catch (...) { ok = false; }
+                if (ok) p.format = AFG_FORMAT_FLAC;
+                else p.flac = FlacRecords();
+            });
+            if (!lost) { flac_stage.res = res0; flac_stage.words = flac_total; flac_stage.base = flac_base.data(); }
+            tm.lap("pass 1b: flac parse into staging");
         }
         // pass 1b: Ogg Vorbis files straight into one page-locked staging buffer (no per-file megabyte vectors to
         // fault in, gather and unmap)
@@ -1113,6 +1155,7 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
                 else p.ogg = afg_vorbis::File();
             });
             if (!lost) { ogg_stage.spec = spec0; ogg_stage.floats = ogg_total; ogg_stage.base = ogg_base.data(); }
+            tm.lap("pass 1b: ogg parse into staging");
         }
         BatchOut *owner = new (std::nothrow) BatchOut;
         if (!owner) return AFG_ERR_OOM;
@@ -1128,6 +1171,7 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             stage.plane = (float *)owner->mp3_plane.p;
             Mp3Pipe pipe;
             if (int rc = pipe.open(stage)) return rc;
+            tm.lap("mp3 pipeline set-up (device planes, streams, table arena)");
             // pass 2, chunk by chunk: all host threads parse a chunk of files, its device work is queued, and they go on
             // with the next chunk while the copies and the kernel of this one run
             size_t want = 8;
@@ -1165,7 +1209,8 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
         } else {
             tm.lap("parse (all threads)");
         }
-        int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr, ogg_stage.floats ? &ogg_stage : nullptr);
+        int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr, ogg_stage.floats ? &ogg_stage : nullptr,
+                               flac_stage.words ? &flac_stage : nullptr);
         tm.lap("decode_parsed total");
         if (rc) return rc;
         afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));

@@ -223,6 +223,45 @@ def bench_qoa_encode(dev, streams, seconds, steps, warmup):
             "oracle_one_thread_samples_per_s": 2 * n / cpu, "byte_mismatches": int((got != want).sum())}
 
 
+def bench_mixed_e2e(files, threads):
+    """One afg_batch_decode call over a mix like BASELINE config C5 (40 % MP3, 25 % Ogg Vorbis, 25 % FLAC, 10 % QOA in
+    place of Opus, whose front-end does not exist): file bytes in host memory -> interleaved floats in host memory."""
+    import time
+    import afgpu
+    import flac_bitstream as fb
+    import mp3_bitstream as mb
+    import oraclelib
+    import vorbis_bitstream as vb
+    rng = np.random.default_rng(4)
+    mp3, _, _ = mb.make_file(5, n_frames=60, version="mpeg1", sr=0, mode="ms", bitrate_index=9)
+    ogg = vb.make_file(11, n_packets=64, force_long_only=True, packet_bytes=(200, 600))
+    n = 4096 * 16
+    t = np.arange(n)
+    pcm = np.stack([9000 * np.sin(0.01 * t) + 800 * rng.standard_normal(n), 7000 * np.sin(0.013 * t + 1) + 800 * rng.standard_normal(n)], 1)
+    flac, _ = fb.encode_file(pcm.round().astype(np.int64), 16, 4096, orders=(8, 12), use_fixed_every=1000)
+    qoa, _ = oraclelib.qoa_encode(pcm[:5120 * 12].round().astype(np.int16), 44100)
+    kinds = [("mp3", mp3)] * 8 + [("ogg", ogg)] * 5 + [("flac", flac)] * 5 + [("qoa", qoa.tobytes())] * 2
+    blobs = [kinds[i % len(kinds)][1] for i in range(files)]
+    afgpu.batch_decode(blobs[:len(kinds)], threads)
+    job = afgpu.BatchDecoded(blobs, threads)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        job.run()
+        best = min(best, time.perf_counter() - t0)
+    items = [dict(o) for o in job.items]
+    samples = sum(o["frames"] * o["channels"] for o in items)
+    ok = all(o["status"] == 0 and o["frames"] > 0 for o in items)
+    per = {}
+    for i, o in enumerate(items):
+        k = kinds[i % len(kinds)][0]
+        per[k] = per.get(k, 0) + o["frames"] * o["channels"]
+    job.close()
+    return {"workload": f"{files} mixed files in one batch (MP3 {len(mp3)} B, OGG {len(ogg)} B, FLAC {len(flac)} B, QOA {len(qoa)} B)",
+            "threads": threads, "all_ok": ok, "seconds": best, "samples": samples, "samples_by_format": per,
+            "samples_per_s_end_to_end": samples / best, "compressed_MBps": sum(len(b) for b in blobs) / best / 1e6}
+
+
 def bench_vorbis_e2e(files, packets, threads):
     """End to end through afg_batch_decode for Ogg Vorbis: file bytes -> host parse (pages, code books, floor 1,
     residues, coupling) -> H2D -> transform kernel -> D2H.  One synthetic stream (random code books) replicated."""
@@ -277,6 +316,8 @@ def main():
         res["qoa"] = bench_qoa(dev, 4096, 4.0, args.steps, args.warmup)
     if args.codec == "mp3_e2e":
         res["mp3_e2e"] = bench_mp3_e2e(args.e2e_files, 60, args.e2e_threads)
+    if args.codec == "mixed_e2e":
+        res["mixed_e2e"] = bench_mixed_e2e(args.e2e_files * 2, args.e2e_threads)
     if args.codec == "qoa_enc":
         res["qoa_enc"] = bench_qoa_encode(dev, 8192, 4.0, args.steps, args.warmup)
     if args.codec == "vorbis_e2e":

@@ -28,7 +28,20 @@ int main(int argc, char **argv)
         uint8_t *p = (uint8_t *)malloc(v.size());
         memcpy(p, v.data(), v.size());
         afg_front::FlacInfo fi; afg_front::FlacRecords rec;
-        if (afg_front::flac_parse(p, v.size(), fi, rec)) total += rec.frames.size();
+        const bool is_flac = afg_front::flac_parse(p, v.size(), fi, rec);
+        if (is_flac) total += rec.frames.size();
+        // the batch path: bound from STREAMINFO, then parse into an exact-size external plane (ASAN guards its end)
+        const size_t bound = afg_front::flac_res_bound(p, v.size());
+        if (bound && !is_flac) { printf("bound without a FLAC stream\n"); return 1; }
+        if (bound && bound < ((size_t)1 << 26)) {
+            int32_t *dst = (int32_t *)malloc(bound * sizeof(int32_t));
+            afg_front::FlacInfo f2; afg_front::FlacRecords r2;
+            const bool ok = afg_front::flac_parse_into(p, v.size(), f2, r2, dst, bound);
+            if (!ok) { printf("staged parse rejected a FLAC stream\n"); return 1; }
+            if (!r2.overflow && (r2.n_res != rec.res.size() || r2.frames.size() != rec.frames.size() ||
+                                 (r2.n_res && memcmp(dst, rec.res.data(), r2.n_res * sizeof(int32_t))))) { printf("staged parse differs\n"); return 1; }
+            free(dst);
+        }
         afg_front::QoaInfo qi; std::vector<afg_qoa_frame> q;
         afg_front::qoa_parse(p, v.size(), qi, q);
         free(p);

@@ -39,7 +39,7 @@ int main(int argc, char **argv)
             afg_vorbis::File o2;
             const bool ok = afg_vorbis::parse_file_into(p, v.size(), o2, dst, bound);
             if (!ok || o2.overflow || o2.n_spec != out.spec.size() || o2.pflags != out.pflags ||
-                memcmp(dst, out.spec.data(), o2.n_spec * sizeof(float))) { printf("staged parse differs\n"); return 1; }
+                (o2.n_spec && memcmp(dst, out.spec.data(), o2.n_spec * sizeof(float)))) { printf("staged parse differs\n"); return 1; }
             free(dst);
         }
         free(p);
