@@ -1083,7 +1083,10 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
         if (int rc = afg::require_device()) return rc;
         StageTimer tm;
         std::vector<Parsed> parsed((size_t)n_files);
-        const unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+        // default: one thread per physical core of an SMT-2 host (half the logical CPUs).  With one thread per logical
+        // CPU the parse stages ran up to 10x longer on a shared 256-CPU box: the stragglers wait for a CPU.
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nt = n_threads > 0 ? (unsigned)n_threads : (hw >= 16 ? hw / 2 : hw);
         // pass 1: containers with a signature are parsed at once; MP3 candidates only get an upper bound of their
         // record count, so that pass 2 can parse them straight into one page-locked staging buffer
         std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0), ogg_bound((size_t)n_files, 0), ogg_base((size_t)n_files, 0),
@@ -1132,36 +1135,13 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             if (!lost) { flac_stage.res = res0; flac_stage.words = flac_total; flac_stage.base = flac_base.data(); }
             tm.lap("pass 1b: flac parse into staging");
         }
-        // pass 1b: Ogg Vorbis files straight into one page-locked staging buffer (no per-file megabyte vectors to
-        // fault in, gather and unmap)
-        StagingPool::Lease ogg_lease;
-        OggStage ogg_stage;
-        if (ogg_total) {
-            if (int rc = g_staging.take(ogg_total * sizeof(float), ogg_lease)) return rc;
-            float *spec0 = (float *)ogg_lease.p;
-            std::atomic<bool> lost{ false };
-            parallel_for((size_t)n_files, nt, [&](size_t i) {
-                if (!ogg_bound[i]) return;
-                Parsed &p = parsed[i];
-                bool ok = false;
-                try {
-                    ok = afg_vorbis::parse_file_into(data[i], length[i], p.ogg, spec0 + ogg_base[i], ogg_bound[i]);
-                    if (ok && p.ogg.overflow) {                  // cannot happen; be safe: the file's own buffer
-                        ok = afg_vorbis::parse_file(data[i], length[i], p.ogg);
-                        lost = true;
-                    }
-                } catch (...) { ok = false; }
-                if (ok) p.format = AFG_FORMAT_OGG;
-                else p.ogg = afg_vorbis::File();
-            });
-            if (!lost) { ogg_stage.spec = spec0; ogg_stage.floats = ogg_total; ogg_stage.base = ogg_base.data(); }
-            tm.lap("pass 1b: ogg parse into staging");
-        }
         BatchOut *owner = new (std::nothrow) BatchOut;
         if (!owner) return AFG_ERR_OOM;
         std::unique_ptr<BatchOut> guard(owner);
         StagingPool::Lease mp3_stage;
         Mp3Stage stage;
+        Mp3Pipe pipe;
+        bool fallback = false;
         if (total_bound) {
             if (int rc = g_staging.take(total_bound * (576 * sizeof(float) + sizeof(uint32_t)), mp3_stage)) return rc;
             if (int rc = g_staging.take(total_bound * 576 * sizeof(float), owner->mp3_plane)) return rc;
@@ -1169,7 +1149,6 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             uint32_t *flags0 = (uint32_t *)(coef0 + total_bound * 576);
             stage.coef = coef0; stage.flags = flags0; stage.blocks = total_bound; stage.base = base.data();
             stage.plane = (float *)owner->mp3_plane.p;
-            Mp3Pipe pipe;
             if (int rc = pipe.open(stage)) return rc;
             tm.lap("mp3 pipeline set-up (device planes, streams, table arena)");
             // pass 2, chunk by chunk: all host threads parse a chunk of files, its device work is queued, and they go on
@@ -1177,7 +1156,6 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             size_t want = 8;
             if (const char *ev = getenv("AFG_MP3_CHUNKS")) want = (size_t)std::max(1, atoi(ev));
             const size_t target = std::max<size_t>((total_bound + want - 1) / want, 8192);
-            bool fallback = false;
             for (size_t f0 = 0; f0 < (size_t)n_files;) {
                 size_t f1 = f0, acc = 0;
                 while (f1 < (size_t)n_files && acc < target) acc += bound[f1++];
@@ -1201,13 +1179,38 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
                 if (!fallback) pipe.submit(parsed, f0, f1);
                 f0 = f1;
             }
-            tm.lap("parse (all threads) | mp3 h2d | kernel | d2h");
+            tm.lap("mp3 parse (all threads) | h2d | kernel | d2h");
+        }
+        // pass 1b: Ogg Vorbis files straight into one page-locked staging buffer (no per-file megabyte vectors to
+        // fault in, gather and unmap) -- while the MP3 chunks queued above are still moving
+        StagingPool::Lease ogg_lease;
+        OggStage ogg_stage;
+        if (ogg_total) {
+            if (int rc = g_staging.take(ogg_total * sizeof(float), ogg_lease)) return rc;
+            float *spec0 = (float *)ogg_lease.p;
+            std::atomic<bool> lost{ false };
+            parallel_for((size_t)n_files, nt, [&](size_t i) {
+                if (!ogg_bound[i]) return;
+                Parsed &p = parsed[i];
+                bool ok = false;
+                try {
+                    ok = afg_vorbis::parse_file_into(data[i], length[i], p.ogg, spec0 + ogg_base[i], ogg_bound[i]);
+                    if (ok && p.ogg.overflow) {                  // cannot happen; be safe: the file's own buffer
+                        ok = afg_vorbis::parse_file(data[i], length[i], p.ogg);
+                        lost = true;
+                    }
+                } catch (...) { ok = false; }
+                if (ok) p.format = AFG_FORMAT_OGG;
+                else p.ogg = afg_vorbis::File();
+            });
+            if (!lost) { ogg_stage.spec = spec0; ogg_stage.floats = ogg_total; ogg_stage.base = ogg_base.data(); }
+            tm.lap("pass 1b: ogg parse into staging");
+        }
+        if (total_bound) {
             const int prc = pipe.close();
             tm.lap("mp3 pipeline drain");
             if (prc) return prc;
             if (fallback) stage.blocks = 0;                   // decode_parsed does those files from their own buffers
-        } else {
-            tm.lap("parse (all threads)");
         }
         int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr, ogg_stage.floats ? &ogg_stage : nullptr,
                                flac_stage.words ? &flac_stage : nullptr);

@@ -304,8 +304,9 @@ int  afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out
 void afg_vorbis_parsed_free(afg_vorbis_parsed *parsed);
 
 /* Batch decode (no reference counterpart: the throughput path).  Files are parsed by n_threads
- * host threads (0 = hardware concurrency), restored on the current device in one launch per
- * format, and returned as interleaved float PCM owned by the result. */
+ * pooled host threads (0 = one per physical core: half the logical CPUs of an SMT host) straight
+ * into page-locked staging, restored on the current device chunk by chunk with upload, kernel and
+ * download overlapped, and returned as interleaved float PCM owned by the result. */
 typedef struct afg_batch_item {
     int         status;        /* afg_status of this file: a bad file never poisons the batch */
     const char *message;       /* static string, NULL when ok */
