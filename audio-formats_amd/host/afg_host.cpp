@@ -1132,7 +1132,12 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
                 if (ok) p.format = AFG_FORMAT_FLAC;
                 else p.flac = FlacRecords();
             });
-            if (!lost) { flac_stage.res = res0; flac_stage.words = flac_total; flac_stage.base = flac_base.data(); }
+            // the staged layout is used only when every FLAC file of the batch is in it (a file of undeclared length
+            // was parsed into its own buffer in pass 1): otherwise everything is gathered, wherever it sits
+            bool all_staged = !lost;
+            for (size_t i = 0; i < (size_t)n_files && all_staged; i++)
+                if (parsed[i].format == AFG_FORMAT_FLAC && !parsed[i].flac.ext_res && parsed[i].flac.res_size()) all_staged = false;
+            if (all_staged) { flac_stage.res = res0; flac_stage.words = flac_total; flac_stage.base = flac_base.data(); }
             tm.lap("pass 1b: flac parse into staging");
         }
         BatchOut *owner = new (std::nothrow) BatchOut;

@@ -110,6 +110,30 @@ def test_batch_decode_mixed_formats_and_bad_files(gpu):
     assert afgpu.batch_decode([]) == []
 
 
+def test_flac_batch_mixes_declared_undeclared_and_misdeclared_lengths(gpu):
+    """The batch path parses FLAC files of declared length straight into a staging plane sized from STREAMINFO; a file
+    that declares nothing, fewer frames than it holds (more audio than the plane reserves) or more (truncated) must
+    come out exactly as it does on its own."""
+    files = []
+    for i in range(5):
+        pcm = make_pcm(2048 + 300 * i, 2, 16, 60 + i)
+        frames, subframes, res, _ = enc.encode(pcm, 16, 512)
+        total = None
+        if i == 1: total = 0                                   # undeclared: own buffer in pass 1
+        if i == 2: total = 700                                 # under-declared: the staged parse overflows its plane
+        if i == 3: total = 100000                              # over-declared (as if truncated)
+        files.append(fb.write_file(frames, subframes, res, 44100, 16, total_samples=total))
+    alone = [afgpu.batch_decode([f], n_threads=1)[0] for f in files]
+    for order in (files, files[::-1], [files[0], files[4]], [files[0], files[2], files[4]]):
+        got = afgpu.batch_decode(order, n_threads=4)
+        for g, f in zip(got, order):
+            a = alone[files.index(f)]
+            assert g["status"] == a["status"] == 0 and g["frames"] == a["frames"] and g["frames"] > 0
+            assert np.array_equal(g["pcm"].view(np.uint32), a["pcm"].view(np.uint32))
+    want = flac_expected(files[0])[1]
+    assert np.array_equal(alone[0]["pcm"].view(np.uint32), want.view(np.uint32))
+
+
 # ---- MP3: file bytes -> host front-end -> device transform -> what mp3dec_ex_read delivers --------------------
 import os  # noqa: E402
 
