@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "afg_batch_decode", "afg_batch_free",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
     "afg_copy_probe_hip",
-    "afg_qoa_encoded_size", "afg_qoa_encode_hip", "afg_wav_encoded_size", "afg_wav_encode",
+    "afg_qoa_encoded_size", "afg_qoa_encode_hip", "afg_wav_encoded_size", "afg_wav_encode", "afg_opus_output_hip",
 ]
 
 
@@ -131,6 +131,7 @@ def lib():
     L.afg_last_error.restype = C.c_char_p
     L.afg_device_count.restype = C.c_int
     L.afg_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    L.afg_opus_output_hip.argtypes = [u64, vp, vp, vp, vp]
     L.afg_qoa_encoded_size.argtypes = [u32, u32]
     L.afg_qoa_encoded_size.restype = u64
     L.afg_qoa_encode_hip.argtypes = [u32, vp, vp, vp, vp, vp]
@@ -328,6 +329,11 @@ def qoa_transform(n_frames, d_frames, d_bytes, d_out_i16=None, d_out_f32=None, s
     """Enqueue the QOA frame decode (afg_qoa_transform_hip)."""
     check(lib().afg_qoa_transform_hip(int(n_frames), _ptr(d_frames), _ptr(d_bytes), _ptr(d_out_i16),
                                       _ptr(d_out_f32), _stream(stream)))
+
+
+def opus_output(n_samples, d_in, d_out_i16=None, d_out_f32=None, stream=None):
+    """Enqueue OpusFile.readFrame's float -> int16 (-> float / 32767) conversion (afg_opus_output_hip)."""
+    check(lib().afg_opus_output_hip(int(n_samples), _ptr(d_in), _ptr(d_out_i16), _ptr(d_out_f32), _stream(stream)))
 
 
 def qoa_encoded_size(samples, channels):

@@ -1045,6 +1045,41 @@ int ensure_tables(const float **d_tables, CeltTables *tb)
 
 }  // namespace
 
+// ---- OpusFile.readFrame's conversion (dopus.d:7923-7926, :8098-8105) and stream.d:480 --------------------------------
+// Float2IntScaled: temp.f = x + (1.5f*(1<<8) + 0.5f/(1<<15)); d = temp.i - (((150-15)<<23) + (1<<22)); saturate.
+// The constant is float-typed: 384 + 2^-16 is exactly half an ulp above 384 and rounds (to even) to 384.0f, so the
+// float addition leaves round-to-nearest-even of x * 32768 in the mantissa -- one v_add_f32 and an integer subtract.
+__global__ __launch_bounds__(256) void opus_output_kernel(const float *__restrict__ in, int16_t *__restrict__ out_i16,
+                                                          float *__restrict__ out_f32, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = in[i] + 384.0f;
+    int d = __float_as_int(t) - (((150 - 15) << 23) + (1 << 22));
+    if ((unsigned)(d + 32768) > 65535u) d = d < 0 ? -32768 : 32767;
+    if (out_i16) out_i16[i] = (int16_t)d;
+    if (out_f32) out_f32[i] = (float)(int16_t)d / 32767.0f;               // stream.d:480
+}
+
+extern "C" int afg_opus_output_hip(uint64_t n_samples, const float *d_in, int16_t *d_out_i16, float *d_out_f32, void *hip_stream)
+{
+    if (n_samples == 0) return AFG_OK;
+    if (!d_in || (!d_out_i16 && !d_out_f32)) {
+        afg::set_error("afg_opus_output_hip: NULL device pointer");
+        return AFG_ERR_INVALID;
+    }
+    if (int rc = afg::require_device()) return rc;
+    const uint64_t blocks = (n_samples + 255) / 256;
+    if (blocks > 0x7fffffffull) {
+        afg::set_error("afg_opus_output_hip: at most 2^39 samples per call");
+        return AFG_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(opus_output_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)hip_stream, d_in, d_out_i16,
+                       d_out_f32, n_samples);
+    AFG_HIP_CHECK(hipGetLastError());
+    return AFG_OK;
+}
+
 extern "C" int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
                                       const float *d_coeffs, float *d_out, float *d_states, void *hip_stream)
 {

@@ -102,6 +102,9 @@ static assert(afg_qoa_frame.sizeof == 24);
 int afg_qoa_transform_hip(ulong n_frames, const(afg_qoa_frame)* d_frames, const(ubyte)* d_bytes,
                           short* d_out_i16, float* d_out_f32, void* hip_stream);
 
+// OpusFile.readFrame's Float2IntScaled + saturation (dopus.d:7923-7926, :8098-8105) and stream.d:480
+int afg_opus_output_hip(ulong n_samples, const(float)* d_in, short* d_out_i16, float* d_out_f32, void* hip_stream);
+
 // ---- output side: QOA encoder (replaces qoa_encode_frame, qoa.d:295-399, and QOAEncoder's framing, :538-700) and
 //      the WAV writer (WAVEncoder, wav.d:365-701; host only) ----
 struct afg_qoa_enc_stream

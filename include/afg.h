@@ -205,6 +205,11 @@ typedef struct afg_celt_frame {
 int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
                            const float *d_coeffs, float *d_out, float *d_states, void *hip_stream);
 
+/* What OpusFile.readFrame and AudioStream.readSamplesFloat do to the decoder's floats (dopus.d:7923-7926,
+ * :8098-8105; stream.d:480): Float2IntScaled (x * 32768 rounded to nearest even by a magic-number add, saturated
+ * to int16), then int16 / 32767.0f.  Element-wise; d_out_f32 may alias d_in; either output may be NULL. */
+int afg_opus_output_hip(uint64_t n_samples, const float *d_in, int16_t *d_out_i16, float *d_out_f32, void *hip_stream);
+
 /* ========================================================================== *
  *  Outer surface: the AudioStream subset (stream.d:102-637) over the host front-ends
  *  that exist so far -- FLAC (native container, drflac.d:680-1695, :1887-2153), QOA

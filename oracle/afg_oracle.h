@@ -257,6 +257,7 @@ void afgo_celt_frame_channel(afgo_celt_state *f, const afgo_celt_frame *fr, cons
                              float *out, int out_stride);                                   /* dopus.d:3680-3702 */
 void afgo_celt_transform(uint32_t n_chan, const uint64_t *rec_base, const afgo_celt_frame *recs,
                          const float *coeffs, float *out, afgo_celt_state *states);
+void afgo_opus_output(uint64_t n, const float *in, int16_t *out_i16, float *out_f32);   /* dopus.d:7923-7926, stream.d:480 */
 
 #ifdef __cplusplus
 }

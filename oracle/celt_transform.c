@@ -282,3 +282,19 @@ void afgo_celt_transform(uint32_t n_chan, const uint64_t *rec_base, const afgo_c
         if (states) states[k] = st;
     }
 }
+
+/* OpusFile.readFrame's Float2IntScaled + saturation (dopus.d:7923-7926, :8098-8105) and AudioStream's
+ * int16 / 32767.0f (stream.d:480).  The magic constant 1.5f*(1<<8) + 0.5f/(1<<15) is a float: 384 + 2^-16 lies
+ * exactly between 384 and the next float and rounds to even, i.e. to 384.0f. */
+void afgo_opus_output(uint64_t n, const float *in, int16_t *out_i16, float *out_f32)
+{
+    const volatile float magic = (float)(1.5f * (float)(1 << (23 - 15)) + 0.5f / (float)(1 << 15));
+    for (uint64_t i = 0; i < n; i++) {
+        union { float f; int32_t i; } temp;
+        temp.f = in[i] + magic;
+        int32_t d = temp.i - (((150 - 15) << 23) + (1 << 22));
+        if ((uint32_t)(d + 32768) > 65535u) d = d < 0 ? -32768 : 32767;
+        if (out_i16) out_i16[i] = (int16_t)d;
+        if (out_f32) out_f32[i] = (float)(int16_t)d / 32767.0f;
+    }
+}

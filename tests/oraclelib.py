@@ -98,6 +98,8 @@ def lib():
     L.afgo_celt_imdct_half.restype = None
     L.afgo_celt_transform.argtypes = [C.c_uint32, u64p, C.c_void_p, f32p, f32p, C.c_void_p]
     L.afgo_celt_transform.restype = None
+    L.afgo_opus_output.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.afgo_opus_output.restype = None
     L.afgo_qoa_transform.argtypes = [C.c_uint64, C.c_void_p, u8p, C.c_void_p, C.c_void_p]
     L.afgo_qoa_transform.restype = None
     L.afgo_qoa_encode.argtypes = [i16p, C.c_uint32, C.c_int, C.c_uint32, u8p, C.c_void_p]
@@ -300,6 +302,15 @@ def qoa_transform(frames, data, out_total, want_float=True):
 
 
 # --------------------------------------------------------------- CELT ------
+def opus_output(x):
+    """float32 array -> (int16, float32) as OpusFile.readFrame + stream.d:480 deliver them."""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    oi = np.zeros(x.size, np.int16)
+    of = np.zeros(x.size, np.float32)
+    lib().afgo_opus_output(x.size, x.ctypes.data, oi.ctypes.data, of.ctypes.data)
+    return oi, of
+
+
 def celt_transform(rec_base, recs, coeffs, out_total, states=None):
     rec_base = np.ascontiguousarray(rec_base, np.uint64)
     recs = np.ascontiguousarray(recs, CELT_FRAME_DTYPE)

@@ -98,3 +98,27 @@ def test_celt_padded_output_stride(gpu):
         written[int(r["out_off"]) + np.arange(int(r["frame_size"])) * int(r["out_stride"])] = True
     assert not np.isnan(got[written]).any() and np.isnan(got[~written]).all()
     assert np.array_equal(got[written].view(np.uint32), want[written].view(np.uint32))
+
+
+def opus_output_inputs():
+    rng = np.random.default_rng(17)
+    k = np.arange(-40000, 40000, 7, dtype=np.float64)
+    ties = ((k + 0.5) / 32768.0).astype(np.float32)                      # exact .5 cases: ties go to even
+    return np.concatenate([ties, (rng.standard_normal(50000) * 0.4).astype(np.float32),
+                           np.array([0, -0.0, 1.0, -1.0, 0.99998474, 1.5, -1.5, 3e4, -3e4, 1e-9, 32767 / 32768], np.float32)])
+
+
+def test_opus_output_conversion_matches_oracle(gpu):
+    """OpusFile.readFrame's Float2IntScaled + saturation and stream.d:480, element-wise, bit-exact."""
+    import torch
+    x = opus_output_inputs()
+    want_i, want_f = oraclelib.opus_output(x)
+    d_in = torch.from_numpy(x).to(gpu)
+    d_i = torch.zeros(x.size, dtype=torch.int16, device=gpu)
+    d_f = torch.zeros(x.size, dtype=torch.float32, device=gpu)
+    afgpu.opus_output(x.size, d_in, d_i, d_f)
+    afgpu.opus_output(x.size, d_in, None, d_in)                           # in place, float only
+    torch.cuda.synchronize()
+    assert np.array_equal(d_i.cpu().numpy(), want_i)
+    assert np.array_equal(d_f.cpu().numpy().view(np.uint32), want_f.view(np.uint32))
+    assert np.array_equal(d_in.cpu().numpy().view(np.uint32), want_f.view(np.uint32))
