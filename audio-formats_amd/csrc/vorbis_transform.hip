@@ -722,6 +722,8 @@ __device__ __forceinline__ void vorbis_wave_body(
             load_spectrum(xin, spec + lane64(so_reg, p) + c * (kNL / 2));
     };
     issue(p_first);
+    settle(xin);                                     // waited for here: a wait at the loop top would be executed by every
+                                                     // iteration and drain the previous packet's PCM stores each time
 
     for (int p = p_first; p < p_end; p++) {
         if (p + 1 - fbase >= 64) refill(p);
