@@ -8,7 +8,7 @@ root = sys.argv[1]
 dbs = glob.glob(root + "/**/*_results.db", recursive=True)
 if dbs:
     for name, calls, total, avg, pct in sqlite3.connect(dbs[0]).execute("select * from top_kernels limit 12"):
-        print(f"{name[:60]:60s} calls {calls:5d}  avg {avg / 1e3:10.3f} us  {pct:5.1f} %")
+        print(f"{name[:60]:60s} calls {calls:5d}  avg {avg / 1e3:10.3f} ms  {pct:5.1f} %")   # the view reports microseconds
 else:
     for f in glob.glob(root + "/**/*kernel_stats.csv", recursive=True):
         print(open(f).read()[:2000])
