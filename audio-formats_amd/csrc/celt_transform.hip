@@ -201,6 +201,11 @@ __device__ __forceinline__ Geo geo_of(const afg_celt_frame &fr)
     return g;
 }
 
+// The dominant record: a 20 ms frame in one block.  With this geometry as a compile-time constant the index
+// arithmetic of the transform folds away (immediate load offsets, fixed trip counts).
+__device__ __forceinline__ Geo geo_960() { return Geo{ 960, 1, 960, 6, 5, 32, 480, 240, 32 }; }
+__device__ __forceinline__ bool is_960(const Geo &g) { return g.F == 960 && g.B == 1; }
+
 // lane (block j, base transform a) fetches the 15 strided input pairs of its 15-point transform (dopus.d:1619-1625)
 __device__ __forceinline__ void load_inputs(float (&xa)[15], float (&xb)[15], const float *__restrict__ coeffs,
                                             const afg_celt_frame &fr, const Geo &g, int l)
@@ -706,7 +711,11 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
         afg_celt_frame fr = recs[my_base], fr_next = fr;
         if (cnt > 1) fr_next = recs[my_base + 1];
         float xa[15], xb[15];
-        load_inputs(xa, xb, coeffs, fr, geo_of(fr), l);
+        {
+            const Geo g0 = geo_of(fr);
+            if (is_960(g0)) load_inputs(xa, xb, coeffs, fr, geo_960(), l);
+            else load_inputs(xa, xb, coeffs, fr, g0, l);
+        }
 
         for (uint64_t q = 0; q < cnt; q++) {
             const Geo g = geo_of(fr);
@@ -714,13 +723,19 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
             afg_celt_frame fr_next2 = recs[my_base + (q + 2 < cnt ? q + 2 : cnt - 1)];
             // iMDCT and overlap-add, dopus.d:3684-3690
 #if AFG_CELT_ABL != 6 && AFG_CELT_ABL != 9
-            frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
+            if (is_960(g)) frame_fft(z, xa, xb, fr, geo_960(), ltab, lwin, tb, l, act);
+            else frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
 #endif
 #if AFG_CELT_ABL != 8 && AFG_CELT_ABL != 9
-            load_inputs(xa, xb, coeffs, fr_next, geo_of(fr_next), l);      // (the last frame's again at the end)
+            {                                                // (the last frame's again at the end)
+                const Geo gn = geo_of(fr_next);
+                if (is_960(gn)) load_inputs(xa, xb, coeffs, fr_next, geo_960(), l);
+                else load_inputs(xa, xb, coeffs, fr_next, gn, l);
+            }
 #endif
 #if AFG_CELT_ABL != 6 && AFG_CELT_ABL != 7 && AFG_CELT_ABL != 9
-            frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+            if (is_960(g)) frame_rest(z, fr, geo_960(), ltab, lwin, tb, l, act);
+            else frame_rest(z, fr, g, ltab, lwin, tb, l, act);
 #endif
             if (act) {                                       // vector_fmul_window of block 0
                 float *d = buf + 1024;
