@@ -297,25 +297,20 @@ __device__ __forceinline__ float from_lane_above(float v)
 }
 
 #ifndef AFG_MP3_MIN_WAVES
-#define AFG_MP3_MIN_WAVES 3
+#define AFG_MP3_MIN_WAVES 4
 #endif
 
-__global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
-    const Mp3Seg *__restrict__ segs, const Mp3Stream *__restrict__ streams,
-    const float *__restrict__ coef, const uint32_t *__restrict__ flags,
-    float *__restrict__ pcm, float *__restrict__ state)
+// The walk of one segment; the channel count is a compile-time constant (a stream is mono or stereo throughout), so
+// the lane-role predicates and the interleave strides fold.
+template <int NCH>
+__device__ __forceinline__ void mp3_segment(
+    const Mp3Seg &seg, const Mp3Stream &st, const float *__restrict__ coef, const uint32_t *__restrict__ flags,
+    float *__restrict__ pcm, float *__restrict__ state, float *const H, float *const Wt)
 {
-    __shared__ __attribute__((aligned(16))) float H[kLdsFloats];
-    __shared__ __attribute__((aligned(16))) float Wt[15 * 16];      // g_win, re-read every granule (saves 16 VGPRs)
     float *const R = H + kRegion;
-
     const int lane = threadIdx.x;
-    for (int i = lane; i < 15 * 16; i += 64) Wt[i] = k_win[i];
-
-    const Mp3Seg seg = segs[blockIdx.x];
-    const Mp3Stream st = streams[seg.stream];
-    const int nch = (int)st.nch;
-    const int nval = nch * 576;                 // floats per granule
+    constexpr int nch = NCH;
+    constexpr int nval = nch * 576;             // floats per granule
 
     // role A: lane = (channel, subband): antialias / IMDCT
     const int ch = lane >> 5;
@@ -566,6 +561,22 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
         for (int i = 0; i < 9; i++) st_blob[lane * 9 + i] = ov[i];
         for (int r = 0; r < kHistRows; r++) st_blob[kStateOverlap + r * 64 + lane] = H[r * kHS + lane];
     }
+}
+
+
+__global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void mp3_transform_kernel(
+    const Mp3Seg *__restrict__ segs, const Mp3Stream *__restrict__ streams,
+    const float *__restrict__ coef, const uint32_t *__restrict__ flags,
+    float *__restrict__ pcm, float *__restrict__ state)
+{
+    __shared__ __attribute__((aligned(16))) float H[kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float Wt[15 * 16];      // g_win, re-read every granule (saves 16 VGPRs)
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 15 * 16; i += 64) Wt[i] = k_win[i];
+    const Mp3Seg seg = segs[blockIdx.x];
+    const Mp3Stream st = streams[seg.stream];
+    if (st.nch == 2) mp3_segment<2>(seg, st, coef, flags, pcm, state, H, Wt);
+    else mp3_segment<1>(seg, st, coef, flags, pcm, state, H, Wt);
 }
 
 }  // namespace
