@@ -52,6 +52,30 @@ template <int G> __global__ __launch_bounds__(64) void kg(const float *__restric
     }
 }
 
+// Variant: non-temporal loads and / or stores (NT & 1: loads, NT & 2: stores)
+template <int NT> __global__ __launch_bounds__(64) void knt(const float *__restrict__ in, float *__restrict__ out, int seg)
+{
+    __shared__ __attribute__((aligned(16))) float H[1152];
+    const int lane = threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * seg;
+    f4 pre[5];
+    auto ld = [&](const f4 *p) { return (NT & 1) ? __builtin_nontemporal_load(p) : *p; };
+    for (int q = 0; q < 5; q++) { const int idx = lane + 64 * q; pre[q] = ld((const f4 *)(in + g0 * 1152) + (idx < 288 ? idx : 287)); }
+    for (size_t g = g0; g < g0 + seg; g++) {
+        for (int q = 0; q < 5; q++) { const int idx = lane + 64 * q; if (idx < 288) ((f4 *)H)[idx] = pre[q]; }
+        if (g + 1 < g0 + seg)
+            for (int q = 0; q < 5; q++) { const int idx = lane + 64 * q; pre[q] = ld((const f4 *)(in + (g + 1) * 1152) + (idx < 288 ? idx : 287)); }
+        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < 5; q++) asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y), "+v"(pre[q].z), "+v"(pre[q].w) : : "memory");
+        f4 *dst = (f4 *)(out + g * 1152);
+        for (int q = 0; q < 5; q++) {
+            const int idx = lane + 64 * q;
+            if (idx < 288) { if (NT & 2) __builtin_nontemporal_store(((const f4 *)H)[idx], dst + idx); else dst[idx] = ((const f4 *)H)[idx]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Variants: the read half / the write half of the pattern alone (coalesced form)
 template <int WHICH> __global__ __launch_bounds__(64) void khalf(const float *__restrict__ in, float *__restrict__ out, int seg)
 {
@@ -141,6 +165,25 @@ int main()
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("G=%d granules per burst: %.3f ms  %.2f TB/s\n", G, ms, 2.0 * ngr * 4608 / ms / 1e9);
+    }
+    for (int nt = 0; nt < 4; nt++) for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(a);
+        if (nt == 0) hipLaunchKernelGGL(knt<0>, dim3(nseg), dim3(64), 0, 0, in, out, seg);
+        if (nt == 1) hipLaunchKernelGGL(knt<1>, dim3(nseg), dim3(64), 0, 0, in, out, seg);
+        if (nt == 2) hipLaunchKernelGGL(knt<2>, dim3(nseg), dim3(64), 0, 0, in, out, seg);
+        if (nt == 3) hipLaunchKernelGGL(knt<3>, dim3(nseg), dim3(64), 0, 0, in, out, seg);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("non-temporal loads=%d stores=%d: %.3f ms  %.2f TB/s\n", nt & 1, (nt >> 1) & 1, ms, 2.0 * ngr * 4608 / ms / 1e9);
+    }
+    for (int waves = 2; waves <= 32; waves *= 2) {                 // resident wavefronts per CU capped through dynamic LDS
+        const size_t dyn = 160 * 1024 / waves - 4608 - 256;
+        hipFuncSetAttribute((const void *)knt<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipEventRecord(a);
+        hipLaunchKernelGGL(knt<3>, dim3(nseg), dim3(64), dyn, 0, in, out, seg);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("<= %2d wavefronts per CU: %.3f ms  %.2f TB/s\n", waves, ms, 2.0 * ngr * 4608 / ms / 1e9);
     }
     for (int seg2 = 24; seg2 <= 192; seg2 *= 2) {
         hipEventRecord(a);
