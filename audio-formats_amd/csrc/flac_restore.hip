@@ -26,7 +26,7 @@
 namespace {
 
 #ifndef AFG_FLAC_TILE
-#define AFG_FLAC_TILE 16
+#define AFG_FLAC_TILE 32
 #endif
 constexpr int kT = AFG_FLAC_TILE;      // samples per tile step (16 or 32)
 constexpr int kRowWords = 2 * kT;      // LDS row: [channel A | channel B], 2*kT/4 pieces of 4 words
