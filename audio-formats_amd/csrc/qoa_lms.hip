@@ -12,13 +12,20 @@
 // Integer results are bit-exact (int arithmetic wraps exactly as in D).
 #include "afg_common.h"
 
+#ifndef AFG_QOA_ABL
+#define AFG_QOA_ABL 0      // development ablations: 1 no global stores, 2 no LMS chain, 3 no staging either
+#endif
+#ifndef AFG_QOA_STEP
+#define AFG_QOA_STEP 8
+#endif
+
 namespace {
 
 constexpr int kSliceLen = 20;
 constexpr int kFramesPerWave = 32;
-constexpr int kStepSlices = 8;                       // slices fetched per channel per refill
+constexpr int kStepSlices = AFG_QOA_STEP;                       // slices fetched per channel per refill
 constexpr int kInRow = kStepSlices * 2 + 1;          // 64-bit words per tile row (+1 pad)
-constexpr int kStoreIters = kFramesPerWave * kSliceLen / 64;   // float2 stores per lane per staged step
+constexpr int kStoreIters = kFramesPerWave * kSliceLen / 2 / 64;   // float4 (two sample pairs) stores per lane per staged step
 
 __device__ const short k_dequant[16 * 8] = {
     1, -1, 3, -3, 5, -5, 7, -7,  5, -5, 18, -18, 32, -32, 49, -49,
@@ -77,12 +84,12 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
 
     // store plan of the all-stereo case: float2 slot (lane + 64*it) of a staged step is sample pair k of frame
     // row r; its output offset and the number of samples left from k are fixed for the whole frame
-    const bool all_stereo = __ballot(C != 2 && me.samples != 0) == 0;
+    const bool all_stereo = __ballot((C != 2 || (me.out_off & 3)) && me.samples != 0) == 0;      // (16-byte aligned rows)
     uint64_t st_off[kStoreIters];
     int st_lim[kStoreIters];
 #pragma unroll
     for (int it = 0; it < kStoreIters; it++) {
-        const int idx2 = lane + 64 * it, r = idx2 / kSliceLen, k = idx2 - r * kSliceLen;
+        const int idx4 = lane + 64 * it, r = idx4 / (kSliceLen / 2), k = 2 * (idx4 - r * (kSliceLen / 2));
         const RowInfo m = rows[r];
         st_off[it] = m.out_off + 2 * k;
         st_lim[it] = (int)m.samples - k;
@@ -101,11 +108,12 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
         }
 
         for (int s0 = 0; s0 < max_slices; s0 += kStepSlices) {
-            // refill: 8 slices of both channel slots of every frame; 16 lanes x 8 B per frame row
+            // refill: kStepSlices slices of both channel slots of every frame; 2 * kStepSlices lanes x 8 B per frame row
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int r = 4 * i + (lane >> 4), wd = lane & 15;      // word = (slice j, slot) = (wd >> 1, wd & 1)
+            for (int i = 0; i < kStepSlices; i++) {
+                constexpr int W = 2 * kStepSlices;                      // 64-bit words per frame row and refill
+                const int r = (64 / W) * i + lane / W, wd = lane % W;   // word = (slice j, slot) = (wd >> 1, wd & 1)
                 const RowInfo m = rows[r];
                 const int cidx = 2 * pair + (wd & 1), sl = s0 + (wd >> 1);
                 const int nsl = ((int)m.samples + kSliceLen - 1) / kSliceLen;
@@ -124,6 +132,10 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
                 float outv[kSliceLen];
 #pragma unroll
                 for (int k = 0; k < kSliceLen; k++) {
+#if AFG_QOA_ABL >= 2
+                    outv[k] = (float)(int)((slice >> (3 * k)) & 7) + (float)(w0 + h0);
+                    continue;
+#endif
                     // qoa_lms_predict (:231-239): wrapping int sum, arithmetic shift
                     const int pred = (int)((unsigned)w0 * (unsigned)h0 + (unsigned)w1 * (unsigned)h1 +
                                            (unsigned)w2 * (unsigned)h2 + (unsigned)w3 * (unsigned)h3) >> 13;
@@ -146,18 +158,27 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
                 for (int k = 0; k < kSliceLen; k++) stage[(fr * kSliceLen + k) * 2 + slot] = outv[k];
                 if (all_stereo) {
                     // every frame of this wavefront is stereo: the staged step is 32 rows of 20 (L,R) pairs, each
-                    // row contiguous in the output; ten 8-byte stores per lane through the offsets set up above
+                    // row contiguous in the output; five 16-byte stores per lane through the offsets set up above
                     // (one wavefront per workgroup: its LDS accesses complete in order, no barrier needed)
                     __builtin_amdgcn_wave_barrier();
                     const int first = sidx * kSliceLen;
 #pragma unroll
                     for (int it = 0; it < kStoreIters; it++) {
-                        const float2 v = ((const float2 *)stage)[lane + 64 * it];
-                        if (first < st_lim[it]) {
-                            const uint64_t o = st_off[it] + (uint64_t)first * 2;
+                        const float4 v = ((const float4 *)stage)[lane + 64 * it];           // sample pairs k, k+1 of a row
+                        const uint64_t o = st_off[it] + (uint64_t)first * 2;
+#if AFG_QOA_ABL != 1 && AFG_QOA_ABL != 3
+                        if (first + 1 < st_lim[it]) {                                        // both pairs inside the frame
+                            if (out_i16) *(short4 *)(out_i16 + o) = make_short4((short)v.x, (short)v.y, (short)v.z, (short)v.w);
+                            if (out_f32)
+                                *(float4 *)(out_f32 + o) = make_float4(v.x * (1.0f / 32767), v.y * (1.0f / 32767),
+                                                                       v.z * (1.0f / 32767), v.w * (1.0f / 32767));
+                        } else if (first < st_lim[it]) {
                             if (out_i16) *(short2 *)(out_i16 + o) = make_short2((short)v.x, (short)v.y);
                             if (out_f32) *(float2 *)(out_f32 + o) = make_float2(v.x * (1.0f / 32767), v.y * (1.0f / 32767));
                         }
+#else
+                        if (v.x == 12345.678f && out_f32 && first < st_lim[it]) out_f32[o] = v.y;
+#endif
                     }
                     __builtin_amdgcn_wave_barrier();
                     continue;
