@@ -25,7 +25,10 @@ constexpr int kSliceLen = 20;
 constexpr int kFramesPerWave = 32;
 constexpr int kStepSlices = AFG_QOA_STEP;                       // slices fetched per channel per refill
 constexpr int kInRow = kStepSlices * 2 + 1;          // 64-bit words per tile row (+1 pad)
-constexpr int kStoreIters = kFramesPerWave * kSliceLen / 2 / 64;   // float4 (two sample pairs) stores per lane per staged step
+constexpr int kFlushSlices = 4;                      // all-stereo path: slices staged per row before a flush (4 x 160 B = five full 128-byte lines)
+constexpr int kRowPairs = kFlushSlices * kSliceLen;  // (L,R) pairs per staged row
+constexpr int kRowPitch = kRowPairs + 2;             // dwords; 82: rows 8-byte aligned, 2-way bank conflicts at most
+constexpr int kFlushIters = kFramesPerWave * kRowPairs / 2 / 64;   // two pairs (8 staged bytes, 16 output bytes) per lane and iteration
 
 __device__ const short k_dequant[16 * 8] = {
     1, -1, 3, -3, 5, -5, 7, -7,  5, -5, 18, -18, 32, -32, 49, -49,
@@ -54,7 +57,9 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
     int16_t *__restrict__ out_i16, float *__restrict__ out_f32, uint64_t n_frames)
 {
     __shared__ uint64_t tile[kFramesPerWave * kInRow];
-    __shared__ __attribute__((aligned(16))) float stage[kFramesPerWave * kSliceLen * 2];
+    __shared__ __attribute__((aligned(16))) uint32_t stage16[kFramesPerWave * kRowPitch];      // all-stereo path: (L,R) int16 pairs
+    static_assert(sizeof(uint32_t) * kFramesPerWave * kRowPitch >= sizeof(float) * kFramesPerWave * kSliceLen * 2, "staging overlay");
+    float *const stage = (float *)stage16;                                                     // general path: one slice of floats
     __shared__ RowInfo rows[kFramesPerWave];
     __shared__ short dq[16 * 8];
 
@@ -82,18 +87,9 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
     }
     const int max_slices = (max_samples + kSliceLen - 1) / kSliceLen;
 
-    // store plan of the all-stereo case: float2 slot (lane + 64*it) of a staged step is sample pair k of frame
-    // row r; its output offset and the number of samples left from k are fixed for the whole frame
-    const bool all_stereo = __ballot((C != 2 || (me.out_off & 3)) && me.samples != 0) == 0;      // (16-byte aligned rows)
-    uint64_t st_off[kStoreIters];
-    int st_lim[kStoreIters];
-#pragma unroll
-    for (int it = 0; it < kStoreIters; it++) {
-        const int idx4 = lane + 64 * it, r = idx4 / (kSliceLen / 2), k = 2 * (idx4 - r * (kSliceLen / 2));
-        const RowInfo m = rows[r];
-        st_off[it] = m.out_off + 2 * k;
-        st_lim[it] = (int)m.samples - k;
-    }
+    // all-stereo wavefronts (every frame two channels, rows 16-byte aligned) stage four slices per row as int16 and
+    // flush them as whole 128-byte lines
+    const bool all_stereo = __ballot((C != 2 || (me.out_off & 3)) && me.samples != 0) == 0;
 
     for (int pair = 0; pair < max_pairs; pair++) {
         const int ch = 2 * pair + slot;
@@ -153,36 +149,44 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
                     h0 = h1; h1 = h2; h2 = h3; h3 = rec;
                     outv[k] = (float)rec;
                 }
-                // stage [frame][sample][slot]
-#pragma unroll
-                for (int k = 0; k < kSliceLen; k++) stage[(fr * kSliceLen + k) * 2 + slot] = outv[k];
                 if (all_stereo) {
-                    // every frame of this wavefront is stereo: the staged step is 32 rows of 20 (L,R) pairs, each
-                    // row contiguous in the output; five 16-byte stores per lane through the offsets set up above
                     // (one wavefront per workgroup: its LDS accesses complete in order, no barrier needed)
-                    __builtin_amdgcn_wave_barrier();
-                    const int first = sidx * kSliceLen;
+                    const int jj = sidx % kFlushSlices;
+                    short *row16 = (short *)(stage16 + fr * kRowPitch + jj * kSliceLen) + slot;
 #pragma unroll
-                    for (int it = 0; it < kStoreIters; it++) {
-                        const float4 v = ((const float4 *)stage)[lane + 64 * it];           // sample pairs k, k+1 of a row
-                        const uint64_t o = st_off[it] + (uint64_t)first * 2;
+                    for (int k = 0; k < kSliceLen; k++) row16[2 * k] = (short)outv[k];
+                    if (jj != kFlushSlices - 1 && sidx != max_slices - 1) continue;
+                    __builtin_amdgcn_wave_barrier();
+                    const int first = (sidx - jj) * kSliceLen;               // first sample of the staged rows
+                    const int have = (jj + 1) * kSliceLen;                   // samples staged per row
+#pragma unroll 4
+                    for (int it = 0; it < kFlushIters; it++) {
+                        const int idx = lane + 64 * it, r = idx / (kRowPairs / 2), k = 2 * (idx - r * (kRowPairs / 2));
+                        const RowInfo m = rows[r];
+                        const uint2 v = *(const uint2 *)(stage16 + r * kRowPitch + k);        // pairs k, k+1 of row r
+                        const short l0 = (short)(v.x & 0xffff), r0 = (short)(v.x >> 16), l1 = (short)(v.y & 0xffff), r1 = (short)(v.y >> 16);
+                        const int left = min((int)m.samples - first, have) - k;               // pairs of this row still to write from k
+                        const uint64_t o = m.out_off + (uint64_t)(first + k) * 2;
 #if AFG_QOA_ABL != 1 && AFG_QOA_ABL != 3
-                        if (first + 1 < st_lim[it]) {                                        // both pairs inside the frame
-                            if (out_i16) *(short4 *)(out_i16 + o) = make_short4((short)v.x, (short)v.y, (short)v.z, (short)v.w);
+                        if (left >= 2) {
+                            if (out_i16) *(short4 *)(out_i16 + o) = make_short4(l0, r0, l1, r1);
                             if (out_f32)
-                                *(float4 *)(out_f32 + o) = make_float4(v.x * (1.0f / 32767), v.y * (1.0f / 32767),
-                                                                       v.z * (1.0f / 32767), v.w * (1.0f / 32767));
-                        } else if (first < st_lim[it]) {
-                            if (out_i16) *(short2 *)(out_i16 + o) = make_short2((short)v.x, (short)v.y);
-                            if (out_f32) *(float2 *)(out_f32 + o) = make_float2(v.x * (1.0f / 32767), v.y * (1.0f / 32767));
+                                *(float4 *)(out_f32 + o) = make_float4((float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767),
+                                                                       (float)l1 * (1.0f / 32767), (float)r1 * (1.0f / 32767));
+                        } else if (left == 1) {
+                            if (out_i16) *(short2 *)(out_i16 + o) = make_short2(l0, r0);
+                            if (out_f32) *(float2 *)(out_f32 + o) = make_float2((float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767));
                         }
 #else
-                        if (v.x == 12345.678f && out_f32 && first < st_lim[it]) out_f32[o] = v.y;
+                        if (l0 == 12345 && out_f32 && left > 0) out_f32[o] = (float)r1;
 #endif
                     }
                     __builtin_amdgcn_wave_barrier();
                     continue;
                 }
+                // stage [frame][sample][slot]
+#pragma unroll
+                for (int k = 0; k < kSliceLen; k++) stage[(fr * kSliceLen + k) * 2 + slot] = outv[k];
                 __syncthreads();
                 // store: frame rows of 20 samples x (1|2) slots
                 for (int idx = lane; idx < kFramesPerWave * kSliceLen * 2; idx += 64) {
