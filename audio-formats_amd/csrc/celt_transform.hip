@@ -847,7 +847,10 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
 #endif
 constexpr int kDeSeq = AFG_CELT_DE_SEQ;                      // channel sequences per wavefront
 constexpr int kDeDepth = AFG_CELT_DE_DEPTH;                  // steps kept in flight
-constexpr int kDeGroup = 40;
+#ifndef AFG_CELT_DE_GROUP
+#define AFG_CELT_DE_GROUP 40
+#endif
+constexpr int kDeGroup = AFG_CELT_DE_GROUP;                  // samples of every sequence per step (divides every CELT frame size)
 constexpr int kDePitch = kDeGroup + 4;                       // floats; rows stay 16-byte aligned
 constexpr int kDeQuads = kDeSeq * kDeGroup / 4;              // float4 per step
 constexpr int kDeLoads = (kDeQuads + 63) / 64;               // float4 per lane per step
@@ -855,7 +858,7 @@ constexpr int kDeLoads = (kDeQuads + 63) / 64;               // float4 per lane 
 template <int STRIDE>
 __device__ __forceinline__ void deemph_rows(float *xs, float *__restrict__ out, bool have, uint64_t off, int n, float &m)
 {
-    constexpr int F = 10 * STRIDE;                           // float4 per row per step
+    constexpr int F = kDeGroup / 4 * STRIDE;                  // float4 per row per step
     const int lane = threadIdx.x;
     float *ptr[kDeLoads];
     int lds_at[kDeLoads];
@@ -863,7 +866,7 @@ __device__ __forceinline__ void deemph_rows(float *xs, float *__restrict__ out, 
 #pragma unroll
     for (int i = 0; i < kDeLoads; i++) {
         const int idx = lane + 64 * i;
-        const int row = (idx * (STRIDE == 1 ? 6554 : 3277)) >> 16, q = idx - row * F;     // idx / F, idx % F
+        const int row = idx / F, q = idx - row * F;
         const int lead = row * STRIDE;                       // first chain lane of the row
         const uint32_t lo = __shfl((uint32_t)off, lead), hi = __shfl((uint32_t)(off >> 32), lead);
         valid[i] = idx < kDeQuads && __shfl((int)have, lead) != 0;
