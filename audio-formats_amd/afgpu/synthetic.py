@@ -44,15 +44,23 @@ def mp3_block_types(rng, n, p_event=0.02, p_mixed=0.0):
     return bt, mixed
 
 
-def mp3_flag_words(bt, mixed):
-    """AFG_MP3_FLAGS for MPEG-1 (n_long_bands = 2 for mixed blocks, minimp3.d:1218)."""
+MP3_NZ_BANDS = (MP3_CUTOFF_LINE + 17) // 18          # subbands that can hold nonzero lines below the cut-off
+
+
+def mp3_flag_words(bt, mixed, nz_bands=None):
+    """AFG_MP3_FLAGS for MPEG-1 (n_long_bands = 2 for mixed blocks, minimp3.d:1218), optionally with
+    AFG_MP3_NZ_BANDS(nz_bands): the spectra above that subband are +0.0 and need not be fetched."""
     n_long = np.where(mixed & (bt == 2), 2, 0).astype(np.uint32)
     aa = np.where(bt == 2, n_long.astype(np.int64) - 1, 31)
-    return (bt.astype(np.uint32) | (n_long << 8) | ((aa + 1).astype(np.uint32) << 16)).astype(np.uint32)
+    w = (bt.astype(np.uint32) | (n_long << 8) | ((aa + 1).astype(np.uint32) << 16)).astype(np.uint32)
+    if nz_bands is not None:
+        w = w | np.uint32((int(nz_bands) + 1) << 24)
+    return w
 
 
-def mp3_batch(seed, granules, channels, p_event=0.05, p_mixed=0.3, amplitude=1.0):
-    """numpy batch: returns (coef[blocks*576] f32, flags[blocks] u32)."""
+def mp3_batch(seed, granules, channels, p_event=0.05, p_mixed=0.3, amplitude=1.0, declare_nz=False):
+    """numpy batch: returns (coef[blocks*576] f32, flags[blocks] u32).  The lines above the cut-off are +0.0;
+    declare_nz puts AFG_MP3_NZ_BANDS into the flag words."""
     granules = np.asarray(granules, np.uint32)
     channels = np.asarray(channels, np.uint8)
     tilt = mp3_tilt()
@@ -60,10 +68,11 @@ def mp3_batch(seed, granules, channels, p_event=0.05, p_mixed=0.3, amplitude=1.0
     for s, (ng, nc) in enumerate(zip(granules, channels)):
         rng = np.random.default_rng([seed, s])
         c = rng.standard_normal((int(ng), int(nc), 576)).astype(np.float32) * tilt * np.float32(amplitude)
+        c[..., MP3_CUTOFF_LINE:] = 0.0                        # +0.0, not the -0.0 a negative draw times 0 leaves
         f = np.zeros((int(ng), int(nc)), np.uint32)
         for ch in range(int(nc)):
             bt, mixed = mp3_block_types(rng, int(ng), p_event, p_mixed)
-            f[:, ch] = mp3_flag_words(bt, mixed)
+            f[:, ch] = mp3_flag_words(bt, mixed, MP3_NZ_BANDS if declare_nz else None)
         coefs.append(c.reshape(-1))
         flags.append(f.reshape(-1))
     if not coefs:
@@ -85,12 +94,13 @@ def mp3_batch_device(seed, n_files, granules_per_file, device, p_event=0.04, fil
         view = coef[f0 * per_file:f1 * per_file].view(-1, 576)
         view.normal_(generator=gen)
         view.mul_(tilt)
+        view[:, MP3_CUTOFF_LINE:] = 0.0                       # +0.0 (a negative draw times 0 is -0.0)
     flags_np = np.zeros((n_files, granules_per_file, 2), np.uint32)
     for f in range(n_files):
         rng = np.random.default_rng([seed, f])
         for ch in range(2):
             bt, mixed = mp3_block_types(rng, granules_per_file, p_event, 0.0)
-            flags_np[f, :, ch] = mp3_flag_words(bt, mixed)
+            flags_np[f, :, ch] = mp3_flag_words(bt, mixed, MP3_NZ_BANDS)     # as the host parser declares it
     flags = torch.from_numpy(flags_np.reshape(-1).view(np.int32)).to(device)
     return coef, flags
 

@@ -337,15 +337,6 @@ __device__ __forceinline__ void mp3_segment(
     // ---- first granule's spectrum: 18 consecutive lines of this lane's subband --------
     const int g_end = (int)(seg.g0 + seg.count);
     const bool ch_on = ch < nch;
-    // Idle lanes (the second channel's half of a mono stream) repeat the first channel's addresses: every load
-    // of the loop is unconditional, so the compiler can count what is in flight instead of draining the queue.
-    const int lane_ld = ch_on ? lane : band;
-    f2 pre[9];
-    {
-        const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)g_first * nch) * 576) + lane_ld * 9;
-#pragma unroll
-        for (int q = 0; q < 9; q++) pre[q] = src[q];
-    }
     // flag words of 64 granules at a time sit in lane registers (lane i: granule fbase + i, one register per
     // channel) and are read with v_readlane: no memory access on the per-granule path
     int fbase = g_first;
@@ -361,6 +352,21 @@ __device__ __forceinline__ void mp3_segment(
         asm volatile("" : "+v"(fl_a), "+v"(fl_b) : : "memory");     // waited for here, never inside the granule loop
     };
     refill(g_first);
+    // Subbands a block declares empty (AFG_MP3_NZ_BANDS in flag bits 24..29) are taken as +0.0 and never fetched: a 128 kbit/s stream is silent above ~16 kHz, a quarter of
+    // the plane.  Lanes of such subbands, and the idle half of a mono stream, issue no load.
+    auto loads_of = [&](int g) -> bool {
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)fl_a, g - fbase);
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)fl_b, g - fbase);
+        const uint32_t nz = ((ch ? w1 : w0) >> 24) & 63u;        // AFG_MP3_NZ_BANDS: 0 = not declared, else count + 1
+        return ch_on && band < (int)(nz ? nz - 1u : 32u);
+    };
+    f2 pre[9];
+    {
+        const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)g_first * nch) * 576) + lane * 9;
+        const bool on = loads_of(g_first);
+#pragma unroll
+        for (int q = 0; q < 9; q++) pre[q] = on ? src[q] : f2{ 0.0f, 0.0f };
+    }
 #pragma unroll
     for (int q = 0; q < 9; q++) asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y) : : "memory");
     WAVE_SYNC();
@@ -376,14 +382,15 @@ __device__ __forceinline__ void mp3_segment(
             x[2 * m] = pre[m].x;
             x[2 * m + 1] = pre[m].y;
         }
-        if (g - fbase >= 64) refill(g);
+        if (g + 1 - fbase >= 64) refill(g);                // the window covers this granule and the next
         const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readlane((int)fl_a, g - fbase);
         const uint32_t fl1 = (uint32_t)__builtin_amdgcn_readlane((int)fl_b, g - fbase);
         const uint32_t fl = ch_on ? (ch ? fl1 : fl0) : 0u;
         if (g + 1 < g_end) {
-            const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)(g + 1) * nch) * 576) + lane_ld * 9;
+            const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)(g + 1) * nch) * 576) + lane * 9;
+            const bool on = loads_of(g + 1);
 #pragma unroll
-            for (int q = 0; q < 9; q++) pre[q] = src[q];
+            for (int q = 0; q < 9; q++) pre[q] = on ? src[q] : f2{ 0.0f, 0.0f };
         }
 
         // C. alias reduction (minimp3.d:1002-1020), IMDCT (:1152-1168), frequency inversion (:1144-1150)

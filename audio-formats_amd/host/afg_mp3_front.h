@@ -2,6 +2,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "../../include/afg.h"
@@ -34,6 +35,15 @@ struct File {
     size_t blocks() const { return n_blocks; }
     void push(const float *x, uint32_t fl)
     {
+        // AFG_MP3_NZ_BANDS: subbands above the last line whose bit pattern is not +0.0 need not be fetched by the device
+        int last = 575;
+        while (last >= 0) {
+            uint32_t bits;
+            std::memcpy(&bits, x + last, 4);
+            if (bits) break;
+            last--;
+        }
+        fl |= AFG_MP3_NZ_BANDS((last + 18) / 18);
         if (ext_coef) {
             if (n_blocks >= ext_cap) { overflow = true; return; }
             for (int i = 0; i < 576; i++) ext_coef[n_blocks * 576 + i] = x[i];

@@ -60,6 +60,11 @@ int         afg_device_name(int device, char *buf, size_t buflen);
  *   n_long_bands  minimp3.d:1218 (0, 2 or 4)
  *   aa_bands      minimp3.d:1217/1222 (31, or n_long_bands-1 for short blocks; -1 = none) */
 
+/* Optional, OR-ed into the flag word: the first `bands` subbands (0..32) are the only ones that may hold nonzero
+ * lines; the lines of the others must be +0.0 (what L3_huffman's zero fill leaves above the last coded line,
+ * minimp3.d:868-883) and are not read by the device.  Absent (field 0): all 576 lines are read. */
+#define AFG_MP3_NZ_BANDS(bands) ((uint32_t)((bands) + 1) << 24)
+
 #define AFG_MP3_STATE_FLOATS 1536   /* opaque per-stream carry state (same size as mdct_overlap+qmf_state, minimp3.d:40-41) */
 
 typedef struct afg_mp3_plan afg_mp3_plan;

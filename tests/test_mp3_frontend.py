@@ -29,9 +29,13 @@ def same_records(data):
            (want["channels"], want["hz"], want["tagged"], want["start_delay"])
     assert info["detected_samples"] == want["detected_samples"] and info["declared_samples"] == want["declared_samples"]
     np.testing.assert_array_equal(runs, want["runs"])
-    np.testing.assert_array_equal(flags, want["flags"])
+    np.testing.assert_array_equal(flags & 0x00ffffff, want["flags"])                  # the reference's per-granule fields
     assert coef.shape == want["coef"].shape
     assert np.array_equal(coef.view(np.uint32), want["coef"].view(np.uint32))          # bit-exact spectra
+    # AFG_MP3_NZ_BANDS (bits 24..29): exactly the subbands up to the last line that is not +0.0
+    bits = coef.view(np.uint32).reshape(-1, 576)
+    last = np.where(bits.any(1), 575 - np.argmax(bits[:, ::-1] != 0, 1), -1)
+    np.testing.assert_array_equal((flags >> 24) & 63, (last + 18) // 18 + 1)
     assert info["pcm_samples"] == len(want["pcm"]) == int(copies[:, 1].sum())
     return (info, runs, coef, flags, copies), want
 

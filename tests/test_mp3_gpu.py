@@ -108,3 +108,31 @@ def test_mp3_linearity_and_silence(gpu):
     a = run_gpu(gpu, granules, channels, coef, flags)
     b = run_gpu(gpu, granules, channels, coef * np.float32(2.0), flags)
     assert (b == a * np.float32(2.0)).all()       # scaling by 2 is exact in float32
+
+
+@pytest.mark.parametrize("channels", [[2, 2, 2], [1, 2, 1]])
+def test_mp3_declared_empty_subbands_are_not_needed(gpu, channels):
+    """AFG_MP3_NZ_BANDS: with the tails declared the device may skip them -- same PCM as the oracle, which reads all
+    576 lines -- including per-granule varying counts, 0 bands (silence) and all 32; and more than 64 granules, so the
+    lane-register flag window is refilled."""
+    granules = [70, 9, 131]
+    coef, flags = synthetic.mp3_batch(23, granules, channels, p_event=0.1, p_mixed=0.4)
+    rng = np.random.default_rng(1)
+    blocks = coef.reshape(-1, 576)
+    nz = rng.integers(0, 33, len(blocks))
+    nz[::7] = 0
+    nz[3::11] = 32
+    for b, n in zip(blocks, nz):
+        b[18 * n:] = 0.0
+    want = oraclelib.mp3_transform(granules, channels, coef, flags)
+    declared = flags | ((nz.astype(np.uint32) + 1) << 24)
+    for seg in (5, 48):
+        got = run_gpu(gpu, granules, channels, coef, declared, seg)
+        rms, nbad = compare(got, want)
+        assert nbad == 0, f"{nbad} samples differ bitwise (rms {rms})"
+    # the contract: data in a subband declared empty is ignored (here garbage, even NaN)
+    poisoned = blocks.copy()
+    for b, n in zip(poisoned, nz):
+        b[18 * n:] = np.nan
+    got = run_gpu(gpu, granules, channels, poisoned.reshape(-1), declared, 48)
+    assert compare(got, want)[1] == 0
