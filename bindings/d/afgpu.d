@@ -35,6 +35,9 @@ uint AFG_MP3_FLAGS(uint block_type, uint n_long_bands, int aa_bands) pure
     return block_type | (n_long_bands << 8) | (cast(uint)(aa_bands + 1) << 16);
 }
 
+// optional, OR-ed into the flag word: only the first `bands` subbands (0..32) may hold lines that are not +0.0
+uint AFG_MP3_NZ_BANDS(uint bands) pure { return (bands + 1) << 24; }
+
 int afg_mp3_plan_create(afg_mp3_plan** plan, uint n_streams, const(uint)* granules,
                         const(ubyte)* channels, uint seg_granules);
 void afg_mp3_plan_destroy(afg_mp3_plan* plan);
