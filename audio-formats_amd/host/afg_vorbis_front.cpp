@@ -614,6 +614,7 @@ bool add_vector_strided(Bits &br, const Book &b, float *out, int len, int step) 
 struct Scratch {
     std::vector<float> spec;                 // channels * n/2
     std::vector<int16_t> y;                  // channels * 256
+    std::vector<int> cls;                    // residue classifications of the submap being decoded
 };
 
 // returns false when the packet cannot be decoded at all (not an audio packet / bad mode); `flags` and the window
@@ -711,8 +712,9 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
         const uint32_t rb = std::min(r.begin, actual), re = std::min(r.end, actual);
         const int part_read = (int)((re - rb) / r.part_size);
         if (classwords <= 0) continue;
-        std::vector<int> cls((size_t)std::max(ch, 1) * (size_t)(part_read + classwords + 1), 0);
         const size_t cls_pitch = (size_t)(part_read + classwords + 1);
+        std::vector<int> &cls = sc.cls;                          // reused across packets: no allocation on the packet path
+        cls.assign((size_t)std::max(ch, 1) * cls_pitch, 0);
         bool done = false;
         if (r.type == 2 && ch != 1) {
             bool any = false;
