@@ -23,6 +23,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -191,8 +192,9 @@ public:
     // One job at a time: a second caller (another host thread in the library) just runs its work alone.
     void run(unsigned helpers, const std::function<void()> &work)
     {
+        if (helpers == 0) { work(); return; }                // (without touching the pool: the caller wants no helpers)
         std::unique_lock<std::mutex> job_lock(job_mu_, std::try_to_lock);
-        if (!job_lock.owns_lock() || helpers == 0) { work(); return; }
+        if (!job_lock.owns_lock()) { work(); return; }
         {
             std::lock_guard<std::mutex> lk(mu_);
             while (workers_.size() < helpers && workers_.size() < 1024) workers_.emplace_back([this] { loop(); });
@@ -254,6 +256,7 @@ struct BatchOut {
     StagingPool::Lease plane;           // all PCM of the batch: FLAC files, then QOA files, then MP3 files; page-locked,
     size_t plane_floats = 0;            // returned to the pool by afg_batch_free / afg_close
     StagingPool::Lease mp3_plane;       // batch path: the MP3 PCM in staging layout, served in place
+    std::unique_ptr<BatchOut> early;    // batch path: the FLAC / QOA files, decoded on a second host thread meanwhile
 };
 
 // Device stage for a set of parsed files: every FLAC record of the batch in one launch, every QOA frame
@@ -375,8 +378,13 @@ struct Mp3Pipe {
 };
 
 int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out,
-                  const Mp3Stage *stage = nullptr, const OggStage *ogg_stage = nullptr, const FlacStage *flac_stage = nullptr)
+                  const Mp3Stage *stage = nullptr, const OggStage *ogg_stage = nullptr, const FlacStage *flac_stage = nullptr,
+                  const uint8_t *own = nullptr)
 {
+    // `own` (optional, one byte per file): the files this call is responsible for.  The batch path decodes its FLAC /
+    // QOA files on a second host thread while the first still parses MP3 / Ogg files: a call never looks at (not even
+    // the format of) a file it does not own.
+    auto fmt_of = [&](const Parsed &q) -> int { return (!own || own[&q - parsed.data()]) ? q.format : -1; };
     const size_t nf = parsed.size();
     out.files.assign(nf, Decoded());
     StageTimer tm;
@@ -386,7 +394,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
     const bool flac_staged = flac_stage && flac_stage->words;
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
-        if (p.format != AFG_FORMAT_FLAC) continue;
+        if (fmt_of(p) != AFG_FORMAT_FLAC) continue;
         res_base[i] = flac_staged ? flac_stage->base[i] : res_total; fr_base[i] = fr_total; sf_base[i] = sf_total;
         out.files[i].pcm_off = flac_out;
         res_total += p.flac.res_size(); fr_total += p.flac.frames.size(); sf_total += p.flac.subframes.size();
@@ -395,7 +403,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
     if (flac_staged) res_total = flac_stage->words;          // the device plane mirrors the staging layout (gaps and all)
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
-        if (p.format != AFG_FORMAT_QOA) continue;
+        if (fmt_of(p) != AFG_FORMAT_QOA) continue;
         qbyte_base[i] = qbytes; qfr_base[i] = qframes;
         out.files[i].pcm_off = flac_out + qoa_out;
         qbytes += (len[i] + 15) & ~(size_t)15;
@@ -406,7 +414,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
     size_t mp3_blocks = 0, mp3_out = 0;
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
-        if (p.format != AFG_FORMAT_MP3) continue;
+        if (fmt_of(p) != AFG_FORMAT_MP3) continue;
         mp3_blk_base[i] = mp3_blocks;
         out.files[i].pcm_off = flac_out + qoa_out + mp3_out;
         mp3_blocks += p.mp3.blocks();
@@ -418,7 +426,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         mp3_out = 0;
         for (size_t i = 0; i < nf; i++) {
             Parsed &p = parsed[i];
-            if (p.format != AFG_FORMAT_MP3) continue;
+            if (fmt_of(p) != AFG_FORMAT_MP3) continue;
             const uint64_t first = p.mp3.copies.empty() ? 0 : p.mp3.copies[0].src;
             out.files[i].pcm_off = stage->base[i] * 576 + (size_t)first;
             out.files[i].in_mp3_plane = true;
@@ -450,11 +458,11 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
     {
         size_t total = 0;
         for (size_t i = 0; i < nf; i++)
-            if (parsed[i].format == AFG_FORMAT_OGG) { total += parsed[i].ogg.n_spec; ogg_packets += parsed[i].ogg.pflags.size(); }
+            if (fmt_of(parsed[i]) == AFG_FORMAT_OGG) { total += parsed[i].ogg.n_spec; ogg_packets += parsed[i].ogg.pflags.size(); }
         const size_t target = std::max<size_t>((total + 7) / 8, (size_t)4 << 20);
         for (size_t f0 = 0; f0 < nf && ogg_packets;) {
             size_t f1 = f0, acc = 0;
-            while (f1 < nf && acc < target) { if (parsed[f1].format == AFG_FORMAT_OGG) acc += parsed[f1].ogg.n_spec; f1++; }
+            while (f1 < nf && acc < target) { if (fmt_of(parsed[f1]) == AFG_FORMAT_OGG) acc += parsed[f1].ogg.n_spec; f1++; }
             OggChunk c;
             c.f0 = f0; c.f1 = f1; c.spec0 = ogg_spec; c.out0 = ogg_out;
             std::vector<uint32_t> npk;
@@ -465,7 +473,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             size_t at = 0, span0 = 0, span1 = 0;
             for (size_t i = f0; i < f1; i++) {
                 const Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_OGG) continue;
+                if (fmt_of(p) != AFG_FORMAT_OGG) continue;
                 c.spec_at[i - f0] = at;
                 at += p.ogg.n_spec;
                 if (p.ogg.pflags.empty()) continue;
@@ -506,7 +514,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             size_t pk = 0;
             for (size_t i = k.f0; i < k.f1; i++) {
                 const Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_OGG) continue;
+                if (fmt_of(p) != AFG_FORMAT_OGG) continue;
                 const size_t n = p.ogg.pflags.size(), C = (size_t)p.ogg.channels;
                 const size_t first_piece = ogg_pieces.size();
                 for (size_t q = 0; q < n;) {
@@ -533,7 +541,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         std::vector<size_t> broken;                          // files whose pieces are not already back to back
         for (size_t i = 0; i < nf; i++) {
             const Parsed &p = parsed[i];
-            if (p.format != AFG_FORMAT_MP3) continue;
+            if (fmt_of(p) != AFG_FORMAT_MP3) continue;
             for (size_t k = 1; k < p.mp3.copies.size(); k++)
                 if (p.mp3.copies[k].src != p.mp3.copies[k - 1].src + p.mp3.copies[k - 1].count) { broken.push_back(i); break; }
         }
@@ -582,15 +590,15 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             const size_t target = std::max<size_t>((res_total + 7) / 8, (size_t)4 << 20);
             for (size_t f0 = 0; f0 < nf && !rc && e == hipSuccess;) {
                 size_t f1 = f0, acc = 0;
-                while (f1 < nf && acc < target) { if (parsed[f1].format == AFG_FORMAT_FLAC) acc += parsed[f1].flac.res_size(); f1++; }
+                while (f1 < nf && acc < target) { if (fmt_of(parsed[f1]) == AFG_FORMAT_FLAC) acc += parsed[f1].flac.res_size(); f1++; }
                 size_t first = nf, last = nf;                // first / last FLAC file of the chunk
                 for (size_t i = f0; i < f1; i++)
-                    if (parsed[i].format == AFG_FORMAT_FLAC) { if (first == nf) first = i; last = i; }
+                    if (fmt_of(parsed[i]) == AFG_FORMAT_FLAC) { if (first == nf) first = i; last = i; }
                 if (first == nf) { f0 = f1; continue; }
                 parallel_for(f1 - f0, threads, [&](size_t k) {
                     const size_t i = f0 + k;
                     Parsed &p = parsed[i];
-                    if (p.format != AFG_FORMAT_FLAC) return;
+                    if (fmt_of(p) != AFG_FORMAT_FLAC) return;
                     for (size_t q = 0; q < p.flac.frames.size(); q++) {
                         afg_flac_frame f = p.flac.frames[q];
                         f.in_off += res_base[i]; f.out_off += out.files[i].pcm_off; f.sf_index += (uint32_t)sf_base[i];
@@ -644,7 +652,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             uint8_t *hb = (uint8_t *)h_in.p + rec_pad;
             parallel_for(nf, threads, [&](size_t i) {
                 Parsed &p = parsed[i];
-                if (p.format != AFG_FORMAT_QOA) return;
+                if (fmt_of(p) != AFG_FORMAT_QOA) return;
                 for (size_t k = 0; k < p.qoa.size(); k++) {
                     afg_qoa_frame f = p.qoa[k];
                     f.byte_off += qbyte_base[i]; f.out_off += out.files[i].pcm_off;
@@ -680,7 +688,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 const size_t target = std::max<size_t>((mp3_blocks + want - 1) / want, 8192);
                 Chunk c{ 0, 0, 0, 0, nullptr, nullptr };
                 for (size_t i = 0; i < nf; i++) {
-                    if (parsed[i].format != AFG_FORMAT_MP3) continue;
+                    if (fmt_of(parsed[i]) != AFG_FORMAT_MP3) continue;
                     if (c.blocks == 0) { c.f0 = i; c.blk0 = mp3_blk_base[i]; }
                     c.blocks += parsed[i].mp3.blocks();
                     c.f1 = i + 1;
@@ -701,7 +709,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 std::vector<uint8_t> channels;
                 for (size_t i = c.f0; i < c.f1; i++) {
                     const Parsed &p = parsed[i];
-                    if (p.format != AFG_FORMAT_MP3) continue;
+                    if (fmt_of(p) != AFG_FORMAT_MP3) continue;
                     for (uint32_t g : p.mp3.run_granules) {
                         granules.push_back(g);
                         channels.push_back((uint8_t)p.mp3.channels);
@@ -717,7 +725,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 if (rc || e != hipSuccess) break;
                 for (size_t i = c.f0; i < c.f1 && e == hipSuccess; i++) {
                     const Parsed &p = parsed[i];
-                    if (p.format != AFG_FORMAT_MP3 || !p.mp3.blocks()) continue;
+                    if (fmt_of(p) != AFG_FORMAT_MP3 || !p.mp3.blocks()) continue;
                     // the batch path parsed this file straight into page-locked staging: one asynchronous copy per file
                     // into the packed device plane (a file parsed on its own comes from ordinary memory)
                     e = hipMemcpyAsync((float *)d_in.p + mp3_blk_base[i] * 576, p.mp3_coef(), p.mp3.blocks() * 576 * sizeof(float),
@@ -735,7 +743,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 // straight from the device PCM plane into the page-locked result plane
                 for (size_t i = c.f0; i < c.f1 && e == hipSuccess; i++) {
                     const Parsed &p = parsed[i];
-                    if (p.format != AFG_FORMAT_MP3) continue;
+                    if (fmt_of(p) != AFG_FORMAT_MP3) continue;
                     const float *src = (const float *)d_pcm.p + mp3_blk_base[i] * 576;
                     float *dst = (float *)out.plane.p + out.files[i].pcm_off;
                     const std::vector<afg_mp3::Copy> &cp = p.mp3.copies;
@@ -782,7 +790,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                     float *hw = (float *)h_spec.p + c.spec0;
                     parallel_for(c.f1 - c.f0, threads, [&](size_t k) {
                         Parsed &p = parsed[c.f0 + k];
-                        if (p.format != AFG_FORMAT_OGG || !p.ogg.n_spec) return;
+                        if (fmt_of(p) != AFG_FORMAT_OGG || !p.ogg.n_spec) return;
                         std::memcpy(hw + c.spec_at[k], p.ogg.spectra(), p.ogg.n_spec * sizeof(float));
                         std::vector<float>().swap(p.ogg.spec);         // the big one: released here, by many threads
                     });
@@ -822,23 +830,23 @@ metadata:
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
         Decoded &dcd = out.files[i];
-        dcd.format = p.format;
-        if (p.format == AFG_FORMAT_FLAC) {
+        dcd.format = fmt_of(p);
+        if (fmt_of(p) == AFG_FORMAT_FLAC) {
             dcd.channels = (int)p.fi.channels;
             dcd.samplerate = (float)p.fi.sample_rate;
             dcd.frames = (int64_t)(p.flac.out_samples / p.fi.channels);
             dcd.declared_frames = (int64_t)p.fi.total_samples;      // totalSampleCount / channels, stream.d:1631
-        } else if (p.format == AFG_FORMAT_MP3) {
+        } else if (fmt_of(p) == AFG_FORMAT_MP3) {
             dcd.channels = p.mp3.channels;
             dcd.samplerate = (float)p.mp3.hz;
             dcd.frames = (int64_t)(p.mp3.pcm_samples / (uint64_t)p.mp3.channels);
             dcd.declared_frames = (int64_t)(p.mp3.declared_samples / (uint64_t)p.mp3.channels);   // stream.d:1737
-        } else if (p.format == AFG_FORMAT_OGG) {
+        } else if (fmt_of(p) == AFG_FORMAT_OGG) {
             dcd.channels = p.ogg.channels;
             dcd.samplerate = (float)p.ogg.sample_rate;
             dcd.frames = (int64_t)p.ogg.pcm_frames;
             dcd.declared_frames = (int64_t)p.ogg.total_samples;    // stb_vorbis_stream_length_in_samples, stream.d:1696
-        } else if (p.format == AFG_FORMAT_QOA) {
+        } else if (fmt_of(p) == AFG_FORMAT_QOA) {
             dcd.channels = (int)p.qi.channels;
             dcd.samplerate = (float)p.qi.samplerate;
             dcd.frames = (int64_t)(p.qoa.back().out_off / p.qi.channels) + p.qoa.back().samples;
@@ -1143,6 +1151,34 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
         BatchOut *owner = new (std::nothrow) BatchOut;
         if (!owner) return AFG_ERR_OOM;
         std::unique_ptr<BatchOut> guard(owner);
+        // The FLAC and QOA files are complete now: their device stage (mostly PCIe time) runs on a second host thread
+        // while this one parses the MP3 and Ogg files.  Each call of decode_parsed only touches the files it owns.
+        std::vector<uint8_t> own_early((size_t)n_files, 0), own_late((size_t)n_files, 1);
+        size_t n_early = 0;
+        for (size_t i = 0; i < (size_t)n_files; i++)
+            if (parsed[i].format == AFG_FORMAT_FLAC || parsed[i].format == AFG_FORMAT_QOA) { own_early[i] = 1; own_late[i] = 0; n_early++; }
+        struct EarlyJob {
+            std::thread th;
+            int rc = AFG_OK;
+            std::string error;
+            ~EarlyJob() { if (th.joinable()) th.join(); }
+        } early_job;
+        const bool split = n_early && (total_bound || ogg_total);
+        if (split) {
+            owner->early.reset(new BatchOut);
+            BatchOut *eo = owner->early.get();
+            const FlacStage *fs = flac_stage.words ? &flac_stage : nullptr;
+            early_job.th = std::thread([&, eo, fs] {
+                try {
+                    early_job.rc = decode_parsed(parsed, data, length, 1 /* no helpers: they are parsing */, *eo, nullptr, nullptr, fs,
+                                                 own_early.data());
+                } catch (...) {
+                    afg::set_error("out of host memory");
+                    early_job.rc = AFG_ERR_OOM;
+                }
+                if (early_job.rc) early_job.error = afg_last_error();
+            });
+        }
         StagingPool::Lease mp3_stage;
         Mp3Stage stage;
         Mp3Pipe pipe;
@@ -1218,20 +1254,26 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             if (fallback) stage.blocks = 0;                   // decode_parsed does those files from their own buffers
         }
         int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr, ogg_stage.floats ? &ogg_stage : nullptr,
-                               flac_stage.words ? &flac_stage : nullptr);
+                               split ? nullptr : (flac_stage.words ? &flac_stage : nullptr), split ? own_late.data() : nullptr);
         tm.lap("decode_parsed total");
+        if (split) {
+            early_job.th.join();
+            tm.lap("flac / qoa thread joined");
+            if (!rc && early_job.rc) { afg::set_error("%s", early_job.error.c_str()); rc = early_job.rc; }
+        }
         if (rc) return rc;
         afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));
         if (!items) return AFG_ERR_OOM;
         for (int i = 0; i < n_files; i++) {
-            const Decoded &d = owner->files[(size_t)i];
+            const BatchOut *src = (split && own_early[(size_t)i]) ? owner->early.get() : owner;
+            const Decoded &d = src->files[(size_t)i];
             items[i].status = d.status;
             items[i].message = d.message;
             items[i].format = d.format;
             items[i].channels = d.channels;
             items[i].samplerate = d.samplerate;
             items[i].frames = d.frames;
-            const float *plane = d.in_mp3_plane ? (const float *)owner->mp3_plane.p : (const float *)owner->plane.p;
+            const float *plane = d.in_mp3_plane ? (const float *)owner->mp3_plane.p : (const float *)src->plane.p;
             items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)plane + d.pcm_off : nullptr;
         }
         out->n_files = n_files;
