@@ -334,9 +334,15 @@ __global__ __launch_bounds__(64 * kAWaves) void celt_imdct_kernel(
         const Geo g = geo_of(fr);
         const int F = g.F;
         float xa[15], xb[15];
-        load_inputs(xa, xb, coeffs, fr, g, l);
-        frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
-        frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+        if (is_960(g)) {
+            load_inputs(xa, xb, coeffs, fr, geo_960(), l);
+            frame_fft(z, xa, xb, fr, geo_960(), ltab, lwin, tb, l, act);
+            frame_rest(z, fr, geo_960(), ltab, lwin, tb, l, act);
+        } else {
+            load_inputs(xa, xb, coeffs, fr, g, l);
+            frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
+            frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+        }
         // frame positions [60, F) -> this frame's slots
         if (paired) {
             f32x2 *o = (f32x2 *)(out + out_even);
