@@ -266,3 +266,38 @@ def test_seek_and_tell_invariants(gpu, which):
     assert s.seekPosition(n - 1) and s.tellPosition() == n - 1
     assert s.readSamplesFloat(np.zeros(16 * ch, np.float32)) == 1        # exactly one frame is left
     assert s.seekPosition(n) and s.readSamplesFloat(np.zeros(16 * ch, np.float32)) == 0
+
+
+def test_batch_decode_from_several_host_threads(gpu):
+    """Distinct calls share no mutable state but the pools (page-locked buffers, helper threads, table caches): four host
+    threads decoding different mixed batches at once get what they get alone."""
+    import threading
+    rng = np.random.default_rng(77)
+    mp3 = open(MP3_FIXTURE, "rb").read()
+    ogg = open(OGG_FIXTURE, "rb").read()
+    pool = [mp3, ogg, mp3[:len(mp3) * 2 // 3], ogg[:len(ogg) * 3 // 4]]
+    for i in range(3):
+        pool.append(fb.encode_file(make_pcm(1500 + 400 * i, 1 + i % 2, 16, 90 + i), 16, 512)[0])
+        pool.append(qoa_file(5120 + 333 * i, 1 + i % 2, 44100, 95 + i)[0])
+    batches = [[pool[int(k)] for k in rng.integers(0, len(pool), 24)] for _ in range(4)]
+    alone = [afgpu.batch_decode(b, n_threads=4) for b in batches]
+    got = [None] * len(batches)
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                got[k] = afgpu.batch_decode(batches[k], n_threads=4)
+        except Exception as e:                                   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(len(batches))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for a, g in zip(alone, got):
+        assert len(a) == len(g)
+        for x, y in zip(a, g):
+            assert (x["status"], x["frames"], x["channels"], x["format"]) == (y["status"], y["frames"], y["channels"], y["format"])
+            if x["pcm"] is not None:
+                assert np.array_equal(x["pcm"].view(np.uint32), y["pcm"].view(np.uint32))
