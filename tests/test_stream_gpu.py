@@ -301,3 +301,27 @@ def test_batch_decode_from_several_host_threads(gpu):
             assert (x["status"], x["frames"], x["channels"], x["format"]) == (y["status"], y["frames"], y["channels"], y["format"])
             if x["pcm"] is not None:
                 assert np.array_equal(x["pcm"].view(np.uint32), y["pcm"].view(np.uint32))
+
+
+def test_flac_lossless_round_trip_over_the_parameter_space(gpu):
+    """encode (test encoder) -> batch decode (HIP) returns the PCM exactly, for 1..8 channels, 8..24 bits and block
+    sizes from 16 to 4608 -- checked against the input itself (stream.d:505-511 conversion), not against the oracle."""
+    rng = np.random.default_rng(2024)
+    cases, files = [], []
+    for k in range(14):
+        ch = int(rng.integers(1, 9))
+        bps = int(rng.choice([8, 12, 16, 20, 24]))
+        block = int(rng.choice([16, 100, 576, 1024, 4096, 4608]))
+        n = int(block * rng.integers(1, 4) + rng.integers(0, block))
+        pcm = make_pcm(n, ch, bps, 300 + k)
+        kw = dict(orders=(0, 1, 2, 4, 8, 12, 32)) if block >= 64 else dict(orders=(0, 1, 2, 4))
+        if ch == 2:
+            kw["assignments"] = (enc.INDEPENDENT, enc.LEFT_SIDE, enc.RIGHT_SIDE, enc.MID_SIDE)
+        files.append(fb.encode_file(pcm, bps, block, sample_rate=44100, **kw)[0])
+        cases.append((pcm, bps))
+    got = afgpu.batch_decode(files, n_threads=4)
+    for g, (pcm, bps) in zip(got, cases):
+        assert g["status"] == 0 and g["frames"] == len(pcm) and g["channels"] == pcm.shape[1]
+        s32 = (pcm.astype(np.int64) << (32 - bps)).astype(np.int32)
+        want = (s32.astype(np.float64) * (1.0 / 2147483647.0)).astype(np.float32)
+        assert np.array_equal(g["pcm"].reshape(-1, pcm.shape[1]).view(np.uint32), want.view(np.uint32))
