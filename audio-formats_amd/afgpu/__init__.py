@@ -55,10 +55,11 @@ ABI_SYMBOLS = [
     "afg_get_length_in_frames", "afg_get_samplerate", "afg_read_samples_float", "afg_close",
     "afg_can_seek", "afg_seek_position", "afg_tell_position",
     "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse", "afg_mp3_parse", "afg_mp3_parsed_free", "afg_vorbis_parse", "afg_vorbis_parsed_free",
-    "afg_batch_decode", "afg_batch_free",
+    "afg_batch_decode", "afg_batch_free", "afg_batch_decode_ex", "afg_set_device", "afg_get_device", "afg_host_pool_trim",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
     "afg_copy_probe_hip",
-    "afg_qoa_encoded_size", "afg_qoa_encode_hip", "afg_wav_encoded_size", "afg_wav_encode", "afg_opus_output_hip",
+    "afg_qoa_encoded_size", "afg_qoa_encode_hip", "afg_wav_encoded_size", "afg_wav_encode", "afg_wav_encode_dithered",
+    "afg_opus_output_hip",
 ]
 
 
@@ -99,11 +100,16 @@ class BatchItem(C.Structure):
                 ("samplerate", C.c_float), ("frames", C.c_int64), ("pcm", C.POINTER(C.c_float))]
 
 
+class BatchOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_threads", C.c_int), ("n_devices", C.c_int), ("devices", C.POINTER(C.c_int))]
+
+
 class BatchResult(C.Structure):
     _fields_ = [("n_files", C.c_int), ("items", C.POINTER(BatchItem)), ("owner", C.c_void_p)]
 
 
 _lib = None
+RAND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)      # afg_rand_fn
 
 
 def mp3_flags(block_type=0, n_long_bands=0, aa_bands=31):
@@ -139,6 +145,8 @@ def lib():
     L.afg_wav_encoded_size.restype = u64
     L.afg_wav_encode.argtypes = [vp, u64, u32, u32, C.c_int, vp, u64]
     L.afg_wav_encode.restype = u64
+    L.afg_wav_encode_dithered.argtypes = [vp, u64, u32, u32, C.c_int, RAND_FN, vp, u32, vp, u64]
+    L.afg_wav_encode_dithered.restype = u64
     L.afg_mp3_plan_create.argtypes = [C.POINTER(vp), u32, vp, vp, u32]
     L.afg_mp3_plan_destroy.argtypes = [vp]
     L.afg_mp3_plan_destroy.restype = None
@@ -188,6 +196,10 @@ def lib():
                                 C.POINTER(C.c_size_t)]
     L.afg_batch_decode.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(BatchResult)]
     L.afg_batch_free.argtypes = [C.POINTER(BatchResult)]
+    L.afg_batch_decode_ex.argtypes = [vp, vp, C.c_int, C.POINTER(BatchOpts), C.POINTER(BatchResult)]
+    L.afg_set_device.argtypes = [C.c_int]
+    L.afg_get_device.restype = C.c_int
+    L.afg_host_pool_trim.restype = u64
     L.afg_batch_free.restype = None
     L.afg_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.afg_device_free.argtypes = [vp]
@@ -358,8 +370,9 @@ def qoa_encode_layout(shapes, samplerate=44100):
     return recs, pcm, out
 
 
-def wav_encode(samples, samplerate, fmt=WAV_FP32LE):
-    """Host WAV writer (afg_wav_encode): samples float32 [frames, channels] -> file bytes."""
+def wav_encode(samples, samplerate, fmt=WAV_FP32LE, dither=None, rng_max=0x7fffffff):
+    """Host WAV writer: samples float32 [frames, channels] -> file bytes.  dither=None: afg_wav_encode (no dither);
+    dither="libc": TPDF dither from libc rand() as the reference; dither=callable: draws in [0, rng_max] from it."""
     x = np.ascontiguousarray(samples, np.float32)
     if x.ndim == 1:
         x = x[:, None]
@@ -368,7 +381,12 @@ def wav_encode(samples, samplerate, fmt=WAV_FP32LE):
     if not size:
         raise AfgError("afg_wav_encode: bad arguments")
     out = np.zeros(size, np.uint8)
-    n = int(lib().afg_wav_encode(x.ctypes.data, frames, ch, int(samplerate), int(fmt), out.ctypes.data, size))
+    if dither is None:
+        n = int(lib().afg_wav_encode(x.ctypes.data, frames, ch, int(samplerate), int(fmt), out.ctypes.data, size))
+    else:
+        cb = RAND_FN() if dither == "libc" else RAND_FN(lambda _user: int(dither()))
+        n = int(lib().afg_wav_encode_dithered(x.ctypes.data, frames, ch, int(samplerate), int(fmt), cb, None, int(rng_max),
+                                              out.ctypes.data, size))
     if n != size:
         raise AfgError("afg_wav_encode failed")
     return out.tobytes()
@@ -510,7 +528,9 @@ class BatchDecoded:
     """Result of afg_batch_decode kept in the library's (page-locked) result plane: ``items[i]`` are dicts whose
     ``pcm`` arrays are views, valid until ``close()`` (or the end of a ``with`` block)."""
 
-    def __init__(self, files, n_threads=0):
+    def __init__(self, files, n_threads=0, devices=None):
+        """devices: None = the current device; "all" = every visible device; or a list of device indices."""
+        self.devices = devices
         self._bufs = [bytes(f) for f in files]
         n = len(self._bufs)
         self._ptrs = (C.c_char_p * max(n, 1))(*self._bufs)
@@ -523,7 +543,13 @@ class BatchDecoded:
     def run(self):
         """The timed part: host parse + device restore + copy back (no Python-side copies)."""
         self.close()
-        check(lib().afg_batch_decode(self._ptrs, self._lens, len(self._bufs), self.n_threads, C.byref(self._res)))
+        opts = BatchOpts(C.sizeof(BatchOpts), self.n_threads, 0, None)
+        if self.devices == "all":
+            opts.n_devices = -1
+        elif self.devices is not None:
+            devs = (C.c_int * len(self.devices))(*[int(d) for d in self.devices])
+            opts.n_devices, opts.devices = len(self.devices), devs
+        check(lib().afg_batch_decode_ex(self._ptrs, self._lens, len(self._bufs), C.byref(opts), C.byref(self._res)))
         self._open = True
         self.items = []
         for i in range(self._res.n_files):
@@ -551,9 +577,26 @@ class BatchDecoded:
     __del__ = close
 
 
-def batch_decode(files, n_threads=0):
-    """afg_batch_decode: list of dicts (status, message, format, channels, samplerate, frames, pcm ndarray copy)."""
-    with BatchDecoded(files, n_threads) as res:
+def set_device(device):
+    """afg_set_device: make `device` current for the calling host thread (and keep torch's notion in step)."""
+    check(lib().afg_set_device(int(device)))
+    try:
+        import torch
+        torch.cuda.set_device(int(device))
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+
+
+def get_device():
+    d = int(lib().afg_get_device())
+    if d < 0:
+        check(d)
+    return d
+
+
+def batch_decode(files, n_threads=0, devices=None):
+    """afg_batch_decode(_ex): list of dicts (status, message, format, channels, samplerate, frames, pcm ndarray copy)."""
+    with BatchDecoded(files, n_threads, devices) as res:
         return [dict(it, pcm=None if it["pcm"] is None else it["pcm"].copy()) for it in res.items]
 
 

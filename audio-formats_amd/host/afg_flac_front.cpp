@@ -295,8 +295,15 @@ size_t flac_res_bound(const uint8_t *d, size_t n)
 {
     FlacInfo fi;
     if (!flac_open(d, n, fi) || !fi.total_samples || !fi.channels) return 0;
-    const uint64_t words = (fi.total_samples + (fi.max_block ? fi.max_block : 65535)) * fi.channels;
-    return words > ((uint64_t)1 << 40) ? 0 : (size_t)words;
+    // STREAMINFO's length is only a claim: the staged plane is also bounded by what the bytes can hold.  A frame takes
+    // at least 10 bytes (sync + header + CRC-8, one byte of subframe header and one of payload per channel, CRC-16) and
+    // carries at most max_block samples per channel, so a 42-byte file declaring 2^36 samples reserves a few blocks,
+    // not terabytes of page-locked memory.  Past the hard cap the file takes the grow-as-parsed path instead.
+    const uint64_t block = fi.max_block ? fi.max_block : 65535;
+    const uint64_t by_bytes = ((uint64_t)n / 10 + 1) * block;
+    const uint64_t frames = std::min<uint64_t>(fi.total_samples + block, by_bytes);
+    const uint64_t words = frames * fi.channels;
+    return words > ((uint64_t)1 << 31) ? 0 : (size_t)words;
 }
 
 bool flac_parse_into(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec, int32_t *res_dst, size_t cap)

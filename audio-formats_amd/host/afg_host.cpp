@@ -104,7 +104,7 @@ struct PinnedBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; }
     int alloc(size_t bytes)
     {
-        hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
         if (e != hipSuccess) { p = nullptr; afg::set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return AFG_ERR_OOM; }
         return AFG_OK;
     }
@@ -140,10 +140,23 @@ public:
         void *p = nullptr;
         const size_t cap = bytes ? bytes : 1;
         if (getenv("AFG_TRACE")) fprintf(stderr, "[afg] staging pool miss: pinning %.1f MB\n", cap / 1e6);
-        hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, cap, hipHostMallocPortable);
         if (e != hipSuccess) { afg::set_error("hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); return AFG_ERR_OOM; }
         out.pool = this; out.p = p; out.cap = cap;
         return AFG_OK;
+    }
+    // Frees every buffer that is not on lease (afg_host_pool_trim): a long-lived process gives the pinned memory back.
+    size_t trim()
+    {
+        std::vector<std::pair<void *, size_t>> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            drop.swap(free_);
+            held_ = 0;
+        }
+        size_t bytes = 0;
+        for (auto &b : drop) { (void)hipHostFree(b.first); bytes += b.second; }
+        return bytes;
     }
 private:
     void give_back(void *p, size_t cap)
@@ -234,6 +247,9 @@ private:
     bool stop_ = false;
 };
 HelperPool g_helpers;
+// A multi-device batch runs one host thread per device, each with its own helpers (g_helpers serves one job at a time)
+HelperPool g_device_helpers[16];
+thread_local HelperPool *tl_helpers = nullptr;
 
 template <typename F>
 void parallel_for(size_t n, unsigned threads, F fn)
@@ -248,7 +264,7 @@ void parallel_for(size_t n, unsigned threads, F fn)
             fn(i);
         }
     };
-    g_helpers.run(threads - 1, work);
+    (tl_helpers ? *tl_helpers : g_helpers).run(threads - 1, work);
 }
 
 struct BatchOut {
@@ -885,7 +901,15 @@ afg_stream *afg_open_from_memory(const uint8_t *data, size_t length)
         const size_t lp[1] = { length };
         if (decode_parsed(parsed, dp, lp, 1, out) != AFG_OK) { s->error = kErrorDecodingError; return s; }
         s->d = out.files[0];
-        if (out.plane_floats) s->pcm.assign((const float *)out.plane.p, (const float *)out.plane.p + out.plane_floats);
+        // keep the delivered samples only: a file's PCM starts at pcm_off of the plane (an Ogg stream whose delivery
+        // starts late -- deferred discard, leading packets with nothing to take -- has its first piece further in)
+        const size_t want = (size_t)std::max<int64_t>(s->d.frames, 0) * (size_t)std::max(s->d.channels, 0);
+        if (want && s->d.status == AFG_OK) {
+            if (s->d.pcm_off + want > out.plane_floats) { s->error = kErrorDecodingError; return s; }
+            const float *src = (const float *)out.plane.p + s->d.pcm_off;
+            s->pcm.assign(src, src + want);
+        }
+        s->d.pcm_off = 0;
         s->error = s->d.status == AFG_OK ? nullptr : kErrorDecodingError;
     } catch (...) {
         s->error = kErrorDecoderInitializationFailed;      // out of memory while decoding
@@ -1082,13 +1106,23 @@ int afg_qoa_parse(const uint8_t *data, size_t length, uint32_t *channels, uint32
     return AFG_OK;
 }
 
-int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_files, int n_threads, afg_batch_result *out)
+}  // extern "C"
+
+namespace {
+
+// What a batch result owns: one BatchOut per device the batch ran on.
+struct BatchOwner {
+    std::vector<std::unique_ptr<BatchOut>> parts;
+};
+
+// The whole batch path for the files handed in, on the calling thread's current device; fills items[0..n_files).
+int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_files, int n_threads, afg_batch_item *items,
+                        std::unique_ptr<BatchOut> &keep)
 {
-    try {
-        if (!out || n_files < 0 || (n_files && (!data || !length))) return AFG_ERR_INVALID;
-        out->n_files = 0; out->items = nullptr; out->owner = nullptr;
-        if (n_files == 0) return AFG_OK;
+    {
         if (int rc = afg::require_device()) return rc;
+        int cur_dev = 0;
+        AFG_HIP_CHECK(hipGetDevice(&cur_dev));
         StageTimer tm;
         std::vector<Parsed> parsed((size_t)n_files);
         // default: one thread per physical core of an SMT-2 host (half the logical CPUs).  With one thread per logical
@@ -1168,8 +1202,10 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             owner->early.reset(new BatchOut);
             BatchOut *eo = owner->early.get();
             const FlacStage *fs = flac_stage.words ? &flac_stage : nullptr;
-            early_job.th = std::thread([&, eo, fs] {
+            early_job.th = std::thread([&, eo, fs, cur_dev] {
                 try {
+                    // HIP's current device is per host thread and starts at 0: this thread works for the caller's device
+                    if (hipSetDevice(cur_dev) != hipSuccess) { afg::set_error("hipSetDevice(%d) failed", cur_dev); early_job.rc = AFG_ERR_HIP; return; }
                     early_job.rc = decode_parsed(parsed, data, length, 1 /* no helpers: they are parsing */, *eo, nullptr, nullptr, fs,
                                                  own_early.data());
                 } catch (...) {
@@ -1262,8 +1298,6 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             if (!rc && early_job.rc) { afg::set_error("%s", early_job.error.c_str()); rc = early_job.rc; }
         }
         if (rc) return rc;
-        afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));
-        if (!items) return AFG_ERR_OOM;
         for (int i = 0; i < n_files; i++) {
             const BatchOut *src = (split && own_early[(size_t)i]) ? owner->early.get() : owner;
             const Decoded &d = src->files[(size_t)i];
@@ -1276,9 +1310,144 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
             const float *plane = d.in_mp3_plane ? (const float *)owner->mp3_plane.p : (const float *)src->plane.p;
             items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)plane + d.pcm_off : nullptr;
         }
+        keep = std::move(guard);
+        return AFG_OK;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int afg_set_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        afg::set_error("no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return AFG_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        afg::set_error("afg_set_device(%d): %d device(s) visible", device, n);
+        return AFG_ERR_INVALID;
+    }
+    AFG_HIP_CHECK(hipSetDevice(device));
+    return afg::require_device();
+}
+
+uint64_t afg_host_pool_trim(void) { return (uint64_t)g_staging.trim(); }
+
+int afg_get_device(void)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        afg::set_error("hipGetDevice failed: %s", hipGetErrorString(e));
+        return e == hipErrorNoDevice ? AFG_ERR_NO_DEVICE : AFG_ERR_HIP;
+    }
+    return dev;
+}
+
+int afg_batch_decode_ex(const uint8_t *const *data, const size_t *length, int n_files, const afg_batch_opts *opts, afg_batch_result *out)
+{
+    try {
+        if (!out || n_files < 0 || (n_files && (!data || !length))) return AFG_ERR_INVALID;
+        out->n_files = 0; out->items = nullptr; out->owner = nullptr;
+        if (opts && opts->struct_size < sizeof(afg_batch_opts)) { afg::set_error("afg_batch_opts.struct_size too small"); return AFG_ERR_INVALID; }
+        if (n_files == 0) return AFG_OK;
+        // ---- which devices ----
+        std::vector<int> devs;
+        const int want = opts ? opts->n_devices : 0;
+        if (want != 0) {
+            const int visible = afg_device_count();
+            if (visible <= 0) { afg::set_error("no HIP device available; this library has no CPU fallback"); return AFG_ERR_NO_DEVICE; }
+            if (want < 0) for (int d = 0; d < visible; d++) devs.push_back(d);
+            else for (int k = 0; k < want; k++) {
+                const int d = opts->devices ? opts->devices[k] : k;
+                if (d < 0 || d >= visible) { afg::set_error("afg_batch_decode_ex: device %d of %d visible", d, visible); return AFG_ERR_INVALID; }
+                devs.push_back(d);
+            }
+            if (devs.size() > 16) { afg::set_error("afg_batch_decode_ex: at most 16 devices"); return AFG_ERR_INVALID; }
+        }
+        const int n_threads = opts ? opts->n_threads : 0;
+        auto owner = std::unique_ptr<BatchOwner>(new BatchOwner);
+        afg_batch_item *items = (afg_batch_item *)std::calloc((size_t)n_files, sizeof(afg_batch_item));
+        if (!items) return AFG_ERR_OOM;
+        struct ItemsGuard { afg_batch_item *p; ~ItemsGuard() { std::free(p); } } items_guard{ items };
+        if (devs.size() <= 1) {
+            // one device: the caller's current one, or the one named
+            int restore = -1;
+            if (devs.size() == 1) {
+                int cur = 0;
+                AFG_HIP_CHECK(hipGetDevice(&cur));
+                if (cur != devs[0]) { restore = cur; AFG_HIP_CHECK(hipSetDevice(devs[0])); }
+            }
+            owner->parts.emplace_back();
+            const int rc = batch_decode_device(data, length, n_files, n_threads, items, owner->parts.back());
+            if (restore >= 0) (void)hipSetDevice(restore);
+            if (rc) return rc;
+        } else {
+            // Files are independent (stream.d:1363-1434 is all per-instance): the batch shards by file, longest file first
+            // onto the least loaded device (compressed bytes stand for decode work), no exchange between devices.
+            const size_t nd = devs.size();
+            std::vector<size_t> order((size_t)n_files);
+            for (size_t i = 0; i < order.size(); i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return length[a] > length[b]; });
+            std::vector<std::vector<size_t>> mine(nd);
+            std::vector<uint64_t> load(nd, 0);
+            for (size_t f : order) {
+                size_t best = 0;
+                for (size_t k = 1; k < nd; k++) if (load[k] < load[best]) best = k;
+                mine[best].push_back(f);
+                load[best] += length[f] + 1;
+            }
+            for (auto &v : mine) std::sort(v.begin(), v.end());
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const unsigned total_threads = n_threads > 0 ? (unsigned)n_threads : (hw >= 16 ? hw / 2 : hw);
+            const int per_dev_threads = (int)std::max<unsigned>(1u, total_threads / (unsigned)nd);
+            owner->parts.resize(nd);
+            struct Part {
+                std::vector<const uint8_t *> data;
+                std::vector<size_t> len;
+                std::vector<afg_batch_item> items;
+                int rc = AFG_OK;
+                std::string error;
+            };
+            std::vector<Part> parts(nd);
+            int caller_dev = 0;
+            AFG_HIP_CHECK(hipGetDevice(&caller_dev));
+            auto run_part = [&](size_t k) {
+                Part &p = parts[k];
+                try {
+                    for (size_t f : mine[k]) { p.data.push_back(data[f]); p.len.push_back(length[f]); }
+                    p.items.assign(mine[k].size(), afg_batch_item{});
+                    if (mine[k].empty()) return;
+                    if (hipSetDevice(devs[k]) != hipSuccess) { p.rc = AFG_ERR_HIP; p.error = "hipSetDevice failed"; return; }
+                    tl_helpers = &g_device_helpers[k];
+                    p.rc = batch_decode_device(p.data.data(), p.len.data(), (int)mine[k].size(), per_dev_threads, p.items.data(), owner->parts[k]);
+                    tl_helpers = nullptr;
+                    if (p.rc) p.error = afg_last_error();
+                } catch (...) {
+                    tl_helpers = nullptr;
+                    p.rc = AFG_ERR_OOM; p.error = "out of host memory";
+                }
+            };
+            {
+                std::vector<std::thread> th;
+                for (size_t k = 1; k < nd; k++) th.emplace_back(run_part, k);
+                run_part(0);
+                for (auto &t : th) t.join();
+            }
+            (void)hipSetDevice(caller_dev);
+            for (size_t k = 0; k < nd; k++)
+                if (parts[k].rc) { afg::set_error("device %d: %s", devs[k], parts[k].error.c_str()); return parts[k].rc; }
+            for (size_t k = 0; k < nd; k++)
+                for (size_t j = 0; j < mine[k].size(); j++) items[mine[k][j]] = parts[k].items[j];
+        }
+        items_guard.p = nullptr;
         out->n_files = n_files;
         out->items = items;
-        out->owner = guard.release();
+        out->owner = owner.release();
         return AFG_OK;
     } catch (...) {
         afg::set_error("out of host memory");
@@ -1286,11 +1455,20 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
     }
 }
 
+int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_files, int n_threads, afg_batch_result *out)
+{
+    afg_batch_opts o;
+    std::memset(&o, 0, sizeof(o));
+    o.struct_size = (uint32_t)sizeof(o);
+    o.n_threads = n_threads;
+    return afg_batch_decode_ex(data, length, n_files, &o, out);
+}
+
 void afg_batch_free(afg_batch_result *r)
 {
     if (!r) return;
     std::free(r->items);
-    delete (BatchOut *)r->owner;
+    delete (BatchOwner *)r->owner;
     r->items = nullptr; r->owner = nullptr; r->n_files = 0;
 }
 

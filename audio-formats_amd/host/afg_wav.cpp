@@ -2,10 +2,14 @@
 //
 // Header exactly as the reference lays it out: "RIFF" <len> "WAVE" "fmt " 16 <tag> <channels> <rate> <bytes/s>
 // <block align> <bits> "data" <len>, no pad byte after an odd-sized data chunk (the reference writes none), lengths as
-// finalizeEncoding computes them (:571-606).  Sample conversions are writeSamples' (:482-527) with dither off.
+// finalizeEncoding computes them (:571-606).  Sample conversions are writeSamples' (:482-527); the TPDF dither of
+// :674-701 (on by default in the reference, EncodingOptions.enableDither stream.d:66) draws from libc rand() there:
+// afg_wav_encode_dithered takes the generator as a callback so that the result is reproducible and testable.
 #include "../../include/afg.h"
 
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -36,8 +40,59 @@ uint64_t afg_wav_encoded_size(uint64_t frames, uint32_t channels, int format)
     return 44 + frames * (uint64_t)channels * (uint64_t)ss;
 }
 
+namespace {
+
+int libc_rand(void *) { return std::rand(); }
+
+// TPDFDither.process for one sample (wav.d:680-699): scale to LSBs, add the offset and two uniform draws, floor,
+// scale back, clamp.  Two draws per sample, in this order.
+struct Dither {
+    afg_rand_fn fn;
+    void *user;
+    double rand_max;
+    double one(double x, double scale) const
+    {
+        const double TUNE0 = 0.25, TUNE1 = TUNE0 * 0.5;
+        x *= scale;
+        x += (0.5 - 0.5 * (TUNE0 + TUNE1));
+        x += TUNE0 * (fn(user) / rand_max);
+        x += TUNE1 * (fn(user) / rand_max);
+        x = std::floor(x);
+        x /= scale;
+        if (x < -1.0) x = -1.0;
+        if (x > 1.0) x = 1.0;
+        return x;
+    }
+};
+
+uint64_t wav_write(const float *samples, uint64_t frames, uint32_t channels, uint32_t samplerate, int format,
+                   const Dither *dither, uint8_t *out, uint64_t cap);
+
+}  // namespace
+
 uint64_t afg_wav_encode(const float *samples, uint64_t frames, uint32_t channels, uint32_t samplerate, int format,
                         uint8_t *out, uint64_t cap)
+{
+    return wav_write(samples, frames, channels, samplerate, format, nullptr, out, cap);
+}
+
+uint64_t afg_wav_encode_dithered(const float *samples, uint64_t frames, uint32_t channels, uint32_t samplerate, int format,
+                                 afg_rand_fn rng, void *rng_user, uint32_t rng_max, uint8_t *out, uint64_t cap)
+{
+    Dither d;
+    d.fn = rng ? rng : libc_rand;
+    d.user = rng_user;
+    d.rand_max = rng ? (double)rng_max : (double)RAND_MAX;
+    if (rng && rng_max == 0) return 0;
+    return wav_write(samples, frames, channels, samplerate, format, &d, out, cap);
+}
+
+}  // extern "C"
+
+namespace {
+
+uint64_t wav_write(const float *samples, uint64_t frames, uint32_t channels, uint32_t samplerate, int format,
+                   const Dither *dither, uint8_t *out, uint64_t cap)
 {
     const uint64_t size = afg_wav_encoded_size(frames, channels, format);
     if (!size || !out || cap < size || (!samples && frames * channels)) return 0;
@@ -61,18 +116,24 @@ uint64_t afg_wav_encode(const float *samples, uint64_t frames, uint32_t channels
     const uint64_t n = frames * channels;
     switch (format) {
     case AFG_WAV_S8:
-        for (uint64_t i = 0; i < n; i++) { const double x = samples[i]; *p++ = (uint8_t)(int8_t)(int)(128.5 + x * 127.0); }      // :486-487
+        for (uint64_t i = 0; i < n; i++) {
+            double x = samples[i];
+            if (dither) x = dither->one(x, 127.0);                         // ditherInput(.., 127.0f), :483
+            *p++ = (uint8_t)(int8_t)(int)(128.5 + x * 127.0);              // :486-487
+        }
         break;
     case AFG_WAV_S16LE:
         for (uint64_t i = 0; i < n; i++) {
-            const double x = samples[i];
+            double x = samples[i];
+            if (dither) x = dither->one(x, 32767.0);                       // :497
             const int s = (int)(32768.5 + x * 32767.0) - 32768;            // :501-502
             put16(p, (uint32_t)s & 0xffff);
         }
         break;
     case AFG_WAV_S24LE:
         for (uint64_t i = 0; i < n; i++) {
-            const double x = samples[i];
+            double x = samples[i];
+            if (dither) x = dither->one(x, 8388607.0);                     // :513
             const int s = (int)(8388608.5 + x * 8388607.0) - 8388608;      // :517-518
             p[0] = (uint8_t)s; p[1] = (uint8_t)(s >> 8); p[2] = (uint8_t)(s >> 16); p += 3;
         }
@@ -87,4 +148,4 @@ uint64_t afg_wav_encode(const float *samples, uint64_t frames, uint32_t channels
     return (uint64_t)(p - out);
 }
 
-}  // extern "C"
+}  // namespace

@@ -1,250 +1,424 @@
 #!/usr/bin/env python3
 """bench.py -- decoded samples/s of the batched transform stage on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by
-torch.distributed.run, one rank per GPU).  A step is one pass of the hot path over one
-device-resident batch: BASELINE.json configs[1], 1024 MP3 CBR-128k stereo files of 60 s
-(2 297 frames x 2 granules x 2 channels x 576 lines each), i.e. one launch of the MP3
-transform kernel.  Files are independent, so N GPUs each own a 1024-file shard (weak
-scaling, no collective on the data path); `value` is the samples all ranks decoded
-divided by the slowest rank's time.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the
+environment this process starts N rank processes itself (one per GPU, before anything here touches a
+GPU) and relays rank 0's line; under `torch.distributed.run` it is one of the N ranks.  Ranks only
+meet in a `gloo` barrier and a MAX-reduce of the elapsed time: files are independent, so there is
+no collective on the data path and no RCCL.
 
-Rank 0 prints ONE JSON line with the `roofline` of the dominant kernel (measured with
-events on the launch stream inside the timed region) and the `cpu_baseline`: the CPU
-oracle (a scalar C port of the reference algorithms; the D reference cannot be built
-here) timed on this box's host cores on a bounded sample of the same workload.
+A *step* is one pass of the hot path over the device-resident batches of the configuration:
+
+  --config c234 (default)  BASELINE.json's metric "batched MP3+OGG+FLAC": configs[1] + [2] + [3] resident
+                           together -- 1024 x 60 s MP3 (C2), 1024 x 2584-packet Ogg Vorbis (C3),
+                           4096 x 323-frame FLAC (C4) -- one launch of each codec's kernel(s) per step.
+                           Every rank owns such a set (weak scaling).
+  --config c2 | c3 | c4    one of them alone.
+  --config c5              configs[4]: the 65 536-file mixed MP3 / Vorbis / FLAC / Opus-CELT corpus sharded by file
+                           over the ranks (strong scaling: the same corpus at every N), walked in waves of
+                           <= 8192 files that fit one GPU; a step is one pass over the rank's whole shard.
+
+Rank 0 prints ONE JSON line with `roofline` (per-kernel event times measured on the launch stream
+inside the timed region; the dominant kernel at the top level) and `cpu_baseline` (the CPU oracle, a
+scalar C port of the reference algorithms -- the D reference cannot be built here -- timed by a native
+thread pool on this box's host cores on a bounded sample of the same workload).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "audio-formats_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-MP3_BYTES_PER_GRCH = 2304 + 4 + 2304   # algorithmic bytes: f32 spectrum + flag word in, f32 PCM out
-FRAMES_PER_FILE = 2297           # 60 s of 128 kbps MPEG-1 Layer III at 44.1 kHz
-GRANULES_PER_FILE = 2 * FRAMES_PER_FILE
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "decoded samples/sec (batched MP3+OGG+FLAC) at 1/2/4/8 MI355X vs CPU ref"
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--files", type=int, default=1024, help="files per GPU (BASELINE config: 1024)")
-    ap.add_argument("--seg", type=int, default=0, help="granules per wavefront segment (0 = library default)")
+    ap.add_argument("--config", default="c234", choices=["c234", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--files", type=int, default=1024, help="C2/C3 files per GPU (C4 has 4x as many); BASELINE: 1024")
+    ap.add_argument("--c5-files", type=int, default=65536, help="files of the mixed corpus (BASELINE: 65536)")
+    ap.add_argument("--seg", type=int, default=0, help="MP3 granules per wavefront segment (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
-    ap.add_argument("--no-extra", action="store_true", help="skip the Vorbis (C3) / FLAC (C4) kernel timings")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-full-fetch", action="store_true", help="skip the MP3 leg that fetches all 32 subbands")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="testing only: ranks beyond the visible devices share them (rank % devices); the line says so")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(coef_files, flag_files, seconds):
-    """Oracle (scalar C port of minimp3.d's transform stage) on the host cores: one file per task."""
-    import threading
+# ----------------------------------------------------------------------------------------------------------------
+# launcher: N rank processes, started before this process has touched a GPU (it never does)
+# ----------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AFG_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [c for c in codes if c]
+    return bad[0] if bad else 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle under a native thread pool (oracle/cpu_bench.c)
+# ----------------------------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """Logical CPUs this process may run on, and the cgroup CPU quota (None = unlimited / unknown)."""
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                         # cgroup v2
+            q, per = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:        # cgroup v1
+                q = float(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                per = float(fh.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            quota = None
+    return cpus, quota
+
+
+def cpu_tasks_from_parts(parts, files_per_part):
+    """Oracle tasks for the first files of each device-resident part (inputs copied to host once)."""
+    import numpy as np
     import oraclelib
-    oraclelib.lib()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    nfiles = len(coef_files)
-    granules = np.array([GRANULES_PER_FILE], np.uint32)
-    channels = np.array([2], np.uint8)
-    tls = threading.local()
+    tasks, keep, desc = [], [], []
+    for p in parts:
+        nfile = files_per_part.get(p.name, 0)
+        if p.name == "mp3":
+            off = 0
+            for f in range(nfile):
+                ng = int(p.granules[f])
+                nb = ng * 2
+                coef = p.coef[off * 576:(off + nb) * 576].cpu().numpy()
+                flags = p.flags[off:off + nb].cpu().numpy().view(np.uint32).copy()
+                keep += [coef, flags]
+                tasks.append(oraclelib.bench_task(0, ng, 2, 0, 0, coef, flags, None, None, nb * 576))
+                off += nb
+        elif p.name == "vorbis":
+            so, oo = p.plan.offsets()
+            pk = 0
+            for f in range(nfile):
+                npk = int(p.plan.packets[f])
+                s0 = int(so[pk])
+                s1 = int(so[pk + npk]) if pk + npk < p.plan.total_packets else p.plan.spec_floats
+                o0 = int(oo[pk])
+                o1 = int(oo[pk + npk]) if pk + npk < p.plan.total_packets else p.plan.out_floats
+                spec = p.spec[s0:s1].cpu().numpy()
+                pf = p.plan.pflags[pk:pk + npk].copy()
+                soff = (so[pk:pk + npk] - np.uint64(s0)).astype(np.uint64)
+                ooff = (oo[pk:pk + npk] - np.uint64(o0)).astype(np.uint64)
+                keep += [spec, pf, soff, ooff]
+                tasks.append(oraclelib.bench_task(1, npk, 2, int(p.plan.bs0[f]), int(p.plan.bs1[f]), spec, pf, soff, ooff, o1 - o0))
+                pk += npk
+        elif p.name == "flac":
+            fr0 = 0
+            for f in range(nfile):
+                nfr = int(p.frames_per_file[f])
+                frames = p.frames_np[fr0:fr0 + nfr].copy()
+                w0 = int(frames["in_off"][0])
+                words = nfr * 2 * p.block_size
+                frames["in_off"] -= np.uint64(w0)
+                frames["out_off"] -= np.uint64(w0)
+                frames["sf_index"] -= np.uint32(2 * fr0)
+                sub = p.sub_np[2 * fr0:2 * (fr0 + nfr)].copy()
+                res = p.res[w0:w0 + words].cpu().numpy()
+                keep += [frames, sub, res]
+                tasks.append(oraclelib.bench_task(2, nfr, 2, 0, 0, frames, sub, res, None, words))
+                fr0 += nfr
+        elif p.name == "celt":
+            r0 = 0
+            for f in range(nfile):
+                nfr = int(p.frames_per_file[f])
+                nrec = 2 * nfr
+                recs = p.recs_np[r0:r0 + nrec].copy()
+                c0, o0 = int(recs["coef_off"].min()), int(recs["out_off"].min())
+                recs["coef_off"] -= np.uint64(c0)
+                recs["out_off"] -= np.uint64(o0)
+                rb = np.array([0, nfr, nrec], np.uint64)
+                coef = p.coef[c0:c0 + nrec * 960].cpu().numpy()
+                keep += [recs, rb, coef]
+                tasks.append(oraclelib.bench_task(3, 2, 2, 0, 0, rb, recs, coef, None, nrec * 960))
+                r0 += nrec
+        desc.append(f"{nfile} {p.name}")
+    return tasks, keep, desc
 
-    def one(i):
-        if not hasattr(tls, "pcm"):
-            tls.pcm = np.empty(coef_files[0].size, np.float32)      # per-thread output, no allocation while timing
-        oraclelib.mp3_transform_into(granules, channels, coef_files[i % nfiles], flag_files[i % nfiles], tls.pcm)
-        return tls.pcm.size
 
-    one(0)                                              # page in
-    t0 = time.perf_counter()
-    n1 = one(0)
-    t1 = time.perf_counter() - t0                       # one file, one thread
-    per_pass = max(nfiles, cores)
-    with ThreadPoolExecutor(max_workers=cores) as pool:
-        t0 = time.perf_counter()
-        sum(pool.map(one, range(per_pass)))             # untimed-for-the-result pass: sizes the run
-        pass_s = time.perf_counter() - t0
-        passes = max(1, min(1000, int(seconds / max(pass_s, 1e-3))))
-        t0 = time.perf_counter()
-        done = sum(pool.map(one, range(per_pass * passes)))
-        dt = time.perf_counter() - t0
+def cpu_baseline(parts, seconds):
+    """The oracle on the host cores, one file per task, files in the workload's own proportions."""
+    import oraclelib
+    cpus, quota = host_cpu_info()
+    threads = max(1, int(min(cpus, quota) if quota else cpus))
+    # files per pass in the proportion the workload holds them (C2:C3:C4 = 1:1:4), scaled to give every thread work
+    counts = {p.name: 0 for p in parts}
+    nfiles = {"mp3": lambda p: len(p.granules), "vorbis": lambda p: len(p.plan.packets),
+              "flac": lambda p: len(p.frames_per_file), "celt": lambda p: len(p.frames_per_file)}
+    least = min(nfiles[p.name](p) for p in parts)
+    for p in parts:
+        ratio = max(1, round(nfiles[p.name](p) / least))
+        counts[p.name] = min(nfiles[p.name](p), ratio * max(2, min(16, threads // 8)))
+    tasks, keep, desc = cpu_tasks_from_parts(parts, counts)
+    t1_wall, t1_cpu, t1_samples = oraclelib.bench_run(tasks, 1, 1)            # single thread, one pass
+    single = t1_samples / t1_wall
+    est_pass = t1_wall / threads
+    # size the run: whole passes, each pass must offer >= 4 tasks per thread so the tail does not dominate
+    reps_min = max(1, -(-4 * threads // len(tasks)))
+    reps = max(reps_min, int(seconds / max(est_pass, 1e-6)))
+    reps = min(reps, max(reps_min, int(3 * seconds / max(est_pass, 1e-6))))
+    wall, cpu_s, samples = oraclelib.bench_run(tasks, reps, threads)
     return {
-        "value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-        "sample": f"{per_pass * passes} file-decodes ({nfiles} distinct 60 s stereo files of the same batch, "
-                  f"{passes} passes) through oracle/mp3_transform.c, one file per thread task, {dt:.1f} s wall",
-        "single_thread_value": n1 / t1,
+        "value": samples / wall, "unit": "samples/s", "cores": threads, "kind": "port",
+        "sample": f"{reps} passes over {' + '.join(desc)} files of this workload (one file per task, native pthread pool, "
+                  f"oracle/*.c scalar -O2), {wall:.1f} s wall",
+        "single_thread_value": single,
+        "logical_cpus": cpus, "cgroup_cpu_quota": quota,
+        "achieved_parallelism": cpu_s / wall, "parallel_efficiency_vs_single_thread": (samples / wall) / (single * threads),
     }
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# rank process
+# ----------------------------------------------------------------------------------------------------------------
+def load_traffic(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as fh:
+            return json.load(fh)
+    except Exception:
+        return None
+
+
+def run_rank(args, world, rank, local_rank):
+    import numpy as np
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)            # barrier + MAX-reduce of a timer only
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if not args.oversubscribe:
+            raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {ndev} device(s) are visible")
+        local_rank %= ndev
+    import afgpu
+    from afgpu import corpus
+    afgpu.lib()
+    afgpu.set_device(local_rank)                     # the C library's device for this (the only) host thread
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_sum(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def timed_steps(wl, steps, warmup, want_events=True):
+        """W warm-up + K timed steps of one resident workload; returns (elapsed s, per-part ms lists)."""
+        for _ in range(warmup):
+            wl.step(stream)
+        barrier()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(wl.parts) + 1)] for _ in range(steps)] if want_events else None
+        t0 = time.perf_counter()
+        for i in range(steps):
+            wl.step(stream, ev[i] if ev else None)       # events on the stream the kernels are launched on
+        barrier()
+        elapsed = time.perf_counter() - t0
+        per_part = None
+        if ev:
+            per_part = [[ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(steps)] for k in range(len(wl.parts))]
+        return elapsed, per_part
+
+    kern = {}                                         # name -> dict(ms list, samples, alg_bytes, units)
+    parity, cpu, extra = {}, None, {}
+    if args.config == "c5":
+        man = corpus.c5_manifest(args.c5_files)
+        waves = corpus.c5_shard_waves(man, rank, world)
+        elapsed, my_samples = 0.0, 0
+        for wi, ids in enumerate(waves):
+            wl = corpus.build_c5_wave(man, ids, dev)
+            e, per_part = timed_steps(wl, args.steps, args.warmup)
+            elapsed += e
+            my_samples += wl.samples
+            for p, ms in zip(wl.parts, per_part):
+                k = kern.setdefault(p.name, {"kernel": p.kernel, "ms": [0.0] * args.steps, "samples": 0, "alg_bytes": 0, "units": 0})
+                k["ms"] = [a + b for a, b in zip(k["ms"], ms)]
+                k["samples"] += p.samples; k["alg_bytes"] += p.alg_bytes; k["units"] += p.units
+            if rank == 0 and wi == 0:
+                import oraclelib
+                parity = {p.name: p.check(oraclelib) for p in wl.parts}
+                if not args.no_cpu_baseline and world == 1:
+                    cpu = cpu_baseline(wl.parts, args.cpu_seconds)
+            del wl
+            torch.cuda.empty_cache()
+        # ranks with fewer waves still meet the others' barriers: every rank has the same wave count by construction
+        total_samples = reduce_sum(float(my_samples))
+        scaling = "strong"
+        workload = (f"{args.c5_files}-file mixed corpus (40% MP3 / 25% Ogg Vorbis / 25% FLAC / 10% Opus-CELT, durations "
+                    f"log-uniform 4-30 s, seed {corpus.C5_SEED:#x}) file-sharded over {world} GPU(s) by LPT on frames x channels, "
+                    f"{len(waves)} wave(s) of <= {corpus.C5_WAVE_FILES} files per GPU, device-resident records -> PCM")
+        cfg_extra = {"files": args.c5_files, "waves_per_gpu": len(waves), "files_this_gpu": int(sum(len(w) for w in waves)),
+                     "lpt_imbalance": corpus.sharding.imbalance(man["work"], world)}
+    else:
+        which = {"c234": ("mp3", "vorbis", "flac"), "c2": ("mp3",), "c3": ("vorbis",), "c4": ("flac",)}[args.config]
+        wl = corpus.build_c234(dev, rank, which, args.files, args.seg)
+        elapsed, per_part = timed_steps(wl, args.steps, args.warmup)
+        my_samples = wl.samples
+        for p, ms in zip(wl.parts, per_part):
+            kern[p.name] = {"kernel": p.kernel, "ms": ms, "samples": p.samples, "alg_bytes": p.alg_bytes, "units": p.units}
+        total_samples = float(my_samples) * world
+        scaling = "weak"
+        names = {"mp3": f"{args.files} x MP3 CBR-128k stereo 60 s (C2)", "vorbis": f"{args.files} x Ogg Vorbis 2048/256 stereo, 2584 packets (C3)",
+                 "flac": f"{4 * args.files} x FLAC 16-bit stereo, 323 frames of 4096, LPC order 8/12 (C4)"}
+        workload = " + ".join(names[w] for w in which) + " per GPU, resident together; device-resident transform-stage records -> PCM"
+        cfg_extra = {"files_per_gpu": {w: (4 * args.files if w == "flac" else args.files) for w in which}}
+        if rank == 0:
+            import oraclelib
+            parity = {p.name: p.check(oraclelib, 2) for p in wl.parts}
+            # MP3 with every subband fetched (no AFG_MP3_NZ_BANDS declaration): the same kernel moving all algorithmic bytes
+            mp3 = next((p for p in wl.parts if p.name == "mp3"), None)
+            if mp3 is not None and not args.no_full_fetch:
+                ms = []
+                for i in range(2 + min(args.steps, 10)):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream); mp3.launch(stream, full_fetch=True); e1.record(stream)
+                    torch.cuda.synchronize()
+                    if i >= 2:
+                        ms.append(e0.elapsed_time(e1))
+                extra["mp3_full_fetch"] = {"avg_kernel_ms": sum(ms) / len(ms), "frac": mp3.alg_bytes / (sum(ms) / len(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "note": "flag words without AFG_MP3_NZ_BANDS: all 32 subbands of every block fetched"}
+            # device-to-device copy with the library's streaming copy kernel: the copy rate this box sustains for a
+            # read-N / write-N stream, reported next to the 8 TB/s spec the roofline is priced against
+            nbytes = 2 << 30
+            try:
+                a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                cms = []
+                for i in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream); afgpu.copy_probe(b, a, nbytes); e1.record(stream)
+                    torch.cuda.synchronize()
+                    if i:
+                        cms.append(e0.elapsed_time(e1))
+                extra["measured_copy_GBs"] = 2 * nbytes / (min(cms) * 1e-3) / 1e9
+                del a, b
+            except torch.cuda.OutOfMemoryError:
+                extra["measured_copy_GBs"] = None
+            if not args.no_cpu_baseline and world == 1:
+                cpu = cpu_baseline(wl.parts, args.cpu_seconds)
+
+    elapsed = reduce_max(elapsed)
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    # ---- the line ----
+    steps = args.steps
+    value = total_samples * steps / elapsed
+    traffic = load_traffic("r02_traffic.json") or {}
+    kernels = []
+    for name, k in kern.items():
+        avg_ms = sum(k["ms"]) / len(k["ms"])
+        ach = k["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+        t = (traffic.get(args.config) or {}).get(name) if isinstance(traffic.get(args.config), dict) else None
+        tb = t.get("hbm_bytes_per_launch") if t else None
+        kernels.append({"codec": name, "kernel": k["kernel"], "avg_kernel_ms": avg_ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": int(k["alg_bytes"]), "units_per_launch": int(k["units"]),
+                        "samples_per_launch": int(k["samples"]), "samples_per_s": k["samples"] / (avg_ms * 1e-3),
+                        "traffic": tb, "frac_by_traffic": (tb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None})
+    dom = max(kernels, key=lambda d: d["avg_kernel_ms"])
+    step_ms = sum(d["avg_kernel_ms"] for d in kernels)
+    step_bytes = sum(d["algorithmic_bytes_per_launch"] for d in kernels)
+    roofline = {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                "traffic": dom["traffic"], "frac_by_traffic": dom["frac_by_traffic"],
+                "kernel": dom["kernel"], "codec": dom["codec"], "avg_kernel_ms": dom["avg_kernel_ms"],
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                "note": "dominant kernel = the codec with the largest share of a step's time; every kernel of the step is listed in `kernels`",
+                "kernels": kernels,
+                "whole_step": {"algorithmic_bytes": int(step_bytes), "kernel_ms": step_ms,
+                               "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "measured_copy_GBs": extra.get("measured_copy_GBs"), "mp3_full_fetch": extra.get("mp3_full_fetch")}
+    line = {
+        "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "f32 (MP3, Vorbis, CELT) + int32 (FLAC)", "data": "synthetic",
+        "config": dict({"workload": workload, "name": args.config, "samples_per_step": int(total_samples),
+                        "parallelism": f"file-sharded x{world}, no collective on the data path (gloo barrier + MAX of the timer only)"},
+                       **cfg_extra),
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+    }
+    if args.oversubscribe and world > ndev:
+        line["oversubscribed"] = f"{world} ranks on {ndev} device(s): a launcher test, not a scaling point"
+    failed = [n for n, p in parity.items() if p["mismatches"]]
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if failed:
+        sys.stderr.write(f"bench.py: parity failure against the oracle in {failed}\n")
+        return 1
+    return 0
 
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    import afgpu
-    from afgpu import synthetic
-    afgpu.lib()
-
-    # ---- device-resident synthetic batch (this rank's shard of files) -----------------
-    n_files = args.files
-    granules = np.full(n_files, GRANULES_PER_FILE, np.uint32)
-    channels = np.full(n_files, 2, np.uint8)
-    seed = 0xA0D10 + 7919 * rank
-    coef, flags = synthetic.mp3_batch_device(seed, n_files, GRANULES_PER_FILE, dev)
-    plan = afgpu.Mp3Plan(granules, channels, args.seg)
-    assert plan.blocks * 576 == coef.numel()
-    pcm = torch.empty_like(coef)
-    stream = torch.cuda.current_stream()
-    samples_per_step = plan.blocks * 576
-    coef_numel = coef.numel()
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        plan.transform(coef, flags, pcm, None, stream)
-    barrier()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        starts[i].record(stream)                       # same stream the kernel is launched on
-        plan.transform(coef, flags, pcm, None, stream)
-        ends[i].record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
-
-    # device-to-device copy of the same byte volume (spectrum plane -> PCM plane) with the library's streaming
-    # copy kernel: the copy rate this box sustains for a read-N/write-N stream, reported next to the 8 TB/s spec
-    # the roofline is priced against (hipMemcpy / torch copy_ reach only ~4.6-4.9 TB/s on the same buffers)
-    copy_ms = []
-    if rank == 0:
-        scratch = torch.empty_like(coef)
-        for i in range(4):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            afgpu.copy_probe(scratch, coef, coef.numel() * 4)
-            e1.record(stream)
-            torch.cuda.synchronize()
-            if i:
-                copy_ms.append(e0.elapsed_time(e1))
-        del scratch
-
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- parity of this very output against the oracle on the first files --------------
-    parity = None
-    cpu = None
-    if rank == 0:
-        import oraclelib
-        per_file = GRANULES_PER_FILE * 2 * 576
-        ncheck = min(2, n_files)
-        c_h = coef[:ncheck * per_file].cpu().numpy()
-        f_h = flags[:ncheck * GRANULES_PER_FILE * 2].cpu().numpy().view(np.uint32)
-        got = pcm[:ncheck * per_file].cpu().numpy()
-        want = oraclelib.mp3_transform(granules[:ncheck], channels[:ncheck], c_h, f_h)
-        diff = got.astype(np.float64) - want.astype(np.float64)
-        parity = {"files_checked": ncheck, "samples": int(got.size),
-                  "bitwise_mismatches": int((got.view(np.uint32) != want.view(np.uint32)).sum()),
-                  "rms_error": float(np.sqrt(np.mean(diff ** 2))), "max_abs_error": float(np.abs(diff).max())}
-        if not args.no_cpu_baseline and world == 1:
-            nsample = min(n_files, max(8, min(64, os.cpu_count() or 1)))
-            c_s = coef[:nsample * per_file].cpu().numpy().reshape(nsample, -1)
-            f_s = flags[:nsample * GRANULES_PER_FILE * 2].cpu().numpy().view(np.uint32).reshape(nsample, -1)
-            cpu = cpu_baseline([c_s[i] for i in range(nsample)], [f_s[i] for i in range(nsample)],
-                               args.cpu_seconds)
-
-    if rank != 0:
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    total_samples = samples_per_step * args.steps * world
-    value = total_samples / elapsed
-    avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3
-    alg_bytes = plan.blocks * MP3_BYTES_PER_GRCH
-    achieved = alg_bytes / avg_kernel_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_mp3.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if tj.get("files") == n_files and tj.get("seg", 0) == args.seg:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    # ---- the other two codecs of the metric (BASELINE configs[2], configs[3]), kernel-level, N = 1 only ----
-    other = None
-    if world == 1 and not args.no_extra:
-        del coef, pcm, flags
-        torch.cuda.empty_cache()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_codecs
-        other = {}
-        try:
-            other["vorbis_c3"] = bench_codecs.bench_vorbis(dev, 1024, 2584, 3, 1, 0)
-            torch.cuda.empty_cache()
-            other["flac_c4"] = bench_codecs.bench_flac(dev, 4096, 323, 3, 1, False)
-        except Exception as e:          # the headline line must still print
-            other["error"] = repr(e)
-
-    line = {
-        "metric": "decoded samples/sec (batched MP3+OGG+FLAC) at 1/2/4/8 MI355X vs CPU ref",
-        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n_files}-file batched MP3 CBR-128k stereo per GPU "
-                               "(L3 antialias+imdct36/12 + DCT-II + polyphase synth kernel), 60 s files, "
-                               "device-resident dequantised spectra -> interleaved f32 PCM",
-                   "files_per_gpu": n_files, "granule_channels_per_gpu": int(plan.blocks),
-                   "samples_per_step_per_gpu": int(samples_per_step), "segments": plan.segments,
-                   "parallelism": f"file-sharded x{world}, no collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "mp3_transform_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
-                     "measured_copy_GBs": (2 * 4 * coef_numel / (min(copy_ms) * 1e-3) / 1e9) if copy_ms else None,
-                     "algorithmic_bytes_per_launch": int(alg_bytes)},
-        "cpu_baseline": cpu,
-        "parity": parity,
-        "other_workloads": other,
-    }
-    print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1:
+            return launch_ranks(args)                  # before anything in this process touches a GPU
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(env_world)
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if args.gpus != world:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a mislabelled run\n")
+            return 2
+    return run_rank(args, world, rank, local_rank)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

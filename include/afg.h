@@ -337,6 +337,32 @@ int  afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fi
                       afg_batch_result *out);
 void afg_batch_free(afg_batch_result *result);
 
+/* Device selection (files are independent -- stream.d:1363-1434 is all per-instance -- so a batch shards
+ * by file across the GPUs of a node, with no exchange between devices).
+ *   afg_set_device   makes `device` current for the calling host thread (HIP's current device is per thread) and
+ *                    checks that it is a gfx950; plans, *_hip entries, afg_open_from_memory and afg_batch_decode
+ *                    all work on the calling thread's current device.
+ *   afg_batch_decode_ex  the batch entry with options: n_devices = 0 runs on the current device (what
+ *                    afg_batch_decode does), n_devices = -1 on every visible device, n_devices = k > 0 on
+ *                    devices[0..k) (NULL: 0..k-1; a device may be named more than once).  Files are assigned
+ *                    longest-first to the least loaded device; every device gets its own host thread, helper
+ *                    threads (n_threads in total, 0 = one per physical core) and stream set.  Per-file results do
+ *                    not depend on the number of devices. */
+typedef struct afg_batch_opts {
+    uint32_t   struct_size;    /* sizeof(afg_batch_opts) */
+    int        n_threads;
+    int        n_devices;
+    const int *devices;
+} afg_batch_opts;
+
+int  afg_set_device(int device);
+int  afg_get_device(void);                 /* current device of the calling thread, < 0: afg_status */
+int  afg_batch_decode_ex(const uint8_t *const *data, const size_t *length, int n_files, const afg_batch_opts *opts,
+                         afg_batch_result *out);
+/* Page-locked staging buffers are pooled between batch calls (pinning costs about as much as the transfer):
+ * this releases every pooled buffer that is not in use and returns the bytes freed. */
+uint64_t afg_host_pool_trim(void);
+
 /* ========================================================================== *
  *  Utilities used by the host mirror, the tests and bench.py
  * ========================================================================== */
@@ -371,8 +397,10 @@ int afg_qoa_encode_hip(uint32_t n_streams, const afg_qoa_enc_stream *d_streams, 
                        const float *d_pcm_f32, uint8_t *d_out, void *hip_stream);
 
 /* WAV writer (wav.d:365-701, host only): 44-byte RIFF/WAVE header ('fmt ' of 16 bytes, tag 1 for PCM, 3 for IEEE
- * float) followed by the samples; PCM conversions are the reference's (wav.d:482-527) with dither off -- the
- * reference's TPDF dither is driven by libc rand() and is not reproducible. */
+ * float) followed by the samples; PCM conversions are the reference's (wav.d:482-527).  afg_wav_encode is
+ * EncodingOptions.enableDither = false; afg_wav_encode_dithered applies TPDFDither.process (wav.d:674-701) to the
+ * integer formats first, as WAVEncoder.writeSamples does by default (stream.d:66): per sample, in order, two draws
+ * rng(user) / rng_max.  rng = NULL is the reference's generator, libc rand() / RAND_MAX (rng_max ignored). */
 #define AFG_WAV_S8     0
 #define AFG_WAV_S16LE  1
 #define AFG_WAV_S24LE  2
@@ -382,6 +410,9 @@ uint64_t afg_wav_encoded_size(uint64_t frames, uint32_t channels, int format);  
 /* Writes the whole file into `out` (capacity `cap`); returns the bytes written, 0 on bad arguments / short buffer. */
 uint64_t afg_wav_encode(const float *samples, uint64_t frames, uint32_t channels, uint32_t samplerate, int format,
                         uint8_t *out, uint64_t cap);
+typedef int (*afg_rand_fn)(void *user);        /* a draw in [0, rng_max] */
+uint64_t afg_wav_encode_dithered(const float *samples, uint64_t frames, uint32_t channels, uint32_t samplerate, int format,
+                                 afg_rand_fn rng, void *rng_user, uint32_t rng_max, uint8_t *out, uint64_t cap);
 
 /* Streaming device-to-device copy (16-byte aligned) used by bench.py to measure the copy rate this device
  * actually sustains, the practical ceiling the HBM-bound kernels are compared with next to the 8 TB/s spec. */

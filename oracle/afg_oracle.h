@@ -103,6 +103,8 @@ typedef struct afgo_vorbis_tables {
 } afgo_vorbis_tables;
 
 int  afgo_vorbis_tables_init(afgo_vorbis_tables *t, int n);  /* stb_vorbis2.d:883-898 */
+/* Which legal D evaluation of the table expressions to use (0 = default, see vorbis_transform.c); tests only. */
+void afgo_vorbis_set_table_mode(int mode);
 void afgo_vorbis_tables_free(afgo_vorbis_tables *t);
 
 /* In-place n/2 spectrum -> n time samples, stb_vorbis2.d:1941-2242.
@@ -252,12 +254,20 @@ typedef struct afgo_celt_frame {
     uint32_t pad2;
 } afgo_celt_frame;           /* 48 bytes */
 
+/* 0 = tables in x87 real (default), 1 = in double (targets where real == double); tests only. */
+void afgo_celt_set_table_mode(int mode);
 void afgo_celt_imdct_half(int N, float *dst, const float *src, int stride, float scale);   /* dopus.d:1611-1637 */
 void afgo_celt_frame_channel(afgo_celt_state *f, const afgo_celt_frame *fr, const float *coeffs,
                              float *out, int out_stride);                                   /* dopus.d:3680-3702 */
 void afgo_celt_transform(uint32_t n_chan, const uint64_t *rec_base, const afgo_celt_frame *recs,
                          const float *coeffs, float *out, afgo_celt_state *states);
 void afgo_opus_output(uint64_t n, const float *in, int16_t *out_i16, float *out_f32);   /* dopus.d:7923-7926, stream.d:480 */
+
+/* ------------------------------------------------------------- WAV out -- */
+typedef int (*afgo_rand_fn)(void *user);
+void afgo_tpdf_dither(double *inout, int frames, double scaleFactor, afgo_rand_fn rng, void *user, double rand_max);  /* wav.d:674-701 */
+int  afgo_wav_pcm(const float *in, int samples, int bits, int enable_dither, afgo_rand_fn rng, void *user, double rand_max,
+                  int32_t *out);                                                                                     /* wav.d:474-527 */
 
 #ifdef __cplusplus
 }

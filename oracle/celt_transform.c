@@ -28,6 +28,9 @@ typedef struct {
 
 static const long double k_pi_real = 3.14159265358979323846264338327950288L;    /* std.math.PI */
 
+static int g_celt_table_mode = 0;
+void afgo_celt_set_table_mode(int mode) { g_celt_table_mode = mode == 1; }
+
 static int imdct15_init(imdct15_ctx *s, int N)                 /* :1465-1517 */
 {
     int len2 = 15 * (1 << N), len = 2 * len2;
@@ -38,17 +41,30 @@ static int imdct15_init(imdct15_ctx *s, int N)                 /* :1465-1517 */
     s->tmp = (cpx *)malloc(sizeof(cpx) * (size_t)len);
     s->twiddle_exptab = (cpx *)malloc(sizeof(cpx) * (size_t)s->len4);
     if (!s->tmp || !s->twiddle_exptab) return -1;
+    /* std.math.PI is a `real`: 80-bit x87 on the x86 targets the reference is built for (mode 0, the default and what the
+     * product builds), plain double where real == double (mode 1, e.g. AArch64).  tests/test_oracle_numeric_readings.py
+     * measures that both give the same PCM within the 1e-5 RMS tolerance. */
     for (int i = 0; i < s->len4; i++) {
-        s->twiddle_exptab[i].re = (float)cosl(2 * k_pi_real * (i + 0.125 + s->len4) / len);
-        s->twiddle_exptab[i].im = (float)sinl(2 * k_pi_real * (i + 0.125 + s->len4) / len);
+        if (g_celt_table_mode == 0) {
+            s->twiddle_exptab[i].re = (float)cosl(2 * k_pi_real * (i + 0.125 + s->len4) / len);
+            s->twiddle_exptab[i].im = (float)sinl(2 * k_pi_real * (i + 0.125 + s->len4) / len);
+        } else {
+            s->twiddle_exptab[i].re = (float)cos(2 * (double)k_pi_real * (i + 0.125 + s->len4) / len);
+            s->twiddle_exptab[i].im = (float)sin(2 * (double)k_pi_real * (i + 0.125 + s->len4) / len);
+        }
     }
     for (int i = 0; i < 6; i++) {
         int NN = 15 * (1 << i);
         s->exptab[i] = (cpx *)malloc(sizeof(cpx) * (size_t)(NN > 19 ? NN : 19));
         if (!s->exptab[i]) return -1;
         for (int j = 0; j < NN; j++) {
-            s->exptab[i][j].re = (float)cosl(2 * k_pi_real * j / NN);
-            s->exptab[i][j].im = (float)sinl(2 * k_pi_real * j / NN);
+            if (g_celt_table_mode == 0) {
+                s->exptab[i][j].re = (float)cosl(2 * k_pi_real * j / NN);
+                s->exptab[i][j].im = (float)sinl(2 * k_pi_real * j / NN);
+            } else {
+                s->exptab[i][j].re = (float)cos(2 * (double)k_pi_real * j / NN);
+                s->exptab[i][j].im = (float)sin(2 * (double)k_pi_real * j / NN);
+            }
         }
     }
     for (int j = 15; j < 19; j++) s->exptab[0][j] = s->exptab[0][j - 15];

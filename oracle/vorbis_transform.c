@@ -41,6 +41,9 @@ static int ilog_vorbis(int32_t n)                           /* :634-650 (log2(1)
 
 static float squaref(float x) { return x * x; }             /* :626-629 */
 
+static int g_table_mode = 0;
+void afgo_vorbis_set_table_mode(int mode) { g_table_mode = (mode >= 0 && mode <= 3) ? mode : 0; }
+
 int afgo_vorbis_tables_init(afgo_vorbis_tables *t, int n)
 {
     int n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
@@ -53,25 +56,51 @@ int afgo_vorbis_tables_init(afgo_vorbis_tables *t, int n)
     t->bitrev = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)n8);
     if (!t->A || !t->B || !t->C || !t->window || !t->bitrev) { afgo_vorbis_tables_free(t); return -1; }
 
-    /* compute_twiddle_factors, :851-866 */
+    /* compute_twiddle_factors, :851-866 / compute_window, :868-873.  M_PI is a float enum (:652), so the D
+     * expression 4*k*M_PI/n has float type -- but D lets an implementation keep float intermediates in higher
+     * precision and std.math.cos(float) has been a float, a double and a real function in different Phobos releases.
+     * g_table_mode selects the reading (tests/test_oracle_numeric_readings.py measures that every one of them gives
+     * the same PCM within the 1e-5 RMS tolerance):
+     *   0  float angle, cos/sin in double                 (default; what the product builds)
+     *   1  float angle, cosf/sinf
+     *   2  angle kept in x87 real, cosl/sinl
+     *   3  float angle, cosl/sinl                                                         */
+    const int mode = g_table_mode;
+#define AFGO_ANG(num, den)  (mode == 2 ? (long double)(num) * (long double)k_pi_f / (long double)(den) \
+                                       : (long double)((float)(num) * k_pi_f / (float)(den)))
+#define AFGO_COS(a) (mode == 1 ? (float)cosf((float)(a)) : mode == 0 ? (float)cos((double)(a)) : (float)cosl(a))
+#define AFGO_SIN(a) (mode == 1 ? (float)sinf((float)(a)) : mode == 0 ? (float)sin((double)(a)) : (float)sinl(a))
     for (int k = 0, k2 = 0; k < n4; ++k, k2 += 2) {
-        float a0 = (float)(4 * k) * k_pi_f / (float)n;
-        float a1 = (float)(k2 + 1) * k_pi_f / (float)n / (float)2;
-        t->A[k2]     = (float) cos((double)a0);
-        t->A[k2 + 1] = (float)-sin((double)a0);
-        t->B[k2]     = (float) cos((double)a1) * 0.5f;
-        t->B[k2 + 1] = (float) sin((double)a1) * 0.5f;
+        long double a0 = AFGO_ANG(4 * k, n);
+        long double a1 = mode == 2 ? (long double)(k2 + 1) * (long double)k_pi_f / (long double)n / 2.0L
+                                   : (long double)((float)(k2 + 1) * k_pi_f / (float)n / (float)2);
+        t->A[k2]     =  AFGO_COS(a0);
+        t->A[k2 + 1] = -AFGO_SIN(a0);
+        t->B[k2]     =  AFGO_COS(a1) * 0.5f;
+        t->B[k2 + 1] =  AFGO_SIN(a1) * 0.5f;
     }
     for (int k = 0, k2 = 0; k < n8; ++k, k2 += 2) {
-        float a2 = (float)(2 * (k2 + 1)) * k_pi_f / (float)n;
-        t->C[k2]     = (float) cos((double)a2);
-        t->C[k2 + 1] = (float)-sin((double)a2);
+        long double a2 = AFGO_ANG(2 * (k2 + 1), n);
+        t->C[k2]     =  AFGO_COS(a2);
+        t->C[k2 + 1] = -AFGO_SIN(a2);
     }
-    /* compute_window, :868-873 */
+    /* compute_window, :868-873: double arithmetic with the float-rounded pi; the inner sine is rounded to float by the
+     * cast before square() (:626).  Modes 2/3 evaluate the sines in real, mode 1 in float. */
     for (int i = 0; i < n2; ++i) {
-        double inner = sin((i - 0 + 0.5) / n2 * 0.5 * (double)k_pi_f);
-        t->window[i] = (float) sin(0.5 * (double)k_pi_f * (double)squaref((float)inner));
+        if (mode == 0) {
+            double inner = sin((i - 0 + 0.5) / n2 * 0.5 * (double)k_pi_f);
+            t->window[i] = (float) sin(0.5 * (double)k_pi_f * (double)squaref((float)inner));
+        } else if (mode == 1) {
+            float inner = sinf((float)((i - 0 + 0.5) / n2 * 0.5 * (double)k_pi_f));
+            t->window[i] = sinf((float)(0.5 * (double)k_pi_f * (double)squaref(inner)));
+        } else {
+            long double inner = sinl((i - 0 + 0.5L) / n2 * 0.5L * (long double)k_pi_f);
+            t->window[i] = (float) sinl(0.5L * (long double)k_pi_f * (long double)squaref((float)inner));
+        }
     }
+#undef AFGO_ANG
+#undef AFGO_COS
+#undef AFGO_SIN
     /* compute_bitreverse, :875-881 */
     int ld = ilog_vorbis(n) - 1;
     for (int i = 0; i < n8; ++i)

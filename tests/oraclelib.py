@@ -319,3 +319,48 @@ def celt_transform(rec_base, recs, coeffs, out_total, states=None):
                               np.ascontiguousarray(coeffs, np.float32), out,
                               states.ctypes.data if states is not None else None)
     return out
+
+
+# ------------------------------------------------------- CPU baseline pool ------
+class BenchTask(C.Structure):
+    _fields_ = [("codec", C.c_int32), ("n", C.c_uint32), ("channels", C.c_uint32), ("bs0", C.c_uint16), ("bs1", C.c_uint16),
+                ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("d", C.c_void_p), ("out_floats", C.c_uint64)]
+
+
+def bench_task(codec, n, channels, bs0, bs1, a, b, c, d, out_floats):
+    """One file for oracle/cpu_bench.c (the arrays must stay alive while the pool runs)."""
+    def ptr(x):
+        if x is None:
+            return None
+        assert x.flags.c_contiguous
+        return x.ctypes.data
+    return BenchTask(codec, n, channels, bs0, bs1, ptr(a), ptr(b), ptr(c), ptr(d), out_floats)
+
+
+def bench_run(tasks, repeats, threads):
+    """afgo_bench_run: (wall seconds, CPU seconds summed over the workers, output values produced)."""
+    L = lib()
+    L.afgo_bench_run.argtypes = [C.POINTER(BenchTask), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.afgo_bench_run.restype = C.c_double
+    arr = (BenchTask * len(tasks))(*tasks)
+    cpu, samples = C.c_double(0), C.c_uint64(0)
+    wall = L.afgo_bench_run(arr, len(tasks), int(repeats), int(threads), C.byref(cpu), C.byref(samples))
+    if wall < 0:
+        raise RuntimeError("afgo_bench_run failed")
+    return wall, cpu.value, samples.value
+
+
+# ------------------------------------------------------------ WAV out ------
+RAND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+def wav_pcm(x, bits, dither=None, rng_max=0x7fffffff):
+    """The integer samples WAVEncoder.writeSamples writes for float input (wav.d:474-527).  dither: None = off,
+    "libc" = the reference's rand(), or a callable returning draws in [0, rng_max]."""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    out = np.zeros(x.size, np.int32)
+    L = lib()
+    L.afgo_wav_pcm.argtypes = [f32p, C.c_int, C.c_int, C.c_int, RAND_FN, C.c_void_p, C.c_double, i32p]
+    cb = RAND_FN() if dither in (None, "libc") else RAND_FN(lambda _u: int(dither()))
+    assert L.afgo_wav_pcm(x, x.size, bits, int(dither is not None), cb, None, float(rng_max), out) == 0
+    return out

@@ -1,0 +1,276 @@
+"""Multi-device execution and the C5 mixed corpus on the device (BASELINE configs[4]).
+
+* device selection through the C ABI (afg_set_device / afg_get_device / afg_batch_decode_ex);
+* a batch spread over several device entries (the same GPU named twice on a one-GPU box: the sharding, the
+  per-device host threads, stream sets and helper pools are the ones a multi-GPU node runs) gives every file the
+  samples the single-device run gives it;
+* a wave of the mixed corpus (MP3 + Vorbis + FLAC + CELT records resident together) matches the oracle file by file;
+* two rank *processes* (gloo, sharing the GPU) decode their LPT shards with the library: per-file samples are the
+  single-process samples and the oracle's;
+* `bench.py --gpus 2` without torchrun starts two ranks itself.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import afgpu
+import oraclelib
+from afgpu import corpus, sharding
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def small_manifest(n_files=40, seed=0x5C5):
+    """The C5 manifest with every duration divided by 16 (0.25..1.9 s): same mix, same generators, seconds to decode."""
+    m = corpus.c5_manifest(n_files, seed)
+    m["units"] = np.maximum(2, m["units"] // 16)
+    per_unit = np.array([576, 1024, 4096, 960], np.int64)[m["kind"]]
+    m["work"] = m["units"] * per_unit * 2
+    return m
+
+
+def oracle_file_outputs(part):
+    """The oracle's output of every file of a part, from the part's own device-resident inputs."""
+    outs = []
+    if part.name == "mp3":
+        off = 0
+        for ng in part.granules:
+            nb = int(ng) * 2
+            outs.append(oraclelib.mp3_transform([int(ng)], [2], part.coef[off * 576:(off + nb) * 576].cpu().numpy(),
+                                                part.flags[off:off + nb].cpu().numpy().view(np.uint32)))
+            off += nb
+    elif part.name == "vorbis":
+        p = part.plan
+        so, oo = p.offsets()
+        want = oraclelib.vorbis_transform(p.packets, p.channels, p.bs0, p.bs1, p.pflags, so, oo, part.spec.cpu().numpy(), p.out_floats)
+        b = part.file_bounds()
+        outs = [want[int(b[i]):int(b[i + 1])] for i in range(len(b) - 1)]
+    elif part.name == "flac":
+        want = oraclelib.flac_transform(part.frames_np, part.sub_np, part.res.cpu().numpy(), part.samples)
+        b = part.file_bounds()
+        outs = [want[int(b[i]):int(b[i + 1])] for i in range(len(b) - 1)]
+    elif part.name == "celt":
+        want = oraclelib.celt_transform(part.rb_np, part.recs_np, part.coef.cpu().numpy(), part.samples)
+        b = part.file_bounds()
+        outs = [want[int(b[i]):int(b[i + 1])] for i in range(len(b) - 1)]
+    return outs
+
+
+def decode_wave(manifest, ids, device):
+    """file id -> output array (float32 bits or int32) of one wave through the library."""
+    import torch
+    wl = corpus.build_c5_wave(manifest, ids, device, host=True)
+    wl.step(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    got = {}
+    for part in wl.parts:
+        for fid, arr in zip(part.file_ids, part.file_outputs()):
+            got[int(fid)] = arr.view(np.uint32).copy()
+    return got, wl
+
+
+def test_device_selection(gpu):
+    L = afgpu.lib()
+    assert afgpu.device_count() >= 1
+    afgpu.set_device(0)
+    assert afgpu.get_device() == 0
+    rc = L.afg_set_device(afgpu.device_count())          # one past the last device
+    assert rc == -1 and b"device" in L.afg_last_error()
+    assert afgpu.get_device() == 0                       # a refused call leaves the current device alone
+    assert L.afg_host_pool_trim() >= 0
+
+
+def mixed_files():
+    import flac_bitstream as fb
+    import mp3_bitstream as mb
+    import vorbis_bitstream as vb
+    rng = np.random.default_rng(9)
+    files = []
+    for k in range(3):
+        files.append(mb.make_file(20 + k, n_frames=12 + 5 * k, version="mpeg1", sr=0, mode="ms", bitrate_index=9)[0])
+        files.append(vb.make_file(30 + k, n_packets=20 + 7 * k))
+        n = 4096 * (2 + k) + 100 * k
+        t = np.arange(n)
+        pcm = np.stack([9000 * np.sin(0.01 * t) + 800 * rng.standard_normal(n), 7000 * np.sin(0.013 * t + 1) + 800 * rng.standard_normal(n)], 1)
+        files.append(fb.encode_file(pcm.round().astype(np.int64), 16, 4096, orders=(8, 12))[0])
+        files.append(oraclelib.qoa_encode(pcm[:5120 + 777 * k].round().astype(np.int16), 44100)[0].tobytes())
+    files.append(b"not audio at all")
+    return files
+
+
+def test_batch_over_several_device_entries_equals_one_device(gpu):
+    files = mixed_files()
+    one = afgpu.batch_decode(files)
+    assert sum(o["status"] == 0 for o in one) == len(files) - 1 and one[-1]["status"] != 0
+    for devices in ([0], [0, 0], [0, 0, 0], "all"):
+        many = afgpu.batch_decode(files, devices=devices)
+        assert len(many) == len(one)
+        for a, b in zip(one, many):
+            assert (a["status"], a["format"], a["channels"], a["frames"], a["samplerate"]) == \
+                   (b["status"], b["format"], b["channels"], b["frames"], b["samplerate"])
+            if a["pcm"] is not None:
+                assert np.array_equal(a["pcm"].view(np.uint32), b["pcm"].view(np.uint32))
+    # a device that does not exist is refused, nothing is decoded on a fallback
+    with pytest.raises(afgpu.AfgError):
+        afgpu.batch_decode(files, devices=[afgpu.device_count()])
+
+
+def test_stream_api_equals_batch_for_late_delivery_ogg(gpu):
+    """Ogg streams whose delivery starts late (deferred discard / leading packets with nothing to take): the
+    AudioStream surface must serve the same frames afg_batch_decode returns (pcm_off was ignored)."""
+    import vorbis_bitstream as vb
+    late = 0
+    for seed in range(60):
+        data = vb.make_file(seed)
+        rec = afgpu.vorbis_parse(data)
+        first = next((p for p in range(len(rec["take_count"])) if rec["take_count"][p] > 0), None)
+        if first is None or (first <= 1 and rec["take_from"][first] == 0):
+            continue
+        late += 1
+        want = afgpu.batch_decode([data])[0]
+        s = afgpu.AudioStream()
+        s.openFromMemory(data)
+        assert not s.isError()
+        buf = np.zeros(max(1, want["frames"] + 8) * want["channels"], np.float32)
+        got = s.readSamplesFloat(buf)
+        assert got == want["frames"]
+        if got:
+            assert np.array_equal(buf[:got * want["channels"]].view(np.uint32), want["pcm"].reshape(-1).view(np.uint32))
+        s.cleanUp()
+    assert late >= 3
+
+
+def test_unsupported_ogg_does_not_poison_the_batch(gpu):
+    """Vorbis block sizes 64/128 are legal but unsupported: such a file gets its own verdict."""
+    import vorbis_bitstream as vb
+    good = vb.make_file(3)
+    bad = bytearray(vb.make_file(4))
+    # identification header: byte 28 of the packet holds the two block-size exponents; the packet starts after the
+    # 27-byte page header + 1 lacing value.  Exponent 6 = block size 64.  The page CRC is not checked while decoding.
+    pos = 28 + 28
+    bad[pos] = (bad[pos] & 0xF0) | 6
+    res = afgpu.batch_decode([good, bytes(bad), good])
+    assert res[0]["status"] == 0 and res[2]["status"] == 0 and res[1]["status"] != 0
+    assert np.array_equal(res[0]["pcm"], res[2]["pcm"])
+
+
+def test_flac_header_lying_about_its_length_is_bounded(gpu):
+    """A tiny FLAC file declaring 2^36-1 samples must not make the batch pin terabytes."""
+    import flac_bitstream as fb
+    pcm = (np.arange(2 * 4096).reshape(-1, 2) % 1000).astype(np.int64)
+    good, _ = fb.encode_file(pcm, 16, 4096)
+    lie = bytearray(good)
+    # STREAMINFO: 4 'fLaC' + 4 block header + 18 bytes -> 36-bit total samples at bits 108..143 of the block
+    si = 8
+    lie[si + 13] |= 0x0F
+    lie[si + 14:si + 18] = b"\xff\xff\xff\xff"
+    res = afgpu.batch_decode([bytes(lie), good])
+    assert res[1]["status"] == 0
+    assert res[0]["status"] == 0 and res[0]["frames"] == res[1]["frames"]
+    assert np.array_equal(res[0]["pcm"], res[1]["pcm"])
+
+
+@pytest.mark.parametrize("celt_path", ["stream", "split"])
+def test_c5_wave_matches_the_oracle_file_by_file(gpu, monkeypatch, celt_path):
+    monkeypatch.setenv("AFG_CELT_PATH", celt_path)
+    man = small_manifest(48)
+    assert set(man["kind"]) == {0, 1, 2, 3}
+    got, wl = decode_wave(man, np.arange(48), gpu)
+    assert len(got) == 48
+    assert {p.name for p in wl.parts} == {"mp3", "vorbis", "flac", "celt"}
+    for part in wl.parts:
+        for fid, want in zip(part.file_ids, oracle_file_outputs(part)):
+            assert np.array_equal(got[int(fid)], want.view(np.uint32)), (part.name, int(fid))
+
+
+def test_c5_file_results_do_not_depend_on_the_sharding(gpu):
+    man = small_manifest(40)
+    whole, _ = decode_wave(man, np.arange(40), gpu)
+    for world in (2, 4):
+        for r in range(world):
+            for ids in corpus.c5_shard_waves(man, r, world, wave_files=7):
+                part, _ = decode_wave(man, ids, gpu)
+                for fid, arr in part.items():
+                    assert np.array_equal(arr, whole[fid]), (world, r, fid)
+
+
+_RANK_SCRIPT = r"""
+import os, sys, pickle
+import numpy as np
+sys.path[:0] = [os.path.join({root!r}, "audio-formats_amd"), os.path.join({root!r}, "tests")]
+import torch
+import torch.distributed as dist
+import afgpu
+from afgpu import corpus
+from test_multidevice_gpu import small_manifest, decode_wave
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+afgpu.set_device(0)                                  # both ranks share the one GPU of the test box
+man = small_manifest(40)
+mine = {{}}
+for ids in corpus.c5_shard_waves(man, rank, world, wave_files=11):
+    got, _ = decode_wave(man, ids, torch.device("cuda:0"))
+    mine.update(got)
+dist.barrier()
+gathered = [None] * world
+dist.all_gather_object(gathered, mine)
+if rank == 0:
+    with open({out!r}, "wb") as fh:
+        pickle.dump(gathered, fh)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_processes_decode_their_shards_with_the_library(gpu, tmp_path):
+    import pickle
+    man = small_manifest(40)
+    whole, wl = decode_wave(man, np.arange(40), gpu)
+    out = str(tmp_path / "gathered.pkl")
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT, out=out))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    with open(out, "rb") as fh:
+        gathered = pickle.load(fh)
+    assert len(gathered) == 2 and all(len(g) > 0 for g in gathered)
+    assert sorted(list(gathered[0]) + list(gathered[1])) == list(range(40))            # a partition: no file twice, none lost
+    rank_of = sharding.lpt_partition(man["work"], 2)
+    for r, g in enumerate(gathered):
+        for fid, arr in g.items():
+            assert rank_of[fid] == r
+            assert np.array_equal(arr, whole[fid]), fid                                 # per-file samples, not checksums
+    for part in wl.parts:                                                               # ... which are the oracle's
+        for fid, want in zip(part.file_ids, oracle_file_outputs(part)):
+            assert np.array_equal(gathered[rank_of[int(fid)]][int(fid)], want.view(np.uint32))
+
+
+def test_bench_launches_its_own_ranks(gpu):
+    """`bench.py --gpus 2` without torchrun: two rank processes, one JSON line from rank 0, n_gpus = 2."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--config", "c5", "--c5-files", "96",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["name"] == "c5"
+    assert set(line["parity"]) == {"mp3", "vorbis", "flac", "celt"}
+    assert all(p["mismatches"] == 0 for p in line["parity"].values())
+    assert line["value"] > 0 and {k["codec"] for k in line["roofline"]["kernels"]} == {"mp3", "vorbis", "flac", "celt"}
+    # a mislabelled run is refused: --gpus must agree with WORLD_SIZE
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

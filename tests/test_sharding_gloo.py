@@ -1,60 +1,104 @@
-"""N > 1 path on CPU: two gloo ranks shard a batch by file with the product's partition logic,
-decode their shards (the oracle stands in for the kernels here), and agree with a single process:
-same samples regardless of the number of ranks, whole-job count = sum over ranks, time = max."""
+"""N > 1 path on CPU: two gloo ranks shard the mixed corpus (BASELINE configs[4] in miniature) by file with the
+product's partition and wave logic, gather **per-file samples** on rank 0, and agree file by file with a single
+process.  The product has no CPU path, so on this box the oracle stands in for the kernels; the same
+test with the library doing the decoding runs on the GPU box (tests/test_multidevice_gpu.py)."""
 import os
 import socket
 
 import numpy as np
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oraclelib
-from afgpu import sharding, synthetic
+from afgpu import corpus, sharding
 
-GRANULES = [7, 3, 12, 5, 9, 4, 6, 11]
-CHANNELS = [2, 1, 2, 2, 1, 2, 2, 1]
+N_FILES = 24
 
 
-def decode_files(idx):
-    out = {}
-    for f in idx:
-        coef, flags = synthetic.mp3_batch(100 + int(f), [GRANULES[f]], [CHANNELS[f]])
-        out[int(f)] = oraclelib.mp3_transform([GRANULES[f]], [CHANNELS[f]], coef, flags)
-    return out
+def manifest():
+    m = corpus.c5_manifest(N_FILES, 0x5C5)
+    m["units"] = np.maximum(2, m["units"] // 64)
+    per_unit = np.array([576, 1024, 4096, 960], np.int64)[m["kind"]]
+    m["work"] = m["units"] * per_unit * 2
+    return m
+
+
+def decode_file(m, fid, seed=corpus.C5_SEED):
+    """One corpus file from its per-file generators through the oracle (bit pattern of the output)."""
+    kind, n = int(m["kind"][fid]), int(m["units"][fid])
+    ids = [fid]
+    if kind == corpus.KIND_MP3:
+        out = oraclelib.mp3_transform([n], [2], corpus.mp3_coefs_numpy(seed, [n], ids), corpus.mp3_flag_plane(seed, [n], ids))
+    elif kind == corpus.KIND_VORBIS:
+        pf = corpus.vorbis_flag_plane(seed, [n], ids)
+        so, oo, _, total = oraclelib.vorbis_layout(np.array([n], np.uint32), [2], [256], [2048], pf)
+        out = oraclelib.vorbis_transform(np.array([n], np.uint32), np.array([2], np.uint8), np.array([256], np.uint16),
+                                         np.array([2048], np.uint16), pf, so, oo, corpus.vorbis_spec_numpy(seed, pf, [n], ids), total)
+    elif kind == corpus.KIND_FLAC:
+        fr, sf = corpus.flac_records(seed, [n], ids)
+        out = oraclelib.flac_transform(fr, sf, corpus.flac_residuals_numpy(seed, [n], ids), n * 2 * 4096)
+    else:
+        rb, recs, total, _ = corpus.celt_records(seed, [n], ids)
+        out = oraclelib.celt_transform(rb, recs, corpus.celt_coefs_numpy(seed, [n], ids), total)
+    return out.view(np.uint32).copy()
 
 
 def worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    work = np.array(GRANULES) * np.array(CHANNELS)
-    mine = sharding.shard(work, rank, world)
-    dec = decode_files(mine)
-    n = torch.tensor([sum(v.size for v in dec.values())], dtype=torch.int64)
-    csum = torch.tensor([sum(float(np.abs(v).astype(np.float64).sum()) for v in dec.values())], dtype=torch.float64)
-    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
-    dist.all_reduce(n); dist.all_reduce(csum); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.barrier()
+    m = manifest()
+    mine = {}
+    waves = corpus.c5_shard_waves(m, rank, world, wave_files=5)
+    for ids in waves:
+        for fid in ids:
+            mine[int(fid)] = decode_file(m, int(fid))
+        dist.barrier()                                # every rank has the same number of waves
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
     if rank == 0:
-        q.put((int(n.item()), float(csum.item()), float(t.item()), [int(i) for i in mine]))
+        q.put((gathered, len(waves)))
+    dist.barrier()
     dist.destroy_process_group()
 
 
 def test_partition_is_deterministic_and_balanced():
-    work = np.array(GRANULES) * np.array(CHANNELS)
+    m = corpus.c5_manifest()
+    assert len(m["kind"]) == 65536
+    frac = np.bincount(m["kind"], minlength=4) / 65536
+    assert np.allclose(frac, [0.40, 0.25, 0.25, 0.10], atol=0.01)                      # SURVEY 8d mix
+    assert 4.0 <= m["seconds"].min() and m["seconds"].max() <= 30.0
+    assert abs(m["seconds"].mean() - 12.9) < 0.3                                       # log-uniform 4..30 s
+    assert 7.0e10 < m["work"].sum() < 8.0e10                                           # ~7.5e10 samples
+    assert (corpus.c5_manifest()["units"] == m["units"]).all()                         # seeds fixed
     for world in (1, 2, 4, 8):
-        r = sharding.lpt_partition(work, world)
-        assert (r == sharding.lpt_partition(work, world)).all() and r.max() < world
-        assert sorted(np.concatenate([sharding.shard(work, k, world) for k in range(world)])) == list(range(len(work)))
-    assert sharding.imbalance(work, 2) < 1.1
-    big = np.random.default_rng(0).integers(1000, 8000, 4096)
-    assert sharding.imbalance(big, 8) < 1.001
+        r = sharding.lpt_partition(m["work"], world)
+        assert (r == sharding.lpt_partition(m["work"], world)).all() and r.max() < world
+        waves = [corpus.c5_shard_waves(m, k, world) for k in range(world)]
+        assert len({len(w) for w in waves}) == 1                                       # same wave count on every rank
+        assert max(len(x) for w in waves for x in w) <= corpus.C5_WAVE_FILES
+        assert sorted(np.concatenate([np.concatenate(w) for w in waves])) == list(range(65536))
+        assert sharding.imbalance(m["work"], world) < 1.001
 
 
-def test_two_ranks_equal_one_process():
-    single = decode_files(range(len(GRANULES)))
-    want_n = sum(v.size for v in single.values())
-    want_c = sum(float(np.abs(v).astype(np.float64).sum()) for v in single.values())
+def test_file_inputs_do_not_depend_on_their_neighbours():
+    """A file's records and inputs are keyed by its id: the same whether generated alone or inside a plane."""
+    seed = corpus.C5_SEED
+    g = corpus.mp3_coefs_numpy(seed, [3, 5, 4], [7, 9, 11])
+    assert np.array_equal(g[3 * 1152:8 * 1152], corpus.mp3_coefs_numpy(seed, [5], [9]))
+    f = corpus.mp3_flag_plane(seed, [3, 5, 4], [7, 9, 11])
+    assert np.array_equal(f[6:16], corpus.mp3_flag_plane(seed, [5], [9]))
+    fr, sf = corpus.flac_records(seed, [2, 3], [4, 5])
+    fr1, sf1 = corpus.flac_records(seed, [3], [5])
+    assert np.array_equal(sf[4:], sf1) and np.array_equal(fr["assignment"][2:], fr1["assignment"])
+    rb, recs, _, _ = corpus.celt_records(seed, [4, 6], [1, 2])
+    rb1, recs1, _, _ = corpus.celt_records(seed, [6], [2])
+    for k in ("blocks", "pf_period_new", "pf_gains_new"):
+        assert np.array_equal(recs[k][8:], recs1[k])
+
+
+def test_two_ranks_equal_one_process_file_by_file():
+    m = manifest()
+    single = {f: decode_file(m, f) for f in range(N_FILES)}
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
@@ -62,10 +106,15 @@ def test_two_ranks_equal_one_process():
     procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    n, c, t, mine0 = q.get(timeout=120)
+    gathered, n_waves = q.get(timeout=300)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert n == want_n and abs(c - want_c) < 1e-6 * want_c
-    assert t == 0.2                                   # MAX over ranks, as bench.py reports it
-    assert 0 < len(mine0) < len(GRANULES)
+    assert n_waves >= 2 and len(gathered) == 2
+    assert sorted(list(gathered[0]) + list(gathered[1])) == list(range(N_FILES))       # a partition of the corpus
+    rank_of = sharding.lpt_partition(m["work"], 2)
+    for r, g in enumerate(gathered):
+        assert 0 < len(g) < N_FILES
+        for fid, arr in g.items():
+            assert rank_of[fid] == r
+            assert np.array_equal(arr, single[fid]), fid                               # per-file samples, not a checksum

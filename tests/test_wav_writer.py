@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import afgpu
+import oraclelib
 
 
 def header(data):
@@ -60,3 +61,69 @@ def test_bad_arguments():
         afgpu.wav_encode(np.zeros((4, 2), np.float32), 44100, 9)
     assert afgpu.lib().afg_wav_encoded_size(10, 2000, afgpu.WAV_S16LE) == 0              # > 1024 channels, wav.d:400
     assert afgpu.wav_encode(np.zeros((0, 2), np.float32), 44100)[40:44] == b"\0\0\0\0"   # empty file: header only
+
+
+def _lcg(seed):
+    state = [seed & 0x7fffffff]
+
+    def draw():
+        state[0] = (state[0] * 1103515245 + 12345) & 0x7fffffff
+        return state[0]
+    return draw
+
+
+def _pcm_of(data, fmt):
+    raw = np.frombuffer(data[44:], np.uint8)
+    if fmt == afgpu.WAV_S8:
+        return raw.view(np.int8).astype(np.int32)
+    if fmt == afgpu.WAV_S16LE:
+        return raw.view("<i2").astype(np.int32)
+    b = raw.reshape(-1, 3).astype(np.int32)
+    v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+    return np.where(v & 0x800000, v - (1 << 24), v)
+
+
+@pytest.mark.parametrize("fmt,bits", [(afgpu.WAV_S8, 8), (afgpu.WAV_S16LE, 16), (afgpu.WAV_S24LE, 24)])
+def test_tpdf_dither_matches_the_restatement_on_the_same_draws(fmt, bits):
+    """TPDFDither.process (wav.d:674-701) in front of the integer conversions (wav.d:483, :497, :513), fed the same
+    generator as the oracle's restatement: identical bytes; with dither off the old behaviour."""
+    rng = np.random.default_rng(bits)
+    x = np.concatenate([np.array([-1.0, 1.0, 0.0, 0.999999, -0.999999, 1e-7], np.float32),
+                        rng.uniform(-1, 1, 3000).astype(np.float32), (0.3 * np.sin(np.arange(500) * 0.01)).astype(np.float32)])
+    got = _pcm_of(afgpu.wav_encode(x[:, None], 44100, fmt, dither=_lcg(7)), fmt)
+    want = oraclelib.wav_pcm(x, bits, dither=_lcg(7))
+    assert np.array_equal(got, want)
+    assert np.array_equal(_pcm_of(afgpu.wav_encode(x[:, None], 44100, fmt), fmt), oraclelib.wav_pcm(x, bits))        # dither off
+    plain = oraclelib.wav_pcm(x, bits)
+    assert (got != plain).any() and np.abs(got - plain).max() <= 1                   # dither moves samples by at most one step
+    # two draws per sample, in order: a different seed gives a different file
+    assert (_pcm_of(afgpu.wav_encode(x[:, None], 44100, fmt, dither=_lcg(8)), fmt) != got).any()
+
+
+def test_tpdf_dither_statistics():
+    """What the dither is for: a constant between two 8-bit steps comes out as a mix of both.  The reference's tuning adds
+    0.3125 + U1/4 + U2/8 before the floor (wav.d:688-692), i.e. a triangular-ish offset in [0.3125, 0.6875] of mean 0.5:
+    a level half-way between two steps lands on either with probability 1/2, one within 0.31 of a step always on it."""
+    def s8(level, dither):
+        x = np.full(20000, level / 127.0, np.float32)
+        raw = np.frombuffer(afgpu.wav_encode(x[:, None], 8000, afgpu.WAV_S8, dither=dither)[44:], np.uint8)
+        return raw.astype(np.int32) - 128                     # 8-bit WAV is offset binary (cast(byte)(128.5 + x*127), wav.d:487)
+    half = s8(40.5, _lcg(3))
+    assert set(np.unique(half)) == {40, 41} and abs(float((half == 41).mean()) - 0.5) < 0.03
+    assert set(np.unique(s8(40.6, None))) == {41} and set(np.unique(s8(40.4, None))) == {40}    # without dither: plain rounding
+    assert set(np.unique(s8(40.2, _lcg(3)))) == {40} and set(np.unique(s8(40.8, _lcg(3)))) == {41}
+
+
+def test_default_generator_is_libc_rand():
+    """rng = NULL draws from libc rand() like the reference: reseeding libc reproduces the file, and the oracle
+    restatement drawing from the same libc stream agrees."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    x = np.random.default_rng(0).uniform(-1, 1, 2000).astype(np.float32)
+    libc.srand(1234)
+    a = afgpu.wav_encode(x[:, None], 44100, afgpu.WAV_S16LE, dither="libc")
+    libc.srand(1234)
+    b = afgpu.wav_encode(x[:, None], 44100, afgpu.WAV_S16LE, dither="libc")
+    libc.srand(1234)
+    want = oraclelib.wav_pcm(x, 16, dither="libc")
+    assert a == b and np.array_equal(_pcm_of(a, afgpu.WAV_S16LE), want)
