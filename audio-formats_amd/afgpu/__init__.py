@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "afg_vorbis_transform_hip",
     "afg_flac_transform_hip",
     "afg_qoa_transform_hip",
-    "afg_celt_transform_hip",
+    "afg_celt_transform_hip", "afg_celt_transform_streams_hip",
     "afg_open_from_memory", "afg_is_error", "afg_error_message", "afg_get_format", "afg_get_num_channels",
     "afg_get_length_in_frames", "afg_get_samplerate", "afg_read_samples_float", "afg_close",
     "afg_can_seek", "afg_seek_position", "afg_tell_position",
@@ -166,6 +166,7 @@ def lib():
     L.afg_flac_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
     L.afg_qoa_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp]
     L.afg_celt_transform_hip.argtypes = [u32, vp, vp, vp, vp, vp, vp]
+    L.afg_celt_transform_streams_hip.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp]
     L.afg_open_from_memory.argtypes = [vp, C.c_size_t]
     L.afg_open_from_memory.restype = vp
     L.afg_is_error.argtypes = [vp]
@@ -392,10 +393,15 @@ def wav_encode(samples, samplerate, fmt=WAV_FP32LE, dither=None, rng_max=0x7ffff
     return out.tobytes()
 
 
-def celt_transform(n_chan, d_rec_base, d_recs, d_coeffs, d_out, d_states=None, stream=None):
-    """Enqueue the CELT transform stage (afg_celt_transform_hip)."""
-    check(lib().afg_celt_transform_hip(int(n_chan), _ptr(d_rec_base), _ptr(d_recs), _ptr(d_coeffs), _ptr(d_out),
-                                       _ptr(d_states), _stream(stream)))
+def celt_transform(n_chan, d_rec_base, d_recs, d_coeffs, d_out, d_states=None, stream=None, tail_stream=None):
+    """Enqueue the CELT transform stage (afg_celt_transform_hip; with tail_stream afg_celt_transform_streams_hip: the
+    per-sequence passes go to that stream behind an event, the caller joins)."""
+    if tail_stream is None:
+        check(lib().afg_celt_transform_hip(int(n_chan), _ptr(d_rec_base), _ptr(d_recs), _ptr(d_coeffs), _ptr(d_out),
+                                           _ptr(d_states), _stream(stream)))
+    else:
+        check(lib().afg_celt_transform_streams_hip(int(n_chan), _ptr(d_rec_base), _ptr(d_recs), _ptr(d_coeffs), _ptr(d_out),
+                                                   _ptr(d_states), _stream(stream), _stream(tail_stream)))
 
 
 def flac_parse(file_bytes):

@@ -484,6 +484,9 @@ __global__ __launch_bounds__(64) void celt_postfilter_kernel(
 {
     __shared__ __attribute__((aligned(16))) float rings[2][kRing];
     __shared__ float win2[120];
+    // a serial walk whose length sets the kernel's (and, beside other kernels on a second stream, the batch's) duration:
+    // its instructions go first whenever they are ready
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
     const uint32_t chan = blockIdx.x, pchan = chan ^ 1u;
     const uint64_t base = rec_base[chan], cnt = rec_base[chan + 1] - base;
@@ -837,167 +840,266 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
     }
 }
 
-// De-emphasis and output scaling (dopus.d:3695-3701) over the planes celt_transform_kernel wrote:
+// De-emphasis and output scaling (dopus.d:3695-3701) over the planes the transform kernels wrote:
 //   tmp = x[j] + m;  m = tmp * 0.85000610f;  out[j] = tmp / 32768
 // a one-pole IIR across the whole channel sequence whose float rounding order cannot be re-associated, so the
-// time axis is serial and the parallel axis is the channel sequence: one lane per sequence, 32 sequences per
-// wavefront.  Memory is touched in whole rows: a step takes 40 samples of every sequence (40 divides every CELT
-// frame size) as 16-byte loads along the interleaved rows, transposes them through LDS (de-interleaving stereo
-// rows), runs the 32 chains, and goes back the same way; two steps are kept in flight in registers.  Layouts
-// the row scheme does not cover (stride > 2, unaligned or ragged rows) take the per-lane strided path.
-#ifndef AFG_CELT_DE_SEQ
-#define AFG_CELT_DE_SEQ 32
-#endif
-#ifndef AFG_CELT_DE_DEPTH
-#define AFG_CELT_DE_DEPTH 4
-#endif
-constexpr int kDeSeq = AFG_CELT_DE_SEQ;                      // channel sequences per wavefront
-constexpr int kDeDepth = AFG_CELT_DE_DEPTH;                  // steps kept in flight
-#ifndef AFG_CELT_DE_GROUP
-#define AFG_CELT_DE_GROUP 40
-#endif
-constexpr int kDeGroup = AFG_CELT_DE_GROUP;                  // samples of every sequence per step (divides every CELT frame size)
-constexpr int kDePitch = kDeGroup + 4;                       // floats; rows stay 16-byte aligned
-constexpr int kDeQuads = kDeSeq * kDeGroup / 4;              // float4 per step
-constexpr int kDeLoads = (kDeQuads + 63) / 64;               // float4 per lane per step
-
-template <int STRIDE>
-__device__ __forceinline__ void deemph_rows(float *xs, float *__restrict__ out, bool have, uint64_t off, int n, float &m)
+// time axis is serial and the parallel axis is the channel sequence: one lane per sequence, SEQ sequences per
+// wavefront.  Memory is touched in whole rows: a step takes GROUP samples of every sequence (GROUP divides every
+// CELT frame size) as 16-byte loads along the interleaved rows, transposes them through LDS (de-interleaving stereo
+// rows), runs the SEQ chains, and goes back the same way; kDeDepth steps are kept in flight in registers.
+// SEQ x GROUP is about constant (the bytes one step moves), SEQ is chosen by the host from the number of sequences:
+// 32 lanes of chains per wavefront when there are tens of thousands of sequences (few issue slots per sample: the
+// pass runs at its memory rate), down to 2 when there are few, long ones -- the mixed corpus has ~1600 sequences
+// of up to 1.4 M samples per wave: with 32 per wavefront 52 wavefronts crawled through 36 000 latency-bound steps
+// each (100 ms); with 2 per wavefront 820 wavefronts each run their chain at ~10 cycles per sample behind loads
+// issued four steps (8 us) ahead.  Layouts the row scheme does not cover (stride > 2, unaligned or ragged rows) take
+// the per-lane strided path.
+// Pipelining: the ring of D steps runs across frame boundaries.  A frame's record fields (out_off, stride, size) are
+// fetched two frames ahead, and while the last D steps of a frame are chained the first D steps of the next frame are
+// already being loaded (same slots) when that frame has the same geometry -- so neither the record fetch nor the
+// first row fetch of a frame is ever waited for at full memory latency.  All prefetch loads are unconditional
+// (address-selected), which lets the compiler count them instead of draining the queue at every step.
+template <int STRIDE, int SEQ, int GROUP, int D>
+__device__ __forceinline__ void deemph_rows(float *xs, float *__restrict__ out, bool have, uint64_t off, uint64_t off_next,
+                                            int n, float &m, f32x4 (&ring)[D][(SEQ * GROUP / 4 + 63) / 64], bool primed,
+                                            bool chain_next)
 {
-    constexpr int F = kDeGroup / 4 * STRIDE;                  // float4 per row per step
+    constexpr int PITCH = GROUP + 4;                          // floats; rows stay 16-byte aligned
+    constexpr int QUADS = SEQ * GROUP / 4;                    // float4 per step
+    constexpr int LOADS = (QUADS + 63) / 64;                  // float4 per lane per step
+    constexpr int F = GROUP / 4 * STRIDE;                     // float4 per row per step
+    constexpr int GS = GROUP * STRIDE;                        // floats a row advances per step
+    constexpr int CH = (GROUP / 4) % 10 == 0 ? 10 : GROUP / 4;   // float4 per chain chunk held in registers
+    static_assert((GROUP / 4) % CH == 0, "chunking");
     const int lane = threadIdx.x;
-    float *ptr[kDeLoads];
-    int lds_at[kDeLoads];
-    bool valid[kDeLoads];
+    float *ptr[LOADS];                                        // where this lane's float4 of a step lives (stores)
+    const float *lptr[LOADS], *lptr_n[LOADS];                 // load addresses: this frame / the next one (always valid memory)
+    int lds_at[LOADS];
+    bool valid[LOADS];
+    const int lead0 = __ffsll((unsigned long long)__ballot(have)) - 1;
+    const uint64_t safe = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off >> 32), lead0) << 32) | (uint32_t)__shfl((int)(uint32_t)off, lead0);
 #pragma unroll
-    for (int i = 0; i < kDeLoads; i++) {
+    for (int i = 0; i < LOADS; i++) {
         const int idx = lane + 64 * i;
         const int row = idx / F, q = idx - row * F;
-        const int lead = row * STRIDE;                       // first chain lane of the row
+        const int lead = (row * STRIDE) & 63;                // first chain lane of the row
         const uint32_t lo = __shfl((uint32_t)off, lead), hi = __shfl((uint32_t)(off >> 32), lead);
-        valid[i] = idx < kDeQuads && __shfl((int)have, lead) != 0;
+        const uint32_t nlo = __shfl((uint32_t)off_next, lead), nhi = __shfl((uint32_t)(off_next >> 32), lead);
+        valid[i] = idx < QUADS && __shfl((int)have, lead) != 0;
         ptr[i] = out + (((uint64_t)hi << 32) | lo) + 4 * q;
-        lds_at[i] = STRIDE == 1 ? row * kDePitch + 4 * q : (2 * row) * kDePitch + 2 * q;
+        lptr[i] = valid[i] ? ptr[i] : out + safe;
+        lptr_n[i] = (valid[i] && chain_next) ? out + (((uint64_t)nhi << 32) | nlo) + 4 * q : lptr[i];
+        lds_at[i] = STRIDE == 1 ? row * PITCH + 4 * q : (2 * row) * PITCH + 2 * q;
     }
-    f32x4 ring[kDeDepth][kDeLoads];
-    const int groups = n / kDeGroup;
-    auto load = [&](f32x4 (&b)[kDeLoads], int g) {
+    const int groups = n / GROUP;
+    if (!primed) {
 #pragma unroll
-        for (int i = 0; i < kDeLoads; i++)
-            if (valid[i]) b[i] = __builtin_nontemporal_load((const f32x4 *)(ptr[i] + (size_t)g * (kDeGroup * STRIDE)));
-    };
-    auto step = [&](f32x4 (&b)[kDeLoads], int g, int g_next) {
+        for (int d = 0; d < D; d++) {
+            const int g = d < groups ? d : groups - 1;
 #pragma unroll
-        for (int i = 0; i < kDeLoads; i++) {
-            if (kDeQuads % 64 != 0 && lane + 64 * i >= kDeQuads) continue;
+            for (int i = 0; i < LOADS; i++) ring[d][i] = __builtin_nontemporal_load((const f32x4 *)(lptr[i] + (size_t)g * GS));
+        }
+    }
+    auto step = [&](f32x4 (&b)[LOADS], int g) {
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) {
+            if (QUADS % 64 != 0 && lane + 64 * i >= QUADS) continue;
             if (STRIDE == 1) {
                 *(f32x4 *)(xs + lds_at[i]) = b[i];
             } else {                                         // (L,R,L,R) -> two samples of each channel's row
                 *(f32x2 *)(xs + lds_at[i]) = f32x2{ b[i].x, b[i].z };
-                *(f32x2 *)(xs + lds_at[i] + kDePitch) = f32x2{ b[i].y, b[i].w };
+                *(f32x2 *)(xs + lds_at[i] + PITCH) = f32x2{ b[i].y, b[i].w };
             }
         }
-        if (g_next < groups) load(b, g_next);
+        {   // refill the slot: D steps ahead in this frame, else the next frame's step (same slot: groups % D == 0 there),
+            // else a harmless re-read of this step (end of the sequence)
+            const int gn = g + D;
+            const bool here = gn < groups;
+            const size_t at = (size_t)(here ? gn : (chain_next ? gn - groups : g)) * GS;
+#pragma unroll
+            for (int i = 0; i < LOADS; i++)
+                b[i] = __builtin_nontemporal_load((const f32x4 *)(((here || !chain_next) ? lptr[i] : lptr_n[i]) + at));
+        }
         __builtin_amdgcn_wave_barrier();
-        if (lane < kDeSeq && have) {
-            f32x4 *row = (f32x4 *)(xs + lane * kDePitch);
-            f32x4 v[kDeGroup / 4];
+        if (lane < SEQ && have) {
+            f32x4 *row = (f32x4 *)(xs + lane * PITCH);
+            // two register chunks, ping-pong: while one is chained (14 cycles per sample, measured: tools/ubench_chain.hip)
+            // the LDS reads of the other are in flight; no register copies on the chain's path
+            auto chain = [&](f32x4 (&c)[CH], int k0) {
 #pragma unroll
-            for (int k = 0; k < kDeGroup / 4; k++) v[k] = row[k];
+                for (int k = 0; k < CH; k++) {
 #pragma unroll
-            for (int k = 0; k < kDeGroup / 4; k++) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float t = v[k][e] + m;
-                    m = t * 0.85000610f;
-                    v[k][e] = t * (1.0f / 32768.0f);                                // tmp / 32768. (exact)
+                    for (int e = 0; e < 4; e++) {
+                        const float t = c[k][e] + m;                               // the chain: two dependent operations per
+                        m = t * 0.85000610f;                                       // sample on SEQ lanes, nothing else
+                        c[k][e] = t;
+                    }
+                    row[k0 + k] = c[k];
                 }
-                row[k] = v[k];
+            };
+            auto fill = [&](f32x4 (&c)[CH], int k0) {
+#pragma unroll
+                for (int k = 0; k < CH; k++) c[k] = row[k0 + k];
+            };
+            constexpr int NCH = GROUP / 4 / CH;               // chunks per step: 1 (GROUP 40, 60), 3, 6 or 12
+            f32x4 ca[CH], cb[CH];
+            fill(ca, 0);
+            if (NCH == 1) {
+                chain(ca, 0);
+            } else {
+#pragma unroll 1
+                for (int k0 = 0; k0 < GROUP / 4; k0 += 2 * CH) {
+                    const bool two = k0 + CH < GROUP / 4;     // (an odd chunk count ends on `ca`)
+                    if (two) fill(cb, k0 + CH);
+                    chain(ca, k0);
+                    if (k0 + 2 * CH < GROUP / 4) fill(ca, k0 + 2 * CH);
+                    if (two) chain(cb, k0 + CH);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < kDeLoads; i++) {
+        for (int i = 0; i < LOADS; i++) {
             f32x4 o;
-            if (kDeQuads % 64 != 0 && lane + 64 * i >= kDeQuads) continue;
+            if (QUADS % 64 != 0 && lane + 64 * i >= QUADS) continue;
             if (STRIDE == 1) {
                 o = *(const f32x4 *)(xs + lds_at[i]);
             } else {
-                const f32x2 l = *(const f32x2 *)(xs + lds_at[i]), r = *(const f32x2 *)(xs + lds_at[i] + kDePitch);
+                const f32x2 l = *(const f32x2 *)(xs + lds_at[i]), r = *(const f32x2 *)(xs + lds_at[i] + PITCH);
                 o = f32x4{ l.x, r.x, l.y, r.y };
             }
-            if (valid[i]) *(f32x4 *)(ptr[i] + (size_t)g * (kDeGroup * STRIDE)) = o;
+            o *= (1.0f / 32768.0f);                                                // tmp / 32768. (exact), on all 64 lanes
+            if (valid[i]) *(f32x4 *)(ptr[i] + (size_t)g * GS) = o;
         }
         __builtin_amdgcn_wave_barrier();
     };
+    for (int g = 0; g < groups; g += D) {
 #pragma unroll
-    for (int d = 0; d < kDeDepth; d++)
-        if (d < groups) load(ring[d], d);
-    for (int g = 0; g < groups; g += kDeDepth) {
-#pragma unroll
-        for (int d = 0; d < kDeDepth; d++)
-            if (g + d < groups) step(ring[d], g + d, g + d + kDeDepth);
+        for (int d = 0; d < D; d++)
+            if (g + d < groups) step(ring[d], g + d);
     }
 }
 
+template <int SEQ, int GROUP>
 __global__ __launch_bounds__(64) void celt_deemph_kernel(
     const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs, float *__restrict__ out,
     float *__restrict__ states, uint32_t n_chan)
 {
-    __shared__ __attribute__((aligned(16))) float xs[kDeSeq * kDePitch];
+    constexpr int D = (960 / GROUP) >= 4 ? 4 : 2;            // steps in flight (divides the steps of a 20 ms frame)
+    constexpr int LOADS = (SEQ * GROUP / 4 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float xs[SEQ * (GROUP + 4)];
+    __builtin_amdgcn_s_setprio(3);                            // a serial chain: its instructions go first whenever ready
     const int lane = threadIdx.x;
-    const uint32_t chan = blockIdx.x * (uint32_t)kDeSeq + (uint32_t)lane;
-    const bool mine = lane < kDeSeq && chan < n_chan;
+    const uint32_t chan = blockIdx.x * (uint32_t)SEQ + (uint32_t)lane;
+    const bool mine = lane < SEQ && chan < n_chan;
+    const uint32_t chan_c = chan < n_chan ? chan : n_chan - 1;
     float *st = (states && mine) ? states + (size_t)chan * AFG_CELT_STATE_FLOATS : nullptr;
     float m = st ? st[2056] : 0.0f;
-    uint64_t r = mine ? rec_base[chan] : 0;
-    const uint64_t r_end = mine ? rec_base[chan + 1] : 0;
-    while (__any(r < r_end)) {
-        const bool have = r < r_end;
-        int n = 0, stride = 0;
-        uint64_t off = 0;
-        if (have) {
-            const afg_celt_frame *fr = recs + r;
-            n = fr->frame_size; stride = (int)fr->out_stride; off = fr->out_off;
-            r++;
-        }
-        // can this step of the 32 sequences be walked as rows?
-        const int n0 = __builtin_amdgcn_readfirstlane(n), s0 = __builtin_amdgcn_readfirstlane(stride);
+    const uint64_t total = rec_base[n_chan];                  // records in the batch
+    if (total == 0) return;
+    uint64_t r = rec_base[chan_c];
+    const uint64_t r_end = mine ? rec_base[chan_c + 1] : r;
+    struct Rec { uint32_t n, stride; uint64_t off; };
+    static_assert(offsetof(afg_celt_frame, out_off) == 8 && offsetof(afg_celt_frame, out_stride) == 16 &&
+                  offsetof(afg_celt_frame, frame_size) == 20, "record layout");
+    auto fetch = [&](uint64_t idx) -> Rec {                   // always a valid record: the fields of one past the end are unused
+        const uint64_t *p = (const uint64_t *)(recs + (idx < total ? idx : total - 1));
+        const uint64_t a = p[1], b = p[2];
+        return Rec{ (uint32_t)(b >> 32) & 0xffffu, (uint32_t)b, a };
+    };
+    // can a step of the SEQ sequences be walked as rows?  Geometry of the first lane that still has a record
+    // (sequences of a wavefront may end at different frames: the finished ones sit the step out)
+    auto rows_ok = [&](const Rec &rc, bool hv, int &n0, int &s0) -> bool {
+        const unsigned long long bal = __ballot(hv);
+        n0 = s0 = 0;
+        if (!bal) return false;
+        const int first = __ffsll(bal) - 1;
+        n0 = __shfl((int)rc.n, first);
+        s0 = __shfl((int)rc.stride, first);
         bool bad = false;
-        if (lane < kDeSeq) {
-            if (have) bad = n != n0 || stride != s0;
+        const bool p_have = __shfl_xor((int)hv, 1) != 0;
+        const uint32_t plo = __shfl_xor((uint32_t)rc.off, 1), phi = __shfl_xor((uint32_t)(rc.off >> 32), 1);
+        const uint64_t p_off = ((uint64_t)phi << 32) | plo;
+        if (lane < SEQ) {
+            if (hv) bad = (int)rc.n != n0 || (int)rc.stride != s0;
             if (s0 == 2) {
-                const bool p_have = __shfl_xor((int)have, 1) != 0;
-                const uint32_t plo = __shfl_xor((uint32_t)off, 1), phi = __shfl_xor((uint32_t)(off >> 32), 1);
-                const uint64_t p_off = ((uint64_t)phi << 32) | plo;
-                if (have != p_have) bad = true;
-                else if (have) bad = bad || ((lane & 1) ? off != p_off + 1 : (off & 3) != 0);
-            } else if (have) {
-                bad = bad || (off & 3) != 0;
+                if (hv != p_have) bad = true;
+                else if (hv) bad = bad || ((lane & 1) ? rc.off != p_off + 1 : (rc.off & 3) != 0);
+            } else if (hv) {
+                bad = bad || (rc.off & 3) != 0;
             }
         }
-        const bool rows = (s0 == 1 || s0 == 2) && n0 > 0 && n0 % kDeGroup == 0 && !__any(bad);
+        return (s0 == 1 || s0 == 2) && n0 > 0 && n0 % GROUP == 0 && !__any(bad);
+    };
+    Rec cur = fetch(r), nxt = fetch(r + 1);
+    bool have = r < r_end;
+    bool primed = false;
+    f32x4 ring[D][LOADS];
+    while (__any(have)) {
+        const Rec nn = fetch(r + 2);                          // lands while this frame is chained
+        const bool have_n = r + 1 < r_end;
+        int n0, s0, n1, s1;
+        const bool rows = rows_ok(cur, have, n0, s0);
+        const bool rows_n = rows_ok(nxt, have_n, n1, s1);
+        const bool chain_next = rows && rows_n && n1 == n0 && s1 == s0 && __ballot(have_n) == __ballot(have) && (n0 / GROUP) % D == 0;
         if (rows) {
-            if (s0 == 2) deemph_rows<2>(xs, out, have, off, n0, m);
-            else deemph_rows<1>(xs, out, have, off, n0, m);
-        } else if (have) {
-            float *o = out + off;
-            for (int j0 = 0; j0 < n; j0 += 8) {
-                float x[8];
+            if (s0 == 2) deemph_rows<2, SEQ, GROUP, D>(xs, out, have, cur.off, nxt.off, n0, m, ring, primed, chain_next);
+            else deemph_rows<1, SEQ, GROUP, D>(xs, out, have, cur.off, nxt.off, n0, m, ring, primed, chain_next);
+            primed = chain_next;
+        } else {
+            primed = false;
+            if (have) {
+                const int n = (int)cur.n, stride = (int)cur.stride;
+                float *o = out + cur.off;
+                for (int j0 = 0; j0 < n; j0 += 8) {
+                    float x[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = j0 + k < n ? o[(size_t)(j0 + k) * stride] : 0.0f;
+                    for (int k = 0; k < 8; k++) x[k] = j0 + k < n ? o[(size_t)(j0 + k) * stride] : 0.0f;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if (j0 + k < n) {
-                        const float t = x[k] + m;
-                        m = t * 0.85000610f;
-                        o[(size_t)(j0 + k) * stride] = t * (1.0f / 32768.0f);
+                    for (int k = 0; k < 8; k++) {
+                        if (j0 + k < n) {
+                            const float t = x[k] + m;
+                            m = t * 0.85000610f;
+                            o[(size_t)(j0 + k) * stride] = t * (1.0f / 32768.0f);
+                        }
                     }
                 }
             }
         }
+        cur = nxt;
+        nxt = nn;
+        r++;
+        have = r < r_end;
     }
     if (st) st[2056] = m;
+}
+
+// Sequences per wavefront from the number of sequences: the most chain lanes per wavefront that still leaves about a
+// wavefront per two SIMDs (512 wavefronts; measured: 16384 sequences run at the pass's memory rate with 32 per
+// wavefront).  AFG_CELT_DE_SEQ overrides (tests run every instantiation).
+int deemph_seq_for(uint32_t n_chan)
+{
+    if (const char *e = getenv("AFG_CELT_DE_SEQ")) {
+        const int v = atoi(e);
+        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) return v;
+    }
+    for (int seq = 32; seq > 2; seq >>= 1)
+        if (n_chan / (uint32_t)seq >= 512u) return seq;
+    return 2;
+}
+
+void launch_deemph(const uint64_t *d_rec_base, const afg_celt_frame *d_recs, float *d_out, float *d_states, uint32_t n_chan,
+                   hipStream_t stream)
+{
+    const int seq = deemph_seq_for(n_chan);
+    const dim3 grid((n_chan + (uint32_t)seq - 1) / (uint32_t)seq), block(64);
+    switch (seq) {
+    case 32: hipLaunchKernelGGL((celt_deemph_kernel<32, 40>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;
+    case 16: hipLaunchKernelGGL((celt_deemph_kernel<16, 60>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;
+    case 8:  hipLaunchKernelGGL((celt_deemph_kernel<8, 120>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;
+    case 4:  hipLaunchKernelGGL((celt_deemph_kernel<4, 240>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;
+    default: hipLaunchKernelGGL((celt_deemph_kernel<2, 480>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;
+    }
 }
 
 // ---- host: tables exactly as ff_imdct15_init (dopus.d:1489-1499), in x87 long double like D's real ----
@@ -1013,7 +1115,10 @@ bool use_stream_path(uint32_t pairs)
     const char *e = getenv("AFG_CELT_PATH");
     if (e && !strcmp(e, "stream")) return true;
     if (e && !strcmp(e, "split")) return false;
-    return pairs >= 512;
+    // The stream walk runs one wavefront per stereo stream for the stream's whole length (~30-80 us per frame of
+    // wavefront latency: its throughput comes from thousands of resident wavefronts).  Below about two wavefronts per
+    // SIMD the record-parallel transform + per-sequence filter passes finish sooner.
+    return pairs >= 2048;
 }
 
 int ensure_tables(const float **d_tables, CeltTables *tb)
@@ -1104,8 +1209,26 @@ extern "C" int afg_opus_output_hip(uint64_t n_samples, const float *d_in, int16_
     return AFG_OK;
 }
 
+static int celt_transform_impl(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs, const float *d_coeffs,
+                               float *d_out, float *d_states, hipStream_t hip_stream, hipStream_t tail_stream);
+
 extern "C" int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
                                       const float *d_coeffs, float *d_out, float *d_states, void *hip_stream)
+{
+    return celt_transform_impl(n_chan, d_rec_base, d_recs, d_coeffs, d_out, d_states, (hipStream_t)hip_stream, nullptr);
+}
+
+extern "C" int afg_celt_transform_streams_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
+                                              const float *d_coeffs, float *d_out, float *d_states, void *hip_stream,
+                                              void *hip_tail_stream)
+{
+    if (!hip_tail_stream || hip_tail_stream == hip_stream)
+        return celt_transform_impl(n_chan, d_rec_base, d_recs, d_coeffs, d_out, d_states, (hipStream_t)hip_stream, nullptr);
+    return celt_transform_impl(n_chan, d_rec_base, d_recs, d_coeffs, d_out, d_states, (hipStream_t)hip_stream, (hipStream_t)hip_tail_stream);
+}
+
+static int celt_transform_impl(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs, const float *d_coeffs,
+                               float *d_out, float *d_states, hipStream_t hip_stream, hipStream_t tail_stream)
 {
     if (n_chan == 0) return AFG_OK;
     if (!d_rec_base || !d_recs || !d_coeffs || !d_out) {
@@ -1119,6 +1242,15 @@ extern "C" int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_bas
     // wavefronts per channel sequence in the record-parallel kernel: enough to fill the device whatever n_chan is
     const uint32_t pairs = (n_chan + 1) / 2;
     if (use_stream_path(pairs)) {
+        if (tail_stream) {                                   // the whole walk is the serial part: all of it behind the event
+            hipEvent_t done = nullptr;
+            AFG_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            hipError_t e = hipEventRecord(done, hip_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(tail_stream, done, 0);
+            (void)hipEventDestroy(done);
+            if (e != hipSuccess) { afg::set_error("afg_celt_transform_streams_hip: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+            hip_stream = tail_stream;
+        }
         // enough streams to fill the device: one pass over the coefficients, one over the PCM
         static_assert(kSLdsFloats * sizeof(float) <= 160 * 1024, "LDS budget");
         AFG_HIP_CHECK(hipFuncSetAttribute((const void *)celt_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1127,8 +1259,7 @@ extern "C" int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_bas
                            kSLdsFloats * sizeof(float), (hipStream_t)hip_stream, d_rec_base, d_recs, d_coeffs, d_out,
                            d_states, d_tables, tb, g_tab_floats, n_chan);
         AFG_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(celt_deemph_kernel, dim3((n_chan + kDeSeq - 1) / kDeSeq), dim3(64), 0, (hipStream_t)hip_stream,
-                           d_rec_base, d_recs, d_out, d_states, n_chan);
+        launch_deemph(d_rec_base, d_recs, d_out, d_states, n_chan, (hipStream_t)hip_stream);
         AFG_HIP_CHECK(hipGetLastError());
         return AFG_OK;
     }
@@ -1140,11 +1271,21 @@ extern "C" int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_bas
                        (hipStream_t)hip_stream, d_rec_base, d_recs, d_coeffs, d_out, d_states, d_tables, tb,
                        g_tab_floats, n_chan, per_pair);
     AFG_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(celt_postfilter_kernel, dim3(n_chan), dim3(64), 0, (hipStream_t)hip_stream,
-                       d_rec_base, d_recs, d_out, d_states, n_chan);
+    // The per-sequence passes are serial chains that occupy a fraction of the device for their whole length: with a tail
+    // stream they run there, behind an event, beside whatever the caller queues on hip_stream next.
+    hipStream_t serial = (hipStream_t)hip_stream;
+    if (tail_stream) {
+        hipEvent_t done = nullptr;
+        AFG_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(done, (hipStream_t)hip_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(tail_stream, done, 0);
+        (void)hipEventDestroy(done);                                        // released once the record has completed
+        if (e != hipSuccess) { afg::set_error("afg_celt_transform_streams_hip: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+        serial = tail_stream;
+    }
+    hipLaunchKernelGGL(celt_postfilter_kernel, dim3(n_chan), dim3(64), 0, serial, d_rec_base, d_recs, d_out, d_states, n_chan);
     AFG_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(celt_deemph_kernel, dim3((n_chan + kDeSeq - 1) / kDeSeq), dim3(64), 0, (hipStream_t)hip_stream,
-                       d_rec_base, d_recs, d_out, d_states, n_chan);
+    launch_deemph(d_rec_base, d_recs, d_out, d_states, n_chan, serial);
     AFG_HIP_CHECK(hipGetLastError());
     return AFG_OK;
 }

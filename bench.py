@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-full-fetch", action="store_true", help="skip the MP3 leg that fetches all 32 subbands")
+    ap.add_argument("--only", default="", help="development: restrict --config c5 to these codecs (comma list)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: ranks beyond the visible devices share them (rank % devices); the line says so")
     return ap.parse_args(argv)
@@ -254,20 +255,20 @@ def run_rank(args, world, rank, local_rank):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
-    def timed_steps(wl, steps, warmup, want_events=True):
+    side = torch.cuda.Stream(device=dev) if args.config == "c5" else None
+
+    def timed_steps(wl, steps, warmup):
         """W warm-up + K timed steps of one resident workload; returns (elapsed s, per-part ms lists)."""
         for _ in range(warmup):
-            wl.step(stream)
+            wl.step(stream, None, side)
         barrier()
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(wl.parts) + 1)] for _ in range(steps)] if want_events else None
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in wl.parts] for _ in range(steps)]
         t0 = time.perf_counter()
         for i in range(steps):
-            wl.step(stream, ev[i] if ev else None)       # events on the stream the kernels are launched on
+            wl.step(stream, ev[i], side)                 # events on the stream each kernel is launched on
         barrier()
         elapsed = time.perf_counter() - t0
-        per_part = None
-        if ev:
-            per_part = [[ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(steps)] for k in range(len(wl.parts))]
+        per_part = [[ev[i][k][0].elapsed_time(ev[i][k][1]) for i in range(steps)] for k in range(len(wl.parts))]
         return elapsed, per_part
 
     kern = {}                                         # name -> dict(ms list, samples, alg_bytes, units)
@@ -278,6 +279,8 @@ def run_rank(args, world, rank, local_rank):
         elapsed, my_samples = 0.0, 0
         for wi, ids in enumerate(waves):
             wl = corpus.build_c5_wave(man, ids, dev)
+            if args.only:
+                wl.parts = [p for p in wl.parts if p.name in args.only.split(",")]
             e, per_part = timed_steps(wl, args.steps, args.warmup)
             elapsed += e
             my_samples += wl.samples
@@ -378,6 +381,7 @@ def run_rank(args, world, rank, local_rank):
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                 "note": "dominant kernel = the codec with the largest share of a step's time; every kernel of the step is listed in `kernels`",
                 "kernels": kernels,
+                "overlapped_on_a_second_stream": ["celt"] if args.config == "c5" else [],
                 "whole_step": {"algorithmic_bytes": int(step_bytes), "kernel_ms": step_ms,
                                "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "measured_copy_GBs": extra.get("measured_copy_GBs"), "mp3_full_fetch": extra.get("mp3_full_fetch")}

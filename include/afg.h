@@ -210,6 +210,16 @@ typedef struct afg_celt_frame {
 int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
                            const float *d_coeffs, float *d_out, float *d_states, void *hip_stream);
 
+/* The same with the sequential part on a second stream.  The post-filter and the de-emphasis are serial chains per
+ * channel sequence: with few, long sequences (a file-sharded mixed corpus holds ~1600 of up to 1.4 M samples per wave)
+ * they occupy a fraction of the device for the length of the longest sequence.  Here the record-parallel transform is
+ * queued on hip_stream and the per-sequence passes on hip_tail_stream behind an event, so that they run beside whatever
+ * the caller queues on hip_stream next; the caller joins the two streams (an event on hip_tail_stream) before it reads
+ * d_out.  hip_tail_stream NULL or equal to hip_stream: afg_celt_transform_hip. */
+int afg_celt_transform_streams_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
+                                   const float *d_coeffs, float *d_out, float *d_states, void *hip_stream,
+                                   void *hip_tail_stream);
+
 /* What OpusFile.readFrame and AudioStream.readSamplesFloat do to the decoder's floats (dopus.d:7923-7926,
  * :8098-8105; stream.d:480): Float2IntScaled (x * 32768 rounded to nearest even by a magic-number add, saturated
  * to int16), then int16 / 32767.0f.  Element-wise; d_out_f32 may alias d_in; either output may be NULL. */

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""transcode input.{mp3|flac|ogg|qoa} output.{wav|qoa} -- the reference's examples/transcode flow (main.d:12-84) over the
-device library: open, report format / rate / channels / length, read 1024-frame chunks, write them out with the
-library's own writers (afg_wav_encode / afg_qoa_encode_hip).  The WAV output is
-32-bit float WAV (the reference example writes 24-bit PCM with TPDF dither driven by libc rand(), whose bytes are
-not reproducible; BASELINE config C1 is checked on the decoded floats)."""
+"""transcode [--format s24|s16|s8|f32] [--no-dither | --dither-seed N] input.{mp3|flac|ogg|qoa} output.{wav|qoa}
+
+The reference's examples/transcode flow (main.d:12-84) over the device library: open, report format / rate /
+channels / length, read 1024-frame chunks, write them out with the library's own writers (afg_wav_encode[_dithered] /
+afg_qoa_encode_hip).  Defaults are the example's: 24-bit PCM with TPDF dither drawn from libc rand() (main.d:54-56).
+--dither-seed N draws from a seeded LCG instead so that the bytes are reproducible (tests/test_transcode_gpu.py);
+--format f32 writes the decoded floats untouched (BASELINE config C1 is checked on those)."""
 import os
 import sys
 
@@ -13,10 +15,29 @@ sys.path.insert(0, os.path.join(ROOT, "audio-formats_amd"))
 import numpy as np  # noqa: E402
 
 
+def lcg(seed):
+    """The generator --dither-seed feeds the dither: 31-bit LCG (the classic rand() constants)."""
+    state = [seed & 0x7fffffff]
+
+    def draw():
+        state[0] = (state[0] * 1103515245 + 12345) & 0x7fffffff
+        return state[0]
+    return draw
+
+
 def main(argv):
-    if len(argv) != 3:
-        print("usage: transcode input.{mp3|flac|ogg|qoa} output.{wav|qoa}")
+    import argparse
+    ap = argparse.ArgumentParser(prog="transcode", usage="transcode [options] input.{mp3|flac|ogg|qoa} output.{wav|qoa}")
+    ap.add_argument("--format", default="s24", choices=["s24", "s16", "s8", "f32"])
+    ap.add_argument("--no-dither", action="store_true")
+    ap.add_argument("--dither-seed", type=int, default=None)
+    ap.add_argument("input")
+    ap.add_argument("output")
+    try:
+        args = ap.parse_args(argv[1:])
+    except SystemExit:
         return 2
+    argv = [argv[0], args.input, args.output]
     import afgpu
     data = open(argv[1], "rb").read()
     s = afgpu.AudioStream()
@@ -53,8 +74,10 @@ def main(argv):
                          d_pcm_f32=torch.from_numpy(np.clip(pcm, -1, 1).reshape(-1).copy()).to(dev))
         torch.cuda.synchronize()
         out = d_out.cpu().numpy()[:afgpu.qoa_encoded_size(len(pcm), ch)].tobytes()
-    else:                                                # the library's WAV writer (afg_wav_encode), 32-bit float
-        out = afgpu.wav_encode(pcm, int(rate), afgpu.WAV_FP32LE)
+    else:                                                # the library's WAV writer
+        fmt = {"s24": afgpu.WAV_S24LE, "s16": afgpu.WAV_S16LE, "s8": afgpu.WAV_S8, "f32": afgpu.WAV_FP32LE}[args.format]
+        dither = None if (args.no_dither or args.format == "f32") else ("libc" if args.dither_seed is None else lcg(args.dither_seed))
+        out = afgpu.wav_encode(pcm, int(rate), fmt, dither=dither)
     with open(argv[2], "wb") as fh:
         fh.write(out)
     print(f"=> {total} frames decoded and written to {argv[2]}")
