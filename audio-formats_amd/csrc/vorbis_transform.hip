@@ -21,6 +21,7 @@
 #include "afg_common.h"
 #include "afg_pk.h"
 
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <vector>
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(kThreads) void vorbis_transform_kernel(
     const VorbisStream st = streams[seg.stream];
     const int C = (int)st.nch;
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
+    const uint32_t tab0 = st.tab[0], tab1 = st.tab[1];
     const int nmax = bs1;
 
     float *chan = smem;                          // C * nmax   (channel_buffers)
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void vorbis_transform_kernel(
         const int n2 = n >> 1;
         const int which = (fl & AFG_VORBIS_LONG) ? 1 : 0;
         const int ld = 31 - __clz(n);
-        const float *T = tables + st.tab[which];
+        const float *T = tables + (which ? tab1 : tab0);            // (a runtime index into the struct would put it in scratch memory)
         const float *A = T, *B = T + n2, *Ct = T + n;
 
         // spectrum -> LDS (coalesced rows)
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void vorbis_transform_kernel(
         const bool emit = (p >= (int)seg.p0) && previous_length > 0;
         if (emit) {
             const int pn = previous_length;
-            const float *w = tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);   // window of size 2*pn (:2245-2251)
+            const float *w = tables + ((pn * 2 == bs1) ? tab1 : tab0) + (pn * 2) + (pn * 2 / 4);   // window of size 2*pn (:2245-2251)
             float *o = out + out_off[gp];
             const int total = (right - left) * C;
             for (int idx = tid; idx < total; idx += kThreads) {
@@ -464,6 +466,7 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     f2 *const V = (f2 *)(smem + kUFloats);
     const f2 *A2p = (const f2 *)A;
 
+#if !(AFG_VORBIS_ABL & 64)
     // step 0 (:1972-1994): item q and the mirrored item n8-1-q share one 16-byte load
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -478,10 +481,12 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         const f2 g = pk_mul_nhh_nhl(xb, a1) + pk_mul_nhl_hh(xa, a1);
         V[q] = g;                                   // buf2[n4-2-2q'] = buf2[2q]
     }
+#endif
     __builtin_amdgcn_wave_barrier();
     after_step0();                                  // the spectrum registers are free from here on
     lane = fresh_lane();
 
+#if !(AFG_VORBIS_ABL & 4)
     // step 2 (:2006-2040): half-iteration `it` makes points n4-1-it and n8-1-it
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -598,6 +603,8 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
 
+#endif
+#if !(AFG_VORBIS_ABL & 16)
     // step 7 (:2133-2175) fused with step 8 (:2187-2238).  Item s works on pairs v2[s] and
     // v2[n4-1-s]; the results feed step-8 items x = n4-1-s and x = s.  All of buf2 is read
     // before the first output is written (the output aliases it).
@@ -645,12 +652,18 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
             }
         }
     }
+#endif
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
 }
 
 #ifndef AFG_VORBIS_MIN_WAVES
 #define AFG_VORBIS_MIN_WAVES 2
+#endif
+// Development ablations (tools/build_variant.sh <name> -DAFG_VORBIS_ABL=<bits>): 1 = no PCM stores, 2 = no spectrum
+// loads, 4 = no butterfly passes (step 2 .. bit-reverse), 8 = no window / overlap arithmetic.  Results are wrong by design.
+#ifndef AFG_VORBIS_ABL
+#define AFG_VORBIS_ABL 0
 #endif
 // Make the prefetched spectrum resident *here*: the wait this forces only covers loads that were
 // issued a whole transform ago.  (Loads and stores share one in-order counter on gfx9-class hardware;
@@ -672,6 +685,7 @@ __device__ __forceinline__ void vorbis_wave_body(
 {
     const int lane = threadIdx.x & 63;
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
+    const uint32_t tab0 = st.tab[0], tab1 = st.tab[1];
     const int C = (int)st.nch, c = (int)seg.pad;      // channels of the stream, channel of this wavefront
 
     LaneTwiddles tw;
@@ -718,6 +732,7 @@ __device__ __forceinline__ void vorbis_wave_body(
     // and are waited for (settle) just before the PCM stores of transform k enter the queue.
     float4 xin[4];
     auto issue = [&](int p) {
+        if ((AFG_VORBIS_ABL & 2) && p != p_first) return;
         if (p < p_end && (flags_of(p) & AFG_VORBIS_LONG))
             load_spectrum(xin, spec + lane64(so_reg, p) + c * (kNL / 2));
     };
@@ -732,10 +747,10 @@ __device__ __forceinline__ void vorbis_wave_body(
         window_bounds(bs0, bs1, fl, n, left, right, right_end);
         const int n2 = n >> 1;
         const int which = (fl & AFG_VORBIS_LONG) ? 1 : 0;
-        const float *T = tables + st.tab[which];
+        const float *T = tables + (which ? tab1 : tab0);            // (a runtime index into the struct would put it in scratch memory)
         const float *A = T, *B = T + n2, *Ct = T + n;
         const float *src = spec + lane64(so_reg, p);
-        const bool emit = (p >= (int)seg.p0) && previous_length > 0;
+        const bool emit = (p >= (int)seg.p0) && previous_length > 0 && (!(AFG_VORBIS_ABL & 1) || spec == nullptr);
         const int pn = previous_length;
         const int nout = right - left, plen = right_end - right;
         float *o = out + lane64(oo_reg, p);
@@ -755,14 +770,20 @@ __device__ __forceinline__ void vorbis_wave_body(
             // channel stores its own 4-byte column of the interleaved frames (merged in L2)
             if (emit) {
                 const int nwin = pn < nout ? pn : nout;
-                if (pn * 2 == kNL) {                               // get_window(pn), :2245-2251: the long window (LDS)
+                if (pn * 2 == kNL && nout == kNL / 2) {            // long after long: all 1024 outputs are windowed, no conditions
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int jj = lane + 64 * i;
+                        o[jj * C + c] = smem[left + jj] * lwin[jj] + pv[i] * lwin[1023 - jj];                  // :2624-2626
+                    }
+                } else if (pn * 2 == kNL) {                        // get_window(pn), :2245-2251: the long window (LDS)
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
                         const int jj = lane + 64 * i;
                         if (jj < nwin) o[jj * C + c] = smem[left + jj] * lwin[jj] + pv[i] * lwin[1023 - jj];   // :2624-2626
                     }
                 } else {
-                    const float *wt = tables + st.tab[(pn * 2 == bs1) ? 1 : 0] + (pn * 2) + (pn * 2 / 4);
+                    const float *wt = tables + ((pn * 2 == bs1) ? tab1 : tab0) + (pn * 2) + (pn * 2 / 4);
 #pragma unroll
                     for (int i = 0; i < 2; i++) {                  // pn is 64 or 128 here
                         const int jj = lane + 64 * i;
@@ -771,20 +792,404 @@ __device__ __forceinline__ void vorbis_wave_body(
                 }
                 for (int jj = nwin + lane; jj < nout; jj += 64) o[jj * C + c] = smem[left + jj];
             }
+#if !(AFG_VORBIS_ABL & 32)
+            if (plen == kNL / 2) {                                                     // :2641-2643; the long-long case:
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                if (64 * i < plen) pv[i] = smem[right + lane + 64 * i];                 // :2641-2643
+                for (int i = 0; i < 16; i++) pv[i] = smem[right + lane + 64 * i];      // sixteen reads, no conditions
+            } else {                                                                   // 64 or 128 samples
+                pv[0] = smem[right + lane];
+                if (plen > 64) pv[1] = smem[right + lane + 64];
+            }
+#endif
             __builtin_amdgcn_wave_barrier();
         }
         previous_length = plen;
     }
 }
 
+// =========================================================================================
+// Two channels per wavefront (stereo streams): the transforms of the left and the right channel of a packet are
+// independent, so every pass issues the LDS reads of both, computes both, writes both.  The second channel's reads
+// are in flight while the first is being computed -- the single-channel walk spent half its life in s_waitcnt
+// (profiles/r02_pmc_vorbis_wave_kernel.json) -- the tables are read once for both, and the PCM leaves as
+// interleaved (L, R) 8-byte stores, half as many instructions for the same bytes.
+// =========================================================================================
+constexpr int kDualStride = kWaveLds;               // channel 1's transform area follows channel 0's
+
+template <typename AfterStep0>
+__device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], float *smem, const LaneTwiddles &tw,
+                                                 const float *A, const float *B, const float *C, AfterStep0 after_step0)
+{
+    constexpr int n = kNL, n2 = n / 2, n4 = n / 4, n8 = n / 8;
+    int lane = fresh_lane();
+    f2 *const U0 = (f2 *)smem;
+    f2 *const V0 = (f2 *)(smem + kUFloats);
+    constexpr int CS = kDualStride / 2;             // channel stride in f2
+    const f2 *A2p = (const f2 *)A;
+
+#if !(AFG_VORBIS_ABL & 64)
+    // step 0 (:1972-1994)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int q = lane + 64 * r, qm = n8 - 1 - q;
+        const f2 a0 = A2p[q];
+        const f2 a1 = A2p[n8 + qm];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            const f2 xa = f2{ xin[ch][r].x, xin[ch][r].y }, xb = f2{ xin[ch][r].z, xin[ch][r].w };
+            const f2 d = pk_mul_lh_ll(xa, a0) + pk_mul_ll_lnh(xb, a0);
+            V0[ch * CS + n4 - 1 - q] = d;
+            const f2 g = pk_mul_nhh_nhl(xb, a1) + pk_mul_nhl_hh(xa, a1);
+            V0[ch * CS + q] = g;
+        }
+    }
+#endif
+    __builtin_amdgcn_wave_barrier();
+    after_step0();                                  // the spectrum registers are free from here on
+    lane = fresh_lane();
+
+#if !(AFG_VORBIS_ABL & 4)
+    // step 2 (:2006-2040)
+    {
+        f2 e0[2][4], e1[2][4];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int it = lane + 64 * r;
+                e0[ch][r] = V0[ch * CS + n8 + it];
+                e1[ch][r] = V0[ch * CS + it];
+            }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int it = lane + 64 * r;
+                const f2 aa = tw.p1(r);
+                const f2 df = e0[ch][r] - e1[ch][r];
+                const f2 hi = pk_add_swap(e0[ch][r], e1[ch][r]);
+                const f2 lo = pk_mul_hl_ll(df, aa) + pk_mul_nlh_hh(df, aa);
+                U0[ch * CS + pad_e(n8 - 1 - it)] = hi;
+                U0[ch * CS + pad_e(n4 - 1 - it)] = lo;
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
+
+    // stages l = 0, 1 (:2053-2060)
+    {
+        const int j = lane;
+        const f2 w00 = tw.pa(0), w01 = tw.pa(1), w1 = tw.pa(2);
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++) {
+            const int base = hb * (n4 / 2) + j;
+            f2 e[2][4];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) e[ch][r] = U0[ch * CS + pad_e(base + 64 * r)];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                bfly2(e[ch][0], e[ch][2], w00);
+                bfly2(e[ch][1], e[ch][3], w01);
+                bfly2(e[ch][0], e[ch][1], w1);
+                bfly2(e[ch][2], e[ch][3], w1);
+#pragma unroll
+                for (int r = 0; r < 4; r++) U0[ch * CS + pad_e(base + 64 * r)] = e[ch][r];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
+
+    // stages l = 2, 3, 4 (:2062-2083)
+    {
+        const int g = lane >> 3, jp = lane & 7;
+        const int base = 64 * g + jp;
+        f2 e[2][8];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[ch][k] = U0[ch * CS + pad_e(base + 8 * k)];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) bfly2(e[ch][k], e[ch][k + 4], tw.pb(k));
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const f2 w = tw.pb(4 + k);
+                bfly2(e[ch][k], e[ch][k + 2], w);
+                bfly2(e[ch][k + 4], e[ch][k + 6], w);
+            }
+            {
+                const f2 w = tw.pb(6);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) bfly2(e[ch][k], e[ch][k + 1], w);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) U0[ch * CS + pad_e(base + 8 * k)] = e[ch][k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
+
+    // last three stages (:1898-1939) + steps 4-6 folded into the store (:2096-2124)
+    {
+        const float A2 = A[n >> 3];
+        const f2 A2p2 = f2{ A2, A2 };
+        const int b9 = 9 * lane;
+        f2 t[2][8];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[ch][k] = U0[ch * CS + b9 + k];
+        f2 *const Vr = V0 - (int)(__brev((unsigned)(63 - lane)) >> 26);
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            f2 (&tt)[8] = t[ch];
+            {
+                const f2 K = tt[0] - tt[4];
+                const f2 L = tt[1] - tt[5];
+                tt[0] = tt[0] + tt[4];
+                tt[1] = tt[1] + tt[5];
+                tt[4] = K;
+                tt[5] = pk_add_lh_hnl(L, L) * A2p2;
+            }
+            {
+                const f2 L = tt[3] - tt[7];
+                const f2 k6 = pk_add_hnh_nll(tt[2], tt[6]);
+                tt[2] = tt[2] + tt[6];
+                tt[3] = tt[3] + tt[7];
+                tt[6] = k6;
+                tt[7] = pk_add_hnl_lh(L, L) * f2{ A2, -A2 };
+            }
+#pragma unroll
+            for (int h = 0; h < 8; h += 4) {
+                const f2 y02 = tt[h] + tt[h + 2];
+                const f2 i01 = tt[h] - tt[h + 2];
+                const f2 y23 = tt[h + 1] + tt[h + 3];
+                const f2 i23 = tt[h + 1] - tt[h + 3];
+                tt[h] = y02 + y23;
+                tt[h + 1] = y02 - y23;
+                tt[h + 2] = pk_add_lh_hnl(i01, i23);
+                tt[h + 3] = pk_add_lnh_hl(i01, i23);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                constexpr int rev2[4] = { 0, 2, 1, 3 };
+                const int kk = 7 - k;
+                Vr[ch * CS + ((kk & 1) ? n8 - 1 : n4 - 1) - 64 * rev2[kk >> 1]] = tt[k];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
+
+#endif
+#if !(AFG_VORBIS_ABL & 16)
+    // step 7 (:2133-2175) fused with step 8 (:2187-2238); all of buf2 is read before the first output is written
+    {
+        const f2 *const C2 = (const f2 *)C;
+        const f2 *const B2 = (const f2 *)B;
+        f2 dn[2][4], en[2][4];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int sidx = lane + 64 * r;
+                dn[ch][r] = V0[ch * CS + sidx];
+                en[ch][r] = V0[ch * CS + n4 - 1 - sidx];
+            }
+        __builtin_amdgcn_wave_barrier();
+        lane = fresh_lane();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int sidx = lane + 64 * r;
+            const f2 cc = C2[sidx];
+            const f2 bb0 = B2[n4 - 1 - sidx], bb1 = B2[sidx];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                float *const sm = smem + ch * kDualStride;
+                const f2 aa = pk_add_lnl_hh(dn[ch][r], en[ch][r]);
+                const f2 bs = pk_add_ll_hnh(dn[ch][r], en[ch][r]);
+                const f2 bq = pk_mul_lh_hh(aa, cc) + pk_mul_hl_nll(aa, cc);
+                const f2 dnew = bs + bq;
+                const f2 enew = pk_add_lnl_nhh(bs, bq);
+                {
+                    const int x = sidx;
+                    const f2 pp = pk_mul_lh_nll(enew, bb0) + pk_mul_nhl_nhh(enew, bb0);
+                    sm[x] = pp.x;
+                    sm[n2 - 1 - x] = -pp.x;
+                    sm[n2 + x] = pp.y;
+                    sm[n - 1 - x] = pp.y;
+                }
+                {
+                    const int x = n4 - 1 - sidx;
+                    const f2 pp = pk_mul_lh_nll(dnew, bb1) + pk_mul_nhl_nhh(dnew, bb1);
+                    sm[x] = pp.x;
+                    sm[n2 - 1 - x] = -pp.x;
+                    sm[n2 + x] = pp.y;
+                    sm[n - 1 - x] = pp.y;
+                }
+            }
+        }
+    }
+#endif
+    __builtin_amdgcn_wave_barrier();
+    lane = fresh_lane();
+}
+
+__device__ __forceinline__ void settle2(float4 (&x)[2][4])
+{
+    settle(x[0]);
+    settle(x[1]);
+}
+
+// One wavefront walks BOTH channels of a stereo segment.
+__device__ __forceinline__ void vorbis_wave2_body(
+    float *smem, const float *ltab, const VorbisSeg &seg, const VorbisStream &st,
+    const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
+    const uint64_t *__restrict__ out_off, const float *tables,
+    const float *__restrict__ spec, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
+    const uint32_t tab0 = st.tab[0], tab1 = st.tab[1];
+
+    LaneTwiddles tw;
+    load_lane_twiddles(tw, ltab, ltab + kTabBase);
+    int previous_length = 0;
+    const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
+    const int p_end = (int)(seg.p0 + seg.count);
+    const float *const lwin = ltab + kNL + kNL / 4;   // window of n = 2048 (LDS)
+
+    float pv[2][16];                                   // previous_window (:2641-2643) of both channels, in registers
+#pragma unroll
+    for (int i = 0; i < 16; i++) pv[0][i] = pv[1][i] = 0.0f;
+
+    int fbase = 0;
+    unsigned fl_reg = 0;
+    uint64_t so_reg = 0, oo_reg = 0;
+    auto refill = [&](int from) {
+        fbase = from;
+        const int q = from + lane;
+        const bool in = q < p_end;
+        fl_reg = in ? (unsigned)pflags[st.pkt_base + (uint64_t)q] : 0u;
+        so_reg = in ? spec_off[st.pkt_base + (uint64_t)q] : 0;
+        oo_reg = in ? out_off[st.pkt_base + (uint64_t)q] : 0;
+        uint32_t s0 = (uint32_t)so_reg, s1 = (uint32_t)(so_reg >> 32), o0 = (uint32_t)oo_reg, o1 = (uint32_t)(oo_reg >> 32);
+        asm volatile("" : "+v"(fl_reg), "+v"(s0), "+v"(s1), "+v"(o0), "+v"(o1) : : "memory");
+        so_reg = ((uint64_t)s1 << 32) | s0;
+        oo_reg = ((uint64_t)o1 << 32) | o0;
+    };
+    auto flags_of = [&](int p) -> unsigned { return (unsigned)__builtin_amdgcn_readlane((int)fl_reg, p - fbase); };
+    auto lane64 = [&](uint64_t v, int p) -> uint64_t {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, p - fbase);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), p - fbase);
+        return ((uint64_t)hi << 32) | lo;
+    };
+    refill(p_first);
+
+    float4 xin[2][4];
+    auto issue = [&](int p) {
+        if ((AFG_VORBIS_ABL & 2) && p != p_first) return;
+        if (p < p_end && (flags_of(p) & AFG_VORBIS_LONG)) {
+            const float *src = spec + lane64(so_reg, p);
+            load_spectrum(xin[0], src);
+            load_spectrum(xin[1], src + kNL / 2);
+        }
+    };
+    issue(p_first);
+    settle2(xin);
+
+    for (int p = p_first; p < p_end; p++) {
+        if (p + 1 - fbase >= 64) refill(p);
+        const unsigned fl = flags_of(p);
+        int n, left, right, right_end;
+        window_bounds(bs0, bs1, fl, n, left, right, right_end);
+        const int n2 = n >> 1;
+        const int which = (fl & AFG_VORBIS_LONG) ? 1 : 0;
+        const float *T = tables + (which ? tab1 : tab0);            // (a runtime index into the struct would put it in scratch memory)
+        const float *A = T, *B = T + n2, *Ct = T + n;
+        const float *src = spec + lane64(so_reg, p);
+        const bool emit = (p >= (int)seg.p0) && previous_length > 0 && (!(AFG_VORBIS_ABL & 1) || spec == nullptr);
+        const int pn = previous_length;
+        const int nout = right - left, plen = right_end - right;
+        f2 *o = (f2 *)(out + lane64(oo_reg, p));           // interleaved frames: one (L, R) pair per frame, 8-byte aligned
+        float *const sm0 = smem, *const sm1 = smem + kDualStride;
+
+        auto next = [&]() { issue(p + 1); };
+        if (which) {
+            imdct_2048_wave2(xin, smem, tw, ltab, ltab + kNL / 2, ltab + kNL, next);   // :2526-2527, tables in LDS
+        } else {
+            for (int ch = 0; ch < 2; ch++) {
+                float *sm = smem + ch * kDualStride;
+                for (int k = lane; k < n2; k += 64) sm[k] = src[ch * n2 + k];
+                __builtin_amdgcn_wave_barrier();
+                inverse_mdct_lds<64>(sm, sm + n, n, 31 - __clz(n), A, B, Ct);
+            }
+            next();
+        }
+        settle2(xin);
+        // vorbis_finish_frame (:2606-2657) + interleave (:3927-3952)
+        if (emit) {
+            const int nwin = pn < nout ? pn : nout;
+            if (pn * 2 == kNL && nout == kNL / 2) {            // long after long: all 1024 frames are windowed
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int jj = lane + 64 * i;
+                    const float w0 = lwin[jj], w1 = lwin[1023 - jj];
+                    o[jj] = f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 };   // :2624-2626
+                }
+            } else if (pn * 2 == kNL) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int jj = lane + 64 * i;
+                    if (jj < nwin) {
+                        const float w0 = lwin[jj], w1 = lwin[1023 - jj];
+                        o[jj] = f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 };
+                    }
+                }
+            } else {
+                const float *wt = tables + ((pn * 2 == bs1) ? tab1 : tab0) + (pn * 2) + (pn * 2 / 4);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {                  // pn is 64 or 128 here
+                    const int jj = lane + 64 * i;
+                    if (jj < nwin) {
+                        const float w0 = wt[jj], w1 = wt[pn - 1 - jj];
+                        o[jj] = f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 };
+                    }
+                }
+            }
+            for (int jj = nwin + lane; jj < nout; jj += 64) o[jj] = f2{ sm0[left + jj], sm1[left + jj] };
+        }
+#if !(AFG_VORBIS_ABL & 32)
+        if (plen == kNL / 2) {                                 // :2641-2643
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                pv[0][i] = sm0[right + lane + 64 * i];
+                pv[1][i] = sm1[right + lane + 64 * i];
+            }
+        } else {
+            pv[0][0] = sm0[right + lane];
+            pv[1][0] = sm1[right + lane];
+            if (plen > 64) {
+                pv[0][1] = sm0[right + lane + 64];
+                pv[1][1] = sm1[right + lane + 64];
+            }
+        }
+#endif
+        __builtin_amdgcn_wave_barrier();
+        previous_length = plen;
+    }
+}
+
 #ifndef AFG_VORBIS_GROUP_WAVES
-#define AFG_VORBIS_GROUP_WAVES 2
+#define AFG_VORBIS_GROUP_WAVES 8
 #endif
 constexpr int kWavesPerGroup = AFG_VORBIS_GROUP_WAVES;
-constexpr int kWaveStride = kWaveLds;                 // transform area only: previous_window is in registers
+constexpr int kWaveStride = 2 * kWaveLds;             // transform areas of two channels: previous_window is in registers
+constexpr uint32_t kBothChannels = 0xffffffffu;       // VorbisSeg.pad of a wavefront that walks both channels of a stereo stream
 
 #ifndef AFG_VORBIS_WAVES_PER_EU
 #define AFG_VORBIS_WAVES_PER_EU 2
@@ -794,21 +1199,47 @@ void vorbis_wave_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
     const uint64_t *__restrict__ out_off, const float *tables, uint32_t tab2048,
-    const float *__restrict__ spec, float *__restrict__ out)
+    const float *__restrict__ spec, float *__restrict__ out, uint32_t *__restrict__ next_seg)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *ltab = lds;                                                   // one copy per workgroup
-    for (int i = threadIdx.x; i < kTabBase; i += 64 * kWavesPerGroup) ltab[i] = tables[tab2048 + i];
+    {   // 14 KB of tables: every 16-byte piece in flight at once (a dependent load -> LDS-store loop of 28 rounds cost
+        // 15 % of a 16-packet wavefront's life)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        constexpr int kQuads = kTabBase / 4, kPer = (kQuads + 64 * kWavesPerGroup - 1) / (64 * kWavesPerGroup);
+        static_assert(kTabBase % 4 == 0, "table quads");
+        const v4f *src = (const v4f *)(tables + tab2048);                // tab2048 is a multiple of 4 floats (16-byte aligned)
+        v4f t[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const int i = (int)threadIdx.x + k * 64 * kWavesPerGroup;
+            t[k] = src[i < kQuads ? i : kQuads - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const int i = (int)threadIdx.x + k * 64 * kWavesPerGroup;
+            if (i < kQuads) ((v4f *)ltab)[i] = t[k];
+        }
+    }
     for (int i = threadIdx.x; i < (AFG_VORBIS_TW_REGS ? 0 : kLaneTw * 64); i += 64 * kWavesPerGroup)
         ((f2 *)(ltab + kTabBase))[i] = ((const f2 *)(tables + tab2048))[lane_twiddle_index(i >> 6, i & 63)];
     __syncthreads();                                                     // the only block-level barrier
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: segment and
-    const uint32_t sidx = blockIdx.x * kWavesPerGroup + wave;                                  // stream records load as SMEM
-    if (sidx >= n_segs) return;
+    // Persistent wavefronts: the grid is one workgroup per CU (the LDS holds exactly one) and every wavefront draws
+    // segments from a counter until none are left.  Launching a workgroup per 8 segments instead left each CU idle
+    // between workgroups -- a new one cannot start before all 8 wavefronts of the old one have ended, and then pays
+    // the launch and the table staging again: 2 of 11.5 ms on the C3 batch (profiles/r02_pmc_vorbis_*.json).
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *smem = lds + kTabFloats + wave * kWaveStride;
-    const VorbisSeg seg = segs[sidx];
-    const VorbisStream st = streams[seg.stream];
-    vorbis_wave_body(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
+    for (;;) {
+        uint32_t sidx = 0;
+        if ((threadIdx.x & 63) == 0) sidx = atomicAdd(next_seg, 1u);
+        sidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sidx);                             // scalar: segment and stream
+        if (sidx >= n_segs) return;                                                            // records load as SMEM
+        const VorbisSeg seg = segs[sidx];
+        const VorbisStream st = streams[seg.stream];
+        if (seg.pad == kBothChannels) vorbis_wave2_body(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
+        else vorbis_wave_body(smem, ltab, seg, st, pflags, spec_off, out_off, tables, spec, out);
+    }
 }
 
 int ilog_host(int n)       // stb_vorbis2.d:634-650
@@ -860,6 +1291,11 @@ struct afg_vorbis_plan {
     uint32_t n_wave_segs = 0;      // segments of streams on the wave-level fast path
     uint32_t tab2048 = 0;          // float offset of the n = 2048 table set
     afg::DeviceArray d_segs, d_wave_segs, d_streams, d_pflags, d_spec_off, d_out_off, d_tables;
+    // work counters of the persistent wave kernel: launch k uses (and first clears, on its stream) counter k % 64, so
+    // launches of one plan that overlap on different streams do not share one
+    afg::DeviceArray d_counters;
+    mutable std::atomic<uint32_t> launches{ 0 };
+    uint32_t wave_groups = 0;      // workgroups the persistent kernel is launched with
 };
 
 extern "C" int afg_vorbis_plan_create(afg_vorbis_plan **plan, uint32_t n_streams, const uint32_t *packets,
@@ -955,7 +1391,9 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
         }
         for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
             uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
-            if (fast)
+            if (fast && channels[s] == 2 && !getenv("AFG_VORBIS_SINGLE"))
+                wave_segs.push_back(VorbisSeg{ s, p0, cnt, kBothChannels });                                  // both channels, interleaved
+            else if (fast)
                 for (uint32_t c = 0; c < channels[s]; c++) wave_segs.push_back(VorbisSeg{ s, p0, cnt, c });   // one per channel
             else
                 segs.push_back(VorbisSeg{ s, p0, cnt, 0 });
@@ -981,6 +1419,14 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     if (!rc) rc = p->d_spec_off.upload(p->h_spec_off.data(), p->h_spec_off.size() * sizeof(uint64_t));
     if (!rc) rc = p->d_out_off.upload(p->h_out_off.data(), p->h_out_off.size() * sizeof(uint64_t));
     if (!rc) rc = p->d_tables.upload(tables.data(), tables.size() * sizeof(float));
+    if (!rc && p->n_wave_segs) {
+        const uint32_t zeros[64] = {};
+        rc = p->d_counters.upload(zeros, sizeof(zeros));
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const uint32_t need = (p->n_wave_segs + kWavesPerGroup - 1) / kWavesPerGroup;
+        p->wave_groups = need < (uint32_t)cus ? need : (uint32_t)cus;
+    }
     if (!rc && p->n_wave_segs) {
         hipError_t e = hipFuncSetAttribute((const void *)vorbis_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(sizeof(float) * (kTabFloats + kWavesPerGroup * kWaveStride)));
@@ -1017,6 +1463,7 @@ void afg_vorbis_plan_destroy(afg_vorbis_plan *plan)
     plan->d_spec_off.release();
     plan->d_out_off.release();
     plan->d_tables.release();
+    plan->d_counters.release();
     delete plan;
 }
 
@@ -1040,13 +1487,16 @@ int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, f
         afg::set_error("afg_vorbis_transform_hip: NULL device pointer");
         return AFG_ERR_INVALID;
     }
-    if (plan->n_wave_segs)
-        hipLaunchKernelGGL(vorbis_wave_kernel, dim3((plan->n_wave_segs + kWavesPerGroup - 1) / kWavesPerGroup),
+    if (plan->n_wave_segs) {
+        uint32_t *counter = (uint32_t *)plan->d_counters.ptr + (plan->launches.fetch_add(1) & 63u);
+        AFG_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), (hipStream_t)hip_stream));
+        hipLaunchKernelGGL(vorbis_wave_kernel, dim3(plan->wave_groups),
                            dim3(64 * kWavesPerGroup), sizeof(float) * (kTabFloats + kWavesPerGroup * kWaveStride),
                            (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_wave_segs.ptr, plan->n_wave_segs,
                            (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
                            (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
-                           (const float *)plan->d_tables.ptr, plan->tab2048, d_spec, d_out);
+                           (const float *)plan->d_tables.ptr, plan->tab2048, d_spec, d_out, counter);
+    }
     if (plan->n_segs)
         hipLaunchKernelGGL(vorbis_transform_kernel, dim3(plan->n_segs), dim3(kThreads), plan->lds_bytes,
                            (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_segs.ptr,
