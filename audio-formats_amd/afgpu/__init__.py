@@ -44,7 +44,7 @@ WAV_S8, WAV_S16LE, WAV_S24LE, WAV_FP32LE, WAV_FP64LE = range(5)
 ABI_SYMBOLS = [
     "afg_abi_version", "afg_status_string", "afg_last_error", "afg_device_count", "afg_device_name",
     "afg_mp3_plan_create", "afg_mp3_plan_destroy", "afg_mp3_plan_blocks", "afg_mp3_plan_segments",
-    "afg_mp3_transform_hip",
+    "afg_mp3_transform_hip", "afg_mp3_requant_hip", "afg_mp3_parse_q", "afg_mp3_parsed_q_free", "afg_mp3_qtables",
     "afg_vorbis_plan_create", "afg_vorbis_plan_destroy", "afg_vorbis_plan_packets",
     "afg_vorbis_plan_spec_floats", "afg_vorbis_plan_out_floats", "afg_vorbis_plan_offsets",
     "afg_vorbis_transform_hip",
@@ -86,6 +86,17 @@ class Mp3Parsed(C.Structure):
                 ("n_runs", C.c_uint64), ("n_blocks", C.c_uint64), ("n_copies", C.c_uint64),
                 ("run_granules", C.c_void_p), ("coef", C.c_void_p), ("flags", C.c_void_p), ("copies", C.c_void_p),
                 ("owner", C.c_void_p)]
+
+
+class Mp3ParsedQ(C.Structure):
+    _fields_ = [("base", Mp3Parsed), ("n_granules", C.c_uint64), ("n_sdesc", C.c_uint64), ("q", C.c_void_p),
+                ("granules", C.c_void_p), ("sdesc", C.c_void_p)]
+
+
+MP3_QGRANULE_DTYPE = np.dtype([("q_off", np.uint64), ("coef_off", np.uint64), ("sdesc", np.uint32), ("nch", np.uint8),
+                               ("stereo", np.uint8), ("table", np.uint8, (2,)), ("scale", np.float32, (2, 40))], align=True)
+MP3_SDESC_DTYPE = np.dtype([("type", np.uint8, (40,)), ("fl", np.float32, (40,)), ("fr", np.float32, (40,))], align=True)
+assert MP3_QGRANULE_DTYPE.itemsize == 344 and MP3_SDESC_DTYPE.itemsize == 360
 
 
 class VorbisParsed(C.Structure):
@@ -190,6 +201,10 @@ def lib():
     L.afg_mp3_parse.argtypes = [vp, C.c_size_t, C.POINTER(Mp3Parsed)]
     L.afg_mp3_parsed_free.argtypes = [C.POINTER(Mp3Parsed)]
     L.afg_mp3_parsed_free.restype = None
+    L.afg_mp3_parse_q.argtypes = [vp, C.c_size_t, C.POINTER(Mp3ParsedQ)]
+    L.afg_mp3_parsed_q_free.argtypes = [C.POINTER(Mp3ParsedQ)]
+    L.afg_mp3_parsed_q_free.restype = None
+    L.afg_mp3_requant_hip.argtypes = [u64, vp, vp, vp, vp, vp]
     L.afg_vorbis_parse.argtypes = [vp, C.c_size_t, C.POINTER(VorbisParsed)]
     L.afg_vorbis_parsed_free.argtypes = [C.POINTER(VorbisParsed)]
     L.afg_vorbis_parsed_free.restype = None
@@ -442,6 +457,43 @@ def mp3_parse(file_bytes):
                 view(out.copies, out.n_copies * 2, np.uint64).reshape(-1, 2))
     finally:
         lib().afg_mp3_parsed_free(C.byref(out))
+
+
+def mp3_parse_q(file_bytes):
+    """Host front-end in quantised mode (afg_mp3_parse_q): (info, run_granules, q int16 [blocks, 576], flags, copies,
+    granule records, stereo descriptors).  Raises AfgError (unsupported) for streams the device requantiser does not cover."""
+    buf = bytes(file_bytes)
+    out = Mp3ParsedQ()
+    check(lib().afg_mp3_parse_q(buf, len(buf), C.byref(out)))
+    try:
+        def view(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype)
+            raw = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(raw, dtype=dtype, count=count).copy()
+        b = out.base
+        info = {k: int(getattr(b, k)) for k in ("channels", "hz", "tagged", "start_delay", "detected_samples",
+                                                "declared_samples", "pcm_samples")}
+        return (info, view(b.run_granules, b.n_runs, np.uint32), view(out.q, b.n_blocks * 576, np.int16).reshape(-1, 576),
+                view(b.flags, b.n_blocks, np.uint32), view(b.copies, b.n_copies * 2, np.uint64).reshape(-1, 2),
+                view(out.granules, out.n_granules, MP3_QGRANULE_DTYPE), view(out.sdesc, out.n_sdesc, MP3_SDESC_DTYPE))
+    finally:
+        lib().afg_mp3_parsed_q_free(C.byref(out))
+
+
+def mp3_qtables():
+    """afg_mp3_qtables: (band_of_line uint8 [24, 576], dst_of_src uint16 [24, 576], pow43 float32 [145])."""
+    bol, dst, p43 = np.zeros((24, 576), np.uint8), np.zeros((24, 576), np.uint16), np.zeros(145, np.float32)
+    fn = lib().afg_mp3_qtables
+    fn.argtypes = [C.c_void_p] * 3
+    fn.restype = None
+    fn(bol.ctypes.data, dst.ctypes.data, p43.ctypes.data)
+    return bol, dst, p43
+
+
+def mp3_requant(n_granules, d_granules, d_q, d_sdesc, d_coef, stream=None):
+    """Enqueue the MP3 requantisation (afg_mp3_requant_hip)."""
+    check(lib().afg_mp3_requant_hip(int(n_granules), _ptr(d_granules), _ptr(d_q), _ptr(d_sdesc), _ptr(d_coef), _stream(stream)))
 
 
 def vorbis_parse(file_bytes):

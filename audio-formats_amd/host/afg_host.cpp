@@ -1048,6 +1048,68 @@ void afg_mp3_parsed_free(afg_mp3_parsed *p)
     std::memset(p, 0, sizeof(*p));
 }
 
+int afg_mp3_parse_q(const uint8_t *data, size_t length, afg_mp3_parsed_q *out)
+{
+    try {
+        if (!out) return AFG_ERR_INVALID;
+        std::memset(out, 0, sizeof(*out));
+        if (!data) return AFG_ERR_INVALID;
+        auto *own = new (std::nothrow) afg_mp3::File;
+        if (!own) return AFG_ERR_OOM;
+        own->quantised = true;
+        if (!afg_mp3::parse_file(data, length, *own)) {
+            delete own;
+            afg::set_error("afg_mp3_parse_q: no MPEG Layer III stream found");
+            return AFG_ERR_UNSUPPORTED;
+        }
+        if (own->q_unsupported) {
+            delete own;
+            afg::set_error("afg_mp3_parse_q: the stream holds MPEG-2.5 8 kHz mixed blocks, which the device requantiser does not cover");
+            return AFG_ERR_UNSUPPORTED;
+        }
+        afg_mp3_parsed &b = out->base;
+        b.channels = own->channels;
+        b.hz = own->hz;
+        b.tagged = own->tagged ? 1 : 0;
+        b.start_delay = own->start_delay;
+        b.detected_samples = own->detected_samples;
+        b.declared_samples = own->declared_samples;
+        b.pcm_samples = own->pcm_samples;
+        b.n_runs = own->run_granules.size();
+        b.n_blocks = own->blocks();
+        b.n_copies = own->copies.size();
+        b.run_granules = own->run_granules.data();
+        b.coef = nullptr;
+        b.flags = own->flags.data();
+        b.copies = (afg_mp3_copy *)own->copies.data();
+        b.owner = own;
+        out->n_granules = own->qgr.size();
+        out->n_sdesc = own->sdesc.size();
+        out->q = own->q.data();
+        out->granules = own->qgr.data();
+        out->sdesc = own->sdesc.data();
+        return AFG_OK;
+    } catch (...) {
+        afg::set_error("out of host memory");
+        return AFG_ERR_OOM;
+    }
+}
+
+void afg_mp3_qtables(uint8_t band_of_line[24][576], uint16_t dst_of_src[24][576], float pow43[145])
+{
+    const afg_mp3::QTables &t = afg_mp3::qtables();
+    if (band_of_line) std::memcpy(band_of_line, t.band_of_line, sizeof(t.band_of_line));
+    if (dst_of_src) std::memcpy(dst_of_src, t.dst_of_src, sizeof(t.dst_of_src));
+    if (pow43) std::memcpy(pow43, t.pow43, sizeof(t.pow43));
+}
+
+void afg_mp3_parsed_q_free(afg_mp3_parsed_q *p)
+{
+    if (!p) return;
+    delete (afg_mp3::File *)p->base.owner;
+    std::memset(p, 0, sizeof(*p));
+}
+
 int afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out)
 {
     try {

@@ -330,7 +330,10 @@ void band_scales(const Header &hd, uint8_t *ist, Bits &b, const Granule &g, floa
 
 // L3_huffman by spectral line: big-value pairs of the three regions, then count1 quads up to the end of
 // part2_3 (a quad that ends past it is discarded) or the end of the band table.
-void spectrum(float *line, const uint8_t *main_data, int *bitpos, const Granule &g, const float *scale, int limit)
+// With `qline` the Huffman values themselves are recorded (sign included) instead of the requantised lines: the device
+// requantises them (afg_mp3_requant_hip).
+void spectrum(float *line, const uint8_t *main_data, int *bitpos, const Granule &g, const float *scale, int limit,
+              int16_t *qline = nullptr)
 {
     int ends[41], nb = 0, acc = 0;
     for (; g.bands[nb]; nb++) ends[nb] = (acc += g.bands[nb]);
@@ -364,7 +367,10 @@ void spectrum(float *line, const uint8_t *main_data, int *bitpos, const Granule 
                     v += (int)win.peek(extra);
                     win.drop(extra);
                     win.fill();
-                    line[i + j] = one * pow43(v) * (win.top() ? -1 : 1);
+                    if (qline) qline[i + j] = (int16_t)(win.top() ? -v : v);
+                    else line[i + j] = one * pow43(v) * (win.top() ? -1 : 1);
+                } else if (qline) {
+                    qline[i + j] = (int16_t)((v && win.top()) ? -v : v);
                 } else {
                     line[i + j] = bits_f32(k_pow43_bits[16 + v - (win.top() ? 16 : 0)]) * one;
                 }
@@ -389,15 +395,20 @@ void spectrum(float *line, const uint8_t *main_data, int *bitpos, const Granule 
         while (band < nb && i >= ends[band]) band++;
         if (band >= nb) break;
         float one = scale[band];
-        if (e & 8) { line[i] = win.top() ? -one : one; win.drop(1); }
-        if (e & 4) { line[i + 1] = win.top() ? -one : one; win.drop(1); }
+        auto unit = [&](int at) {                          // a count1 line: +-1 (requantised: +-one)
+            if (qline) qline[at] = (int16_t)(win.top() ? -1 : 1);
+            else line[at] = win.top() ? -one : one;
+            win.drop(1);
+        };
+        if (e & 8) unit(i);
+        if (e & 4) unit(i + 1);
         if (i + 2 >= total) break;
         int b2 = band;
         while (b2 < nb && i + 2 >= ends[b2]) b2++;
         if (b2 >= nb) break;
         one = scale[b2];
-        if (e & 2) { line[i + 2] = win.top() ? -one : one; win.drop(1); }
-        if (e & 1) { line[i + 3] = win.top() ? -one : one; win.drop(1); }
+        if (e & 2) unit(i + 2);
+        if (e & 1) unit(i + 3);
         win.fill();
     }
     *bitpos = limit;
@@ -413,17 +424,24 @@ void mid_side(float *l, int n)
     }
 }
 
-// L3_intensity_stereo + L3_stereo_process
-void intensity(float *left, uint8_t *ist, const Granule *g, const Header &hd)
+// L3_intensity_stereo + L3_stereo_process, in two halves: the plan (which band gets which treatment: needs to know where
+// the right channel still has energy) and its application to the lines.  The quantised path ships the plan to the device.
+struct StereoPlan {
+    uint8_t type[40];                  // per band of the left channel's table: 0 leave, 1 mid/side, 2 intensity
+    float fl[40], fr[40];
+};
+
+template <typename RightNonzero>
+void intensity_plan(StereoPlan &plan, uint8_t *ist, const Granule *g, const Header &hd, RightNonzero right_nonzero)
 {
     const int nb = g->n_long + g->n_short, blocks = g->n_short ? 3 : 1;
     int top[3] = { -1, -1, -1 };
     {   // last band of the right channel with energy, per window
-        const float *r = left + 576;
+        int at = 0;
         for (int b = 0; b < nb; b++) {
             for (int k = 0; k < g->bands[b]; k += 2)
-                if (r[k] != 0 || r[k + 1] != 0) { top[b % 3] = b; break; }
-            r += g->bands[b];
+                if (right_nonzero(at + k) || right_nonzero(at + k + 1)) { top[b % 3] = b; break; }
+            at += g->bands[b];
         }
     }
     if (g->n_long) top[0] = top[1] = top[2] = std::max(std::max(top[0], top[1]), top[2]);
@@ -433,10 +451,9 @@ void intensity(float *left, uint8_t *ist, const Granule *g, const Header &hd)
     }
     const int lsf_shift = g[1].sf_compress & 1;
     const unsigned max_pos = hd.mpeg1() ? 7 : 64;
-    float *l = left;
+    std::memset(&plan, 0, sizeof(plan));
     for (int b = 0; g->bands[b]; b++) {
         const unsigned ipos = ist[b];
-        const int n = g->bands[b];
         if (b > top[b % 3] && ipos < max_pos) {
             const float s = hd.ms_bit() ? 1.41421356f : 1;
             float kl, kr;
@@ -451,12 +468,30 @@ void intensity(float *left, uint8_t *ist, const Granule *g, const Header &hd)
                     kr = 1;
                 }
             }
-            const float fl = kl * s, fr = kr * s;
+            plan.type[b] = 2;
+            plan.fl[b] = kl * s;
+            plan.fr[b] = kr * s;
+        } else if (hd.ms_bit()) {
+            plan.type[b] = 1;
+        }
+    }
+}
+
+void intensity(float *left, uint8_t *ist, const Granule *g, const Header &hd)
+{
+    StereoPlan plan;
+    const float *r = left + 576;
+    intensity_plan(plan, ist, g, hd, [&](int k) { return r[k] != 0; });
+    float *l = left;
+    for (int b = 0; g->bands[b]; b++) {
+        const int n = g->bands[b];
+        if (plan.type[b] == 2) {
+            const float fl = plan.fl[b], fr = plan.fr[b];
             for (int i = 0; i < n; i++) {
                 l[i + 576] = l[i] * fr;
                 l[i] = l[i] * fl;
             }
-        } else if (hd.ms_bit()) {
+        } else if (plan.type[b] == 1) {
             mid_side(l, n);
         }
         l += n;
@@ -473,6 +508,17 @@ struct Work {
     float scale[40];                   // directly behind the spectra, as mp3dec_scratch_t.scf (minimp3.d:179-181)
     float slack[24];
 };
+
+// which of the 24 scalefactor-band tables a granule's `bands` points into: kind * 8 + sample-rate row
+int band_table_id(const uint8_t *bands)
+{
+    const uint8_t *bases[3] = { &k_sfb_long[0][0], &k_sfb_short[0][0], &k_sfb_mixed[0][0] };
+    const size_t row_bytes[3] = { sizeof(k_sfb_long[0]), sizeof(k_sfb_short[0]), sizeof(k_sfb_mixed[0]) };
+    for (int kind = 0; kind < 3; kind++)
+        for (int row = 0; row < 8; row++)
+            if (bands == bases[kind] + (size_t)row * row_bytes[kind]) return kind * 8 + row;
+    return -1;
+}
 
 void interleave_windows(float *x, const uint8_t *bands)
 {
@@ -623,10 +669,76 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
         std::memset(&wk, 0, sizeof(wk));
         float (&x)[2][576] = wk.x;
         float *scale = wk.scale;
+        // Intensity positions persist across the granules of a frame (scfsi copies them, minimp3.d:632) and start from zero
+        // in every frame.  The reference keeps them in an uninitialised stack scratch (mp3dec_scratch_t.ist_pos): a stream
+        // that reads one it never wrote (scfsi in granule 0; a long right channel under a short left one, whose plan walks
+        // 39 bands) gets whatever the stack held there.  Zero is the convention here and in the oracle.
+        uint8_t ist[2][40];
+        std::memset(ist, 0, sizeof(ist));
         for (int gr = 0; gr < ngr; gr++) {
             std::memset(x, 0, sizeof(wk.x));
-            uint8_t ist[2][40];
             const Granule *g = gi + gr * nch;
+            if (out && out->quantised) {
+                // ---- quantised records: Huffman values + what the device needs to requantise them ----
+                int16_t qv[2][576];
+                std::memset(qv, 0, sizeof(qv));
+                afg_mp3_qgranule rec;
+                std::memset(&rec, 0, sizeof(rec));
+                rec.nch = (uint8_t)nch;
+                rec.sdesc = AFG_MP3_NO_SDESC;
+                uint32_t fl[2] = { 0, 0 };
+                int tab[2] = { 0, 0 };
+                const QTables &qt = qtables();
+                for (int ch = 0; ch < nch; ch++) {
+                    const int limit = bitpos + g[ch].part23;
+                    Bits sfb(md.data(), md_bytes);
+                    sfb.pos = bitpos;
+                    band_scales(hd, ist[ch], sfb, g[ch], scale, ch);
+                    bitpos = sfb.pos;
+                    spectrum(nullptr, md.data(), &bitpos, g[ch], scale, limit, qv[ch]);
+                    std::memcpy(rec.scale[ch], scale, sizeof(rec.scale[ch]));
+                    tab[ch] = band_table_id(g[ch].bands);
+                    const int n_long_bands = (g[ch].mixed ? 2 : 0) << (hd.low_rate_25() ? 1 : 0);
+                    int long_lines = 0;
+                    for (int b = 0; b < g[ch].n_long; b++) long_lines += g[ch].bands[b];
+                    if (tab[ch] < 0 || (g[ch].n_short && long_lines != n_long_bands * 18)) out->q_unsupported = true;
+                    rec.table[ch] = (uint8_t)((tab[ch] < 0 ? 0 : tab[ch]) | (g[ch].n_short ? 0x80 : 0));
+                    fl[ch] = AFG_MP3_FLAGS(g[ch].block_type, n_long_bands, g[ch].n_short ? n_long_bands - 1 : 31);
+                }
+                // a line of the right channel is nonzero exactly when its value is and its band's scale is (the
+                // requantised magnitude of a nonzero value is at least 1)
+                if (hd.intensity()) {
+                    StereoPlan plan;
+                    const uint8_t *rb = tab[1] >= 0 ? qt.band_of_line[tab[1]] : qt.band_of_line[0];
+                    intensity_plan(plan, ist[1], g, hd, [&](int k) { return qv[1][k] != 0 && rec.scale[1][rb[k]] != 0; });
+                    afg_mp3_sdesc sd;
+                    std::memcpy(sd.type, plan.type, sizeof(sd.type));
+                    std::memcpy(sd.fl, plan.fl, sizeof(sd.fl));
+                    std::memcpy(sd.fr, plan.fr, sizeof(sd.fr));
+                    rec.stereo = 2;
+                    rec.sdesc = (uint32_t)out->sdesc.size();
+                    out->sdesc.push_back(sd);
+                } else if (hd.ms_stereo()) {
+                    rec.stereo = 1;
+                }
+                for (int ch = 0; ch < nch; ch++) {       // AFG_MP3_NZ_BANDS: with stereo processing a line of either channel
+                    int last = -1;                       // can make both outputs nonzero
+                    const uint16_t *dst = qt.dst_of_src[tab[ch] < 0 ? 0 : tab[ch]];
+                    for (int i = 0; i < 576; i++) {
+                        if (!(qv[ch][i] || (rec.stereo && qv[ch ^ 1][i]))) continue;
+                        const int d = g[ch].n_short ? dst[i] : i;
+                        last = std::max(last, d);
+                    }
+                    fl[ch] |= AFG_MP3_NZ_BANDS((last + 18) / 18);
+                }
+                if (*fresh_state || out->run_granules.empty()) {
+                    out->run_granules.push_back(0);
+                    *fresh_state = false;
+                }
+                out->run_granules.back()++;
+                out->push_q(qv, nch, rec, fl);
+                continue;
+            }
             for (int ch = 0; ch < nch; ch++) {
                 const int limit = bitpos + g[ch].part23;
                 Bits sfb(md.data(), md_bytes);
@@ -679,6 +791,42 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
 
 }  // namespace
 
+const QTables &qtables()
+{
+    static const QTables tabs = [] {
+        QTables t;
+        std::memset(&t, 0, sizeof(t));
+        const uint8_t *bases[3] = { &k_sfb_long[0][0], &k_sfb_short[0][0], &k_sfb_mixed[0][0] };
+        const size_t row_bytes[3] = { sizeof(k_sfb_long[0]), sizeof(k_sfb_short[0]), sizeof(k_sfb_mixed[0]) };
+        for (int kind = 0; kind < 3; kind++)
+            for (int row = 0; row < 8; row++) {
+                const uint8_t *bands = bases[kind] + (size_t)row * row_bytes[kind];
+                uint8_t *bol = t.band_of_line[kind * 8 + row];
+                uint16_t *dst = t.dst_of_src[kind * 8 + row];
+                for (int i = 0; i < 576; i++) dst[i] = (uint16_t)i;
+                int at = 0, nb = 0;
+                for (; bands[nb] && at < 576; nb++)
+                    for (int k = 0; k < bands[nb] && at < 576; k++) bol[at++] = (uint8_t)nb;
+                // the short part: groups of three equal widths (one per window), as L3_reorder walks them.  Long tables have
+                // none; short tables are all groups; mixed tables start their groups after the long bands (8 at MPEG-1
+                // rates, 6 below: L3_read_side_info; rows 5..7 of the tables are the MPEG-1 rates)
+                const int first = kind == 0 ? nb : kind == 1 ? 0 : (row >= 5 ? 8 : 6);
+                int s0 = 0;
+                for (int b = 0; b < first && b < nb; b++) s0 += bands[b];
+                for (int b = first; b + 2 < nb + 0 && s0 < 576; b += 3) {
+                    const int len = bands[b];
+                    for (int w = 0; w < 3; w++)
+                        for (int k = 0; k < len; k++)
+                            if (s0 + w * len + k < 576 && s0 + 3 * k + w < 576) dst[s0 + w * len + k] = (uint16_t)(s0 + 3 * k + w);
+                    s0 += 3 * len;
+                }
+            }
+        for (int i = 0; i < 145; i++) t.pow43[i] = bits_f32(k_pow43_bits[i]);
+        return t;
+    }();
+    return tabs;
+}
+
 bool looks_like_mp3(const uint8_t *data, size_t size)
 {
     if (!data || size < 10) return false;
@@ -726,7 +874,13 @@ bool parse_file(const uint8_t *data, size_t size, File &f) { return parse_file_i
 
 bool parse_file_into(const uint8_t *data, size_t size, File &f, float *coef_dst, uint32_t *flags_dst, size_t cap)
 {
+    const bool quantised = f.quantised;                    // the caller's choices survive the reset
+    int16_t *const ext_q = f.ext_q;
+    afg_mp3_qgranule *const ext_qgr = f.ext_qgr;
     f = File();
+    f.quantised = quantised;
+    f.ext_q = ext_q;
+    f.ext_qgr = ext_qgr;
     f.ext_coef = coef_dst;
     f.ext_flags = flags_dst;
     f.ext_cap = cap;

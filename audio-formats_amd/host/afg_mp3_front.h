@@ -32,7 +32,39 @@ struct File {
     size_t ext_cap = 0, n_blocks = 0;
     bool overflow = false;
 
+    // Quantised mode (set `quantised` before parsing): instead of dequantised lines the parser records
+    // the Huffman values (int16, 576 per block) and per granule what afg_mp3_requant_hip needs to turn them into the
+    // same floats on the device: band scales, band tables, the stereo plan.  coef stays empty.
+    bool quantised = false;
+    bool q_unsupported = false;          // a granule the device requantiser does not cover was met (MPEG-2.5 8 kHz mixed
+                                         // blocks, whose reorder walks outside the channel: minimp3.d:1218-1223)
+    std::vector<int16_t> q;
+    std::vector<afg_mp3_qgranule> qgr;
+    std::vector<afg_mp3_sdesc> sdesc;
+    int16_t *ext_q = nullptr;            // optional caller storage, like ext_coef: ext_cap blocks of 576 values ...
+    afg_mp3_qgranule *ext_qgr = nullptr; // ... and ext_cap granule records (record k describes the granule whose first
+                                         // block is k: slots of second channels stay unused)
+    size_t n_granules = 0;
+
     size_t blocks() const { return n_blocks; }
+    // one granule in quantised mode: values of its nch channels, its record (q_off / coef_off filled here), its flags
+    void push_q(const int16_t (*qv)[576], int nch, afg_mp3_qgranule rec, const uint32_t *fl)
+    {
+        if (ext_q) {
+            if (n_blocks + (size_t)nch > ext_cap) { overflow = true; return; }
+            std::memcpy(ext_q + n_blocks * 576, qv, (size_t)nch * 576 * sizeof(int16_t));
+            rec.q_off = rec.coef_off = (uint64_t)n_blocks * 576;
+            ext_qgr[n_blocks] = rec;
+            for (int c = 0; c < nch; c++) ext_flags[n_blocks + (size_t)c] = fl[c];
+        } else {
+            rec.q_off = rec.coef_off = (uint64_t)n_blocks * 576;
+            q.insert(q.end(), &qv[0][0], &qv[0][0] + (size_t)nch * 576);
+            qgr.push_back(rec);
+            for (int c = 0; c < nch; c++) flags.push_back(fl[c]);
+        }
+        n_blocks += (size_t)nch;
+        n_granules++;
+    }
     void push(const float *x, uint32_t fl)
     {
         // AFG_MP3_NZ_BANDS: subbands above the last line whose bit pattern is not +0.0 need not be fetched by the device
@@ -57,7 +89,14 @@ struct File {
     void truncate(size_t nb)
     {
         n_blocks = nb;
-        if (!ext_coef) {
+        if (quantised) {
+            if (!ext_q) {
+                q.resize(nb * 576);
+                flags.resize(nb);
+                while (!qgr.empty() && qgr.back().q_off >= (uint64_t)nb * 576) qgr.pop_back();
+            }
+            n_granules = channels ? nb / (size_t)channels : 0;
+        } else if (!ext_coef) {
             coef.resize(nb * 576);
             flags.resize(nb);
         }
@@ -70,5 +109,14 @@ bool parse_file(const uint8_t *data, size_t size, File &out);      // false: no 
 bool parse_file_into(const uint8_t *data, size_t size, File &out, float *coef, uint32_t *flags, size_t cap);
 // an upper bound for the number of granule-channel blocks parse_file will produce (frame-header walk only)
 size_t max_blocks(const uint8_t *data, size_t size);
+
+// Tables of the device requantiser, derived from the scalefactor-band tables (24 = 3 kinds x 8 sample-rate rows):
+// band of every line, and where a line of the short part goes when L3_reorder interleaves the windows.
+struct QTables {
+    uint8_t band_of_line[24][576];
+    uint16_t dst_of_src[24][576];
+    float pow43[145];                    // g_pow43 (minimp3.d:722-735): 16 negative entries, then 0 .. 128
+};
+const QTables &qtables();
 
 }  // namespace afg_mp3

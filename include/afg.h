@@ -88,6 +88,40 @@ uint32_t afg_mp3_plan_segments(const afg_mp3_plan *plan);   /* workgroups one la
 int afg_mp3_transform_hip(const afg_mp3_plan *plan, const float *d_coef, const uint32_t *d_flags,
                           float *d_pcm, float *d_state, void *hip_stream);
 
+/* -------------------------------------------------------------------------- *
+ *  MP3 requantisation on the device (ship the Huffman values, not floats)
+ *  replaces, between the entropy decoder and the transform stage above:
+ *    minimp3.d:722-746   L3_pow_43 and the `* sf` of L3_huffman (:835-858, :868-879)
+ *    minimp3.d:885-982   L3_midside_stereo / L3_intensity_stereo / L3_stereo_process
+ *    minimp3.d:984-1000  L3_reorder
+ *  The host keeps Huffman decoding and the scalefactor arithmetic (L3_decode_scalefactors, :616-719: 39 floats per
+ *  granule-channel) and decides the stereo plan (which band is mid/side or intensity coded, with which factors); the
+ *  device turns int16 values into exactly the floats L3_decode holds in grbuf at :1226 -- 2 bytes per line cross the
+ *  bus instead of 4.  MPEG-2.5 8 kHz mixed blocks are not covered (their reorder walks outside the channel,
+ *  :1218-1223): afg_mp3_parse_q reports AFG_ERR_UNSUPPORTED for such a file and the float path takes it.
+ * -------------------------------------------------------------------------- */
+#define AFG_MP3_NO_SDESC 0xffffffffu
+
+typedef struct afg_mp3_qgranule {
+    uint64_t q_off;          /* int16 index of channel 0's 576 values; channel c at q_off + 576*c */
+    uint64_t coef_off;       /* float index of channel 0's block in the coefficient plane; channel c at + 576*c */
+    uint32_t sdesc;          /* stereo == 2: index of the granule's afg_mp3_sdesc, else AFG_MP3_NO_SDESC */
+    uint8_t  nch;            /* 1 | 2 */
+    uint8_t  stereo;         /* 0 none, 1 mid/side on every line (:1203), 2 per band (intensity frames, :1201) */
+    uint8_t  table[2];       /* per channel: scalefactor-band table (kind*8 + rate row; kind 0 long, 1 short, 2 mixed),
+                                bit 7: the short part is reordered (block_type 2) */
+    float    scale[2][40];   /* band scales of each channel (scf[] of L3_decode_scalefactors) */
+} afg_mp3_qgranule;          /* 344 bytes */
+
+typedef struct afg_mp3_sdesc {
+    uint8_t type[40];        /* per band of channel 0's table: 0 leave, 1 mid/side, 2 intensity */
+    float   fl[40], fr[40];  /* intensity: right = left * fr, then left = left * fl (:929-936) */
+} afg_mp3_sdesc;             /* 360 bytes */
+
+/* d_q: quantised lines (sign included, |v| <= 8206); d_coef receives 576 floats per granule-channel. */
+int afg_mp3_requant_hip(uint64_t n_granules, const afg_mp3_qgranule *d_granules, const int16_t *d_q,
+                        const afg_mp3_sdesc *d_sdesc, float *d_coef, void *hip_stream);
+
 /* ========================================================================== *
  *  Vorbis transform stage
  *  replaces stb_vorbis2.d:2526-2527 (inverse_mdct per channel) and
@@ -303,6 +337,22 @@ typedef struct afg_mp3_parsed {
 
 int  afg_mp3_parse(const uint8_t *data, size_t length, afg_mp3_parsed *out);   /* AFG_ERR_UNSUPPORTED: no Layer III stream */
 void afg_mp3_parsed_free(afg_mp3_parsed *parsed);
+
+/* The same front-end in quantised mode: `coef` stays NULL, the records of afg_mp3_requant_hip come back instead
+ * (coef_off = q_off = 576 * first block of the granule). */
+typedef struct afg_mp3_parsed_q {
+    afg_mp3_parsed    base;          /* coef == NULL */
+    uint64_t          n_granules, n_sdesc;
+    int16_t          *q;             /* n_blocks * 576 */
+    afg_mp3_qgranule *granules;
+    afg_mp3_sdesc    *sdesc;
+} afg_mp3_parsed_q;
+
+int  afg_mp3_parse_q(const uint8_t *data, size_t length, afg_mp3_parsed_q *out);
+void afg_mp3_parsed_q_free(afg_mp3_parsed_q *parsed);
+/* The requantiser's tables, as the device holds them (24 scalefactor-band tables = 3 kinds x 8 rate rows): band of every
+ * line, destination of every line under L3_reorder, and g_pow43 (minimp3.d:722-735).  Any pointer may be NULL. */
+void afg_mp3_qtables(uint8_t band_of_line[24][576], uint16_t dst_of_src[24][576], float pow43[145]);
 
 /* Ogg Vorbis I front-end on its own: Ogg pages and lacing, the three header packets (code books, floor 1,
  * residues 0/1/2, mappings, modes: stb_vorbis2.d:2669-3266) and every audio packet up to the transform seam

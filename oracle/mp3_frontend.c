@@ -612,6 +612,8 @@ static int decode_frame(dec_t *dec, const uint8_t *mp3, int mp3_bytes, float *pc
     if (h_crc(hdr)) get_bits(&bs_frame, 16);
     if (info->layer != 3) return -1;                                   /* Layer I/II: not handled by this build */
     memset(&scratch.maindata, 0, sizeof(scratch.maindata));           /* the reference leaves the tail undefined */
+    memset(scratch.ist_pos, 0, sizeof(scratch.ist_pos));              /* ... and ist_pos: uninitialised stack in the reference
+                                                                         (minimp3.d:179-181); zero at every frame here and in the product */
     int main_data_begin = read_side_info(&bs_frame, scratch.gr_info, hdr);
     if (main_data_begin < 0 || bs_frame.pos > bs_frame.limit) {
         dec->header[0] = 0;                                            /* mp3dec_init, mp3:1486-1489 */
