@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64) void mp3_requant_kernel(const afg_mp3_qgranule 
     const afg_mp3_qgranule *g = grs + gi;
     const int lane = threadIdx.x;
     const int nch = g->nch;
+    if (nch == 0) return;                                // an unused record slot (the host pipeline keeps one slot per block)
     const unsigned stereo = nch == 2 ? g->stereo : 0;
     const int t0 = g->table[0] & 0x1f, t1 = g->table[1] & 0x1f;
     const bool ro0 = (g->table[0] & 0x80) != 0, ro1 = (g->table[1] & 0x80) != 0;

@@ -283,7 +283,9 @@ struct BatchOut {
 // a file's PCM is served where it lands (a per-file copy costs ~20 us of submission: 2 x 2048 of them were the whole
 // end-to-end time of a 2048-file batch).
 struct Mp3Stage {
-    const float *coef = nullptr;
+    const float *coef = nullptr;        // float upload: dequantised spectra, blocks * 576 ...
+    const int16_t *q = nullptr;         // ... or quantised upload: Huffman values, blocks * 576, and one record slot
+    const afg_mp3_qgranule *recs = nullptr;   // per block (the slot of a granule's first block is used, nch = 0 elsewhere)
     const uint32_t *flags = nullptr;
     size_t blocks = 0;
     const size_t *base = nullptr;
@@ -319,12 +321,30 @@ struct Mp3Pipe {
     int rc = AFG_OK;
     hipError_t e = hipSuccess;
 
+    DeviceBuf d_qin;                    // quantised upload: int16 plane, record slots, stereo descriptors
+    int16_t *d_q = nullptr;
+    afg_mp3_qgranule *d_recs = nullptr;
+    afg_mp3_sdesc *d_sdesc = nullptr;
+    StagingPool::Lease h_sdesc;
+    size_t sdesc_cap = 0, sdesc_used = 0;
+    uint64_t h2d_bytes = 0;
+
     int open(const Mp3Stage &stage)
     {
         st = &stage;
         const size_t coef_bytes = stage.blocks * 576 * sizeof(float), flag_bytes = (stage.blocks * 4 + 15) & ~(size_t)15;
         if (int r = d_in.alloc(coef_bytes + flag_bytes)) return r;
         if (int r = d_pcm.alloc(coef_bytes)) return r;
+        if (stage.q) {
+            const size_t q_bytes = (stage.blocks * 576 * sizeof(int16_t) + 15) & ~(size_t)15;
+            const size_t rec_bytes = stage.blocks * sizeof(afg_mp3_qgranule);
+            sdesc_cap = 4096;                            // intensity-stereo granules of the whole batch (grown on demand: rare)
+            if (int r = d_qin.alloc(q_bytes + rec_bytes + sdesc_cap * sizeof(afg_mp3_sdesc))) return r;
+            d_q = (int16_t *)d_qin.p;
+            d_recs = (afg_mp3_qgranule *)((uint8_t *)d_qin.p + q_bytes);
+            d_sdesc = (afg_mp3_sdesc *)((uint8_t *)d_recs + rec_bytes);
+            if (int r = g_staging.take(sdesc_cap * sizeof(afg_mp3_sdesc), h_sdesc)) return r;
+        }
         d_flags = (uint32_t *)((uint8_t *)d_in.p + coef_bytes);
         e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
@@ -366,9 +386,35 @@ struct Mp3Pipe {
         if (e != hipSuccess) return;
         events.push_back(done);
         const size_t nb = b1 - b0;
-        e = hipMemcpyAsync((float *)d_in.p + b0 * 576, st->coef + b0 * 576, nb * 576 * sizeof(float), hipMemcpyHostToDevice, up);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_flags + b0, st->flags + b0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, up);
-        if (e != hipSuccess) return;
+        if (st->q) {
+            // quantised upload: 2 bytes per line + a record per granule, requantised on the device into the plane the
+            // transform reads (afg_mp3_requant_hip); the stereo descriptors of intensity frames are gathered per chunk
+            afg_mp3_qgranule *hrecs = const_cast<afg_mp3_qgranule *>(st->recs);
+            const size_t sd0 = sdesc_used;
+            for (size_t i = f0; i < f1; i++) {
+                const Parsed &p = parsed[i];
+                if (p.format != AFG_FORMAT_MP3 || p.mp3.sdesc.empty()) continue;
+                if (sdesc_used + p.mp3.sdesc.size() > sdesc_cap) { afg::set_error("MP3 stage: more than %zu intensity-stereo granules in one batch", sdesc_cap); rc = AFG_ERR_UNSUPPORTED; return; }
+                std::memcpy((afg_mp3_sdesc *)h_sdesc.p + sdesc_used, p.mp3.sdesc.data(), p.mp3.sdesc.size() * sizeof(afg_mp3_sdesc));
+                for (size_t k = st->base[i]; k < st->base[i] + p.mp3.blocks(); k++)
+                    if (hrecs[k].nch && hrecs[k].sdesc != AFG_MP3_NO_SDESC) hrecs[k].sdesc += (uint32_t)sdesc_used;
+                sdesc_used += p.mp3.sdesc.size();
+            }
+            e = hipMemcpyAsync(d_q + b0 * 576, st->q + b0 * 576, nb * 576 * sizeof(int16_t), hipMemcpyHostToDevice, up);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_recs + b0, st->recs + b0, nb * sizeof(afg_mp3_qgranule), hipMemcpyHostToDevice, up);
+            if (e == hipSuccess && sdesc_used > sd0)
+                e = hipMemcpyAsync(d_sdesc + sd0, (afg_mp3_sdesc *)h_sdesc.p + sd0, (sdesc_used - sd0) * sizeof(afg_mp3_sdesc), hipMemcpyHostToDevice, up);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_flags + b0, st->flags + b0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, up);
+            if (e != hipSuccess) return;
+            h2d_bytes += nb * (576 * sizeof(int16_t) + sizeof(afg_mp3_qgranule) + sizeof(uint32_t));
+            rc = afg_mp3_requant_hip(nb, d_recs + b0, d_q, d_sdesc, (float *)d_in.p, up);
+            if (rc) return;
+        } else {
+            e = hipMemcpyAsync((float *)d_in.p + b0 * 576, st->coef + b0 * 576, nb * 576 * sizeof(float), hipMemcpyHostToDevice, up);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_flags + b0, st->flags + b0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, up);
+            if (e != hipSuccess) return;
+            h2d_bytes += nb * (576 * sizeof(float) + sizeof(uint32_t));
+        }
         rc = afg_mp3_transform_hip(plan, (const float *)d_in.p, d_flags, (float *)d_pcm.p, nullptr, up);
         if (rc) return;
         e = hipEventRecord(done, up);
@@ -1282,11 +1328,28 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
         Mp3Pipe pipe;
         bool fallback = false;
         if (total_bound) {
-            if (int rc = g_staging.take(total_bound * (576 * sizeof(float) + sizeof(uint32_t)), mp3_stage)) return rc;
+            // Quantised upload by default: int16 Huffman values + a record per granule, requantised on the device.
+            // AFG_MP3_FLOAT_UPLOAD=1 keeps the float spectra of round 1 (A/B of the bytes that cross the bus).
+            const bool qmode = !std::getenv("AFG_MP3_FLOAT_UPLOAD");
+            const size_t per_block = qmode ? 576 * sizeof(int16_t) + sizeof(afg_mp3_qgranule) + sizeof(uint32_t)
+                                           : 576 * sizeof(float) + sizeof(uint32_t);
+            if (int rc = g_staging.take(total_bound * per_block + 64, mp3_stage)) return rc;
             if (int rc = g_staging.take(total_bound * 576 * sizeof(float), owner->mp3_plane)) return rc;
-            float *coef0 = (float *)mp3_stage.p;
-            uint32_t *flags0 = (uint32_t *)(coef0 + total_bound * 576);
-            stage.coef = coef0; stage.flags = flags0; stage.blocks = total_bound; stage.base = base.data();
+            float *coef0 = nullptr;
+            int16_t *q0 = nullptr;
+            afg_mp3_qgranule *recs0 = nullptr;
+            uint32_t *flags0 = nullptr;
+            if (qmode) {
+                recs0 = (afg_mp3_qgranule *)mp3_stage.p;                           // 8-byte aligned records first
+                flags0 = (uint32_t *)(recs0 + total_bound);
+                q0 = (int16_t *)(flags0 + total_bound);
+                stage.q = q0; stage.recs = recs0;
+            } else {
+                coef0 = (float *)mp3_stage.p;
+                flags0 = (uint32_t *)(coef0 + total_bound * 576);
+                stage.coef = coef0;
+            }
+            stage.flags = flags0; stage.blocks = total_bound; stage.base = base.data();
             stage.plane = (float *)owner->mp3_plane.p;
             if (int rc = pipe.open(stage)) return rc;
             tm.lap("mp3 pipeline set-up (device planes, streams, table arena)");
@@ -1305,8 +1368,25 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                     Parsed &p = parsed[i];
                     bool ok = false;
                     try {
-                        ok = afg_mp3::parse_file_into(data[i], length[i], p.mp3, coef0 + base[i] * 576, flags0 + base[i], bound[i]);
-                        if (ok && p.mp3.overflow) {              // cannot happen; be safe: parse into the file's own buffers
+                        if (qmode) {
+                            std::memset(recs0 + base[i], 0, bound[i] * sizeof(afg_mp3_qgranule));     // nch = 0: slot unused
+                            p.mp3.quantised = true;
+                            p.mp3.ext_q = q0 + base[i] * 576;
+                            p.mp3.ext_qgr = recs0 + base[i];
+                            ok = afg_mp3::parse_file_into(data[i], length[i], p.mp3, nullptr, flags0 + base[i], bound[i]);
+                            if (ok && !p.mp3.overflow && !p.mp3.q_unsupported) {
+                                const uint64_t shift = (uint64_t)base[i] * 576;                       // file-relative -> plane offsets
+                                for (size_t k = 0; k < p.mp3.blocks(); k++)
+                                    if (recs0[base[i] + k].nch) { recs0[base[i] + k].q_off += shift; recs0[base[i] + k].coef_off += shift; }
+                            }
+                        } else {
+                            ok = afg_mp3::parse_file_into(data[i], length[i], p.mp3, coef0 + base[i] * 576, flags0 + base[i], bound[i]);
+                        }
+                        if (ok && (p.mp3.overflow || p.mp3.q_unsupported)) {
+                            // overflow cannot happen; a stream the device requantiser does not cover (MPEG-2.5 8 kHz mixed
+                            // blocks) can: either way the file is parsed into its own float buffers and the batch takes the
+                            // gathered path
+                            p.mp3 = afg_mp3::File();
                             ok = afg_mp3::parse_file(data[i], length[i], p.mp3);
                             lost = true;
                         }
@@ -1317,6 +1397,20 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 if (lost) fallback = true;
                 if (!fallback) pipe.submit(parsed, f0, f1);
                 f0 = f1;
+            }
+            if (fallback && qmode) {
+                // the gathered path works from float records: the files that were parsed into the quantised staging are
+                // parsed again into their own buffers (rare: one file of the batch is outside the requantiser's coverage)
+                parallel_for((size_t)n_files, nt, [&](size_t i) {
+                    if (!bound[i] || parsed[i].format != AFG_FORMAT_MP3 || !parsed[i].mp3.quantised) return;
+                    Parsed &p = parsed[i];
+                    bool ok = false;
+                    try {
+                        p.mp3 = afg_mp3::File();
+                        ok = afg_mp3::parse_file(data[i], length[i], p.mp3);
+                    } catch (...) { ok = false; }
+                    if (!ok) { p.mp3 = afg_mp3::File(); p.format = AFG_FORMAT_UNKNOWN; }
+                });
             }
             tm.lap("mp3 parse (all threads) | h2d | kernel | d2h");
         }

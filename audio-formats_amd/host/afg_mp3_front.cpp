@@ -721,15 +721,18 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
                 } else if (hd.ms_stereo()) {
                     rec.stereo = 1;
                 }
-                for (int ch = 0; ch < nch; ch++) {       // AFG_MP3_NZ_BANDS: with stereo processing a line of either channel
-                    int last = -1;                       // can make both outputs nonzero
-                    const uint16_t *dst = qt.dst_of_src[tab[ch] < 0 ? 0 : tab[ch]];
-                    for (int i = 0; i < 576; i++) {
-                        if (!(qv[ch][i] || (rec.stereo && qv[ch ^ 1][i]))) continue;
-                        const int d = g[ch].n_short ? dst[i] : i;
-                        last = std::max(last, d);
+                {   // AFG_MP3_NZ_BANDS: the last line that can be nonzero.  With stereo processing a value of either channel
+                    // can make both outputs nonzero; a reordered line stays inside its window group.
+                    int top[2] = { -1, -1 };
+                    for (int ch = 0; ch < nch; ch++)
+                        for (int i = 575; i >= 0; i--)
+                            if (qv[ch][i]) { top[ch] = i; break; }
+                    if (rec.stereo) top[0] = top[1] = std::max(top[0], top[1]);
+                    for (int ch = 0; ch < nch; ch++) {
+                        int last = top[ch];
+                        if (last >= 0 && g[ch].n_short) last = qt.group_end[tab[ch] < 0 ? 0 : tab[ch]][last] - 1;
+                        fl[ch] |= AFG_MP3_NZ_BANDS((last + 18) / 18);
                     }
-                    fl[ch] |= AFG_MP3_NZ_BANDS((last + 18) / 18);
                 }
                 if (*fresh_state || out->run_granules.empty()) {
                     out->run_granules.push_back(0);
@@ -803,7 +806,8 @@ const QTables &qtables()
                 const uint8_t *bands = bases[kind] + (size_t)row * row_bytes[kind];
                 uint8_t *bol = t.band_of_line[kind * 8 + row];
                 uint16_t *dst = t.dst_of_src[kind * 8 + row];
-                for (int i = 0; i < 576; i++) dst[i] = (uint16_t)i;
+                uint16_t *gend = t.group_end[kind * 8 + row];
+                for (int i = 0; i < 576; i++) { dst[i] = (uint16_t)i; gend[i] = (uint16_t)(i + 1); }
                 int at = 0, nb = 0;
                 for (; bands[nb] && at < 576; nb++)
                     for (int k = 0; k < bands[nb] && at < 576; k++) bol[at++] = (uint8_t)nb;
@@ -817,7 +821,10 @@ const QTables &qtables()
                     const int len = bands[b];
                     for (int w = 0; w < 3; w++)
                         for (int k = 0; k < len; k++)
-                            if (s0 + w * len + k < 576 && s0 + 3 * k + w < 576) dst[s0 + w * len + k] = (uint16_t)(s0 + 3 * k + w);
+                            if (s0 + w * len + k < 576 && s0 + 3 * k + w < 576) {
+                                dst[s0 + w * len + k] = (uint16_t)(s0 + 3 * k + w);
+                                gend[s0 + w * len + k] = (uint16_t)std::min(576, s0 + 3 * len);
+                            }
                     s0 += 3 * len;
                 }
             }

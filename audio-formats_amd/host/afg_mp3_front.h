@@ -88,8 +88,12 @@ struct File {
     }
     void truncate(size_t nb)
     {
+        const size_t n_blocks_seen = n_blocks;
         n_blocks = nb;
         if (quantised) {
+            if (ext_q) {
+                for (size_t k = nb; k < n_blocks_seen; k++) ext_qgr[k].nch = 0;       // slots of dropped granules: unused again
+            }
             if (!ext_q) {
                 q.resize(nb * 576);
                 flags.resize(nb);
@@ -115,6 +119,8 @@ size_t max_blocks(const uint8_t *data, size_t size);
 struct QTables {
     uint8_t band_of_line[24][576];
     uint16_t dst_of_src[24][576];
+    uint16_t group_end[24][576];         // one past the window group a line belongs to (line + 1 in the long part): the
+                                         // reorder permutes lines inside their group only
     float pow43[145];                    // g_pow43 (minimp3.d:722-735): 16 negative entries, then 0 .. 128
 };
 const QTables &qtables();

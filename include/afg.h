@@ -106,7 +106,7 @@ typedef struct afg_mp3_qgranule {
     uint64_t q_off;          /* int16 index of channel 0's 576 values; channel c at q_off + 576*c */
     uint64_t coef_off;       /* float index of channel 0's block in the coefficient plane; channel c at + 576*c */
     uint32_t sdesc;          /* stereo == 2: index of the granule's afg_mp3_sdesc, else AFG_MP3_NO_SDESC */
-    uint8_t  nch;            /* 1 | 2 */
+    uint8_t  nch;            /* 1 | 2; 0: unused record slot, skipped */
     uint8_t  stereo;         /* 0 none, 1 mid/side on every line (:1203), 2 per band (intensity frames, :1201) */
     uint8_t  table[2];       /* per channel: scalefactor-band table (kind*8 + rate row; kind 0 long, 1 short, 2 mixed),
                                 bit 7: the short part is reordered (block_type 2) */

@@ -56,3 +56,39 @@ def test_quantised_path_end_to_end_equals_the_oracle_decode(gpu):
         plane = d_pcm.cpu().numpy()
         pcm = np.concatenate([plane[int(s):int(s) + int(c)] for s, c in copies]) if len(copies) else np.zeros(0, np.float32)
         assert np.array_equal(pcm.view(np.uint32), want["pcm"].view(np.uint32))
+
+
+def test_batch_path_uploads_quantised_values_and_matches_the_float_upload(gpu, monkeypatch):
+    """afg_batch_decode ships int16 values by default; AFG_MP3_FLOAT_UPLOAD=1 ships round 1's float spectra.  Same PCM, and
+    the oracle's."""
+    blobs = files()
+    monkeypatch.delenv("AFG_MP3_FLOAT_UPLOAD", raising=False)
+    a = afgpu.batch_decode(blobs, n_threads=4)
+    monkeypatch.setenv("AFG_MP3_FLOAT_UPLOAD", "1")
+    b = afgpu.batch_decode(blobs, n_threads=4)
+    for blob, x, y in zip(blobs, a, b):
+        want = oraclelib.mp3_decode_file(blob)
+        assert x["status"] == 0 and y["status"] == 0 and x["frames"] == y["frames"] == len(want["pcm"]) // x["channels"]
+        if x["frames"]:
+            assert np.array_equal(x["pcm"].reshape(-1).view(np.uint32), want["pcm"].view(np.uint32))
+            assert np.array_equal(y["pcm"].reshape(-1).view(np.uint32), want["pcm"].view(np.uint32))
+
+
+def test_a_file_outside_the_requantisers_coverage_sends_the_batch_down_the_float_path(gpu, monkeypatch):
+    monkeypatch.delenv("AFG_MP3_FLOAT_UPLOAD", raising=False)
+    odd = None
+    for seed in range(40):
+        data = mb.make_file(70 + seed, n_frames=8, version="mpeg25", sr=2, mode="stereo")[0]
+        try:
+            afgpu.mp3_parse_q(data)
+        except afgpu.AfgError:
+            odd = data
+            break
+    assert odd is not None
+    blobs = files()[:4] + [odd] + files()[4:7]
+    got = afgpu.batch_decode(blobs, n_threads=4)
+    for blob, x in zip(blobs, got):
+        want = oraclelib.mp3_decode_file(blob)
+        assert x["status"] == 0 and x["frames"] * x["channels"] == len(want["pcm"])
+        if x["frames"]:
+            assert np.array_equal(x["pcm"].reshape(-1).view(np.uint32), want["pcm"].view(np.uint32))
