@@ -306,6 +306,33 @@ size_t flac_res_bound(const uint8_t *d, size_t n)
     return words > ((uint64_t)1 << 31) ? 0 : (size_t)words;
 }
 
+bool flac_open_info(const uint8_t *d, size_t n, FlacInfo &fi) { return flac_open(d, n, fi); }
+
+int flac_parse_frames(const uint8_t *d, size_t n, const FlacInfo &fi, FlacRecords &rec, size_t *pos, int max_frames, bool *ended)
+{
+    *ended = false;
+    if (fi.first_frame + *pos >= n) { *ended = true; return 0; }
+    const size_t avail = n - fi.first_frame - *pos;
+    BitReader br(d + fi.first_frame + *pos, avail);
+    int got = 0;
+    while (got < max_frames) {
+        if (br.byte_pos() + 2 >= avail) { *ended = true; break; }
+        const size_t keep_f = rec.frames.size(), keep_s = rec.subframes.size(), keep_r = rec.res_size();
+        const size_t before = br.byte_pos();
+        if (!flac_frame(br, fi, rec)) {                        // the stream ends at the first frame that does not parse
+            rec.frames.resize(keep_f);
+            rec.subframes.resize(keep_s);
+            rec.res_truncate(keep_r);
+            *ended = true;
+            *pos += before;
+            return got;
+        }
+        got++;
+    }
+    *pos += br.byte_pos();
+    return got;
+}
+
 bool flac_parse_into(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec, int32_t *res_dst, size_t cap)
 {
     if (!flac_open(d, n, fi)) return false;

@@ -47,6 +47,10 @@ struct FlacRecords {
 // whole file -> records; stops at the first frame that does not parse (drflac.d:2860).  false: not FLAC.
 bool flac_parse(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec);
 bool flac_parse_into(const uint8_t *d, size_t n, FlacInfo &fi, FlacRecords &rec, int32_t *res_dst, size_t cap);
+// Chunked reading for the AudioStream surface: the container walk alone (STREAMINFO, first frame), then up to max_frames
+// frames from byte *pos behind the first frame (advanced past what was parsed).  *ended: no further frame parses.
+bool flac_open_info(const uint8_t *d, size_t n, FlacInfo &fi);
+int flac_parse_frames(const uint8_t *d, size_t n, const FlacInfo &fi, FlacRecords &rec, size_t *pos, int max_frames, bool *ended);
 // Residual words a well-formed file needs ((STREAMINFO total + one block) x channels); 0: not FLAC or length unknown.
 size_t flac_res_bound(const uint8_t *d, size_t n);
 

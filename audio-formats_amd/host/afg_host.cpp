@@ -64,28 +64,6 @@ struct Parsed {
     const uint32_t *mp3_flags() const { return mp3.ext_flags ? mp3.ext_flags : mp3.flags.data(); }
 };
 
-// startDecoding's probe order for the formats handled here (stream.d:1586-1838): FLAC, QOA, OGG, then MP3 (whose
-// detection is the weakest: a frame-sync search, which is why the reference tries it after the containers)
-void parse_file_unguarded(const uint8_t *d, size_t n, Parsed &p);
-void parse_file(const uint8_t *d, size_t n, Parsed &p)
-{
-    try {
-        parse_file_unguarded(d, n, p);
-    } catch (...) {                                        // out of memory inside a parser: the file is simply not decodable
-        p = Parsed();
-    }
-}
-void parse_file_unguarded(const uint8_t *d, size_t n, Parsed &p)
-{
-    if (flac_parse(d, n, p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
-    p.flac = FlacRecords();
-    if (qoa_parse(d, n, p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
-    if (afg_vorbis::parse_file(d, n, p.ogg)) { p.format = AFG_FORMAT_OGG; return; }
-    p.ogg = afg_vorbis::File();
-    if (afg_mp3::looks_like_mp3(d, n) && afg_mp3::parse_file(d, n, p.mp3)) { p.format = AFG_FORMAT_MP3; return; }
-    p.mp3 = afg_mp3::File();
-}
-
 struct DeviceBuf {
     void *p = nullptr;
     ~DeviceBuf() { if (p) (void)hipFree(p); }
@@ -439,9 +417,17 @@ struct Mp3Pipe {
     ~Mp3Pipe() { (void)close(); }
 };
 
+// Decoder state an MP3 stream carries from one chunk of frames to the next (chunked AudioStream reads): the overlap and
+// polyphase history of the run that was open when the previous chunk ended, as the transform kernel left it.
+struct Mp3Carry {
+    DeviceBuf state;                    // AFG_MP3_STATE_FLOATS floats
+    bool valid = false;                 // `state` holds the end of the previous chunk
+    bool continues = false;             // this chunk's first run goes on from it
+};
+
 int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out,
                   const Mp3Stage *stage = nullptr, const OggStage *ogg_stage = nullptr, const FlacStage *flac_stage = nullptr,
-                  const uint8_t *own = nullptr)
+                  const uint8_t *own = nullptr, Mp3Carry *carry = nullptr)
 {
     // `own` (optional, one byte per file): the files this call is responsible for.  The batch path decodes its FLAC /
     // QOA files on a second host thread while the first still parses MP3 / Ogg files: a call never looks at (not even
@@ -742,19 +728,19 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             if (int rc = d_pcm.alloc(coef_bytes)) return rc;
             // The files are cut into a few chunks of similar size, each with its own plan: the upload and kernel of
             // chunk k+1 (stream `up`) run while chunk k's PCM goes back (stream `down`) -- PCIe is full duplex.
-            struct Chunk { size_t f0, f1, blk0, blocks; afg_mp3_plan *plan; hipEvent_t done; };
+            struct Chunk { size_t f0, f1, blk0, blocks; afg_mp3_plan *plan; hipEvent_t done; size_t runs = 0; };
             std::vector<Chunk> chunks;
             {
                 size_t want = 8;
                 if (const char *ev = getenv("AFG_MP3_CHUNKS")) want = (size_t)std::max(1, atoi(ev));
                 const size_t target = std::max<size_t>((mp3_blocks + want - 1) / want, 8192);
-                Chunk c{ 0, 0, 0, 0, nullptr, nullptr };
+                Chunk c{ 0, 0, 0, 0, nullptr, nullptr, 0 };
                 for (size_t i = 0; i < nf; i++) {
                     if (fmt_of(parsed[i]) != AFG_FORMAT_MP3) continue;
                     if (c.blocks == 0) { c.f0 = i; c.blk0 = mp3_blk_base[i]; }
                     c.blocks += parsed[i].mp3.blocks();
                     c.f1 = i + 1;
-                    if (c.blocks >= target) { chunks.push_back(c); c = Chunk{ 0, 0, 0, 0, nullptr, nullptr }; }
+                    if (c.blocks >= target) { chunks.push_back(c); c = Chunk{ 0, 0, 0, 0, nullptr, nullptr, 0 }; }
                 }
                 if (c.blocks) chunks.push_back(c);
             }
@@ -780,6 +766,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 }
                 rc = afg_mp3_plan_create(&c.plan, (uint32_t)granules.size(), granules.data(), channels.data(), 0);
                 if (!rc) e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
+                c.runs = granules.size();
             }
             tm.lap("mp3 plans");
             uint32_t *d_flags = (uint32_t *)((uint8_t *)d_in.p + coef_bytes);
@@ -796,9 +783,30 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 if (e == hipSuccess)
                     e = hipMemcpyAsync(d_flags + c.blk0, hfl + c.blk0, c.blocks * sizeof(uint32_t), hipMemcpyHostToDevice, up);
                 if (e != hipSuccess) break;
+                // chunked stream: one state blob per run of the chunk, zero (a fresh decoder) except the first when the chunk
+                // goes on from the previous one; the last run's blob is what the next chunk goes on from
+                DeviceBuf d_states;
+                float *states = nullptr;
+                if (carry && chunks.size() == 1 && c.runs) {
+                    const size_t sb = AFG_MP3_STATE_FLOATS * sizeof(float);
+                    if ((rc = d_states.alloc(c.runs * sb)) != AFG_OK) break;
+                    states = (float *)d_states.p;
+                    e = hipMemsetAsync(states, 0, c.runs * sb, up);
+                    if (e == hipSuccess && carry->continues && carry->valid)
+                        e = hipMemcpyAsync(states, carry->state.p, sb, hipMemcpyDeviceToDevice, up);
+                    if (e != hipSuccess) break;
+                }
                 rc = afg_mp3_transform_hip(c.plan, (const float *)d_in.p + c.blk0 * 576, d_flags + c.blk0,
-                                           (float *)d_pcm.p + c.blk0 * 576, nullptr, up);
+                                           (float *)d_pcm.p + c.blk0 * 576, states, up);
                 if (rc) break;
+                if (states) {
+                    const size_t sb = AFG_MP3_STATE_FLOATS * sizeof(float);
+                    if (!carry->state.p && (rc = carry->state.alloc(sb)) != AFG_OK) break;
+                    e = hipMemcpyAsync(carry->state.p, states + (c.runs - 1) * AFG_MP3_STATE_FLOATS, sb, hipMemcpyDeviceToDevice, up);
+                    if (e == hipSuccess) e = hipStreamSynchronize(up);          // d_states goes out of scope below
+                    if (e != hipSuccess) break;
+                    carry->valid = true;
+                }
                 e = hipEventRecord(c.done, up);
                 if (e == hipSuccess) e = hipStreamWaitEvent(down, c.done, 0);
                 // delivery: the copy plan of each file, merged into maximal contiguous pieces (one per undamaged file),
@@ -923,11 +931,118 @@ metadata:
 
 }  // namespace
 
+// The AudioStream surface decodes as the caller pulls (stream.d:429-637 keeps O(1) state per stream): open parses
+// the container only, a read decodes the next chunk of frames (about 1.5 s of audio) on the device when the FIFO of
+// delivered samples runs dry.  Memory per handle: the file bytes (the reference copies them too, stream.d:2031-2041),
+// one chunk of PCM, and for MP3 the 6 KB decoder state that lives on the device between chunks.
 struct afg_stream {
     const char *error = kErrorNotInitialized;      // stream.d:1379
-    Decoded d;
-    std::vector<float> pcm;
-    int64_t position = 0;
+    int format = AFG_FORMAT_UNKNOWN, channels = 0;
+    float samplerate = 0;
+    int64_t declared_frames = AFG_UNKNOWN_LENGTH;
+    std::vector<uint8_t> bytes;
+    // per-format readers
+    FlacInfo fi;
+    size_t flac_pos = 0;
+    QoaInfo qi;
+    std::vector<afg_qoa_frame> qoa;
+    size_t qoa_next = 0;
+    std::unique_ptr<afg_mp3::Reader> mp3;
+    std::unique_ptr<afg_vorbis::Reader> ogg;
+    Mp3Carry carry;
+    // delivered samples not yet read
+    std::vector<float> fifo;
+    size_t fifo_at = 0;                 // floats of `fifo` already handed out
+    int64_t position = 0;               // frames handed out so far (tellPosition)
+    bool ended = false;                 // nothing further can be decoded
+
+    static constexpr int kMp3Frames = 64, kOggPackets = 64, kFlacFrames = 16, kQoaFrames = 16;
+
+    // (re)start the readers at the head of the stream
+    bool rewind()
+    {
+        fifo.clear();
+        fifo_at = 0;
+        position = 0;
+        ended = false;
+        flac_pos = 0;
+        qoa_next = 0;
+        carry.valid = carry.continues = false;
+        if (format == AFG_FORMAT_MP3) {
+            afg_mp3::File meta;
+            mp3.reset(new afg_mp3::Reader);
+            return mp3->open(bytes.data(), bytes.size(), meta);
+        }
+        if (format == AFG_FORMAT_OGG) {
+            afg_vorbis::File meta;
+            ogg.reset(new afg_vorbis::Reader);
+            return ogg->open(bytes.data(), bytes.size(), meta);
+        }
+        return true;
+    }
+
+    // decode the next chunk into the FIFO; false: end of stream (or error state set)
+    bool refill()
+    {
+        if (ended) return false;
+        if (fifo_at == fifo.size()) { fifo.clear(); fifo_at = 0; }
+        std::vector<Parsed> parsed(1);
+        Parsed &p = parsed[0];
+        const uint8_t *dp[1] = { bytes.data() };
+        size_t lp[1] = { bytes.size() };
+        Mp3Carry *cr = nullptr;
+        if (format == AFG_FORMAT_FLAC) {
+            bool done = false;
+            p.fi = fi;
+            const int got = flac_parse_frames(bytes.data(), bytes.size(), fi, p.flac, &flac_pos, kFlacFrames, &done);
+            if (done) ended = true;
+            if (!got) { ended = true; return false; }
+            p.format = AFG_FORMAT_FLAC;
+        } else if (format == AFG_FORMAT_QOA) {
+            if (qoa_next >= qoa.size()) { ended = true; return false; }
+            const size_t k1 = std::min(qoa.size(), qoa_next + (size_t)kQoaFrames);
+            const uint64_t byte0 = qoa[qoa_next].byte_off, out0 = qoa[qoa_next].out_off;
+            for (size_t k = qoa_next; k < k1; k++) {
+                afg_qoa_frame f = qoa[k];
+                f.byte_off -= byte0;
+                f.out_off -= out0;
+                p.qoa.push_back(f);
+            }
+            const uint64_t byte1 = k1 < qoa.size() ? qoa[k1].byte_off : (uint64_t)bytes.size();
+            dp[0] = bytes.data() + byte0;
+            lp[0] = (size_t)(byte1 - byte0);
+            p.qi = qi;
+            p.format = AFG_FORMAT_QOA;
+            qoa_next = k1;
+            if (qoa_next >= qoa.size()) ended = true;
+        } else if (format == AFG_FORMAT_OGG) {
+            if (!ogg->more(p.ogg, kOggPackets)) { ended = true; return false; }
+            p.format = AFG_FORMAT_OGG;
+        } else if (format == AFG_FORMAT_MP3) {
+            bool continues = false;
+            if (!mp3->more(p.mp3, kMp3Frames, &continues)) { ended = true; return false; }
+            carry.continues = continues;
+            cr = &carry;
+            p.format = AFG_FORMAT_MP3;
+        } else {
+            ended = true;
+            return false;
+        }
+        BatchOut out;
+        if (decode_parsed(parsed, dp, lp, 1, out, nullptr, nullptr, nullptr, nullptr, cr) != AFG_OK || out.files[0].status != AFG_OK) {
+            error = kErrorDecodingError;
+            ended = true;
+            return false;
+        }
+        const Decoded &d = out.files[0];
+        const size_t want = (size_t)std::max<int64_t>(d.frames, 0) * (size_t)channels;
+        if (want) {
+            if (d.pcm_off + want > out.plane_floats) { error = kErrorDecodingError; ended = true; return false; }
+            const float *src = (const float *)out.plane.p + d.pcm_off;
+            fifo.insert(fifo.end(), src, src + want);
+        }
+        return true;
+    }
 };
 
 extern "C" {
@@ -938,41 +1053,53 @@ afg_stream *afg_open_from_memory(const uint8_t *data, size_t length)
     if (!s) return nullptr;
     if (!data || length == 0) { s->error = kErrorUnknownFormat; return s; }
     try {
-        std::vector<Parsed> parsed(1);
-        parse_file(data, length, parsed[0]);
-        if (parsed[0].format == AFG_FORMAT_UNKNOWN) { s->error = kErrorUnknownFormat; return s; }
-        if (afg::require_device() != AFG_OK) { s->error = kErrorDecoderInitializationFailed; return s; }
-        BatchOut out;
-        const uint8_t *dp[1] = { data };
-        const size_t lp[1] = { length };
-        if (decode_parsed(parsed, dp, lp, 1, out) != AFG_OK) { s->error = kErrorDecodingError; return s; }
-        s->d = out.files[0];
-        // keep the delivered samples only: a file's PCM starts at pcm_off of the plane (an Ogg stream whose delivery
-        // starts late -- deferred discard, leading packets with nothing to take -- has its first piece further in)
-        const size_t want = (size_t)std::max<int64_t>(s->d.frames, 0) * (size_t)std::max(s->d.channels, 0);
-        if (want && s->d.status == AFG_OK) {
-            if (s->d.pcm_off + want > out.plane_floats) { s->error = kErrorDecodingError; return s; }
-            const float *src = (const float *)out.plane.p + s->d.pcm_off;
-            s->pcm.assign(src, src + want);
+        s->bytes.assign(data, data + length);
+        const uint8_t *d = s->bytes.data();
+        // startDecoding's probe order for the formats handled here (stream.d:1586-1838): FLAC, QOA, OGG, then MP3
+        afg_mp3::File m3;
+        afg_vorbis::File og;
+        if (flac_open_info(d, length, s->fi)) {
+            s->format = AFG_FORMAT_FLAC;
+            s->channels = (int)s->fi.channels;
+            s->samplerate = (float)s->fi.sample_rate;
+            s->declared_frames = (int64_t)s->fi.total_samples;            // totalSampleCount / channels, stream.d:1631
+        } else if (qoa_parse(d, length, s->qi, s->qoa)) {
+            s->format = AFG_FORMAT_QOA;
+            s->channels = (int)s->qi.channels;
+            s->samplerate = (float)s->qi.samplerate;
+            s->declared_frames = (int64_t)s->qi.samples;
+        } else if ((s->ogg.reset(new afg_vorbis::Reader), s->ogg->open(d, length, og))) {
+            s->format = AFG_FORMAT_OGG;
+            s->channels = og.channels;
+            s->samplerate = (float)og.sample_rate;
+            s->declared_frames = (int64_t)og.total_samples;               // stb_vorbis_stream_length_in_samples, stream.d:1696
+        } else if (afg_mp3::looks_like_mp3(d, length) && (s->mp3.reset(new afg_mp3::Reader), s->mp3->open(d, length, m3))) {
+            s->format = AFG_FORMAT_MP3;
+            s->channels = m3.channels;
+            s->samplerate = (float)m3.hz;
+            s->declared_frames = (int64_t)(m3.declared_samples / (uint64_t)std::max(1, m3.channels));   // stream.d:1737
+        } else {
+            s->error = kErrorUnknownFormat;
+            return s;
         }
-        s->d.pcm_off = 0;
-        s->error = s->d.status == AFG_OK ? nullptr : kErrorDecodingError;
+        if (afg::require_device() != AFG_OK) { s->error = kErrorDecoderInitializationFailed; return s; }
+        s->error = nullptr;
     } catch (...) {
-        s->error = kErrorDecoderInitializationFailed;      // out of memory while decoding
+        s->error = kErrorDecoderInitializationFailed;      // out of memory
     }
     return s;
 }
 
 int afg_is_error(const afg_stream *s) { return !s || s->error != nullptr; }
 const char *afg_error_message(const afg_stream *s) { return s ? s->error : kErrorNotInitialized; }
-int afg_get_format(const afg_stream *s) { return (s && !s->error) ? s->d.format : AFG_FORMAT_UNKNOWN; }
-int afg_get_num_channels(const afg_stream *s) { return (s && !s->error) ? s->d.channels : 0; }
-float afg_get_samplerate(const afg_stream *s) { return (s && !s->error) ? s->d.samplerate : 0.0f; }
+int afg_get_format(const afg_stream *s) { return (s && !s->error) ? s->format : AFG_FORMAT_UNKNOWN; }
+int afg_get_num_channels(const afg_stream *s) { return (s && !s->error) ? s->channels : 0; }
+float afg_get_samplerate(const afg_stream *s) { return (s && !s->error) ? s->samplerate : 0.0f; }
 
 int64_t afg_get_length_in_frames(const afg_stream *s)
 {
     if (!s || s->error) return AFG_UNKNOWN_LENGTH;
-    return s->d.declared_frames;       // stream.d:404-407: whatever the container declares (FLAC: may be 0)
+    return s->declared_frames;         // stream.d:404-407: whatever the container declares (FLAC: may be 0)
 }
 
 int afg_read_samples_float(afg_stream *s, float *out, int frames)
@@ -980,11 +1107,24 @@ int afg_read_samples_float(afg_stream *s, float *out, int frames)
     if (!s || s->error || frames <= 0) return 0;
     // stream.d:498: a FLAC stream stops once the position equals the declared length (a STREAMINFO that
     // declares 0 samples therefore reads nothing); the check is made on entry only, like the reference's.
-    if (s->d.format == AFG_FORMAT_FLAC && s->position == s->d.declared_frames) return 0;
-    const int64_t n = std::max<int64_t>(0, std::min<int64_t>(s->d.frames - s->position, frames));
-    if (out && n) std::memcpy(out, s->pcm.data() + s->position * s->d.channels, (size_t)n * s->d.channels * sizeof(float));
-    s->position += n;
-    return (int)n;
+    if (s->format == AFG_FORMAT_FLAC && s->position == s->declared_frames) return 0;
+    try {
+        const size_t C = (size_t)std::max(1, s->channels);
+        int done = 0;
+        while (done < frames) {
+            if (s->fifo_at == s->fifo.size() && !s->refill()) break;
+            const size_t avail = (s->fifo.size() - s->fifo_at) / C;
+            const size_t n = std::min<size_t>(avail, (size_t)(frames - done));
+            if (out && n) std::memcpy(out + (size_t)done * C, s->fifo.data() + s->fifo_at, n * C * sizeof(float));
+            s->fifo_at += n * C;
+            done += (int)n;
+        }
+        s->position += done;
+        return done;
+    } catch (...) {
+        s->error = kErrorDecodingError;
+        return 0;
+    }
 }
 
 int afg_can_seek(const afg_stream *s) { return s && !s->error; }
@@ -992,12 +1132,36 @@ int afg_can_seek(const afg_stream *s) { return s && !s->error; }
 int afg_seek_position(afg_stream *s, int frame)
 {
     if (!s || s->error) return 0;
-    // the reference bounds a seek by the declared length (stream.d:1104, :1113, :1137); what can actually be served is
-    // bounded by what was decoded
-    const int64_t limit = std::max<int64_t>(s->d.declared_frames, 0);
+    // the reference bounds a seek by the declared length (stream.d:1104, :1113, :1137); what can actually be reached is
+    // bounded by what decodes.  Backwards: the readers start over; forwards: chunks are decoded and dropped (a chunk
+    // is ~1.5 s of audio and takes about a millisecond on the device).
+    const int64_t limit = std::max<int64_t>(s->declared_frames, 0);
     if (frame < 0 || frame > limit) return 0;
-    s->position = std::min<int64_t>(frame, s->d.frames);
-    return 1;
+    try {
+        if (frame < s->position) {
+            // still inside the FIFO?  then just step back
+            const size_t C = (size_t)std::max(1, s->channels);
+            const int64_t fifo_first = s->position - (int64_t)(s->fifo_at / C);
+            if (frame >= fifo_first) {
+                s->fifo_at -= (size_t)(s->position - frame) * C;
+                s->position = frame;
+                return 1;
+            }
+            if (!s->rewind()) { s->error = kErrorDecodingError; return 0; }
+        }
+        const size_t C = (size_t)std::max(1, s->channels);
+        while (s->position < frame) {
+            if (s->fifo_at == s->fifo.size() && !s->refill()) break;
+            const size_t avail = (s->fifo.size() - s->fifo_at) / C;
+            const size_t n = std::min<size_t>(avail, (size_t)(frame - s->position));
+            s->fifo_at += n * C;
+            s->position += (int64_t)n;
+        }
+        return s->error ? 0 : 1;
+    } catch (...) {
+        s->error = kErrorDecodingError;
+        return 0;
+    }
 }
 
 int afg_tell_position(const afg_stream *s) { return (s && !s->error) ? (int)s->position : -1; }

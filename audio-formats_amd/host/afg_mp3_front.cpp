@@ -879,6 +879,162 @@ bool parse_file_into(const uint8_t *data, size_t size, File &f, float *coef, uin
 // mp3dec_ex_open (index scan or Xing/Info tag) followed by mp3dec_ex_read to the end of the stream
 bool parse_file(const uint8_t *data, size_t size, File &f) { return parse_file_into(data, size, f, nullptr, nullptr, 0); }
 
+namespace {
+
+// mp3dec_ex_open (index scan or Xing/Info tag) followed by mp3dec_ex_read, resumable: `open` does the scan, `run` decodes
+// frames until the stream ends or `max_frames` have been consumed.  A whole file (parse_file_into) and a chunked
+// stream (Reader) run the same code.
+struct Walk {
+    std::vector<uint8_t> padded;
+    const uint8_t *buf = nullptr;
+    size_t n = 0;
+    Decoder dec;
+    uint64_t start = 0, declared = 0, detected = 0;
+    int to_skip = 0;
+    bool tagged = false;
+    int ch0 = 0, hz0 = 0, layer0 = 0;
+    bool fresh = true, done = false;
+    uint64_t off = 0, cur = 0;
+
+    bool open(const uint8_t *data, size_t size)
+    {
+        if (!data || size < 10) return false;
+        const uint8_t *src = data;
+        n = size;
+        {
+            size_t id3 = id3v2_size(src, n);
+            if (id3) {
+                id3 = std::min(id3, n);
+                src += id3;
+                n -= id3;
+            }
+            trim_trailing_tags(src, &n);
+        }
+        if (!n) return false;
+        // keep 16 readable bytes behind the data for the windowed readers
+        padded.assign(n + 16, 0);
+        std::memcpy(padded.data(), src, n);
+        buf = padded.data();
+
+        int counted = 0, probe = 0;
+        bool have = false;
+        {
+            const uint8_t *p = buf;
+            size_t left = n;
+            for (;;) {
+                int fb = 0, sz = 0;
+                const int i = next_frame(p, (int)std::min<size_t>(left, 0x7fffffff), &fb, &sz);
+                p += i;
+                left -= (size_t)i;
+                if (i && !sz) continue;
+                if (!sz) break;
+                const Header hd{ p };
+                const int nch = hd.mono() ? 1 : 2;
+                const uint64_t at = (uint64_t)(p - buf);
+                if (!have) {
+                    have = true;
+                    ch0 = nch;
+                    hz0 = (int)hd.hz();
+                    layer0 = 4 - hd.layer_code();
+                    start = at;
+                    if (layer0 == 3) {
+                        uint32_t frames = 0;
+                        int delay = 0, padding = 0;
+                        const int t = info_tag(p, sz, &frames, &delay, &padding);
+                        if (t) start = at + (uint64_t)sz;
+                        if (t > 0) {
+                            padding *= nch;
+                            to_skip = delay * nch;
+                            declared = (uint64_t)hd.samples() * (uint64_t)nch * frames;
+                            if (declared >= (uint64_t)to_skip) declared -= (uint64_t)to_skip;
+                            if (padding > 0 && declared >= (uint64_t)padding) declared -= (uint64_t)padding;
+                            detected = declared;
+                            tagged = true;
+                            break;
+                        }
+                        if (t < 0) {
+                            p += sz;
+                            left -= (size_t)sz;
+                            continue;
+                        }
+                    }
+                }
+                counted++;
+                if (!probe && counted < 256) {                 // early frames may lack their reservoir: count what decodes
+                    bool fr_fresh = false;
+                    const FrameResult fr = frame(dec, p, (int)std::min<size_t>(left, 0x7fffffff), nullptr, &fr_fresh);
+                    probe = fr.stop ? 0 : fr.samples;
+                    declared += (uint64_t)probe * (uint64_t)nch;
+                } else {
+                    declared += (uint64_t)hd.samples() * (uint64_t)nch;
+                }
+                p += sz;
+                left -= (size_t)sz;
+            }
+        }
+        if (!have || layer0 != 3) return false;
+        dec.reset();
+        fresh = true;
+        off = start;
+        cur = 0;
+        done = false;
+        return true;
+    }
+
+    void describe(File &f) const
+    {
+        f.channels = ch0;
+        f.hz = hz0;
+        f.tagged = tagged;
+        f.start_delay = to_skip;
+        f.detected_samples = detected;
+        f.declared_samples = declared;
+    }
+
+    // frames into `f` until the stream ends or max_frames were consumed; copies are relative to f's own blocks
+    void run(File &f, int max_frames)
+    {
+        uint64_t chunk_samples = 0;
+        for (int k = 0; k < max_frames && !done; k++) {
+            if (detected && cur >= detected) { done = true; break; }
+            const uint64_t left = n - off;
+            if (!left) { done = true; break; }
+            const uint64_t blocks_before = f.blocks();
+            const std::vector<uint32_t> runs_before = f.run_granules;
+            const FrameResult fr = frame(dec, buf + off, (int)std::min<uint64_t>(left, 0x7fffffff), &f, &fresh);
+            if (fr.stop || fr.hz != hz0 || fr.layer != layer0 || fr.channels != ch0) {
+                // MP3D_E_DECODE (minimp3_ex.d:851-857; also what "no further frame" turns into, since the frame info
+                // stays zero then): the stream ends here; records of this frame are dropped
+                f.truncate(blocks_before);
+                f.run_granules = runs_before;
+                done = true;
+                break;
+            }
+            if (fr.samples) {
+                const int total = fr.samples * fr.channels;
+                int used = 0;
+                if (to_skip) {
+                    used = std::min(total, to_skip);
+                    to_skip -= used;
+                }
+                uint64_t take = (uint64_t)(total - used);
+                if (detected && cur + take >= detected) take = detected - cur;
+                if (take) f.copies.push_back(Copy{ blocks_before * 576 + (uint64_t)used, take });
+                cur += take;
+                chunk_samples += take;
+            } else if (to_skip) {
+                const int fs = (int)Header{ buf + off }.samples() * fr.channels;
+                to_skip -= std::min(fs, to_skip);
+            }
+            off += (uint64_t)fr.consumed;
+        }
+        f.pcm_samples += chunk_samples;
+        // trailing granules that no copy refers to are still part of their run (the device needs whole runs)
+    }
+};
+
+}  // namespace
+
 bool parse_file_into(const uint8_t *data, size_t size, File &f, float *coef_dst, uint32_t *flags_dst, size_t cap)
 {
     const bool quantised = f.quantised;                    // the caller's choices survive the reset
@@ -891,128 +1047,39 @@ bool parse_file_into(const uint8_t *data, size_t size, File &f, float *coef_dst,
     f.ext_coef = coef_dst;
     f.ext_flags = flags_dst;
     f.ext_cap = cap;
-    if (!data || size < 10) return false;
-    const uint8_t *buf = data;
-    size_t n = size;
-    {
-        size_t id3 = id3v2_size(buf, n);
-        if (id3) {
-            id3 = std::min(id3, n);
-            buf += id3;
-            n -= id3;
-        }
-        trim_trailing_tags(buf, &n);
-    }
-    if (!n) return false;
-    // keep 16 readable bytes behind the data for the windowed readers
-    std::vector<uint8_t> padded(n + 16, 0);
-    std::memcpy(padded.data(), buf, n);
-    buf = padded.data();
-
-    Decoder dec;
-    uint64_t start = 0, declared = 0, detected = 0;
-    int to_skip = 0, counted = 0, probe = 0;
-    bool have = false, tagged = false;
-    int ch0 = 0, hz0 = 0, layer0 = 0;
-    {
-        const uint8_t *p = buf;
-        size_t left = n;
-        for (;;) {
-            int fb = 0, sz = 0;
-            const int i = next_frame(p, (int)std::min<size_t>(left, 0x7fffffff), &fb, &sz);
-            p += i;
-            left -= (size_t)i;
-            if (i && !sz) continue;
-            if (!sz) break;
-            const Header hd{ p };
-            const int nch = hd.mono() ? 1 : 2;
-            const uint64_t off = (uint64_t)(p - buf);
-            if (!have) {
-                have = true;
-                ch0 = nch;
-                hz0 = (int)hd.hz();
-                layer0 = 4 - hd.layer_code();
-                start = off;
-                if (layer0 == 3) {
-                    uint32_t frames = 0;
-                    int delay = 0, padding = 0;
-                    const int t = info_tag(p, sz, &frames, &delay, &padding);
-                    if (t) start = off + (uint64_t)sz;
-                    if (t > 0) {
-                        padding *= nch;
-                        to_skip = delay * nch;
-                        declared = (uint64_t)hd.samples() * (uint64_t)nch * frames;
-                        if (declared >= (uint64_t)to_skip) declared -= (uint64_t)to_skip;
-                        if (padding > 0 && declared >= (uint64_t)padding) declared -= (uint64_t)padding;
-                        detected = declared;
-                        tagged = true;
-                        break;
-                    }
-                    if (t < 0) {
-                        p += sz;
-                        left -= (size_t)sz;
-                        continue;
-                    }
-                }
-            }
-            counted++;
-            if (!probe && counted < 256) {                 // early frames may lack their reservoir: count what decodes
-                bool fresh = false;
-                const FrameResult fr = frame(dec, p, (int)std::min<size_t>(left, 0x7fffffff), nullptr, &fresh);
-                probe = fr.stop ? 0 : fr.samples;
-                declared += (uint64_t)probe * (uint64_t)nch;
-            } else {
-                declared += (uint64_t)hd.samples() * (uint64_t)nch;
-            }
-            p += sz;
-            left -= (size_t)sz;
-        }
-    }
-    if (!have || layer0 != 3) return false;
-    f.channels = ch0;
-    f.hz = hz0;
-    f.tagged = tagged;
-    f.start_delay = to_skip;
-    f.detected_samples = detected;
-    f.declared_samples = declared;
-
-    dec.reset();
-    bool fresh = true;
-    uint64_t off = start, cur = 0;
-    for (;;) {
-        if (detected && cur >= detected) break;
-        const uint64_t left = n - off;
-        if (!left) break;
-        const uint64_t blocks_before = f.blocks();
-        const std::vector<uint32_t> runs_before = f.run_granules;
-        const FrameResult fr = frame(dec, buf + off, (int)std::min<uint64_t>(left, 0x7fffffff), &f, &fresh);
-        if (fr.stop || fr.hz != hz0 || fr.layer != layer0 || fr.channels != ch0) {
-            // MP3D_E_DECODE (minimp3_ex.d:851-857; also what "no further frame" turns into, since the frame info
-            // stays zero then): the stream ends here; records of this frame are dropped
-            f.truncate(blocks_before);
-            f.run_granules = runs_before;
-            break;
-        }
-        if (fr.samples) {
-            const int total = fr.samples * fr.channels;
-            int used = 0;
-            if (to_skip) {
-                used = std::min(total, to_skip);
-                to_skip -= used;
-            }
-            uint64_t take = (uint64_t)(total - used);
-            if (detected && cur + take >= detected) take = detected - cur;
-            if (take) f.copies.push_back(Copy{ blocks_before * 576 + (uint64_t)used, take });
-            cur += take;
-        } else if (to_skip) {
-            const int fs = (int)Header{ buf + off }.samples() * fr.channels;
-            to_skip -= std::min(fs, to_skip);
-        }
-        off += (uint64_t)fr.consumed;
-    }
-    f.pcm_samples = cur;
-    // trailing granules that no copy refers to are still part of their run (the device needs whole runs)
+    Walk w;
+    if (!w.open(data, size)) return false;
+    w.describe(f);
+    while (!w.done) w.run(f, 1 << 20);
+    f.pcm_samples = w.cur;
     return true;
+}
+
+// ---- chunked reading (the AudioStream surface decodes as the caller pulls, stream.d:429-637, minimp3_ex.d:787-888) ----
+struct Reader::Impl {
+    Walk w;
+};
+
+Reader::Reader() : p(new Impl) {}
+Reader::~Reader() { delete p; }
+
+bool Reader::open(const uint8_t *data, size_t size, File &meta)
+{
+    *p = Impl();
+    if (!p->w.open(data, size)) return false;
+    meta = File();
+    p->w.describe(meta);
+    return true;
+}
+
+bool Reader::more(File &out, int max_frames, bool *continues)
+{
+    out = File();
+    p->w.describe(out);
+    if (p->w.done) return false;
+    *continues = !p->w.fresh;                              // the first run of this chunk goes on from the previous chunk's state
+    p->w.run(out, max_frames);
+    return out.blocks() != 0 || !p->w.done;
 }
 
 }  // namespace afg_mp3

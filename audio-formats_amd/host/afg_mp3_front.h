@@ -114,6 +114,23 @@ bool parse_file_into(const uint8_t *data, size_t size, File &out, float *coef, u
 // an upper bound for the number of granule-channel blocks parse_file will produce (frame-header walk only)
 size_t max_blocks(const uint8_t *data, size_t size);
 
+// Chunked reading for the AudioStream surface (the reference decodes as the caller pulls: stream.d:429-637,
+// minimp3_ex.d:787-888): `open` does mp3dec_ex_open's scan (tags, Xing/Info, length), `more` decodes the next frames
+// into fresh records whose copy plan is relative to that chunk.  *continues tells whether the chunk's first run goes on
+// from the decoder state the previous chunk ended with (the device keeps it in an AFG_MP3_STATE_FLOATS blob).
+class Reader {
+public:
+    Reader();
+    ~Reader();
+    Reader(const Reader &) = delete;
+    Reader &operator=(const Reader &) = delete;
+    bool open(const uint8_t *data, size_t size, File &meta);
+    bool more(File &out, int max_frames, bool *continues);      // false: the stream has ended and out holds nothing
+private:
+    struct Impl;
+    Impl *p;
+};
+
 // Tables of the device requantiser, derived from the scalefactor-band tables (24 = 3 kinds x 8 sample-rate rows):
 // band of every line, and where a line of the short part goes when L3_reorder interleaves the windows.
 struct QTables {

@@ -982,29 +982,41 @@ size_t max_spec_floats(const uint8_t *data, size_t size)
 
 bool parse_file(const uint8_t *data, size_t size, File &f) { return parse_file_into(data, size, f, nullptr, 0); }
 
-bool parse_file_into(const uint8_t *data, size_t size, File &f, float *spec_dst, size_t cap)
-{
-    f = File();
+namespace {
+
+// The packet loop of the pull API with the reference's position bookkeeping (:2531-2596), one packet per call, so that
+// a whole file (parse_file_into) and a chunked stream (Reader) run the same code.
+struct Walk {
+    const uint8_t *data = nullptr;
+    size_t size = 0;
     Demux dm;
     Setup st;
-    if (!open_stream(data, size, f, dm, st)) { f = File(); return false; }
-    f.ext_spec = spec_dst;
-    f.ext_cap = cap;
-
-    // audio packets with the reference's position bookkeeping (:2531-2596)
     Scratch sc;
     bool first = true, loc_valid = false;
     uint32_t cur_loc = 0;
     int deferred = 0, prev_overlap = 0;
-    for (size_t k = 3; k < dm.packets.size(); k++) {
+    size_t k = 3;                                          // next packet (0..2 are the headers)
+    // the last packet recorded: a chunked stream repeats it at the head of the next chunk (the transform overlaps a
+    // block with its predecessor, which the device re-derives from the predecessor's spectrum)
+    std::vector<float> last_spec;
+    unsigned last_flags = 0;
+    bool have_last = false;
+
+    // Decodes packet k into `f`; false: the stream ends here (nothing recorded).  `recorded` tells whether a record was
+    // appended (non-audio packets are skipped).
+    bool step(File &f, bool &recorded, bool keep_last)
+    {
+        recorded = false;
+        if (k >= dm.packets.size()) return false;
         const Packet &pk = dm.packets[k];
         unsigned flags = 0;
         int n = 0;
         bool audio = true;
-        if (!decode_packet(data, dm, pk, st, sc, flags, n, audio)) break;
+        if (!decode_packet(data, dm, pk, st, sc, flags, n, audio)) return false;
         if (!audio) {
-            if (!pk.complete) break;
-            continue;
+            if (!pk.complete) return false;
+            k++;
+            return true;
         }
         const int n2 = n >> 1;
         int left_start, right_start, right_end;
@@ -1021,7 +1033,7 @@ bool parse_file_into(const uint8_t *data, size_t size, File &f, float *spec_dst,
             // the same length, which is what consistent prev/next window flags guarantee.  A stream that breaks this
             // (the reference mixes windows of different lengths then, :2618-2627) ends at that packet here.
             const int left_end = ((flags & AFG_VORBIS_LONG) && !(flags & AFG_VORBIS_PREV)) ? (n + f.blocksize0) >> 2 : n2;
-            if (prev_overlap && prev_overlap != left_end - left_start) break;
+            if (prev_overlap && prev_overlap != left_end - left_start) return false;
             prev_overlap = right_end - right_start;
         }
         int left = left_start, len = right_end;
@@ -1057,14 +1069,21 @@ bool parse_file_into(const uint8_t *data, size_t size, File &f, float *spec_dst,
         }
         if (!len_set && loc_valid) cur_loc += (uint32_t)(right_start - left);
         // record
+        if (f.ext_spec && f.n_spec + (size_t)f.channels * (size_t)n2 > f.ext_cap) { f.overflow = true; return false; }
         f.pflags.push_back((uint8_t)flags);
         if (f.ext_spec) {
-            if (f.n_spec + (size_t)f.channels * (size_t)n2 > f.ext_cap) { f.overflow = true; break; }
             for (int c = 0; c < f.channels; c++)
                 std::memcpy(f.ext_spec + f.n_spec + (size_t)c * (size_t)n2, sc.spec.data() + (size_t)c * (size_t)n, (size_t)n2 * sizeof(float));
         } else {
             for (int c = 0; c < f.channels; c++)
                 f.spec.insert(f.spec.end(), sc.spec.begin() + (size_t)c * (size_t)n, sc.spec.begin() + (size_t)c * (size_t)n + (size_t)n2);
+        }
+        if (keep_last) {
+            last_spec.resize((size_t)f.channels * (size_t)n2);
+            for (int c = 0; c < f.channels; c++)
+                std::memcpy(last_spec.data() + (size_t)c * (size_t)n2, sc.spec.data() + (size_t)c * (size_t)n, (size_t)n2 * sizeof(float));
+            last_flags = flags;
+            have_last = true;
         }
         f.n_spec += (size_t)f.channels * (size_t)n2;
         int r = std::min(right_start, len);
@@ -1073,10 +1092,72 @@ bool parse_file_into(const uint8_t *data, size_t size, File &f, float *spec_dst,
         f.take_count.push_back(count);
         f.pcm_frames += (uint64_t)count;
         first = false;
-        if (!pk.complete) break;                             // the data ended inside this packet
+        recorded = true;
+        k++;
+        if (!pk.complete) k = dm.packets.size();            // the data ended inside this packet: nothing follows
+        return true;
     }
-    f.total_samples = stream_length(data, size, dm.first_audio_page);
+};
+
+}  // namespace
+
+bool parse_file_into(const uint8_t *data, size_t size, File &f, float *spec_dst, size_t cap)
+{
+    f = File();
+    Walk w;
+    if (!open_stream(data, size, f, w.dm, w.st)) { f = File(); return false; }
+    w.data = data;
+    w.size = size;
+    f.ext_spec = spec_dst;
+    f.ext_cap = cap;
+    bool recorded = false;
+    while (w.step(f, recorded, false)) {}
+    f.total_samples = stream_length(data, size, w.dm.first_audio_page);
     return true;
+}
+
+// ---- chunked reading (the AudioStream surface decodes as the caller pulls, stream.d:429-637) ----
+struct Reader::Impl {
+    Walk w;
+    File meta;
+};
+
+Reader::Reader() : p(new Impl) {}
+Reader::~Reader() { delete p; }
+
+bool Reader::open(const uint8_t *data, size_t size, File &meta)
+{
+    *p = Impl();
+    p->meta = File();
+    if (!open_stream(data, size, p->meta, p->w.dm, p->w.st)) return false;
+    p->w.data = data;
+    p->w.size = size;
+    p->meta.total_samples = stream_length(data, size, p->w.dm.first_audio_page);
+    meta = p->meta;
+    return true;
+}
+
+bool Reader::more(File &out, int max_packets)
+{
+    out = File();
+    out.channels = p->meta.channels;
+    out.blocksize0 = p->meta.blocksize0;
+    out.blocksize1 = p->meta.blocksize1;
+    out.sample_rate = p->meta.sample_rate;
+    out.total_samples = p->meta.total_samples;
+    Walk &w = p->w;
+    if (w.have_last) {                                     // the predecessor of this chunk's first packet: primes the overlap only
+        out.pflags.push_back((uint8_t)w.last_flags);
+        out.spec = w.last_spec;
+        out.n_spec = out.spec.size();
+        out.take_from.push_back(0);
+        out.take_count.push_back(0);
+    }
+    int got = 0;
+    bool recorded = false;
+    while (got < max_packets && w.step(out, recorded, true))
+        if (recorded) got++;
+    return got > 0;
 }
 
 }  // namespace afg_vorbis

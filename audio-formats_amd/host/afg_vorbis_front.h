@@ -28,4 +28,21 @@ bool parse_file(const uint8_t *data, size_t size, File &out);      // false: not
 bool parse_file_into(const uint8_t *data, size_t size, File &out, float *spec_dst, size_t cap);
 size_t max_spec_floats(const uint8_t *data, size_t size);          // 0: parse_file would return false
 
+// Chunked reading for the AudioStream surface (stream.d:429-637: the reference decodes as the caller pulls): `open`
+// parses the three headers and the stream length, `more` decodes the next audio packets into fresh records.  From the
+// second chunk on the records start with the previous chunk's last packet (nothing to take from it): the transform
+// stage re-derives the overlap from its spectrum, so no device state is carried between chunks.
+class Reader {
+public:
+    Reader();
+    ~Reader();
+    Reader(const Reader &) = delete;
+    Reader &operator=(const Reader &) = delete;
+    bool open(const uint8_t *data, size_t size, File &meta);
+    bool more(File &out, int max_packets);     // false: the stream has ended (out holds nothing to deliver)
+private:
+    struct Impl;
+    Impl *p;
+};
+
 }  // namespace afg_vorbis

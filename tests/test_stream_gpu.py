@@ -325,3 +325,64 @@ def test_flac_lossless_round_trip_over_the_parameter_space(gpu):
         s32 = (pcm.astype(np.int64) << (32 - bps)).astype(np.int32)
         want = (s32.astype(np.float64) * (1.0 / 2147483647.0)).astype(np.float32)
         assert np.array_equal(g["pcm"].reshape(-1, pcm.shape[1]).view(np.uint32), want.view(np.uint32))
+
+
+# ---- chunked reading: the stream decodes as the caller pulls (stream.d:429-637) -------------------------------------
+def long_files():
+    """One file per format, each several decode chunks long (64 MP3 frames / 64 Vorbis packets / 16 FLAC or QOA frames)."""
+    import mp3_bitstream as mb
+    import vorbis_bitstream as vb
+    rng = np.random.default_rng(77)
+    n = 4096 * 50 + 321
+    t = np.arange(n)
+    pcm = np.stack([9000 * np.sin(0.01 * t) + 800 * rng.standard_normal(n), 7000 * np.sin(0.013 * t + 1) + 800 * rng.standard_normal(n)], 1)
+    out = {"flac": fb.encode_file(pcm.round().astype(np.int64), 16, 4096, orders=(8, 12))[0],
+           "qoa": oraclelib.qoa_encode(pcm[:5120 * 40 + 99].round().astype(np.int16), 44100)[0].tobytes(),
+           "mp3": mb.make_file(123, n_frames=300, version="mpeg1", sr=0, mode="ms", bitrate_index=9)[0],
+           "ogg": vb.make_file(124, n_packets=300)}
+    d = bytearray(out["mp3"])
+    del d[40000:40123]                                   # a damaged copy: the decoder resynchronises (a new run) inside a chunk
+    out["mp3_damaged"] = bytes(d)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["flac", "qoa", "mp3", "mp3_damaged", "ogg"])
+def test_chunked_reads_equal_the_batch_decode(gpu, kind):
+    data = long_files()[kind]
+    want = afgpu.batch_decode([data])[0]
+    assert want["status"] == 0 and want["frames"] > 20000
+    ch = want["channels"]
+    for chunk in (1024, 777, 100000):                    # the example's read size, an odd one, one larger than a decode chunk
+        s = afgpu.AudioStream()
+        s.openFromMemory(data)
+        assert not s.isError(), s.errorMessage()
+        assert s.getNumChannels() == ch and s.getSamplerate() == want["samplerate"]
+        got = read_all(s, ch, chunk)
+        assert not s.isError()
+        assert got.shape == (want["frames"], ch)
+        assert np.array_equal(got.view(np.uint32), want["pcm"].view(np.uint32))
+        assert s.tellPosition() == want["frames"]
+        s.cleanUp()
+
+
+@pytest.mark.parametrize("kind", ["flac", "qoa", "mp3", "ogg"])
+def test_seeks_across_decode_chunks(gpu, kind):
+    """seekPosition / tellPosition / readSamplesFloat stay consistent when seeks jump forwards and backwards over several
+    decode chunks (examples/transcode additionalTests, main.d:93-160, on a stream that is not held decoded)."""
+    data = long_files()[kind]
+    want = afgpu.batch_decode([data])[0]
+    ch, total = want["channels"], want["frames"]
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    length = s.getLengthInFrames()
+    rng = np.random.default_rng(5)
+    for target in [total // 2, 10, total - 7, total // 3, 0, total // 3 + 1, min(length, total)]:
+        assert s.seekPosition(int(target))
+        assert s.tellPosition() == min(target, total)
+        buf = np.zeros(500 * ch, np.float32)
+        got = s.readSamplesFloat(buf)
+        assert got == min(500, total - min(target, total))
+        assert np.array_equal(buf[:got * ch].view(np.uint32), want["pcm"][target:target + got].reshape(-1).view(np.uint32))
+        assert s.tellPosition() == min(target, total) + got
+    assert not s.seekPosition(-1) and not s.seekPosition(int(length) + 1)
+    s.cleanUp()
