@@ -240,6 +240,25 @@ struct afg_batch_result
     void* owner;
 }
 int afg_batch_decode(const(ubyte*)* data, const(size_t)* length, int n_files, int n_threads, afg_batch_result* result);
+
+// ---- round 2: device selection, multi-device batches, MP3 quantised upload, CELT on two streams, dithered WAV ----
+struct afg_batch_opts { uint struct_size; int n_threads; int n_devices; const(int)* devices; }
+int afg_set_device(int device);
+int afg_get_device();
+int afg_batch_decode_ex(const(ubyte*)* data, const(size_t)* length, int n_files, const(afg_batch_opts)* opts, afg_batch_result* result);
+ulong afg_host_pool_trim();
+
+enum uint AFG_MP3_NO_SDESC = 0xffffffffu;
+struct afg_mp3_qgranule { ulong q_off; ulong coef_off; uint sdesc; ubyte nch; ubyte stereo; ubyte[2] table; float[40][2] scale; }
+struct afg_mp3_sdesc { ubyte[40] type; float[40] fl; float[40] fr; }
+static assert(afg_mp3_qgranule.sizeof == 344 && afg_mp3_sdesc.sizeof == 360);
+int afg_mp3_requant_hip(ulong n_granules, const(afg_mp3_qgranule)* d_granules, const(short)* d_q,
+                        const(afg_mp3_sdesc)* d_sdesc, float* d_coef, void* hip_stream);
+int afg_celt_transform_streams_hip(uint n_chan, const(ulong)* d_rec_base, const(afg_celt_frame)* d_recs, const(float)* d_coeffs,
+                                   float* d_out, float* d_states, void* hip_stream, void* hip_tail_stream);
+alias afg_rand_fn = extern(C) int function(void* user) nothrow @nogc;
+ulong afg_wav_encode_dithered(const(float)* samples, ulong frames, uint channels, uint samplerate, int format,
+                              afg_rand_fn rng, void* rng_user, uint rng_max, ubyte* outData, ulong cap);
 void afg_batch_free(afg_batch_result* result);
 
 /// Drop-in for the decoding use of `AudioStream` (stream.d:102): same member names and error-state contract

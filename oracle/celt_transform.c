@@ -250,14 +250,22 @@ void afgo_celt_frame_channel(afgo_celt_state *f, const afgo_celt_frame *fr, cons
     const int frame_size = fr->frame_size, blocks = fr->blocks, blocksize = frame_size / blocks;
     int N = 0;
     while ((15 << N) < blocksize) N++;
-    imdct15_ctx ctx;
-    if (imdct15_init(&ctx, N)) return;
+    /* the reference builds its four contexts once per decoder (dopus.d:3792-3796); here once per thread and table
+     * reading, so that timing this restatement does not time 2000 cosl/sinl calls per frame */
+    static __thread imdct15_ctx cache[8];
+    static __thread int cache_key[8];
+    if (cache_key[N] != 1 + g_celt_table_mode) {
+        if (cache_key[N]) imdct15_free(&cache[N]);
+        cache_key[N] = 0;
+        if (imdct15_init(&cache[N], N)) return;
+        cache_key[N] = 1 + g_celt_table_mode;
+    }
+    const imdct15_ctx ctx = cache[N];
     for (int j = 0; j < blocks; j++) {
         float *dst = f->buf + 1024 + j * blocksize;
         imdct15_half(&ctx, dst + 60, coeffs + j, blocks, fr->imdct_scale);
         fmul_window(dst, dst, dst + 60, k_celt_window, 60);
     }
-    imdct15_free(&ctx);
 
     {   /* celt_postfilter */
         int len = frame_size;

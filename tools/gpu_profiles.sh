@@ -1,0 +1,20 @@
+#!/bin/bash
+# round-2 evidence: kernel-trace summary of the default bench command, PMC passes per kernel, bench lines (run on the GPU box)
+R="$GRAFT_REPO_ROOT"; [ -z "$R" ] && R=/root/repo
+cd "$R"; export TMPDIR=/tmp; mkdir -p gpurun_out/r02_prof
+( timeout 900 python bench.py --steps 20 --warmup 3 2> gpurun_out/r02_prof/bench.err ) > gpurun_out/r02_prof/bench.json
+( timeout 900 python bench.py --config c5 --steps 3 --warmup 1 --cpu-seconds 8 2> gpurun_out/r02_prof/c5.err ) > gpurun_out/r02_prof/c5.json
+( timeout 600 python tools/bench_codecs.py --codec all --steps 5 --warmup 2 2>/dev/null | tail -1 ) > gpurun_out/r02_prof/codecs.json
+cd /tmp
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/r02_prof/stats" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> "$R/gpurun_out/r02_prof/stats.err"
+cd "$R"
+python tools/export_kernel_stats.py gpurun_out/r02_prof/stats gpurun_out/r02_prof/r02_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline" > /dev/null
+find gpurun_out/r02_prof/stats -name "*.db" -delete
+bash tools/pmc_collect.sh r02_pmc_mp3_transform_kernel mp3_transform_kernel bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-full-fetch > /dev/null
+bash tools/pmc_collect.sh r02_pmc_vorbis_wave_kernel vorbis_wave_kernel bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
+bash tools/pmc_collect.sh r02_pmc_flac_restore_kernel "flac_restore_kernelILi8ELi12ELb0ELb1" bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
+bash tools/pmc_collect.sh r02_pmc_celt_stream_kernel celt_stream_kernel tools/bench_codecs.py --codec celt --steps 3 > /dev/null
+bash tools/pmc_collect.sh r02_pmc_celt_deemph_kernel celt_deemph_kernel tools/bench_codecs.py --codec celt --steps 3 > /dev/null
+bash tools/pmc_collect.sh r02_pmc_qoa_decode_kernel qoa_decode_kernel tools/bench_codecs.py --codec qoa --steps 3 > /dev/null
+head -12 gpurun_out/r02_prof/r02_kernel_stats.csv | cut -c1-160
+for k in mp3_transform_kernel vorbis_wave_kernel flac_restore_kernel celt_stream_kernel celt_deemph_kernel qoa_decode_kernel; do echo "== $k"; grep -E "hbm_bytes|valu_instructions|wait_any|active_inst_valu_over|wait_inst_any" gpurun_out/r02_pmc_$k/derived.txt; done
