@@ -263,6 +263,22 @@ void afgo_celt_transform(uint32_t n_chan, const uint64_t *rec_base, const afgo_c
                          const float *coeffs, float *out, afgo_celt_state *states);
 void afgo_opus_output(uint64_t n, const float *in, int16_t *out_i16, float *out_f32);   /* dopus.d:7923-7926, stream.d:480 */
 
+/* Ogg Opus front-end, CELT-only (opus_frontend.c).  frames[i] is channel 0's transform record of frame i (out_off /
+ * out_stride address interleaved PCM); channel c of the same frame: coef_off + c * frame_size, out_off + c. */
+typedef struct afgo_opus_file {
+    int32_t  channels, preskip, gain_i, error;
+    float    gain;                   /* what opus_decode_packet multiplies the floats by when gain_i != 0 (dopus.d:6690) */
+    int32_t  pad;
+    int64_t  declared_frames;        /* last page's granule position - preskip (dopus.d:8159): AudioStream's length */
+    uint64_t pcm_frames;             /* frames the packets decode to */
+    uint64_t n_frames;
+    afgo_celt_frame *frames;
+    uint64_t n_coeffs;
+    float   *coeffs;
+} afgo_opus_file;
+int  afgo_opus_decode_file(const uint8_t *data, size_t size, afgo_opus_file *out);
+void afgo_opus_file_free(afgo_opus_file *f);
+
 /* ------------------------------------------------------------- WAV out -- */
 typedef int (*afgo_rand_fn)(void *user);
 void afgo_tpdf_dither(double *inout, int frames, double scaleFactor, afgo_rand_fn rng, void *user, double rand_max);  /* wav.d:674-701 */

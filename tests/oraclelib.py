@@ -321,6 +321,64 @@ def celt_transform(rec_base, recs, coeffs, out_total, states=None):
     return out
 
 
+class _OpusFile(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("preskip", C.c_int32), ("gain_i", C.c_int32), ("error", C.c_int32),
+                ("gain", C.c_float), ("pad", C.c_int32), ("declared_frames", C.c_int64), ("pcm_frames", C.c_uint64),
+                ("n_frames", C.c_uint64), ("frames", C.c_void_p), ("n_coeffs", C.c_uint64), ("coeffs", C.POINTER(C.c_float))]
+
+
+def opus_decode_file(data):
+    """Oracle Ogg Opus front-end (CELT-only) over a whole file in memory: transform-stage records of channel 0 per
+    frame + the coefficient plane (channels consecutive per frame).  Returns the integer status (-1 not an Opus file the
+    reference opens, -3 SILK / hybrid) instead of a dict on failure."""
+    buf = bytes(data)
+    f = _OpusFile()
+    fn = lib().afgo_opus_decode_file
+    fn.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_OpusFile)]
+    fn.restype = C.c_int
+    rc = fn(buf, len(buf), C.byref(f))
+    if rc != 0:
+        return rc
+    try:
+        n = int(f.n_frames)
+        frames = np.frombuffer(C.string_at(f.frames, n * CELT_FRAME_DTYPE.itemsize), CELT_FRAME_DTYPE).copy() if n \
+            else np.zeros(0, CELT_FRAME_DTYPE)
+        nc = int(f.n_coeffs)
+        coeffs = np.ctypeslib.as_array(f.coeffs, shape=(nc,)).copy() if nc else np.zeros(0, np.float32)
+        return {"channels": f.channels, "preskip": f.preskip, "gain_i": f.gain_i, "gain": float(np.float32(f.gain)),
+                "error": bool(f.error), "declared_frames": int(f.declared_frames), "pcm_frames": int(f.pcm_frames),
+                "frames": frames, "coeffs": coeffs}
+    finally:
+        free = lib().afgo_opus_file_free
+        free.argtypes = [C.POINTER(_OpusFile)]
+        free.restype = None
+        free(C.byref(f))
+
+
+def opus_channel_records(rec):
+    """records of opus_decode_file -> (rec_base, recs) of afgo_celt_transform: one sequence per output channel."""
+    ch, fr = rec["channels"], rec["frames"]
+    recs = np.zeros(ch * len(fr), CELT_FRAME_DTYPE)
+    for c in range(ch):
+        part = fr.copy()
+        part["coef_off"] += np.uint64(c) * part["frame_size"].astype(np.uint64)
+        part["out_off"] += np.uint64(c)
+        recs[c * len(fr):(c + 1) * len(fr)] = part
+    return np.arange(ch + 1, dtype=np.uint64) * np.uint64(len(fr)), recs
+
+
+def opus_file_pcm(rec):
+    """records of opus_decode_file -> what AudioStream.readSamplesFloat delivers: transform oracle, gain (dopus.d:6690),
+    int16 conversion / 32767 (dopus.d:8098-8105, stream.d:480), clipped to the declared length (stream.d:439-442)."""
+    ch = rec["channels"]
+    base, recs = opus_channel_records(rec)
+    pcm = celt_transform(base, recs, rec["coeffs"], rec["pcm_frames"] * ch)
+    if rec["gain_i"]:
+        pcm = pcm * np.float32(rec["gain"])
+    _, of = opus_output(pcm)
+    return of.reshape(-1, ch)[:max(0, min(rec["pcm_frames"], rec["declared_frames"]))]
+
+
 # ------------------------------------------------------- CPU baseline pool ------
 class BenchTask(C.Structure):
     _fields_ = [("codec", C.c_int32), ("n", C.c_uint32), ("channels", C.c_uint32), ("bs0", C.c_uint16), ("bs1", C.c_uint16),
