@@ -55,6 +55,7 @@ ABI_SYMBOLS = [
     "afg_get_length_in_frames", "afg_get_samplerate", "afg_read_samples_float", "afg_close",
     "afg_can_seek", "afg_seek_position", "afg_tell_position",
     "afg_flac_parse", "afg_flac_parsed_free", "afg_qoa_parse", "afg_mp3_parse", "afg_mp3_parsed_free", "afg_vorbis_parse", "afg_vorbis_parsed_free",
+    "afg_opus_parse", "afg_opus_parsed_free", "afg_opus_output_gain_hip",
     "afg_batch_decode", "afg_batch_free", "afg_batch_decode_ex", "afg_set_device", "afg_get_device", "afg_host_pool_trim",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
     "afg_copy_probe_hip",
@@ -106,6 +107,13 @@ class VorbisParsed(C.Structure):
                 ("take_count", C.c_void_p), ("owner", C.c_void_p)]
 
 
+class OpusParsed(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("preskip", C.c_int32), ("gain_i", C.c_int32), ("error", C.c_int32),
+                ("gain", C.c_float), ("pad", C.c_int32), ("declared_frames", C.c_int64), ("pcm_frames", C.c_uint64),
+                ("n_frames", C.c_uint64), ("n_coeffs", C.c_uint64), ("frames", C.c_void_p), ("coeffs", C.c_void_p),
+                ("owner", C.c_void_p)]
+
+
 class BatchItem(C.Structure):
     _fields_ = [("status", C.c_int), ("message", C.c_char_p), ("format", C.c_int), ("channels", C.c_int),
                 ("samplerate", C.c_float), ("frames", C.c_int64), ("pcm", C.POINTER(C.c_float))]
@@ -149,6 +157,10 @@ def lib():
     L.afg_device_count.restype = C.c_int
     L.afg_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.afg_opus_output_hip.argtypes = [u64, vp, vp, vp, vp]
+    L.afg_opus_output_gain_hip.argtypes = [u64, vp, C.c_float, vp, vp, vp]
+    L.afg_opus_parse.argtypes = [vp, C.c_size_t, C.POINTER(OpusParsed)]
+    L.afg_opus_parsed_free.argtypes = [C.POINTER(OpusParsed)]
+    L.afg_opus_parsed_free.restype = None
     L.afg_qoa_encoded_size.argtypes = [u32, u32]
     L.afg_qoa_encoded_size.restype = u64
     L.afg_qoa_encode_hip.argtypes = [u32, vp, vp, vp, vp, vp]
@@ -359,9 +371,13 @@ def qoa_transform(n_frames, d_frames, d_bytes, d_out_i16=None, d_out_f32=None, s
                                       _ptr(d_out_f32), _stream(stream)))
 
 
-def opus_output(n_samples, d_in, d_out_i16=None, d_out_f32=None, stream=None):
-    """Enqueue OpusFile.readFrame's float -> int16 (-> float / 32767) conversion (afg_opus_output_hip)."""
-    check(lib().afg_opus_output_hip(int(n_samples), _ptr(d_in), _ptr(d_out_i16), _ptr(d_out_f32), _stream(stream)))
+def opus_output(n_samples, d_in, d_out_i16=None, d_out_f32=None, stream=None, gain=None):
+    """Enqueue OpusFile.readFrame's float -> int16 (-> float / 32767) conversion (afg_opus_output_hip); gain: the decoder's
+    output gain is applied first (afg_opus_output_gain_hip)."""
+    if gain is None:
+        check(lib().afg_opus_output_hip(int(n_samples), _ptr(d_in), _ptr(d_out_i16), _ptr(d_out_f32), _stream(stream)))
+    else:
+        check(lib().afg_opus_output_gain_hip(int(n_samples), _ptr(d_in), float(gain), _ptr(d_out_i16), _ptr(d_out_f32), _stream(stream)))
 
 
 def qoa_encoded_size(samples, channels):
@@ -515,6 +531,27 @@ def vorbis_parse(file_bytes):
                 "take_from": view(out.take_from, n, np.int32), "take_count": view(out.take_count, n, np.int32)}
     finally:
         lib().afg_vorbis_parsed_free(C.byref(out))
+
+
+def opus_parse(file_bytes):
+    """Host front-end only (afg_opus_parse): dict with channels, preskip, gain_i, gain, error, declared_frames, pcm_frames,
+    frames (CELT_FRAME_DTYPE, channel 0's record per frame) and coeffs (numpy copies).  Raises AfgError for a stream that
+    is not Ogg Opus or that holds SILK / hybrid packets."""
+    buf = bytes(file_bytes)
+    out = OpusParsed()
+    check(lib().afg_opus_parse(buf, len(buf), C.byref(out)))
+    try:
+        def view(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype)
+            raw = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(raw, dtype=dtype, count=count).copy()
+        return {"channels": out.channels, "preskip": out.preskip, "gain_i": out.gain_i, "gain": float(np.float32(out.gain)),
+                "error": bool(out.error), "declared_frames": int(out.declared_frames), "pcm_frames": int(out.pcm_frames),
+                "frames": view(out.frames, int(out.n_frames), CELT_FRAME_DTYPE),
+                "coeffs": view(out.coeffs, int(out.n_coeffs), np.float32)}
+    finally:
+        lib().afg_opus_parsed_free(C.byref(out))
 
 
 def qoa_parse(file_bytes):

@@ -1178,35 +1178,83 @@ int ensure_tables(const float **d_tables, CeltTables *tb)
 // Float2IntScaled: temp.f = x + (1.5f*(1<<8) + 0.5f/(1<<15)); d = temp.i - (((150-15)<<23) + (1<<22)); saturate.
 // The constant is float-typed: 384 + 2^-16 is exactly half an ulp above 384 and rounds (to even) to 384.0f, so the
 // float addition leaves round-to-nearest-even of x * 32768 in the mantissa -- one v_add_f32 and an integer subtract.
+// GAIN: opus_decode_packet's vector_fmul_scalar by the header / R128 gain first (dopus.d:6688-6691), a float multiply of its own.
+// Four samples per lane (the element-wise pass is pure HBM traffic); the tail of a count that is not a multiple of four
+// goes through the scalar path of the last lane.
+template <bool GAIN>
 __global__ __launch_bounds__(256) void opus_output_kernel(const float *__restrict__ in, int16_t *__restrict__ out_i16,
-                                                          float *__restrict__ out_f32, uint64_t n)
+                                                          float *__restrict__ out_f32, uint64_t n, float gain)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    const float t = in[i] + 384.0f;
-    int d = __float_as_int(t) - (((150 - 15) << 23) + (1 << 22));
-    if ((unsigned)(d + 32768) > 65535u) d = d < 0 ? -32768 : 32767;
-    if (out_i16) out_i16[i] = (int16_t)d;
-    if (out_f32) out_f32[i] = (float)(int16_t)d / 32767.0f;               // stream.d:480
+    auto one = [&](float x) -> int {
+        if (GAIN) x = x * gain;
+        const float t = x + 384.0f;
+        // D's int arithmetic wraps (for -768 < x < -384 the difference passes INT_MIN and the sample saturates to +32767):
+        // unsigned arithmetic keeps that behaviour defined here
+        int d = (int)(__float_as_uint(t) - (unsigned)(((150 - 15) << 23) + (1 << 22)));
+        if ((unsigned)d + 32768u > 65535u) d = d < 0 ? -32768 : 32767;
+        return d;
+    };
+    const bool aligned = ((((uintptr_t)in) | ((uintptr_t)out_f32)) & 15) == 0 && (((uintptr_t)out_i16) & 7) == 0;
+    if (i + 4 <= n && aligned) {
+        const float4 v = *reinterpret_cast<const float4 *>(in + i);
+        const int d0 = one(v.x), d1 = one(v.y), d2 = one(v.z), d3 = one(v.w);
+        if (out_i16) {
+            short4 o;
+            o.x = (short)d0; o.y = (short)d1; o.z = (short)d2; o.w = (short)d3;
+            *reinterpret_cast<short4 *>(out_i16 + i) = o;
+        }
+        if (out_f32) {
+            float4 o;
+            o.x = (float)(int16_t)d0 / 32767.0f;                            // stream.d:480
+            o.y = (float)(int16_t)d1 / 32767.0f;
+            o.z = (float)(int16_t)d2 / 32767.0f;
+            o.w = (float)(int16_t)d3 / 32767.0f;
+            *reinterpret_cast<float4 *>(out_f32 + i) = o;
+        }
+        return;
+    }
+    for (uint64_t k = i; k < n && k < i + 4; k++) {
+        const int d = one(in[k]);
+        if (out_i16) out_i16[k] = (int16_t)d;
+        if (out_f32) out_f32[k] = (float)(int16_t)d / 32767.0f;
+    }
+}
+
+static int opus_output_launch(const char *who, uint64_t n_samples, const float *d_in, bool apply_gain, float gain, int16_t *d_out_i16,
+                              float *d_out_f32, void *hip_stream)
+{
+    if (n_samples == 0) return AFG_OK;
+    if (!d_in || (!d_out_i16 && !d_out_f32)) {
+        afg::set_error("%s: NULL device pointer", who);
+        return AFG_ERR_INVALID;
+    }
+    if (int rc = afg::require_device()) return rc;
+    const uint64_t blocks = (n_samples + 1023) / 1024;
+    if (blocks > 0x7fffffffull) {
+        afg::set_error("%s: at most 2^41 samples per call", who);
+        return AFG_ERR_INVALID;
+    }
+    if (apply_gain)
+        hipLaunchKernelGGL(opus_output_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)hip_stream, d_in, d_out_i16, d_out_f32,
+                           n_samples, gain);
+    else
+        hipLaunchKernelGGL(opus_output_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)hip_stream, d_in, d_out_i16, d_out_f32,
+                           n_samples, 1.0f);
+    AFG_HIP_CHECK(hipGetLastError());
+    return AFG_OK;
 }
 
 extern "C" int afg_opus_output_hip(uint64_t n_samples, const float *d_in, int16_t *d_out_i16, float *d_out_f32, void *hip_stream)
 {
-    if (n_samples == 0) return AFG_OK;
-    if (!d_in || (!d_out_i16 && !d_out_f32)) {
-        afg::set_error("afg_opus_output_hip: NULL device pointer");
-        return AFG_ERR_INVALID;
-    }
-    if (int rc = afg::require_device()) return rc;
-    const uint64_t blocks = (n_samples + 255) / 256;
-    if (blocks > 0x7fffffffull) {
-        afg::set_error("afg_opus_output_hip: at most 2^39 samples per call");
-        return AFG_ERR_INVALID;
-    }
-    hipLaunchKernelGGL(opus_output_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)hip_stream, d_in, d_out_i16,
-                       d_out_f32, n_samples);
-    AFG_HIP_CHECK(hipGetLastError());
-    return AFG_OK;
+    return opus_output_launch("afg_opus_output_hip", n_samples, d_in, false, 1.0f, d_out_i16, d_out_f32, hip_stream);
+}
+
+extern "C" int afg_opus_output_gain_hip(uint64_t n_samples, const float *d_in, float gain, int16_t *d_out_i16, float *d_out_f32,
+                                        void *hip_stream)
+{
+    return opus_output_launch("afg_opus_output_gain_hip", n_samples, d_in, true, gain, d_out_i16, d_out_f32, hip_stream);
 }
 
 static int celt_transform_impl(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs, const float *d_coeffs,

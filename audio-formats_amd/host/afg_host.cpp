@@ -12,6 +12,7 @@
 #include "../csrc/afg_common.h"
 #include "afg_flac_front.h"
 #include "afg_mp3_front.h"
+#include "afg_opus_front.h"
 #include "afg_vorbis_front.h"
 
 #include <algorithm>
@@ -36,6 +37,8 @@ const char *const kErrorUnknownFormat = "Cannot decode stream: unrecognized enco
 const char *const kErrorDecodingError = "Decoder encountered an error";
 const char *const kErrorDecoderInitializationFailed = "Decoder initialization failed";
 const char *const kErrorNotInitialized = "Stream not initialized";
+// this library's own: the reference decodes such files, the device path does not (out of scope)
+const char *const kErrorOpusMode = "Cannot decode stream: Opus SILK / hybrid packets are not supported (CELT-only).";
 
 // ---------------------------------------------------------------------------------------------
 // decoded files: one result plane for a whole batch
@@ -60,6 +63,8 @@ struct Parsed {
     std::vector<afg_qoa_frame> qoa;
     afg_mp3::File mp3;
     afg_vorbis::File ogg;
+    afg_opus::File opus;
+    bool opus_mode = false;               // an Ogg Opus file with SILK / hybrid packets: reported, not decoded
     const float *mp3_coef() const { return mp3.ext_coef ? mp3.ext_coef : mp3.coef.data(); }
     const uint32_t *mp3_flags() const { return mp3.ext_flags ? mp3.ext_flags : mp3.flags.data(); }
 };
@@ -425,9 +430,16 @@ struct Mp3Carry {
     bool continues = false;             // this chunk's first run goes on from it
 };
 
+// What an Opus stream carries from one chunk of packets to the next on the device: the transform stage's per-channel
+// memory (overlap, post-filter history, de-emphasis), as afg_celt_transform_hip reads and rewrites it.
+struct OpusCarry {
+    DeviceBuf states;                   // channels * AFG_CELT_STATE_FLOATS floats
+    bool valid = false;
+};
+
 int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out,
                   const Mp3Stage *stage = nullptr, const OggStage *ogg_stage = nullptr, const FlacStage *flac_stage = nullptr,
-                  const uint8_t *own = nullptr, Mp3Carry *carry = nullptr)
+                  const uint8_t *own = nullptr, Mp3Carry *carry = nullptr, OpusCarry *opus_carry = nullptr)
 {
     // `own` (optional, one byte per file): the files this call is responsible for.  The batch path decodes its FLAC /
     // QOA files on a second host thread while the first still parses MP3 / Ogg files: a call never looks at (not even
@@ -605,7 +617,20 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         });
         tm.lap("mp3 delivery (in place)");
     }
-    out.plane_floats = flac_out + qoa_out + mp3_out + ogg_out;
+    // Opus: one channel sequence per output channel of every file; the PCM plane holds the files back to back, interleaved
+    std::vector<size_t> opus_rec_base(nf, 0), opus_coef_base(nf, 0), opus_pcm_base(nf, 0);
+    size_t opus_out = 0, opus_recs = 0, opus_coefs = 0, opus_seqs = 0;
+    for (size_t i = 0; i < nf; i++) {
+        const Parsed &p = parsed[i];
+        if (fmt_of(p) != AFG_FORMAT_OPUS) continue;
+        opus_rec_base[i] = opus_recs; opus_coef_base[i] = opus_coefs; opus_pcm_base[i] = opus_out;
+        out.files[i].pcm_off = flac_out + qoa_out + mp3_out + ogg_out + opus_out;
+        opus_recs += p.opus.frames.size() * (size_t)p.opus.channels;
+        opus_coefs += p.opus.coeffs.size();
+        opus_out += (size_t)p.opus.pcm_frames * (size_t)p.opus.channels;
+        opus_seqs += (size_t)p.opus.channels;
+    }
+    out.plane_floats = flac_out + qoa_out + mp3_out + ogg_out + opus_out;
     if (out.plane_floats == 0) goto metadata;
     {
         if (int rc = g_staging.take(out.plane_floats * sizeof(float), out.plane)) return rc;
@@ -895,6 +920,79 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             }
             tm.lap("vorbis gather | h2d | kernel | d2h (chunks overlapped)");
         }
+        // ---- Opus (CELT): records + coefficients -> transform -> gain / int16 round trip -> result plane ----
+        if (opus_out) {
+            if (opus_seqs > 0xffffffffull) { afg::set_error("Opus stage: too many channel sequences"); return AFG_ERR_INVALID; }
+            const size_t base_bytes = ((opus_seqs + 1) * sizeof(uint64_t) + 15) & ~(size_t)15;
+            const size_t rec_bytes = (opus_recs * sizeof(afg_celt_frame) + 15) & ~(size_t)15;
+            StagingPool::Lease h_in;
+            DeviceBuf d_in, d_pcm;
+            if (int rc = g_staging.take(base_bytes + rec_bytes + opus_coefs * sizeof(float), h_in)) return rc;
+            if (int rc = d_in.alloc(base_bytes + rec_bytes + opus_coefs * sizeof(float))) return rc;
+            if (int rc = d_pcm.alloc(opus_out * sizeof(float))) return rc;
+            uint64_t *hb = (uint64_t *)h_in.p;
+            afg_celt_frame *hr = (afg_celt_frame *)((uint8_t *)h_in.p + base_bytes);
+            float *hc = (float *)((uint8_t *)h_in.p + base_bytes + rec_bytes);
+            {
+                size_t seq = 0;
+                for (size_t i = 0; i < nf; i++) {
+                    const Parsed &p = parsed[i];
+                    if (fmt_of(p) != AFG_FORMAT_OPUS) continue;
+                    for (int c = 0; c < p.opus.channels; c++) hb[seq++] = opus_rec_base[i] + (size_t)c * p.opus.frames.size();
+                }
+                hb[seq] = opus_recs;
+            }
+            parallel_for(nf, threads, [&](size_t i) {
+                Parsed &p = parsed[i];
+                if (fmt_of(p) != AFG_FORMAT_OPUS) return;
+                const size_t n = p.opus.frames.size();
+                for (int c = 0; c < p.opus.channels; c++)
+                    for (size_t k = 0; k < n; k++) {
+                        afg_celt_frame f = p.opus.frames[k];
+                        f.coef_off += opus_coef_base[i] + (uint64_t)c * f.frame_size;
+                        f.out_off += opus_pcm_base[i] + (uint64_t)c;
+                        hr[opus_rec_base[i] + (size_t)c * n + k] = f;
+                    }
+                if (!p.opus.coeffs.empty()) std::memcpy(hc + opus_coef_base[i], p.opus.coeffs.data(), p.opus.coeffs.size() * sizeof(float));
+                std::vector<float>().swap(p.opus.coeffs);
+            });
+            AFG_HIP_CHECK(hipMemcpyAsync(d_in.p, h_in.p, base_bytes + rec_bytes + opus_coefs * sizeof(float), hipMemcpyHostToDevice, stream));
+            // chunked stream (one file): the channel states live on the device between chunks, zero for a fresh decoder
+            float *states = nullptr;
+            if (opus_carry) {
+                const size_t sb = opus_seqs * AFG_CELT_STATE_FLOATS * sizeof(float);
+                if (!opus_carry->states.p) {
+                    if (int rc = opus_carry->states.alloc(sb)) return rc;
+                    opus_carry->valid = false;
+                }
+                if (!opus_carry->valid) AFG_HIP_CHECK(hipMemsetAsync(opus_carry->states.p, 0, sb, stream));
+                opus_carry->valid = true;
+                states = (float *)opus_carry->states.p;
+            }
+            if (int rc = afg_celt_transform_hip((uint32_t)opus_seqs, (const uint64_t *)d_in.p, (const afg_celt_frame *)((const uint8_t *)d_in.p + base_bytes),
+                                                (const float *)((const uint8_t *)d_in.p + base_bytes + rec_bytes), (float *)d_pcm.p, states, stream))
+                return rc;
+            // output gain (when the file asks for one) and the reference's int16 round trip, in place
+            bool any_gain = false;
+            for (size_t i = 0; i < nf; i++) any_gain = any_gain || (fmt_of(parsed[i]) == AFG_FORMAT_OPUS && parsed[i].opus.gain_i != 0);
+            if (!any_gain) {
+                if (int rc = afg_opus_output_hip(opus_out, (const float *)d_pcm.p, nullptr, (float *)d_pcm.p, stream)) return rc;
+            } else {
+                for (size_t i = 0; i < nf; i++) {
+                    const Parsed &p = parsed[i];
+                    if (fmt_of(p) != AFG_FORMAT_OPUS) continue;
+                    float *at = (float *)d_pcm.p + opus_pcm_base[i];
+                    const uint64_t n = p.opus.pcm_frames * (uint64_t)p.opus.channels;
+                    const int rc = p.opus.gain_i ? afg_opus_output_gain_hip(n, at, p.opus.gain, nullptr, at, stream)
+                                                 : afg_opus_output_hip(n, at, nullptr, at, stream);
+                    if (rc) return rc;
+                }
+            }
+            AFG_HIP_CHECK(hipMemcpyAsync((float *)out.plane.p + flac_out + qoa_out + mp3_out + ogg_out, d_pcm.p, opus_out * sizeof(float),
+                                         hipMemcpyDeviceToHost, stream));
+            AFG_HIP_CHECK(hipStreamSynchronize(stream));
+            tm.lap("opus gather | h2d | kernel | d2h");
+        }
     }
 metadata:
     for (size_t i = 0; i < nf; i++) {
@@ -916,6 +1014,16 @@ metadata:
             dcd.samplerate = (float)p.ogg.sample_rate;
             dcd.frames = (int64_t)p.ogg.pcm_frames;
             dcd.declared_frames = (int64_t)p.ogg.total_samples;    // stb_vorbis_stream_length_in_samples, stream.d:1696
+        } else if (fmt_of(p) == AFG_FORMAT_OPUS) {
+            dcd.channels = p.opus.channels;
+            dcd.samplerate = 48000.0f;                              // OpusFileCtx.rate (dopus.d:7973)
+            dcd.declared_frames = p.opus.declared_frames;           // smpduration(), stream.d:1609
+            // the reference never reads past the declared length (stream.d:439-442); the pre-skip samples are not dropped
+            dcd.frames = std::min<int64_t>((int64_t)p.opus.pcm_frames, std::max<int64_t>(p.opus.declared_frames, 0));
+            if (p.opus.error) {                                     // a packet failed: the read that reaches it reports an error
+                dcd.status = AFG_ERR_INVALID;
+                dcd.message = kErrorDecoderInitializationFailed;    // (the string stream.d:454 sets)
+            }
         } else if (fmt_of(p) == AFG_FORMAT_QOA) {
             dcd.channels = (int)p.qi.channels;
             dcd.samplerate = (float)p.qi.samplerate;
@@ -923,7 +1031,7 @@ metadata:
             dcd.declared_frames = (int64_t)p.qi.samples;
         } else {
             dcd.status = AFG_ERR_UNSUPPORTED;
-            dcd.message = kErrorUnknownFormat;
+            dcd.message = p.opus_mode ? kErrorOpusMode : kErrorUnknownFormat;
         }
     }
     return AFG_OK;
@@ -949,14 +1057,20 @@ struct afg_stream {
     size_t qoa_next = 0;
     std::unique_ptr<afg_mp3::Reader> mp3;
     std::unique_ptr<afg_vorbis::Reader> ogg;
+    std::unique_ptr<afg_opus::Reader> opus;
     Mp3Carry carry;
+    OpusCarry opus_carry;
+    int opus_gain_i = 0;
+    float opus_gain = 1.0f;
+    int64_t opus_decoded = 0;           // frames decoded so far (the declared length cuts the delivery, stream.d:439-442)
+    bool opus_failed = false;           // a packet could not be framed: the next refill reports it (stream.d:452-456)
     // delivered samples not yet read
     std::vector<float> fifo;
     size_t fifo_at = 0;                 // floats of `fifo` already handed out
     int64_t position = 0;               // frames handed out so far (tellPosition)
     bool ended = false;                 // nothing further can be decoded
 
-    static constexpr int kMp3Frames = 64, kOggPackets = 64, kFlacFrames = 16, kQoaFrames = 16;
+    static constexpr int kMp3Frames = 64, kOggPackets = 64, kFlacFrames = 16, kQoaFrames = 16, kOpusPackets = 64;
 
     // (re)start the readers at the head of the stream
     bool rewind()
@@ -968,6 +1082,14 @@ struct afg_stream {
         flac_pos = 0;
         qoa_next = 0;
         carry.valid = carry.continues = false;
+        opus_carry.valid = false;
+        opus_decoded = 0;
+        opus_failed = false;
+        if (format == AFG_FORMAT_OPUS) {
+            afg_opus::File meta;
+            opus.reset(new afg_opus::Reader);
+            return opus->open(bytes.data(), bytes.size(), meta) == afg_opus::kOpened;
+        }
         if (format == AFG_FORMAT_MP3) {
             afg_mp3::File meta;
             mp3.reset(new afg_mp3::Reader);
@@ -991,7 +1113,21 @@ struct afg_stream {
         const uint8_t *dp[1] = { bytes.data() };
         size_t lp[1] = { bytes.size() };
         Mp3Carry *cr = nullptr;
-        if (format == AFG_FORMAT_FLAC) {
+        OpusCarry *ocr = nullptr;
+        if (format == AFG_FORMAT_OPUS) {
+            if (opus_failed) { error = kErrorDecoderInitializationFailed; ended = true; return false; }      // stream.d:454
+            if (opus_decoded >= declared_frames || !opus->more(p.opus, kOpusPackets)) { ended = true; return false; }
+            if (p.opus.error) opus_failed = true;
+            p.opus.error = false;                               // this chunk's good frames are delivered first
+            if (p.opus.frames.empty()) { error = kErrorDecoderInitializationFailed; ended = true; return false; }
+            p.opus.channels = channels;
+            p.opus.gain_i = opus_gain_i;
+            p.opus.gain = opus_gain;
+            p.opus.declared_frames = declared_frames - opus_decoded;
+            opus_decoded += (int64_t)p.opus.pcm_frames;
+            ocr = &opus_carry;
+            p.format = AFG_FORMAT_OPUS;
+        } else if (format == AFG_FORMAT_FLAC) {
             bool done = false;
             p.fi = fi;
             const int got = flac_parse_frames(bytes.data(), bytes.size(), fi, p.flac, &flac_pos, kFlacFrames, &done);
@@ -1029,7 +1165,7 @@ struct afg_stream {
             return false;
         }
         BatchOut out;
-        if (decode_parsed(parsed, dp, lp, 1, out, nullptr, nullptr, nullptr, nullptr, cr) != AFG_OK || out.files[0].status != AFG_OK) {
+        if (decode_parsed(parsed, dp, lp, 1, out, nullptr, nullptr, nullptr, nullptr, cr, ocr) != AFG_OK || out.files[0].status != AFG_OK) {
             error = kErrorDecodingError;
             ended = true;
             return false;
@@ -1058,7 +1194,25 @@ afg_stream *afg_open_from_memory(const uint8_t *data, size_t length)
         // startDecoding's probe order for the formats handled here (stream.d:1586-1838): FLAC, QOA, OGG, then MP3
         afg_mp3::File m3;
         afg_vorbis::File og;
-        if (flac_open_info(d, length, s->fi)) {
+        afg_opus::File op;
+        // the reference tries Opus before anything else (stream.d:1596-1614)
+        afg_opus::Status ost = afg_opus::kNotOpus;
+        if (length >= 4 && std::memcmp(d, "OggS", 4) == 0) {
+            s->opus.reset(new afg_opus::Reader);
+            ost = s->opus->open(d, length, op);
+        }
+        if (ost == afg_opus::kUnsupported) {
+            s->error = kErrorOpusMode;
+            return s;
+        }
+        if (ost == afg_opus::kOpened) {
+            s->format = AFG_FORMAT_OPUS;
+            s->channels = op.channels;
+            s->samplerate = 48000.0f;                                     // OpusFileCtx.rate, stream.d:1607
+            s->declared_frames = op.declared_frames;                      // smpduration(), stream.d:1609
+            s->opus_gain_i = op.gain_i;
+            s->opus_gain = op.gain;
+        } else if (flac_open_info(d, length, s->fi)) {
             s->format = AFG_FORMAT_FLAC;
             s->channels = (int)s->fi.channels;
             s->samplerate = (float)s->fi.sample_rate;
@@ -1119,6 +1273,7 @@ int afg_read_samples_float(afg_stream *s, float *out, int frames)
             s->fifo_at += n * C;
             done += (int)n;
         }
+        if (s->error && s->format == AFG_FORMAT_OPUS) return 0;   // stream.d:452-456: the failing read returns 0
         s->position += done;
         return done;
     } catch (...) {
@@ -1360,6 +1515,52 @@ void afg_vorbis_parsed_free(afg_vorbis_parsed *p)
     std::memset(p, 0, sizeof(*p));
 }
 
+int afg_opus_parse(const uint8_t *data, size_t length, afg_opus_parsed *out)
+{
+    try {
+        if (!out) return AFG_ERR_INVALID;
+        std::memset(out, 0, sizeof(*out));
+        if (!data) return AFG_ERR_INVALID;
+        auto *own = new (std::nothrow) afg_opus::File;
+        if (!own) return AFG_ERR_OOM;
+        const afg_opus::Status st = afg_opus::parse_file(data, length, *own);
+        if (st != afg_opus::kOpened) {
+            if (st == afg_opus::kUnsupported) {
+                out->channels = own->channels;
+                out->preskip = own->preskip;
+                afg::set_error("afg_opus_parse: the stream holds SILK or hybrid packets (only CELT-only Opus is decoded)");
+            } else {
+                afg::set_error("afg_opus_parse: not an Ogg Opus stream");
+            }
+            delete own;
+            return AFG_ERR_UNSUPPORTED;
+        }
+        out->channels = own->channels;
+        out->preskip = own->preskip;
+        out->gain_i = own->gain_i;
+        out->error = own->error ? 1 : 0;
+        out->gain = own->gain;
+        out->declared_frames = own->declared_frames;
+        out->pcm_frames = own->pcm_frames;
+        out->n_frames = own->frames.size();
+        out->n_coeffs = own->coeffs.size();
+        out->frames = own->frames.data();
+        out->coeffs = own->coeffs.data();
+        out->owner = own;
+        return AFG_OK;
+    } catch (...) {
+        afg::set_error("out of host memory");
+        return AFG_ERR_OOM;
+    }
+}
+
+void afg_opus_parsed_free(afg_opus_parsed *p)
+{
+    if (!p) return;
+    delete (afg_opus::File *)p->owner;
+    std::memset(p, 0, sizeof(*p));
+}
+
 int afg_qoa_parse(const uint8_t *data, size_t length, uint32_t *channels, uint32_t *samplerate, uint32_t *samples,
                   afg_qoa_frame *frames, size_t frame_cap, size_t *n_frames)
 {
@@ -1409,6 +1610,12 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
             if (!data[i] || !length[i]) return;
             Parsed &p = parsed[i];
             try {
+            if (length[i] >= 4 && std::memcmp(data[i], "OggS", 4) == 0) {                             // Opus is tried first (stream.d:1596)
+                const afg_opus::Status st = afg_opus::parse_file(data[i], length[i], p.opus);
+                if (st == afg_opus::kOpened) { p.format = AFG_FORMAT_OPUS; return; }
+                p.opus = afg_opus::File();
+                if (st == afg_opus::kUnsupported) { p.opus_mode = true; return; }
+            }
             if ((flac_bound[i] = flac_res_bound(data[i], length[i])) != 0) return;                    // parsed in pass 1b
             if (flac_parse(data[i], length[i], p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
             p.flac = FlacRecords();

@@ -258,6 +258,10 @@ int afg_celt_transform_streams_hip(uint32_t n_chan, const uint64_t *d_rec_base, 
  * :8098-8105; stream.d:480): Float2IntScaled (x * 32768 rounded to nearest even by a magic-number add, saturated
  * to int16), then int16 / 32767.0f.  Element-wise; d_out_f32 may alias d_in; either output may be NULL. */
 int afg_opus_output_hip(uint64_t n_samples, const float *d_in, int16_t *d_out_i16, float *d_out_f32, void *hip_stream);
+/* The same behind opus_decode_packet's output gain (dopus.d:6688-6691: every float times OpusContext.gain, applied when the
+ * header gain + R128_TRACK_GAIN is not zero): x * gain rounded to float, then the conversion above. */
+int afg_opus_output_gain_hip(uint64_t n_samples, const float *d_in, float gain, int16_t *d_out_i16, float *d_out_f32,
+                             void *hip_stream);
 
 /* ========================================================================== *
  *  Outer surface: the AudioStream subset (stream.d:102-637) over the host front-ends
@@ -372,6 +376,30 @@ typedef struct afg_vorbis_parsed {
 
 int  afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out);   /* AFG_ERR_UNSUPPORTED: not Ogg Vorbis */
 void afg_vorbis_parsed_free(afg_vorbis_parsed *parsed);
+
+/* Ogg Opus front-end on its own, CELT-only packets: Ogg pages, OpusHead / OpusTags (dopus.d:7791-7829, :8120-8193; output
+ * gain :1311-1316 with R128_TRACK_GAIN :8011-8059), packet framing (ff_opus_parse_packet, :1081-1258), the range decoder
+ * (:809-1034) and the CELT frame decoder up to the transform seam (:2128-3678).  Result: the inputs of
+ * afg_celt_transform_hip for one stream.  frames[i] is channel 0's record of frame i, addressed for interleaved output
+ * (out_off = first sample * channels, out_stride = channels); channel c of the same frame reads coef_off + c * frame_size
+ * and writes out_off + c.  AFG_ERR_UNSUPPORTED: not an Ogg Opus stream the reference opens (no fields set), or one that
+ * holds SILK / hybrid packets, which this front-end does not decode (channels != 0 then; afg_last_error says which). */
+typedef struct afg_opus_parsed {
+    int32_t  channels, preskip;
+    int32_t  gain_i;               /* header gain + R128_TRACK_GAIN, Q7.8 dB; 0: the decoder does not scale */
+    int32_t  error;                /* 1: a packet failed to frame; the records end there and the reference's read reports an error */
+    float    gain;                 /* 10^(gain_i / 5120) as a float: afg_opus_output_gain_hip's factor */
+    int32_t  pad;
+    int64_t  declared_frames;      /* last page's granule position - preskip (dopus.d:8159): AudioStream's length */
+    uint64_t pcm_frames;           /* frames the records decode to (the reference delivers min(pcm_frames, declared_frames)) */
+    uint64_t n_frames, n_coeffs;
+    afg_celt_frame *frames;
+    float   *coeffs;
+    void    *owner;                /* internal */
+} afg_opus_parsed;
+
+int  afg_opus_parse(const uint8_t *data, size_t length, afg_opus_parsed *out);
+void afg_opus_parsed_free(afg_opus_parsed *parsed);
 
 /* Batch decode (no reference counterpart: the throughput path).  Files are parsed by n_threads
  * pooled host threads (0 = one per physical core: half the logical CPUs of an SMT host) straight

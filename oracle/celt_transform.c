@@ -316,8 +316,10 @@ void afgo_opus_output(uint64_t n, const float *in, int16_t *out_i16, float *out_
     for (uint64_t i = 0; i < n; i++) {
         union { float f; int32_t i; } temp;
         temp.f = in[i] + magic;
-        int32_t d = temp.i - (((150 - 15) << 23) + (1 << 22));
-        if ((uint32_t)(d + 32768) > 65535u) d = d < 0 ? -32768 : 32767;
+        /* D's int arithmetic wraps: for -768 < x < -384 (the sum is negative with a magnitude below 384) the subtraction passes
+         * INT_MIN and the sample comes out as +32767.  Unsigned arithmetic states that in C. */
+        int32_t d = (int32_t)((uint32_t)temp.i - (uint32_t)(((150 - 15) << 23) + (1 << 22)));
+        if ((uint32_t)d + 32768u > 65535u) d = d < 0 ? -32768 : 32767;
         if (out_i16) out_i16[i] = (int16_t)d;
         if (out_f32) out_f32[i] = (float)(int16_t)d / 32767.0f;
     }

@@ -1636,14 +1636,23 @@ int afgo_opus_decode_file(const uint8_t *data, size_t size, afgo_opus_file *out)
     celt_flush(s);                                              /* ff_celt_init ends in ff_celt_flush (:3805) */
     size_t cap_frames = 0;
     int rc_err = 0, first = 1;
+    {   /* opusOpen's last checks, and: a file with a SILK or hybrid packet anywhere is outside this restatement as a whole */
+        ogg_rd scan = og;
+        uint8_t *sp = NULL;
+        size_t scap = 0;
+        long sl;
+        while (!rc_err && (sl = ogg_next_packet(&scan, &sp, &scap)) >= 0) {
+            if (first && scan.granule < (uint64_t)preskip) rc_err = -1;     /* :8155: the page the first audio packet came from */
+            else if (sl > 0 && (sp[0] >> 3) < 16) rc_err = -3;
+            first = 0;
+        }
+        free(sp);
+        if (first) rc_err = -1;                                 /* no audio packet: opusOpen's loadPacket fails (:8147) */
+        if (rc_err) { free(s); free(pkt); return rc_err; }
+    }
     while ((len = ogg_next_packet(&og, &pkt, &cap)) >= 0) {
         opus_packet op;
-        if (first) {                                            /* :8155: the page the first audio packet came from */
-            first = 0;
-            if (og.granule < (uint64_t)preskip) { rc_err = -1; break; }
-        }
         if (parse_packet(&op, pkt, (int)len) < 0) { out->error = 1; break; }       /* opus_decode_packet fails: readFrame reports it */
-        if (op.mode != 2) { rc_err = -3; break; }               /* SILK / hybrid: not restated */
         /* readFrame decodes into two halves of 960*3*2 floats (:7961, :8079-8082): a stereo packet of more than 60 ms
          * overruns them in the reference (undefined there); reported as a decode error here */
         if (channels == 2 && op.frame_count * op.frame_duration > 960 * 3) { out->error = 1; break; }
@@ -1660,7 +1669,6 @@ int afgo_opus_decode_file(const uint8_t *data, size_t size, afgo_opus_file *out)
         }
         if (rc_err) break;
     }
-    if (first) rc_err = -1;                                     /* no audio packet: opusOpen's loadPacket fails (:8147) */
     free(s);
     free(pkt);
     if (rc_err) { afgo_opus_file_free(out); return rc_err; }

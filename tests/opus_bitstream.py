@@ -60,7 +60,7 @@ def packet_frames(pkt):
     config, code = pkt[0] >> 3, pkt[0] & 3
     size = CELT_FRAME_SIZES[config & 3] if config >= 16 else (480 << (config & 1) if config >= 12 else
                                                               max(480, 960 * (config & 3)))
-    return ((1, 2, 2)[code] if code < 3 else pkt[1] & 0x3f), size
+    return ((1, 2, 2)[code] if code < 3 else (pkt[1] & 0x3f if len(pkt) > 1 else 0)), size
 
 
 def opus_head(channels, preskip=312, gain=0, rate=48000, map_type=0, version=1, extra=b""):

@@ -1,0 +1,178 @@
+"""Ogg Opus (CELT-only) end to end on the device through the outer surface of the C ABI: file bytes -> afg_batch_decode /
+afg_open_from_memory -> interleaved floats, against the oracle chain (oracle/opus_frontend.c records ->
+afgo_celt_transform -> gain -> afgo_opus_output, clipped to the declared length).
+
+Reference behaviour: stream.d:429-487 (Opus read loop, length clamp, int16 / 32767), :1596-1614 (Opus is probed first,
+48 kHz, length = smpduration), dopus.d:6688-6691 (gain), :8062-8110 (readFrame), :3680-3702 (transform)."""
+import numpy as np
+import pytest
+
+import afgpu
+import opus_bitstream as ob
+import oraclelib
+from test_stream_gpu import read_all
+
+pytestmark = pytest.mark.gpu
+
+
+def expected(data):
+    rec = oraclelib.opus_decode_file(data)
+    assert not isinstance(rec, int)
+    return rec, oraclelib.opus_file_pcm(rec)
+
+
+def same_pcm(got, want):
+    assert got.shape == want.shape
+    # the device transform follows the oracle's expression trees: after the int16 round trip the match is exact
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_batch_of_random_celt_files(gpu):
+    rng = np.random.default_rng(21)
+    files, wants = [], []
+    for k in range(24):
+        ch = 1 + k % 2
+        # (a negative *header* gain reads as a large positive one in the reference; the R128 tag is how a file gets quieter.
+        # The random payloads decode to ~70 dB over full scale: -78 dB brings them inside the int16 range)
+        data, _ = ob.random_celt_file(rng, ch, int(rng.integers(1, 70)), preskip=int(rng.integers(0, 121)), gain=(0, 0, 700)[k % 3],
+                                      comments=(b"R128_TRACK_GAIN=-20000",) if k % 3 == 1 else ())
+        files.append(data)
+        wants.append(expected(data))
+    res = afgpu.batch_decode(files)
+    for r, (rec, pcm) in zip(res, wants):
+        assert r["status"] == 0, r["message"]
+        assert r["format"] == afgpu.FORMAT_OPUS and r["samplerate"] == 48000.0 and r["channels"] == rec["channels"]
+        assert r["frames"] == len(pcm) == min(rec["pcm_frames"], rec["declared_frames"])
+        same_pcm(r["pcm"], pcm)
+    # quiet files exercise the conversion away from the saturation rails too
+    quiet = [r for r, (rec, _) in zip(res, wants) if rec["gain_i"] < 0]
+    assert any(np.abs(r["pcm"]).max() < 1.0 for r in quiet)
+
+
+def test_opus_next_to_the_other_formats_and_bad_files(gpu):
+    import mp3_bitstream as mb
+    import vorbis_bitstream as vb
+    rng = np.random.default_rng(22)
+    opus, _ = ob.random_celt_file(rng, 2, 30, preskip=100)
+    silk = ob.ogg_opus([ob.toc(3, True, 0) + rng.bytes(50)] * 3, 2, preskip=0)
+    broken = ob.ogg_opus([ob.packet(rng, 31, True, 0, sizes=[90]), ob.toc(31, True, 1) + bytes(7)], 2, preskip=0)
+    files = [opus, vb.make_file(5, n_packets=20), silk, mb.make_file(6, n_frames=12)[0], broken, b"OggS" + bytes(100)]
+    res = afgpu.batch_decode(files)
+    assert [r["format"] for r in res[:2]] == [afgpu.FORMAT_OPUS, afgpu.FORMAT_OGG]
+    same_pcm(res[0]["pcm"], expected(opus)[1])
+    assert res[1]["status"] == 0 and res[3]["status"] == 0 and res[3]["format"] == afgpu.FORMAT_MP3
+    assert res[2]["status"] != 0 and "SILK" in res[2]["message"] and res[2]["pcm"] is None
+    assert res[4]["status"] != 0 and res[4]["pcm"] is None                      # a packet that cannot be framed: the file is an error
+    assert res[5]["status"] != 0
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_stream_reads_in_chunks_equal_the_batch_decode(gpu, channels):
+    rng = np.random.default_rng(23 + channels)
+    data, _ = ob.random_celt_file(rng, channels, 400, preskip=312, comments=(b"R128_TRACK_GAIN=-19000",))   # several decode chunks of 64 packets
+    rec, want = expected(data)
+    assert len(want) > 60000
+    for chunk in (1024, 777, 200000):
+        s = afgpu.AudioStream()
+        s.openFromMemory(data)
+        assert not s.isError(), s.errorMessage()
+        assert s.getFormat() == afgpu.FORMAT_OPUS and s.getNumChannels() == channels and s.getSamplerate() == 48000.0
+        assert s.getLengthInFrames() == rec["declared_frames"]
+        got = read_all(s, channels, chunk)
+        assert not s.isError()
+        same_pcm(got, want)
+        assert s.tellPosition() == len(want)
+        buf = np.zeros(16 * channels, np.float32)
+        assert s.readSamplesFloat(buf) == 0                                       # at the declared end: nothing more (stream.d:439-442)
+        s.cleanUp()
+
+
+def test_declared_length_longer_than_the_audio(gpu):
+    rng = np.random.default_rng(25)
+    pkts = [ob.packet(rng, 31, True, 0, sizes=[70]) for _ in range(20)]
+    data = ob.ogg_opus(pkts, 2, preskip=0, trim=-5000)                            # the last page claims 5000 frames too many
+    rec, want = expected(data)
+    assert rec["declared_frames"] == 20 * 960 + 5000 and len(want) == 20 * 960
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    got = read_all(s, 2, 4096)
+    same_pcm(got, want)
+    assert not s.isError()
+    s.cleanUp()
+
+
+def test_seek_and_tell(gpu):
+    rng = np.random.default_rng(26)
+    data, _ = ob.random_celt_file(rng, 2, 300, preskip=100)
+    _, want = expected(data)
+    total = len(want)
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    length = s.getLengthInFrames()
+    for target in [total // 2, 10, total - 7, total // 3, 0, total // 3 + 1, total]:
+        assert s.seekPosition(int(target))
+        assert s.tellPosition() == target
+        buf = np.zeros(500 * 2, np.float32)
+        got = s.readSamplesFloat(buf)
+        assert got == min(500, total - target)
+        assert np.array_equal(buf[:got * 2].view(np.uint32), want[target:target + got].reshape(-1).view(np.uint32))
+    assert not s.seekPosition(-1) and not s.seekPosition(int(length) + 1)
+    s.cleanUp()
+
+
+def test_stream_reports_the_failing_packet_like_the_reference(gpu):
+    """readFrame fails -> the read that reaches the packet sets the error and returns 0 (stream.d:452-456); what was read
+    before stays valid"""
+    rng = np.random.default_rng(27)
+    good = [ob.packet(rng, 31, True, 0, sizes=[90]) for _ in range(100)]
+    data = ob.ogg_opus(good[:70] + [ob.toc(31, True, 1) + bytes(7)] + good[70:], 2, preskip=0)
+    clean = ob.ogg_opus(good[:70], 2, preskip=0)
+    _, want = expected(clean)
+    s = afgpu.AudioStream()
+    s.openFromMemory(data)
+    assert not s.isError()
+    parts = []
+    while True:
+        buf = np.zeros(4096 * 2, np.float32)
+        got = s.readSamplesFloat(buf)
+        if s.isError():
+            assert got == 0
+            break
+        parts.append(buf[:got * 2].copy())
+        assert got == 4096
+    got = np.concatenate(parts).reshape(-1, 2)
+    assert len(got) == (70 * 960 // 4096) * 4096
+    same_pcm(got, want[:len(got)])
+    assert "initialization" in s.errorMessage()
+    s.cleanUp()
+
+
+def test_silk_file_is_refused_at_open(gpu):
+    rng = np.random.default_rng(28)
+    s = afgpu.AudioStream()
+    s.openFromMemory(ob.ogg_opus([ob.toc(9, False, 0) + rng.bytes(30)] * 4, 1, preskip=0))
+    assert s.isError() and "SILK" in s.errorMessage()
+    s.cleanUp()
+
+
+def test_output_gain_kernel_matches_the_oracle(gpu):
+    import torch
+    rng = np.random.default_rng(29)
+    for n in (1, 3, 4, 1023, 4099):
+        x = np.concatenate([rng.uniform(-1.5, 1.5, n).astype(np.float32), np.float32([0.5 / 32768, -0.5 / 32768, 1.0, -1.0, -500.0, -800.0, 900.0])])
+        for gain_i in (-2560, 333, 0):
+            g = np.float32(np.exp2(3.32192809488736234787 * (gain_i / (20.0 * 256))))          # (0: a multiply by 1.0f)
+            want_i, want_f = oraclelib.opus_output(x * g)
+            d_in = torch.from_numpy(x).to(gpu)
+            d_i = torch.zeros(len(x), dtype=torch.int16, device=gpu)
+            d_f = torch.zeros(len(x), dtype=torch.float32, device=gpu)
+            afgpu.opus_output(len(x), d_in, d_i, d_f, gain=float(g))
+            torch.cuda.synchronize()
+            assert np.array_equal(d_i.cpu().numpy(), want_i)
+            assert np.array_equal(d_f.cpu().numpy().view(np.uint32), want_f.view(np.uint32))
+            # unaligned views take the scalar path
+            if len(x) > 8:
+                d_f2 = torch.zeros(len(x), dtype=torch.float32, device=gpu)
+                afgpu.opus_output(len(x) - 1, d_in[1:], None, d_f2[1:], gain=float(g))
+                torch.cuda.synchronize()
+                assert np.array_equal(d_f2.cpu().numpy()[1:].view(np.uint32), want_f[1:].view(np.uint32))
