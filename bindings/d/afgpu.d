@@ -107,6 +107,7 @@ int afg_qoa_transform_hip(ulong n_frames, const(afg_qoa_frame)* d_frames, const(
 
 // OpusFile.readFrame's Float2IntScaled + saturation (dopus.d:7923-7926, :8098-8105) and stream.d:480
 int afg_opus_output_hip(ulong n_samples, const(float)* d_in, short* d_out_i16, float* d_out_f32, void* hip_stream);
+int afg_opus_output_gain_hip(ulong n_samples, const(float)* d_in, float gain, short* d_out_i16, float* d_out_f32, void* hip_stream);
 
 // ---- output side: QOA encoder (replaces qoa_encode_frame, qoa.d:295-399, and QOAEncoder's framing, :538-700) and
 //      the WAV writer (WAVEncoder, wav.d:365-701; host only) ----
@@ -222,6 +223,20 @@ struct afg_vorbis_parsed
 }
 int afg_vorbis_parse(const(ubyte)* data, size_t length, afg_vorbis_parsed* parsed);
 void afg_vorbis_parsed_free(afg_vorbis_parsed* parsed);
+
+struct afg_opus_parsed
+{
+    int channels, preskip, gain_i, error;
+    float gain;
+    int pad;
+    long declared_frames;
+    ulong pcm_frames, n_frames, n_coeffs;
+    afg_celt_frame* frames;
+    float* coeffs;
+    void* owner;
+}
+int afg_opus_parse(const(ubyte)* data, size_t length, afg_opus_parsed* parsed);
+void afg_opus_parsed_free(afg_opus_parsed* parsed);
 
 struct afg_batch_item
 {
