@@ -393,8 +393,10 @@ __device__ __forceinline__ void mp3_segment(
             for (int q = 0; q < 9; q++) pre[q] = on ? src[q] : f2{ 0.0f, 0.0f };
         }
 
-        // C. alias reduction (minimp3.d:1002-1020), IMDCT (:1152-1168), frequency inversion (:1144-1150)
-        {
+        // C. alias reduction (minimp3.d:1002-1020), IMDCT (:1152-1168), frequency inversion (:1144-1150).  A block of subband
+        //    samples (AFG_MP3_SUBBAND: Layer I / II, :1563-1566) skips all three; the flag is the same for every block of a
+        //    stream and comes out of v_readlane, so the branch is scalar.
+        if (!(fl0 >> 31)) {
             const int block_type = (int)(fl & 3u);
             const int n_long = (int)((fl >> 8) & 0xffu);
             const int aa = (int)((fl >> 16) & 0xffu) - 1;

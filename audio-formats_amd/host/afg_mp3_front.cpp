@@ -16,6 +16,7 @@
 #include "afg_mp3_front.h"
 
 #include "mp3_front_tables.h"
+#include "mp3_l12_tables.h"
 
 #include <algorithm>
 #include <cstring>
@@ -601,11 +602,128 @@ struct Decoder {                           // what persists between frames on th
     }
 };
 
+
+// ---- Layer I / II (minimp3.d:286-484) -------------------------------------------------------------------------------
+// Quantiser codes: 0 = no samples, 2..16 = bits per sample ((1 << bits) - 1 levels), kG3 / kG5 / kG9 = three consecutive
+// samples in one 5 / 7 / 10-bit codeword of 3 / 5 / 9 levels each.  The allocation classes below are the columns of
+// ISO 11172-3 tables B.2a-d and 13818-3 table B.1 (what an allocation index means in a given subband).
+enum : uint8_t { kG3 = 17, kG5 = 18, kG9 = 19 };
+const uint8_t kAllocA[16] = { 0, kG3, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };          // B.2a/b subbands 0-2
+const uint8_t kAllocB[16] = { 0, kG3, kG5, 3, kG9, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16 };       // B.2a/b subbands 3-10
+const uint8_t kAllocC[8] = { 0, kG3, kG5, 3, kG9, 4, 5, 16 };                                     // B.2a/b subbands 11-22
+const uint8_t kAllocD[4] = { 0, kG3, kG5, 16 };                                                   // B.2a/b subbands 23-
+const uint8_t kAllocE[16] = { 0, kG3, kG5, kG9, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 };      // B.2c/d; B.1 subbands 4- (first 8 / 4)
+const uint8_t kAllocF[16] = { 0, kG3, kG5, 3, kG9, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14 };       // B.1 subbands 0-3
+const uint8_t kAllocL1[16] = { 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };          // Layer I: index + 1 bits
+struct AllocRun { const uint8_t *quant; uint8_t width, bands; };
+
+struct L12Frame {
+    int bands = 0, two_channel_bands = 0;       // coded subbands; those below two_channel_bands carry both channels separately
+    uint8_t quant[32][2];
+    float factor[32][2][3];                     // per (subband, channel): the scale of each third of the frame
+
+    void read(const Header &hd, Bits &in)       // L12_read_scale_info
+    {
+        static const AllocRun l1[] = { { kAllocL1, 4, 32 } };
+        static const AllocRun lsf[] = { { kAllocF, 4, 4 }, { kAllocE, 3, 7 }, { kAllocE, 2, 19 } };
+        static const AllocRun full[] = { { kAllocA, 4, 3 }, { kAllocB, 4, 8 }, { kAllocC, 3, 12 }, { kAllocD, 2, 7 } };
+        static const AllocRun low[] = { { kAllocE, 4, 2 }, { kAllocE, 3, 10 } };
+        const int mode = (hd.h[3] >> 6) & 3;
+        const int bound = mode == 3 ? 0 : mode == 1 ? (((hd.h[3] >> 4) & 3) << 2) + 4 : 32;
+        const AllocRun *run;
+        if (hd.layer1()) {
+            run = l1;
+            bands = 32;
+        } else if (!hd.mpeg1()) {
+            run = lsf;
+            bands = 30;
+        } else {
+            unsigned per_channel = hd.kbps() >> (mode != 3 ? 1 : 0);
+            if (!per_channel) per_channel = 192;                 // free format
+            run = full;
+            bands = 27;
+            if (per_channel < 56) {
+                run = low;
+                bands = hd.rate_index() == 2 ? 12 : 8;
+            } else if (per_channel >= 96 && hd.rate_index() != 1) {
+                bands = 30;
+            }
+        }
+        two_channel_bands = std::min(bound, bands);
+        std::memset(quant, 0, sizeof(quant));
+        std::memset(factor, 0, sizeof(factor));
+        uint8_t scf_quant[32][2];                                // what the scalefactor pass sees (a shared allocation counts for both)
+        for (int b = 0, left = 0; b < bands; b++) {
+            if (!left) left = run->bands; 
+            uint8_t q = run->quant[in.get(run->width)];
+            scf_quant[b][0] = q;
+            if (b < two_channel_bands) q = run->quant[in.get(run->width)];
+            scf_quant[b][1] = two_channel_bands ? q : 0;
+            if (--left == 0) run++;
+        }
+        uint8_t select[32][2];                                   // scalefactor selection information
+        for (int b = 0; b < bands; b++)
+            for (int c = 0; c < 2; c++) {
+                const uint8_t sel = hd.layer1() ? 2 : (uint8_t)in.get(2);
+                select[b][c] = scf_quant[b][c] ? sel : 6;
+            }
+        for (int b = 0; b < bands; b++)
+            for (int c = 0; c < 2; c++) {
+                const int q = scf_quant[b][c];
+                const int present = q ? 4 + ((19 >> select[b][c]) & 3) : 0;       // which of the three are transmitted
+                float f = 0.0f;
+                for (int third = 0, bit = 4; third < 3; third++, bit >>= 1) {
+                    if (present & bit) {
+                        const int idx = (int)in.get(6);
+                        f = bits_f32(k_l12_deq_bits[q * 3 - 6 + idx % 3]) * (float)(1 << 21 >> idx / 3);
+                    }
+                    factor[b][c][third] = f;
+                }
+            }
+        for (int b = 0; b < bands; b++) {
+            quant[b][0] = scf_quant[b][0];
+            quant[b][1] = b < two_channel_bands ? scf_quant[b][1] : 0;            // above the bound: one set of samples for both
+        }
+    }
+
+    // four sample groups of `per_group` slots each, starting at slot `at` (L12_dequantize_granule)
+    void samples(Bits &in, float (*g)[576], int at, int per_group) const
+    {
+        for (int j = 0; j < 4; j++, at += per_group)
+            for (int b = 0; b < bands; b++)
+                for (int c = 0; c < 2; c++) {
+                    const int q = quant[b][c];
+                    if (!q) continue;
+                    float *dst = g[c] + b * 18 + at;
+                    if (q < kG3) {
+                        const int half = (1 << (q - 1)) - 1;
+                        for (int k = 0; k < per_group; k++) dst[k] = (float)((int)in.get(q) - half);
+                    } else {
+                        const unsigned levels = (2u << (q - kG3)) + 1;
+                        unsigned code = in.get((int)(levels + 2 - (levels >> 3)));
+                        for (int k = 0; k < per_group; k++, code /= levels) dst[k] = (float)((int)(code % levels) - (int)(levels / 2));
+                    }
+                }
+    }
+
+    // scale the 12 slots of a finished granule with the factors of frame third `third` (L12_apply_scf_384)
+    void scale(float (*g)[576], int third) const
+    {
+        for (int b = two_channel_bands; b < bands; b++) std::memcpy(g[1] + b * 18, g[0] + b * 18, 18 * sizeof(float));
+        for (int b = 0; b < bands; b++)
+            for (int k = 0; k < 12; k++) {
+                g[0][b * 18 + k] *= factor[b][0][third];
+                g[1][b * 18 + k] *= factor[b][1][third];
+            }
+    }
+};
+
 struct FrameResult {
     int consumed = 0;          // bytes to advance
     int samples = 0;           // per channel, 0 = nothing decoded
     int channels = 0, hz = 0, layer = 0;
-    bool stop = false;         // Layer I/II or allocation trouble
+    bool stop = false;         // allocation trouble, or a layer the chosen record format does not carry
+    uint64_t pcm_at = 0;       // Layer I / II: float offset of this frame's first sample in the PCM plane of `out`
 };
 
 // mp3dec_decode_frame up to the seam; records go to `out` when given (the open scan passes nullptr)
@@ -635,7 +753,8 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
     r.channels = hd.mono() ? 1 : 2;
     r.hz = (int)hd.hz();
     r.layer = 4 - hd.layer_code();
-    if (r.layer != 3) {
+    if (r.layer != 3 && out && out->quantised) {           // the device requantiser is Layer III's: the caller takes the float path
+        out->q_unsupported = true;
         r.stop = true;
         return r;
     }
@@ -646,6 +765,44 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
     std::memset(body + body_bytes, 0, 16);
     Bits sb(body, body_bytes);
     if (hd.crc()) sb.get(16);
+    if (r.layer != 3) {
+        // Layer I / II (minimp3.d:1557-1578): allocation + scalefactors, then three thirds of the frame; a Layer II third is a
+        // synthesis granule of its own (3 x 4 groups of 3 slots), Layer I gathers its three thirds (4 slots each) into one
+        L12Frame info;
+        info.read(hd, sb);
+        const int per_group = hd.layer1() ? 1 : 3, nch = r.channels;
+        float done[3][2][576];
+        int n_done = 0, filled = 0;
+        std::memset(done, 0, sizeof(done));
+        for (int third = 0; third < 3; third++) {
+            info.samples(sb, done[n_done], filled, per_group);
+            filled += 4 * per_group;
+            if (filled == 12) {
+                info.scale(done[n_done], third);
+                n_done++;
+                filled = 0;
+            }
+            if (sb.pos > sb.limit) {
+                d.header[0] = 0;                           // mp3dec_init: nothing of this frame is kept, the next call resynchronises
+                return r;
+            }
+        }
+        if (out) {
+            if (*fresh_state || out->run_granules.empty()) {
+                out->flush_l12(nch);                       // the run before ends in a padded block
+                if (out->run_granules.empty()) out->continues_previous = !*fresh_state;
+                out->run_granules.push_back(0);
+                *fresh_state = false;
+            }
+            out->layer = r.layer;
+            r.pcm_at = out->l12_pcm_at();
+            for (int k = 0; k < n_done; k++) out->add_l12(done[k], nch);
+        } else {
+            *fresh_state = false;
+        }
+        r.samples = (int)hd.samples();
+        return r;
+    }
     Granule gi[4];
     const int begin = read_side_info(sb, gi, hd);
     if (begin < 0 || sb.pos > sb.limit) {
@@ -735,6 +892,7 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
                     }
                 }
                 if (*fresh_state || out->run_granules.empty()) {
+                    if (out->run_granules.empty()) out->continues_previous = !*fresh_state;
                     out->run_granules.push_back(0);
                     *fresh_state = false;
                 }
@@ -764,6 +922,7 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
             }
             if (out) {
                 if (*fresh_state || out->run_granules.empty()) {
+                    if (out->run_granules.empty()) out->continues_previous = !*fresh_state;
                     out->run_granules.push_back(0);
                     *fresh_state = false;
                 }
@@ -869,7 +1028,8 @@ size_t max_blocks(const uint8_t *data, size_t size)
     for (size_t at = 0; at + 4 <= n; at++) {
         if (buf[at] != 0xff) continue;
         const Header hd{ buf + at };
-        if (hd.valid()) blocks += (size_t)(hd.mpeg1() ? 2 : 1) * (hd.mono() ? 1 : 2);
+        // (Layer III: 2 or 1 granules; Layer II: 36 slots = 2 blocks; Layer I: 12 slots, at most one block with a run's padding)
+        if (hd.valid()) blocks += (size_t)(hd.layer_code() == 1 ? (hd.mpeg1() ? 2 : 1) : hd.layer1() ? 1 : 2) * (hd.mono() ? 1 : 2);
     }
     return blocks + 8;
 }
@@ -972,7 +1132,7 @@ struct Walk {
                 left -= (size_t)sz;
             }
         }
-        if (!have || layer0 != 3) return false;
+        if (!have) return false;
         dec.reset();
         fresh = true;
         off = start;
@@ -985,6 +1145,7 @@ struct Walk {
     {
         f.channels = ch0;
         f.hz = hz0;
+        f.layer = layer0;
         f.tagged = tagged;
         f.start_delay = to_skip;
         f.detected_samples = detected;
@@ -995,18 +1156,24 @@ struct Walk {
     void run(File &f, int max_frames)
     {
         uint64_t chunk_samples = 0;
-        for (int k = 0; k < max_frames && !done; k++) {
+        // (a Layer I chunk goes on until its slots fill whole blocks: three frames make two)
+        for (int k = 0; (k < max_frames || f.l12_slots) && !done; k++) {
             if (detected && cur >= detected) { done = true; break; }
             const uint64_t left = n - off;
             if (!left) { done = true; break; }
             const uint64_t blocks_before = f.blocks();
             const std::vector<uint32_t> runs_before = f.run_granules;
+            const int slots_before = f.l12_slots;
+            float acc_before[2][576];
+            if (slots_before) std::memcpy(acc_before, f.l12_acc, sizeof(acc_before));
             const FrameResult fr = frame(dec, buf + off, (int)std::min<uint64_t>(left, 0x7fffffff), &f, &fresh);
             if (fr.stop || fr.hz != hz0 || fr.layer != layer0 || fr.channels != ch0) {
                 // MP3D_E_DECODE (minimp3_ex.d:851-857; also what "no further frame" turns into, since the frame info
                 // stays zero then): the stream ends here; records of this frame are dropped
                 f.truncate(blocks_before);
                 f.run_granules = runs_before;
+                f.l12_slots = slots_before;
+                if (slots_before) std::memcpy(f.l12_acc, acc_before, sizeof(acc_before));
                 done = true;
                 break;
             }
@@ -1019,7 +1186,8 @@ struct Walk {
                 }
                 uint64_t take = (uint64_t)(total - used);
                 if (detected && cur + take >= detected) take = detected - cur;
-                if (take) f.copies.push_back(Copy{ blocks_before * 576 + (uint64_t)used, take });
+                const uint64_t first = fr.layer != 3 ? fr.pcm_at : blocks_before * 576;
+                if (take) f.copies.push_back(Copy{ first + (uint64_t)used, take });
                 cur += take;
                 chunk_samples += take;
             } else if (to_skip) {
@@ -1028,6 +1196,7 @@ struct Walk {
             }
             off += (uint64_t)fr.consumed;
         }
+        if (done) f.flush_l12(ch0);
         f.pcm_samples += chunk_samples;
         // trailing granules that no copy refers to are still part of their run (the device needs whole runs)
     }
@@ -1077,8 +1246,10 @@ bool Reader::more(File &out, int max_frames, bool *continues)
     out = File();
     p->w.describe(out);
     if (p->w.done) return false;
-    *continues = !p->w.fresh;                              // the first run of this chunk goes on from the previous chunk's state
     p->w.run(out, max_frames);
+    // does the first run of this chunk go on from the previous chunk's state?  Known only once its first frame has been
+    // looked at: a frame that failed at the end of the previous chunk resets the decoder at the next call (minimp3.d:1507)
+    *continues = out.continues_previous;
     return out.blocks() != 0 || !p->w.done;
 }
 

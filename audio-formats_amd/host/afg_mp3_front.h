@@ -15,12 +15,14 @@ struct Copy {                    // `count` floats of the PCM plane starting at 
 
 struct File {
     int channels = 0, hz = 0;
+    int layer = 3;                       // 1 / 2: the blocks hold subband samples (AFG_MP3_SUBBAND), see add_l12
     bool tagged = false;                 // Xing / Info tag found (minimp3_ex.d:586-603)
     int start_delay = 0;                 // samples (channels included) dropped at the start
     uint64_t detected_samples = 0;       // 0: deliver to the end of the data
     uint64_t declared_samples = 0;       // mp3dec_ex_t.samples (AudioStream length = this / channels)
     uint64_t pcm_samples = 0;            // floats the copy plan delivers
     std::vector<uint32_t> run_granules;  // granules per run of continuous decoder state (a resync starts a new one)
+    bool continues_previous = false;     // chunked reading: the first run goes on from the decoder state the previous chunk left
     std::vector<float> coef;             // 576 floats per granule-channel, order [granule][channel]
     std::vector<uint32_t> flags;         // AFG_MP3_FLAGS per granule-channel
     std::vector<Copy> copies;
@@ -85,6 +87,32 @@ struct File {
             flags.push_back(fl);
         }
         n_blocks++;
+    }
+    // Layer I / II (minimp3.d:1557-1578): a frame yields synthesis granules of 12 time slots (32 subband samples each).  The
+    // synthesis filterbank runs slot pair by slot pair over a 15-slot history and knows nothing of granule boundaries, so
+    // the slots of a run are packed into the transform stage's 18-slot blocks (index band * 18 + slot): three granules
+    // make two blocks.  A run that ends inside a block is padded with silent slots whose output is not delivered.
+    float l12_acc[2][576];
+    int l12_slots = 0;                   // slots gathered in l12_acc
+    uint64_t l12_pcm_at() const { return (uint64_t)n_blocks * 576 + (uint64_t)l12_slots * 32 * (uint64_t)channels; }
+    void l12_emit(int nch)
+    {
+        for (int c = 0; c < nch; c++) push(l12_acc[c], AFG_MP3_SUBBAND);
+        if (!run_granules.empty()) run_granules.back()++;
+        l12_slots = 0;
+    }
+    void add_l12(const float (*g)[576], int nch)           // one granule: slots 0..11 of g[ch][band * 18 + slot]
+    {
+        for (int s = 0; s < 12; s++) {
+            if (l12_slots == 0) std::memset(l12_acc, 0, sizeof(l12_acc));
+            for (int c = 0; c < nch; c++)
+                for (int b = 0; b < 32; b++) l12_acc[c][b * 18 + l12_slots] = g[c][b * 18 + s];
+            if (++l12_slots == 18) l12_emit(nch);
+        }
+    }
+    void flush_l12(int nch)
+    {
+        if (l12_slots) l12_emit(nch);
     }
     void truncate(size_t nb)
     {

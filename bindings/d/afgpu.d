@@ -37,6 +37,7 @@ uint AFG_MP3_FLAGS(uint block_type, uint n_long_bands, int aa_bands) pure
 
 // optional, OR-ed into the flag word: only the first `bands` subbands (0..32) may hold lines that are not +0.0
 uint AFG_MP3_NZ_BANDS(uint bands) pure { return (bands + 1) << 24; }
+enum uint AFG_MP3_SUBBAND = 0x80000000;   // the block holds Layer I / II subband samples (band * 18 + slot): synthesis only
 
 int afg_mp3_plan_create(afg_mp3_plan** plan, uint n_streams, const(uint)* granules,
                         const(ubyte)* channels, uint seg_granules);

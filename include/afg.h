@@ -65,6 +65,13 @@ int         afg_device_name(int device, char *buf, size_t buflen);
  * minimp3.d:868-883) and are not read by the device.  Absent (field 0): all 576 lines are read. */
 #define AFG_MP3_NZ_BANDS(bands) ((uint32_t)((bands) + 1) << 24)
 
+/* Optional, OR-ed into the flag word: the block holds subband samples, not a spectrum -- what the Layer I / II decoder
+ * hands to mp3d_synth_granule (minimp3.d:1563-1566): index band * 18 + time slot.  Alias reduction, IMDCT and frequency
+ * inversion are skipped, the 18 slots go to the synthesis (mp3d_DCT_II + mp3d_synth) as they are.  The reference runs
+ * that synthesis 12 slots at a time; it is a filterbank over slot pairs with a 15-slot history and no notion of a
+ * granule, so a front-end packs the slots of a run of frames into 18-slot blocks (three 12-slot granules = two blocks). */
+#define AFG_MP3_SUBBAND 0x80000000u
+
 #define AFG_MP3_STATE_FLOATS 1536   /* opaque per-stream carry state (same size as mdct_overlap+qmf_state, minimp3.d:40-41) */
 
 typedef struct afg_mp3_plan afg_mp3_plan;

@@ -85,9 +85,11 @@ typedef struct afgo_mp3_file {
     uint32_t *flags;
     uint64_t pcm_samples;           /* what mp3dec_ex_read delivers until it returns 0 */
     float *pcm;
+    int layer;                      /* 3, or 1 / 2: the blocks are then 12-slot synthesis granules flagged 0x40000000 (subband
+                                       samples, index band * 18 + slot, slots 12..17 unused), minimp3.d:1557-1578 */
 } afgo_mp3_file;
 
-int afgo_mp3_decode_file(const uint8_t *data, size_t size, afgo_mp3_file *out);   /* 0 ok, -1 not Layer III, -2 memory */
+int afgo_mp3_decode_file(const uint8_t *data, size_t size, afgo_mp3_file *out);   /* 0 ok, -1 no MPEG audio stream, -2 memory */
 void afgo_mp3_file_free(afgo_mp3_file *f);
 
 /* --------------------------------------------------------------- Vorbis -- */

@@ -577,6 +577,168 @@ static int find_frame(const uint8_t *mp3, int mp3_bytes, int *free_format_bytes,
     return mp3_bytes;
 }
 
+
+/* ---- Layer I / II, mp3:286-484 -------------------------------------------------------------------------------- */
+typedef struct { uint8_t tab_offset, code_tab_width, band_count; } l12_alloc_t;
+typedef struct {
+    float scf[3 * 64];
+    uint8_t total_bands, stereo_bands, bitalloc[64], scfcod[64];
+} l12_scale_info;
+
+static const l12_alloc_t *l12_subband_alloc_table(const uint8_t *hdr, l12_scale_info *sci)     /* :286-346 */
+{
+    static const l12_alloc_t g_alloc_L1[] = { { 76, 4, 32 } };
+    static const l12_alloc_t g_alloc_L2M2[] = { { 60, 4, 4 }, { 44, 3, 7 }, { 44, 2, 19 } };
+    static const l12_alloc_t g_alloc_L2M1[] = { { 0, 4, 3 }, { 16, 4, 8 }, { 32, 3, 12 }, { 40, 2, 7 } };
+    static const l12_alloc_t g_alloc_L2M1_lowrate[] = { { 44, 4, 2 }, { 44, 3, 10 } };
+    const l12_alloc_t *alloc;
+    int mode = (hdr[3] >> 6) & 3;
+    int nbands, stereo_bands = (mode == 3) ? 0 : (mode == 1) ? ((((hdr[3]) >> 4) & 3) << 2) + 4 : 32;
+    if (h_l1(hdr)) {
+        alloc = g_alloc_L1;
+        nbands = 32;
+    } else if (!h_mpeg1(hdr)) {
+        alloc = g_alloc_L2M2;
+        nbands = 30;
+    } else {
+        int sample_rate_idx = (hdr[2] >> 2) & 3;
+        unsigned kbps = hdr_kbps(hdr) >> (int)(mode != 3);
+        if (!kbps) kbps = 192;                            /* free-format */
+        alloc = g_alloc_L2M1;
+        nbands = 27;
+        if (kbps < 56) {
+            alloc = g_alloc_L2M1_lowrate;
+            nbands = sample_rate_idx == 2 ? 12 : 8;
+        } else if (kbps >= 96 && sample_rate_idx != 1) {
+            nbands = 30;
+        }
+    }
+    sci->total_bands = (uint8_t)nbands;
+    sci->stereo_bands = (uint8_t)(stereo_bands < nbands ? stereo_bands : nbands);
+    return alloc;
+}
+
+static void l12_read_scalefactors(bs_t *bs, uint8_t *pba, uint8_t *scfcod, int bands, float *scf)      /* :348-384 */
+{
+    /* double literals converted to float, as the D initialiser does */
+    static const float g_deq_L12[18 * 3] = {
+        (float)3.17891e-07, (float)2.52311e-07, (float)2.00259e-07, (float)1.36239e-07, (float)1.08133e-07, (float)8.58253e-08,
+        (float)6.35783e-08, (float)5.04621e-08, (float)4.00518e-08, (float)3.07637e-08, (float)2.44172e-08, (float)1.93799e-08,
+        (float)1.51377e-08, (float)1.20148e-08, (float)9.53615e-09, (float)7.50925e-09, (float)5.96009e-09, (float)4.73053e-09,
+        (float)3.7399e-09, (float)2.96836e-09, (float)2.35599e-09, (float)1.86629e-09, (float)1.48128e-09, (float)1.17569e-09,
+        (float)9.32233e-10, (float)7.39914e-10, (float)5.8727e-10, (float)4.65889e-10, (float)3.69776e-10, (float)2.93492e-10,
+        (float)2.32888e-10, (float)1.84843e-10, (float)1.4671e-10, (float)1.1643e-10, (float)9.24102e-11, (float)7.3346e-11,
+        (float)5.82112e-11, (float)4.62023e-11, (float)3.66708e-11, (float)2.91047e-11, (float)2.31004e-11, (float)1.83348e-11,
+        (float)1.45521e-11, (float)1.155e-11, (float)9.16727e-12, (float)3.17891e-07, (float)2.52311e-07, (float)2.00259e-07,
+        (float)1.90735e-07, (float)1.51386e-07, (float)1.20155e-07, (float)1.05964e-07, (float)8.41035e-08, (float)6.6753e-08
+    };
+    for (int i = 0; i < bands; i++) {
+        float s = 0;
+        int ba = *pba++;
+        int mask = ba ? 4 + ((19 >> scfcod[i]) & 3) : 0;
+        for (int m = 4; m; m >>= 1) {
+            if (mask & m) {
+                int b = (int)get_bits(bs, 6);
+                s = g_deq_L12[ba * 3 - 6 + b % 3] * (float)(1 << 21 >> b / 3);
+            }
+            *scf++ = s;
+        }
+    }
+}
+
+static void l12_read_scale_info(const uint8_t *hdr, bs_t *bs, l12_scale_info *sci)                    /* :386-435 */
+{
+    static const uint8_t g_bitalloc_code_tab[] = {
+        0,17, 3, 4, 5,6,7, 8,9,10,11,12,13,14,15,16,
+        0,17,18, 3,19,4,5, 6,7, 8, 9,10,11,12,13,16,
+        0,17,18, 3,19,4,5,16,
+        0,17,18,16,
+        0,17,18,19, 4,5,6, 7,8, 9,10,11,12,13,14,15,
+        0,17,18, 3,19,4,5, 6,7, 8, 9,10,11,12,13,14,
+        0, 2, 3, 4, 5,6,7, 8,9,10,11,12,13,14,15,16
+    };
+    const l12_alloc_t *subband_alloc = l12_subband_alloc_table(hdr, sci);
+    int i, k = 0, ba_bits = 0;
+    const uint8_t *ba_code_tab = g_bitalloc_code_tab;
+    for (i = 0; i < sci->total_bands; i++) {
+        uint8_t ba;
+        if (i == k) {
+            k += subband_alloc->band_count;
+            ba_bits = subband_alloc->code_tab_width;
+            ba_code_tab = g_bitalloc_code_tab + subband_alloc->tab_offset;
+            subband_alloc++;
+        }
+        ba = ba_code_tab[get_bits(bs, ba_bits)];
+        sci->bitalloc[2 * i] = ba;
+        if (i < sci->stereo_bands) ba = ba_code_tab[get_bits(bs, ba_bits)];
+        sci->bitalloc[2 * i + 1] = sci->stereo_bands ? ba : 0;
+    }
+    for (i = 0; i < 2 * sci->total_bands; i++) {
+        uint8_t temp = h_l1(hdr) ? 2 : (uint8_t)get_bits(bs, 2);
+        sci->scfcod[i] = sci->bitalloc[i] ? temp : 6;
+    }
+    l12_read_scalefactors(bs, sci->bitalloc, sci->scfcod, sci->total_bands * 2, sci->scf);
+    for (i = sci->stereo_bands; i < sci->total_bands; i++) sci->bitalloc[2 * i + 1] = 0;
+}
+
+static int l12_dequantize_granule(float *grbuf, bs_t *bs, l12_scale_info *sci, int group_size)         /* :437-471 */
+{
+    int i, j, k, choff = 576;
+    for (j = 0; j < 4; j++) {
+        float *dst = grbuf + group_size * j;
+        for (i = 0; i < 2 * sci->total_bands; i++) {
+            int ba = sci->bitalloc[i];
+            if (ba != 0) {
+                if (ba < 17) {
+                    int half = (1 << (ba - 1)) - 1;
+                    for (k = 0; k < group_size; k++) dst[k] = (float)((int)get_bits(bs, ba) - half);
+                } else {
+                    unsigned mod = (2u << (ba - 17)) + 1;                 /* 3, 5, 9 */
+                    unsigned code = get_bits(bs, (int)(mod + 2 - (mod >> 3)));  /* 5, 7, 10 */
+                    for (k = 0; k < group_size; k++, code /= mod) dst[k] = (float)((int)(code % mod - mod / 2));
+                }
+            }
+            dst += choff;
+            choff = 18 - choff;
+        }
+    }
+    return group_size * 4;
+}
+
+static void l12_apply_scf_384(l12_scale_info *sci, const float *scf, float *dst)                        /* :473-485 */
+{
+    memcpy(dst + 576 + sci->stereo_bands * 18, dst + sci->stereo_bands * 18, (size_t)(sci->total_bands - sci->stereo_bands) * 18 * sizeof(float));
+    for (int i = 0; i < sci->total_bands; i++, dst += 18, scf += 6) {
+        for (int k = 0; k < 12; k++) {
+            dst[k + 0] *= scf[0];
+            dst[k + 576] *= scf[3];
+        }
+    }
+}
+
+/* records one Layer I/II synthesis granule (12 time slots, layout [ch][band * 18 + slot], mp3:1563-1566) like a Layer III
+ * one: 576 floats per channel with flag AFGO_MP3_L12 (its slots 12..17 are zero and are NOT part of the signal) */
+#define AFGO_MP3_L12 0x40000000u
+static int l12_record(sink_t *sink, const float *grbuf, int nch)
+{
+    afgo_mp3_file *f = sink->f;
+    if (sink->new_stream || f->n_streams == 0) {
+        if (!grow((void **)&f->stream_granules, &sink->cap_streams, f->n_streams + 1, sizeof(uint32_t))) return 0;
+        f->stream_granules[f->n_streams++] = 0;
+        sink->new_stream = 0;
+    }
+    size_t need = (size_t)f->n_blocks + (size_t)nch, cap2 = sink->cap_blocks;
+    if (!grow((void **)&f->coef, &sink->cap_blocks, need, 576 * sizeof(float))) return 0;
+    if (!grow((void **)&f->flags, &cap2, need, sizeof(uint32_t))) return 0;
+    for (int ch = 0; ch < nch; ch++) {
+        memcpy(f->coef + (f->n_blocks + (size_t)ch) * 576, grbuf + 576 * ch, 576 * sizeof(float));
+        f->flags[f->n_blocks + (size_t)ch] = AFGO_MP3_L12;
+    }
+    f->n_blocks += (uint64_t)nch;
+    f->stream_granules[f->n_streams - 1]++;
+    return 1;
+}
+
 typedef struct { int frame_bytes, frame_offset, channels, hz, layer, bitrate_kbps; } frame_info_t;
 
 /* mp3:1491-1581.  pcm == NULL: header only (returns the frame's sample count). */
@@ -610,7 +772,38 @@ static int decode_frame(dec_t *dec, const uint8_t *mp3, int mp3_bytes, float *pc
     if (!pcm) return (int)hdr_frame_samples(hdr);
     bs_init(&bs_frame, hdr + HDR_SIZE, frame_size - HDR_SIZE);
     if (h_crc(hdr)) get_bits(&bs_frame, 16);
-    if (info->layer != 3) return -1;                                   /* Layer I/II: not handled by this build */
+    if (info->layer != 3) {                                            /* Layer I / II, mp3:1557-1578 */
+        l12_scale_info sci;
+        float lins[(12 + 15) * 64];
+        /* (records of a frame that fails below are dropped again: the reference discards the whole frame, :1573-1577) */
+        const uint64_t blocks_at_entry = sink ? sink->f->n_blocks : 0;
+        const uint32_t streams_at_entry = sink ? sink->f->n_streams : 0;
+        const uint32_t last_at_entry = (sink && sink->f->n_streams) ? sink->f->stream_granules[sink->f->n_streams - 1] : 0;
+        memset(&sci, 0, sizeof(sci));
+        l12_read_scale_info(hdr, &bs_frame, &sci);
+        memset(scratch.grbuf, 0, sizeof(scratch.grbuf));
+        for (i = 0, igr = 0; igr < 3; igr++) {
+            if (12 == (i += l12_dequantize_granule(scratch.grbuf[0] + i, &bs_frame, &sci, info->layer | 1))) {
+                i = 0;
+                l12_apply_scf_384(&sci, sci.scf + igr, scratch.grbuf[0]);
+                if (sink && !l12_record(sink, scratch.grbuf[0], info->channels)) return -2;
+                memset(lins, 0, sizeof(lins));                          /* (uninitialised scratch in the reference, see afgo_mp3_granule) */
+                afgo_mp3_synth_granule(dec->tr.qmf_state, scratch.grbuf[0], 12, info->channels, pcm, lins);
+                memset(scratch.grbuf, 0, sizeof(scratch.grbuf));
+                pcm += 384 * info->channels;
+            }
+            if (bs_frame.pos > bs_frame.limit) {
+                dec->header[0] = 0;                                    /* mp3dec_init */
+                if (sink) {
+                    sink->f->n_blocks = blocks_at_entry;
+                    sink->f->n_streams = streams_at_entry;
+                    if (streams_at_entry) sink->f->stream_granules[streams_at_entry - 1] = last_at_entry;
+                }
+                return 0;
+            }
+        }
+        return success * (int)hdr_frame_samples(dec->header);
+    }
     memset(&scratch.maindata, 0, sizeof(scratch.maindata));           /* the reference leaves the tail undefined */
     memset(scratch.ist_pos, 0, sizeof(scratch.ist_pos));              /* ... and ist_pos: uninitialised stack in the reference
                                                                          (minimp3.d:179-181); zero at every frame here and in the product */
@@ -773,11 +966,12 @@ int afgo_mp3_decode_file(const uint8_t *data, size_t size, afgo_mp3_file *f)
         }
     }
     (void)free_format;
-    if (!have_info || first.layer != 3) { free(dec); free(frame_pcm); return -1; }
+    if (!have_info) { free(dec); free(frame_pcm); return -1; }
     /* the index scan decoded with a sink-less decoder: forget everything it recorded (nothing) and reset */
     memset(dec, 0, sizeof(*dec));                                       /* mp3dec_init + the memset of mp3:1508 */
     f->channels = first.channels;
     f->hz = first.hz;
+    f->layer = first.layer;
     f->vbr_tag_found = vbr;
     f->start_delay = to_skip;
     f->detected_samples = detected_samples;

@@ -391,6 +391,7 @@ void afgo_mp3_granule(afgo_mp3_state *st, float *coef, const uint32_t *flags, in
         unsigned n_long = (flags[c] >> 8) & 0xffu;
         int aa_bands = (int)((flags[c] >> 16) & 0xffu) - 1;
         float *g = coef + 576 * c;
+        if (flags[c] & 0x80000000u) continue;             /* AFG_MP3_SUBBAND: Layer I/II samples go to the synthesis as they are */
         afgo_mp3_antialias(g, aa_bands);
         afgo_mp3_imdct_gr(g, st->mdct_overlap[c], block_type, n_long);
         afgo_mp3_change_sign(g);

@@ -190,7 +190,7 @@ class _Mp3File(C.Structure):
     _fields_ = [("channels", C.c_int), ("hz", C.c_int), ("vbr_tag_found", C.c_int), ("start_delay", C.c_int),
                 ("detected_samples", C.c_uint64), ("samples", C.c_uint64), ("n_streams", C.c_uint32),
                 ("stream_granules", C.POINTER(C.c_uint32)), ("n_blocks", C.c_uint64), ("coef", C.POINTER(C.c_float)),
-                ("flags", C.POINTER(C.c_uint32)), ("pcm_samples", C.c_uint64), ("pcm", C.POINTER(C.c_float))]
+                ("flags", C.POINTER(C.c_uint32)), ("pcm_samples", C.c_uint64), ("pcm", C.POINTER(C.c_float)), ("layer", C.c_int)]
 
 
 def mp3_decode_file(data):
@@ -208,7 +208,7 @@ def mp3_decode_file(data):
             a = np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.float32)
             return a.reshape(shape) if shape else a
         nb = int(f.n_blocks)
-        return {"channels": f.channels, "hz": f.hz, "tagged": f.vbr_tag_found, "start_delay": f.start_delay,
+        return {"channels": f.channels, "hz": f.hz, "layer": f.layer, "tagged": f.vbr_tag_found, "start_delay": f.start_delay,
                 "detected_samples": int(f.detected_samples), "declared_samples": int(f.samples),
                 "runs": arr(f.stream_granules, int(f.n_streams)).astype(np.uint32) if f.n_streams else np.zeros(0, np.uint32),
                 "coef": arr(f.coef, nb * 576, (-1, 576)) if nb else np.zeros((0, 576), np.float32),

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef int i4 __attribute__((ext_vector_type(4)));
-template <int ROWS, int T> __global__ __launch_bounds__(64) void k(const int *__restrict__ in, int *__restrict__ out)
+template <int ROWS, int T, int TILED = 0> __global__ __launch_bounds__(64) void k(const int *__restrict__ in, int *__restrict__ out)
 {
     constexpr int PIECES = T / 4;                       // 16-byte pieces per row-channel chunk
     constexpr int LOADS = ROWS * 2 * PIECES / 64;       // 16-byte loads per lane per step
@@ -15,7 +15,9 @@ template <int ROWS, int T> __global__ __launch_bounds__(64) void k(const int *__
     auto load = [&](int t0) {
         for (int i = 0; i < LOADS; i++) {
             const int e = lane + 64 * i, rc = e / PIECES, p = e % PIECES;          // rc = row * 2 + channel
-            nxt[i] = *(const i4 *)(in + (2 * f0 + rc) * 4096 + t0 + 4 * p);
+            // TILED: the residual plane is written tile by tile (a step's ROWS x 2 chunks are contiguous)
+            nxt[i] = TILED ? *(const i4 *)(in + f0 * 8192 + (size_t)(t0 / T) * (ROWS * 2 * T) + 4 * e)
+                           : *(const i4 *)(in + (2 * f0 + rc) * 4096 + t0 + 4 * p);
         }
     };
     load(0);
@@ -27,17 +29,18 @@ template <int ROWS, int T> __global__ __launch_bounds__(64) void k(const int *__
         for (int i = 0; i < LOADS; i++) {                                          // row r, 4 interleaved ints (2 samples x 2 ch)
             const int e = lane + 64 * i, r = e / (2 * PIECES), q = e % (2 * PIECES);
             const i4 v = ((const i4 *)tile)[e];
-            *(i4 *)(out + (f0 + r) * 8192 + 2 * t0 + 4 * q) = v;
+            if (TILED == 2) *(i4 *)(out + f0 * 8192 + (size_t)(t0 / T) * (ROWS * 2 * T) + 4 * e) = v;
+            else *(i4 *)(out + (f0 + r) * 8192 + 2 * t0 + 4 * q) = v;
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
-template <int ROWS, int T> void run(const int *in, int *out, size_t frames, const char *name)
+template <int ROWS, int T, int TILED = 0> void run(const int *in, int *out, size_t frames, const char *name)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((k<ROWS, T>), dim3(frames / ROWS), dim3(64), 0, 0, in, out);
+        hipLaunchKernelGGL((k<ROWS, T, TILED>), dim3(frames / ROWS), dim3(64), 0, 0, in, out);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("%-28s %.3f ms  %.2f TB/s\n", name, ms, 2.0 * frames * 8192 * 4 / ms / 1e9);
@@ -55,5 +58,8 @@ int main()
     run<16, 64>(in, out, frames, "16 rows x 256 B");
     run<16, 128>(in, out, frames, "16 rows x 512 B");
     run<8, 256>(in, out, frames, "8 rows x 1 KB");
+    run<64, 32, 1>(in, out, frames, "64 x 128 B, tiled reads");
+    run<64, 16, 1>(in, out, frames, "64 x 64 B, tiled reads");
+    run<64, 32, 2>(in, out, frames, "64 x 128 B, tiled both");
     return 0;
 }
