@@ -128,8 +128,49 @@ __global__ __launch_bounds__(64) void kc(const float *__restrict__ in, float *__
         __builtin_amdgcn_wave_barrier();
     }
 }
-int main()
+// Variant: does it matter WHERE the resident wavefronts read and write at a given moment?  IL & 1: granule g of segment s is read
+// from block (g * nseg + s) instead of (s * seg + g) -- the wavefronts that run together read neighbouring 4.6 KB blocks;
+// IL & 2: the same for the stores.  (Same bytes, same per-wavefront pattern; only the global address window differs.)
+template <int IL> __global__ __launch_bounds__(64) void kil(const float *__restrict__ in, float *__restrict__ out, int seg, unsigned nseg)
 {
+    __shared__ __attribute__((aligned(16))) float H[1152];
+    const int lane = threadIdx.x;
+    const size_t s = blockIdx.x;
+    auto rblk = [&](int g) -> size_t { return (IL & 1) ? (size_t)g * nseg + s : s * seg + g; };
+    auto wblk = [&](int g) -> size_t { return (IL & 2) ? (size_t)g * nseg + s : s * seg + g; };
+    f4 pre[5];
+    for (int q = 0; q < 5; q++) { const int idx = lane + 64 * q; pre[q] = ((const f4 *)(in + rblk(0) * 1152))[idx < 288 ? idx : 287]; }
+    for (int g = 0; g < seg; g++) {
+        for (int q = 0; q < 5; q++) { const int idx = lane + 64 * q; if (idx < 288) ((f4 *)H)[idx] = pre[q]; }
+        if (g + 1 < seg)
+            for (int q = 0; q < 5; q++) { const int idx = lane + 64 * q; pre[q] = ((const f4 *)(in + rblk(g + 1) * 1152))[idx < 288 ? idx : 287]; }
+        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < 5; q++) asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y), "+v"(pre[q].z), "+v"(pre[q].w) : : "memory");
+        f4 *dst = (f4 *)(out + wblk(g) * 1152);
+        for (int q = 0; q < 5; q++) { const int idx = lane + 64 * q; if (idx < 288) dst[idx] = ((const f4 *)H)[idx]; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) {                                           // `./ubench_mp3pattern il`: only the layout experiment
+        const int seg = 48; const unsigned nseg = 98304; const size_t ngr = (size_t)nseg * seg;
+        float *in, *out; hipMalloc(&in, ngr * 1152 * 4); hipMalloc(&out, ngr * 1152 * 4);
+        hipMemset(in, 0, ngr * 1152 * 4);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int il = 0; il < 4; il++) for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(a);
+            if (il == 0) hipLaunchKernelGGL(kil<0>, dim3(nseg), dim3(64), 0, 0, in, out, seg, nseg);
+            if (il == 1) hipLaunchKernelGGL(kil<1>, dim3(nseg), dim3(64), 0, 0, in, out, seg, nseg);
+            if (il == 2) hipLaunchKernelGGL(kil<2>, dim3(nseg), dim3(64), 0, 0, in, out, seg, nseg);
+            if (il == 3) hipLaunchKernelGGL(kil<3>, dim3(nseg), dim3(64), 0, 0, in, out, seg, nseg);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("interleaved reads=%d writes=%d: %.3f ms  %.2f TB/s\n", il & 1, (il >> 1) & 1, ms, 2.0 * ngr * 4608 / ms / 1e9);
+        }
+        return 0;
+    }
     const int seg = 48; const size_t nseg = 98304, ngr = nseg * seg;      // 4.7M granule pairs = 21.7 GB each way
     float *in, *out; hipMalloc(&in, ngr * 1152 * 4); hipMalloc(&out, ngr * 1152 * 4);
     hipMemset(in, 0, ngr * 1152 * 4);
@@ -185,7 +226,7 @@ int main()
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("<= %2d wavefronts per CU: %.3f ms  %.2f TB/s\n", waves, ms, 2.0 * ngr * 4608 / ms / 1e9);
     }
-    for (int seg2 = 24; seg2 <= 192; seg2 *= 2) {
+    for (int seg2 = 6; seg2 <= 192; seg2 *= 2) {
         hipEventRecord(a);
         hipLaunchKernelGGL(kc, dim3(ngr / seg2), dim3(64), 0, 0, in, out, seg2, 2);
         hipEventRecord(b); hipEventSynchronize(b);
