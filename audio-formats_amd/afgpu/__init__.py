@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "afg_opus_parse", "afg_opus_parsed_free", "afg_opus_output_gain_hip",
     "afg_batch_decode", "afg_batch_free", "afg_batch_decode_ex", "afg_set_device", "afg_get_device", "afg_host_pool_trim",
     "afg_device_malloc", "afg_device_free", "afg_memcpy_h2d", "afg_memcpy_d2h", "afg_stream_synchronize",
-    "afg_copy_probe_hip",
+    "afg_copy_probe_hip", "afg_lds_fill_probe_hip",
     "afg_qoa_encoded_size", "afg_qoa_encode_hip", "afg_wav_encoded_size", "afg_wav_encode", "afg_wav_encode_dithered",
     "afg_opus_output_hip",
 ]
@@ -235,6 +235,7 @@ def lib():
     L.afg_memcpy_d2h.argtypes = [vp, vp, C.c_size_t, vp]
     L.afg_stream_synchronize.argtypes = [vp]
     L.afg_copy_probe_hip.argtypes = [vp, vp, C.c_size_t, vp]
+    L.afg_lds_fill_probe_hip.argtypes = [C.c_uint32, vp]
     _lib = L
     return L
 
@@ -698,6 +699,11 @@ def batch_decode(files, n_threads=0, devices=None):
 def copy_probe(d_dst, d_src, nbytes, stream=None):
     """Enqueue the streaming copy used to measure the practical HBM copy ceiling (afg_copy_probe_hip)."""
     check(lib().afg_copy_probe_hip(_ptr(d_dst), _ptr(d_src), int(nbytes), _stream(stream)))
+
+
+def lds_fill(word=0x7fc00000, stream=None):
+    """Test aid (afg_lds_fill_probe_hip): leave `word` (default: NaN) in the LDS of every compute unit."""
+    check(lib().afg_lds_fill_probe_hip(int(word), _stream(stream)))
 
 
 def device_count():

@@ -142,6 +142,28 @@ __global__ __launch_bounds__(256) void copy_probe_kernel(const probe_f4 *__restr
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void lds_fill_kernel(uint32_t word, uint32_t *sink)
+{
+    extern __shared__ uint32_t lds_words[];
+    for (uint32_t i = threadIdx.x; i < 160u * 1024u / 4u; i += 256) lds_words[i] = word;
+    __syncthreads();
+    if (sink && lds_words[(threadIdx.x * 97u) % (160u * 1024u / 4u)] != word) *sink = 1;     // keeps the stores alive
+}
+}  // namespace
+
+int afg_lds_fill_probe_hip(uint32_t word, void *hip_stream)
+{
+    if (int rc = afg::require_device()) return rc;
+    static uint32_t *sink = nullptr;                          // per process; never read back
+    if (!sink) AFG_HIP_CHECK(hipMalloc(&sink, 256));
+    AFG_HIP_CHECK(hipFuncSetAttribute((const void *)lds_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // one workgroup owns a whole CU's LDS while it runs: 16 x the CU count visits every CU with near certainty
+    hipLaunchKernelGGL(lds_fill_kernel, dim3(256 * 16), dim3(256), 160 * 1024, (hipStream_t)hip_stream, word, sink);
+    AFG_HIP_CHECK(hipGetLastError());
+    return AFG_OK;
+}
+
 int afg_copy_probe_hip(void *d_dst, const void *d_src, size_t bytes, void *hip_stream)
 {
     if (!d_dst || !d_src || (bytes & 15) || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) {

@@ -418,11 +418,19 @@ __device__ __forceinline__ void pf_transition(float *ring, const float *win2, in
         if (on) {
             const float w = win2[i];
 #define RD(x) ring[(n0 + (x)) & (kRing - 1)]
-            const float x0 = RD(i - T1 + 2), x1 = RD(i - T1 + 1), x2 = RD(i - T1), x3 = RD(i - T1 - 1),
-                        x4 = RD(i - T1 - 2);
-            const double acc = (1.0 - w) * pf.g_old[0] * RD(i - T0) +
-                               (1.0 - w) * pf.g_old[1] * (RD(i - T0 - 1) + RD(i - T0 + 1)) +
-                               (1.0 - w) * pf.g_old[2] * (RD(i - T0 - 2) + RD(i - T0 + 2)) +
+            // A dead filter (all gains zero) multiplies whatever it reads by zero -- and on a fresh decoder its period is
+            // still 0, so it "reads" i - 2 .. i + 2: for the last two samples of a 120-sample frame that is past the
+            // frame.  The reference finds the frame's finite overlap tail there (buf + 1024 + F); this kernel's ring holds
+            // whatever LDS held (the tail lives in the next frame's slots), and 0 * NaN is NaN.  A dead filter's taps
+            // are therefore taken as +0.0 without touching memory: the same sum whenever the reference's data are finite
+            // (up to the sign of an all-zero sum).
+            const float x0 = live1 ? RD(i - T1 + 2) : 0.0f, x1 = live1 ? RD(i - T1 + 1) : 0.0f, x2 = live1 ? RD(i - T1) : 0.0f,
+                        x3 = live1 ? RD(i - T1 - 1) : 0.0f, x4 = live1 ? RD(i - T1 - 2) : 0.0f;
+            const float y0 = live0 ? RD(i - T0 + 2) : 0.0f, y1 = live0 ? RD(i - T0 + 1) : 0.0f, y2 = live0 ? RD(i - T0) : 0.0f,
+                        y3 = live0 ? RD(i - T0 - 1) : 0.0f, y4 = live0 ? RD(i - T0 - 2) : 0.0f;
+            const double acc = (1.0 - w) * pf.g_old[0] * y2 +
+                               (1.0 - w) * pf.g_old[1] * (y3 + y1) +
+                               (1.0 - w) * pf.g_old[2] * (y4 + y0) +
                                w * pf.g[0] * x2 +
                                w * pf.g[1] * (x1 + x3) +
                                w * pf.g[2] * (x0 + x4);

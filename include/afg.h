@@ -513,6 +513,11 @@ uint64_t afg_wav_encode_dithered(const float *samples, uint64_t frames, uint32_t
  * actually sustains, the practical ceiling the HBM-bound kernels are compared with next to the 8 TB/s spec. */
 int afg_copy_probe_hip(void *d_dst, const void *d_src, size_t bytes, void *hip_stream);
 
+/* Test aid: fills the LDS of every compute unit with `word` (workgroups of 160 KiB, many times the CU count).  LDS is not
+ * cleared between kernels, so a kernel that reads a location it never wrote normally finds zeros or old finite data and
+ * passes; with 0x7fc00000 (NaN) behind it such a read shows.  The GPU tests run every case behind this. */
+int afg_lds_fill_probe_hip(uint32_t word, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,9 @@ def expected(data):
 def same_pcm(got, want):
     assert got.shape == want.shape
     # the device transform follows the oracle's expression trees: after the int16 round trip the match is exact
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    bad = np.nonzero(got.view(np.uint32).reshape(-1) != want.view(np.uint32).reshape(-1))[0]
+    assert len(bad) == 0, (f"{len(bad)} of {got.size} samples differ, first at {int(bad[0])}, last at {int(bad[-1])}; "
+                           f"got {got.reshape(-1)[bad[:12]]!r} want {want.reshape(-1)[bad[:12]]!r} at {bad[:12]!r}")
 
 
 def test_batch_of_random_celt_files(gpu):
@@ -39,7 +41,9 @@ def test_batch_of_random_celt_files(gpu):
         files.append(data)
         wants.append(expected(data))
     res = afgpu.batch_decode(files)
-    for r, (rec, pcm) in zip(res, wants):
+    for k, (r, (rec, pcm)) in enumerate(zip(res, wants)):
+        print("file", k, "channels", rec["channels"], "frames", len(rec["frames"]), "gain_i", rec["gain_i"],
+              "sizes", sorted(set(int(x) for x in rec["frames"]["frame_size"])))
         assert r["status"] == 0, r["message"]
         assert r["format"] == afgpu.FORMAT_OPUS and r["samplerate"] == 48000.0 and r["channels"] == rec["channels"]
         assert r["frames"] == len(pcm) == min(rec["pcm_frames"], rec["declared_frames"])
