@@ -76,6 +76,8 @@ struct DeviceBuf {
     {
         hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
         if (e != hipSuccess) { p = nullptr; afg::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return AFG_ERR_OOM; }
+        // AFG_POISON_ALLOC=1 (tests): fresh device buffers hold NaN patterns, so that a stage that reads what nobody wrote shows
+        if (bytes && std::getenv("AFG_POISON_ALLOC")) (void)hipMemset(p, 0xff, bytes);
         return AFG_OK;
     }
 };
@@ -117,6 +119,7 @@ public:
                 out.pool = this; out.p = free_[best].first; out.cap = free_[best].second;
                 held_ -= out.cap;
                 free_.erase(free_.begin() + (long)best);
+                if (std::getenv("AFG_POISON_ALLOC")) std::memset(out.p, 0xff, out.cap);     // (tests: see DeviceBuf::alloc)
                 return AFG_OK;
             }
         }
@@ -126,6 +129,7 @@ public:
         hipError_t e = hipHostMalloc(&p, cap, hipHostMallocPortable);
         if (e != hipSuccess) { afg::set_error("hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); return AFG_ERR_OOM; }
         out.pool = this; out.p = p; out.cap = cap;
+        if (std::getenv("AFG_POISON_ALLOC")) std::memset(out.p, 0xff, out.cap);
         return AFG_OK;
     }
     // Frees every buffer that is not on lease (afg_host_pool_trim): a long-lived process gives the pinned memory back.

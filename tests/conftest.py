@@ -9,6 +9,11 @@ for p in (os.path.join(ROOT, "audio-formats_amd"), os.path.join(ROOT, "tests"), 
         sys.path.insert(0, p)
 
 
+# the host pipeline's fresh device and page-locked buffers hold NaN patterns in every test run: a stage that reads what
+# nobody wrote shows up instead of finding zeros (afg_host.cpp: DeviceBuf::alloc, StagingPool::take)
+os.environ.setdefault("AFG_POISON_ALLOC", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
