@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Mutation fuzzing of the whole batch path on a device: damaged MP3 / Ogg Vorbis / FLAC / QOA files through
+"""Mutation fuzzing of the whole batch path on a device: damaged MP3 (Layer I-III) / Ogg Vorbis / Ogg Opus / FLAC / QOA files through
 afg_batch_decode in mixed batches.  Every item must come back (status ok or an error message, never a crash), finite,
 and identical to what the same bytes give when decoded on their own (the staged and the per-file paths agree).
 usage: python tools/fuzz/fuzz_batch.py [batches] [seed]      (run it under `timeout`)"""
@@ -36,6 +36,8 @@ def main():
     import afgpu
     import flac_bitstream as fb
     import mp3_bitstream as mb
+    import mp3_l12_bitstream as lb
+    import opus_bitstream as ob
     import oraclelib
     import vorbis_bitstream as vb
     from test_flac_frontend import make_pcm
@@ -49,7 +51,11 @@ def main():
              vb.make_file(5, n_packets=20), vb.make_file(6, n_packets=12, channels=1),
              fb.encode_file(make_pcm(4096 + 300, 2, 16, 3), 16, 1024, orders=(8, 12, 3))[0],
              fb.encode_file(make_pcm(1152 * 2, 1, 24, 4), 24, 1152)[0],
-             oraclelib.qoa_encode(make_pcm(5120 + 777, 2, 16, 5).astype(np.int16), 44100)[0].tobytes()]
+             oraclelib.qoa_encode(make_pcm(5120 + 777, 2, 16, 5).astype(np.int16), 44100)[0].tobytes(),
+             ob.random_celt_file(np.random.default_rng(7), 2, 25, preskip=0)[0],
+             ob.random_celt_file(np.random.default_rng(8), 1, 18, preskip=0, gain=500)[0],
+             lb.random_file(np.random.default_rng(9), 2, 16, vary_bitrate=True),
+             lb.random_file(np.random.default_rng(10), 1, 30, mode="mono", vary_bitrate=True)]
     ok = bad = 0
     for b in range(batches):
         files = [mutate(rng, seeds[int(rng.integers(0, len(seeds)))]) if rng.random() < 0.8 else seeds[int(rng.integers(0, len(seeds)))]

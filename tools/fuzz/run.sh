@@ -10,6 +10,7 @@ cd "$root/audio-formats_amd/host"
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I. "$root/tools/fuzz/fuzz_mp3.cpp" afg_mp3_front.cpp -o "$out/fuzz_mp3"
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I. "$root/tools/fuzz/fuzz_flac.cpp" afg_flac_front.cpp -o "$out/fuzz_flac"
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I. "$root/tools/fuzz/fuzz_vorbis.cpp" afg_vorbis_front.cpp -o "$out/fuzz_vorbis"
+g++ -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -I. -I/opt/rocm/include "$root/tools/fuzz/fuzz_opus.cpp" afg_opus_front.cpp -o "$out/fuzz_opus"
 for seed in 1 2 3; do "$out/fuzz_mp3" "$root/tests/golden/mathjax_invalid_keypress.mp3" $seed "$n"; done
 for seed in 1 2 3; do "$out/fuzz_vorbis" "$root/tests/golden/mathjax_invalid_keypress.ogg" $seed "$n"; done
 cd "$root/tests" && python3 - "$out" <<'PY'
@@ -23,3 +24,17 @@ d, _ = fb.encode_file(make_pcm(1152 * 3, 2, 24, 4), 24, 1152)
 open(sys.argv[1] + "/b.flac", "wb").write(d)
 PY
 for f in a b; do "$out/fuzz_flac" "$out/$f.flac" 1 "$n"; done
+# Ogg Opus (CELT-only) and MPEG Layer I / II: generated seeds (tests/opus_bitstream.py, tests/mp3_l12_bitstream.py)
+cd "$root/tests" && python3 - "$out" <<'PY'
+import sys
+import numpy as np
+import opus_bitstream as ob
+import mp3_l12_bitstream as lb
+rng = np.random.default_rng(5)
+for i, ch in enumerate((1, 2)):
+    open(f"{sys.argv[1]}/s{i}.opus", "wb").write(ob.random_celt_file(rng, ch, 40, preskip=0)[0])
+for i, layer in enumerate((1, 2)):
+    open(f"{sys.argv[1]}/l{layer}.mp3", "wb").write(lb.random_file(rng, layer, 30, vary_bitrate=True, mode=("joint", "stereo")[i]))
+PY
+for f in s0 s1; do for seed in 1 2; do "$out/fuzz_opus" "$out/$f.opus" $seed "$n"; done; done
+for f in l1 l2; do "$out/fuzz_mp3" "$out/$f.mp3" 1 "$n"; done
