@@ -53,6 +53,7 @@ struct Decoded {
     int64_t declared_frames = AFG_UNKNOWN_LENGTH;
     size_t pcm_off = 0;                 // float offset of this file's interleaved PCM in the result plane
     bool in_mp3_plane = false;          // ... or in the batch's MP3 plane (staging layout, afg_batch_decode)
+    bool in_opus_plane = false;         // ... or in the batch's Opus plane (decoded by the pipelined stage of afg_batch_decode)
 };
 
 struct Parsed {
@@ -259,6 +260,7 @@ struct BatchOut {
     StagingPool::Lease plane;           // all PCM of the batch: FLAC files, then QOA files, then MP3 files; page-locked,
     size_t plane_floats = 0;            // returned to the pool by afg_batch_free / afg_close
     StagingPool::Lease mp3_plane;       // batch path: the MP3 PCM in staging layout, served in place
+    StagingPool::Lease opus_plane;      // batch path: the Opus PCM, files back to back
     std::unique_ptr<BatchOut> early;    // batch path: the FLAC / QOA files, decoded on a second host thread meanwhile
 };
 
@@ -443,8 +445,11 @@ struct OpusCarry {
 
 int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const size_t *len, unsigned threads, BatchOut &out,
                   const Mp3Stage *stage = nullptr, const OggStage *ogg_stage = nullptr, const FlacStage *flac_stage = nullptr,
-                  const uint8_t *own = nullptr, Mp3Carry *carry = nullptr, OpusCarry *opus_carry = nullptr)
+                  const uint8_t *own = nullptr, Mp3Carry *carry = nullptr, OpusCarry *opus_carry = nullptr,
+                  const size_t *opus_done_at = nullptr)
 {
+    // opus_done_at (batch path): the Opus files are already decoded, file i's PCM at float opus_done_at[i] of the batch's
+    // Opus plane; only their metadata is filled in here
     // `own` (optional, one byte per file): the files this call is responsible for.  The batch path decodes its FLAC /
     // QOA files on a second host thread while the first still parses MP3 / Ogg files: a call never looks at (not even
     // the format of) a file it does not own.
@@ -627,6 +632,11 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
     for (size_t i = 0; i < nf; i++) {
         const Parsed &p = parsed[i];
         if (fmt_of(p) != AFG_FORMAT_OPUS) continue;
+        if (opus_done_at) {
+            out.files[i].pcm_off = opus_done_at[i];
+            out.files[i].in_opus_plane = true;
+            continue;
+        }
         opus_rec_base[i] = opus_recs; opus_coef_base[i] = opus_coefs; opus_pcm_base[i] = opus_out;
         out.files[i].pcm_off = flac_out + qoa_out + mp3_out + ogg_out + opus_out;
         opus_recs += p.opus.frames.size() * (size_t)p.opus.channels;
@@ -1587,6 +1597,45 @@ int afg_qoa_parse(const uint8_t *data, size_t length, uint32_t *channels, uint32
 
 namespace {
 
+// Host threads of a batch when the caller leaves the choice to the library: one per physical core of an SMT-2 host (with one
+// per logical CPU the parse stages ran up to 10x longer on a shared 256-CPU box: the stragglers wait for a CPU).
+unsigned default_threads()
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return hw >= 16 ? hw / 2 : hw;
+}
+
+// ... and for a stage that keeps the CPUs busy for longer than a scheduler period: no more than twice the CPU time the process
+// may actually use (a container's cgroup quota).  The GPU boxes of this project show 256 logical CPUs behind a 16-CPU quota:
+// stages of a few tens of milliseconds (FLAC / Vorbis / MP3 parse) finish inside the burst the quota allows and are fastest
+// with 128 threads; the Opus decode of a 2048-file batch takes half a second, is throttled, and runs at 1.7e9 samples/s with
+// 128 threads, 2.3e9 with 32.
+unsigned sustained_threads()
+{
+    static const unsigned n = [] {
+        unsigned t = default_threads();
+        double quota = 0;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                    // cgroup v2: "<quota|max> <period>"
+            char q[32] = { 0 };
+            double period = 0;
+            if (std::fscanf(f, "%31s %lf", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) quota = std::atof(q) / period;
+            std::fclose(f);
+        } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // cgroup v1
+            double us = -1, period = 100000;
+            if (std::fscanf(g, "%lf", &us) != 1) us = -1;
+            std::fclose(g);
+            if (FILE *h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(h, "%lf", &period) != 1) period = 100000;
+                std::fclose(h);
+            }
+            if (us > 0 && period > 0) quota = us / period;
+        }
+        if (quota > 0) t = std::min(t, std::max(1u, (unsigned)(2 * quota + 0.5)));
+        return std::max(1u, t);
+    }();
+    return n;
+}
+
 // What a batch result owns: one BatchOut per device the batch ran on.
 struct BatchOwner {
     std::vector<std::unique_ptr<BatchOut>> parts;
@@ -1604,19 +1653,21 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
         std::vector<Parsed> parsed((size_t)n_files);
         // default: one thread per physical core of an SMT-2 host (half the logical CPUs).  With one thread per logical
         // CPU the parse stages ran up to 10x longer on a shared 256-CPU box: the stragglers wait for a CPU.
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned nt = n_threads > 0 ? (unsigned)n_threads : (hw >= 16 ? hw / 2 : hw);
+        const unsigned nt = n_threads > 0 ? (unsigned)n_threads : default_threads();
+        const unsigned nt_long = n_threads > 0 ? (unsigned)n_threads : sustained_threads();
         // pass 1: containers with a signature are parsed at once; MP3 candidates only get an upper bound of their
         // record count, so that pass 2 can parse them straight into one page-locked staging buffer
         std::vector<size_t> bound((size_t)n_files, 0), base((size_t)n_files, 0), ogg_bound((size_t)n_files, 0), ogg_base((size_t)n_files, 0),
             flac_bound((size_t)n_files, 0), flac_base((size_t)n_files, 0);
+        std::vector<uint8_t> opus_open((size_t)n_files, 0);
         parallel_for((size_t)n_files, nt, [&](size_t i) {
             if (!data[i] || !length[i]) return;
             Parsed &p = parsed[i];
             try {
             if (length[i] >= 4 && std::memcmp(data[i], "OggS", 4) == 0) {                             // Opus is tried first (stream.d:1596)
-                const afg_opus::Status st = afg_opus::parse_file(data[i], length[i], p.opus);
-                if (st == afg_opus::kOpened) { p.format = AFG_FORMAT_OPUS; return; }
+                afg_opus::Reader rd;                                                                  // headers + sizes; decoded in pass 1c
+                const afg_opus::Status st = rd.open(data[i], length[i], p.opus);
+                if (st == afg_opus::kOpened) { opus_open[i] = 1; return; }
                 p.opus = afg_opus::File();
                 if (st == afg_opus::kUnsupported) { p.opus_mode = true; return; }
             }
@@ -1668,6 +1719,142 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
         BatchOut *owner = new (std::nothrow) BatchOut;
         if (!owner) return AFG_ERR_OOM;
         std::unique_ptr<BatchOut> guard(owner);
+        // ---- pass 1c: Ogg Opus.  The open scan gave exact sizes, so every file is decoded (range decoder + CELT frame decoder,
+        // by all helper threads) straight into one page-locked buffer, a chunk of files at a time; the chunk's upload, transform,
+        // output conversion and download are queued on two streams and run while the helpers decode the next chunk.
+        std::vector<size_t> opus_pcm_at((size_t)n_files, 0);
+        bool opus_staged = false;
+        {
+            size_t n_opus = 0, recs_total = 0, coefs_total = 0, seqs_total = 0;
+            std::vector<size_t> rec_at((size_t)n_files, 0), coef_at((size_t)n_files, 0), seq_at((size_t)n_files, 0);
+            for (size_t i = 0; i < (size_t)n_files; i++) {
+                if (!opus_open[i]) continue;
+                const afg_opus::File &m = parsed[i].opus;
+                rec_at[i] = recs_total; coef_at[i] = coefs_total; seq_at[i] = seqs_total;
+                opus_pcm_at[i] = coefs_total;                     // one PCM float per coefficient
+                recs_total += m.bound_frames * (size_t)m.channels;
+                coefs_total += m.bound_coeffs;
+                seqs_total += (size_t)m.channels;
+                n_opus++;
+            }
+            if (n_opus && seqs_total <= 0xffffffffull) {
+                const size_t base_bytes = ((seqs_total + 1) * sizeof(uint64_t) + 15) & ~(size_t)15;
+                const size_t rec_bytes = (recs_total * sizeof(afg_celt_frame) + 15) & ~(size_t)15;
+                StagingPool::Lease h_in;
+                DeviceBuf d_in, d_pcm;
+                if (int rc = g_staging.take(base_bytes + rec_bytes + coefs_total * sizeof(float), h_in)) return rc;
+                if (int rc = g_staging.take(std::max<size_t>(coefs_total, 1) * sizeof(float), owner->opus_plane)) return rc;
+                if (int rc = d_in.alloc(base_bytes + rec_bytes + coefs_total * sizeof(float))) return rc;
+                if (int rc = d_pcm.alloc(std::max<size_t>(coefs_total, 1) * sizeof(float))) return rc;
+                uint64_t *hb = (uint64_t *)h_in.p;
+                afg_celt_frame *hr = (afg_celt_frame *)((uint8_t *)h_in.p + base_bytes);
+                float *hc = (float *)((uint8_t *)h_in.p + base_bytes + rec_bytes);
+                const uint64_t *db = (const uint64_t *)d_in.p;
+                const afg_celt_frame *dr = (const afg_celt_frame *)((const uint8_t *)d_in.p + base_bytes);
+                const float *dc = (const float *)((const uint8_t *)d_in.p + base_bytes + rec_bytes);
+                for (size_t i = 0; i < (size_t)n_files; i++) {
+                    if (!opus_open[i]) continue;
+                    const afg_opus::File &m = parsed[i].opus;
+                    for (int c = 0; c < m.channels; c++) hb[seq_at[i] + (size_t)c] = rec_at[i] + (size_t)c * m.bound_frames;
+                }
+                hb[seqs_total] = recs_total;
+                hipStream_t up = nullptr, down = nullptr;
+                std::vector<hipEvent_t> events;
+                hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_in.p, hb, base_bytes, hipMemcpyHostToDevice, up);
+                int rc = AFG_OK;
+                const size_t target = std::max<size_t>((coefs_total + 7) / 8, (size_t)4 << 20);
+                for (size_t f0 = 0; f0 < (size_t)n_files && !rc && e == hipSuccess;) {
+                    size_t f1 = f0, acc = 0;
+                    while (f1 < (size_t)n_files && acc < target) { if (opus_open[f1]) acc += parsed[f1].opus.bound_coeffs; f1++; }
+                    size_t first = (size_t)n_files, last = (size_t)n_files;
+                    for (size_t i = f0; i < f1; i++)
+                        if (opus_open[i]) { if (first == (size_t)n_files) first = i; last = i; }
+                    if (first == (size_t)n_files) { f0 = f1; continue; }
+                    parallel_for(f1 - f0, nt_long, [&](size_t k) {
+                        const size_t i = f0 + k;
+                        if (!opus_open[i]) return;
+                        Parsed &p = parsed[i];
+                        const size_t nfr = p.opus.bound_frames, nco = p.opus.bound_coeffs;
+                        const int C = p.opus.channels;
+                        afg_celt_frame *recs = hr + rec_at[i];
+                        bool ok = false;
+                        try {
+                            afg_opus::File f;
+                            ok = afg_opus::parse_file_into(data[i], length[i], f, recs, nfr, hc + coef_at[i], nco) == afg_opus::kOpened &&
+                                 !f.overflow && f.n_frames == nfr && f.n_coeffs == nco;
+                            f.ext_frames = nullptr;                // (the staging outlives this record)
+                            f.ext_coeffs = nullptr;
+                            if (ok) p.opus = f;
+                        } catch (...) { ok = false; }
+                        if (!ok) {                                 // cannot happen (the sizes are exact): an empty, failed file
+                            p.opus.error = true;
+                            p.opus.pcm_frames = 0;
+                            std::memset((void *)recs, 0, nfr * (size_t)C * sizeof(afg_celt_frame));
+                            std::memset(hc + coef_at[i], 0, nco * sizeof(float));
+                            for (size_t q = 0; q < nfr * (size_t)C; q++) { recs[q].frame_size = 120; recs[q].blocks = 1; recs[q].out_stride = 1; recs[q].imdct_scale = 1.0f; recs[q].out_off = opus_pcm_at[i]; recs[q].coef_off = coef_at[i]; }
+                            p.format = AFG_FORMAT_OPUS;
+                            return;
+                        }
+                        // channel 0's records are in place (file-relative offsets): make them plane-absolute, derive the others
+                        for (int c = C - 1; c >= 0; c--)
+                            for (size_t q = 0; q < nfr; q++) {
+                                afg_celt_frame r = recs[q];
+                                r.coef_off += coef_at[i] + (uint64_t)c * r.frame_size;
+                                r.out_off += opus_pcm_at[i] + (uint64_t)c;
+                                recs[(size_t)c * nfr + q] = r;
+                            }
+                        p.format = AFG_FORMAT_OPUS;
+                    });
+                    const size_t r0 = rec_at[first], r1 = rec_at[last] + parsed[last].opus.bound_frames * (size_t)parsed[last].opus.channels;
+                    const size_t c0 = coef_at[first], c1 = coef_at[last] + parsed[last].opus.bound_coeffs;
+                    const size_t s0 = seq_at[first], s1 = seq_at[last] + (size_t)parsed[last].opus.channels;
+                    e = hipMemcpyAsync((void *)(dr + r0), hr + r0, (r1 - r0) * sizeof(afg_celt_frame), hipMemcpyHostToDevice, up);
+                    if (e == hipSuccess && c1 > c0) e = hipMemcpyAsync((void *)(dc + c0), hc + c0, (c1 - c0) * sizeof(float), hipMemcpyHostToDevice, up);
+                    if (e != hipSuccess) break;
+                    if (c1 > c0) {
+                        rc = afg_celt_transform_hip((uint32_t)(s1 - s0), db + s0, dr, dc, (float *)d_pcm.p, nullptr, up);
+                        if (rc) break;
+                        bool any_gain = false;
+                        for (size_t i = first; i <= last; i++) any_gain = any_gain || (opus_open[i] && parsed[i].opus.gain_i != 0);
+                        if (!any_gain) {
+                            rc = afg_opus_output_hip(c1 - c0, (const float *)d_pcm.p + c0, nullptr, (float *)d_pcm.p + c0, up);
+                        } else {
+                            for (size_t i = first; i <= last && !rc; i++) {
+                                if (!opus_open[i] || !parsed[i].opus.bound_coeffs) continue;
+                                float *at = (float *)d_pcm.p + opus_pcm_at[i];
+                                const afg_opus::File &m = parsed[i].opus;
+                                rc = m.gain_i ? afg_opus_output_gain_hip(m.bound_coeffs, at, m.gain, nullptr, at, up)
+                                              : afg_opus_output_hip(m.bound_coeffs, at, nullptr, at, up);
+                            }
+                        }
+                        if (rc) break;
+                        hipEvent_t done = nullptr;
+                        e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+                        if (e != hipSuccess) break;
+                        events.push_back(done);
+                        e = hipEventRecord(done, up);
+                        if (e == hipSuccess) e = hipStreamWaitEvent(down, done, 0);
+                        if (e == hipSuccess)
+                            e = hipMemcpyAsync((float *)owner->opus_plane.p + c0, (const float *)d_pcm.p + c0, (c1 - c0) * sizeof(float), hipMemcpyDeviceToHost, down);
+                    }
+                    f0 = f1;
+                }
+                if (up) { hipError_t e2 = hipStreamSynchronize(up); if (e == hipSuccess) e = e2; }
+                if (down) { hipError_t e2 = hipStreamSynchronize(down); if (e == hipSuccess) e = e2; }
+                for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+                if (up) (void)hipStreamDestroy(up);
+                if (down) (void)hipStreamDestroy(down);
+                if (rc) return rc;
+                if (e != hipSuccess) { afg::set_error("Opus stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
+                opus_staged = true;
+                tm.lap("pass 1c: opus decode into staging | h2d | kernels | d2h (chunks overlapped)");
+            } else if (n_opus) {
+                afg::set_error("Opus stage: too many channel sequences");
+                return AFG_ERR_INVALID;
+            }
+        }
         // The FLAC and QOA files are complete now: their device stage (mostly PCIe time) runs on a second host thread
         // while this one parses the MP3 and Ogg files.  Each call of decode_parsed only touches the files it owns.
         std::vector<uint8_t> own_early((size_t)n_files, 0), own_late((size_t)n_files, 1);
@@ -1821,7 +2008,8 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
             if (fallback) stage.blocks = 0;                   // decode_parsed does those files from their own buffers
         }
         int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr, ogg_stage.floats ? &ogg_stage : nullptr,
-                               split ? nullptr : (flac_stage.words ? &flac_stage : nullptr), split ? own_late.data() : nullptr);
+                               split ? nullptr : (flac_stage.words ? &flac_stage : nullptr), split ? own_late.data() : nullptr, nullptr, nullptr,
+                               opus_staged ? opus_pcm_at.data() : nullptr);
         tm.lap("decode_parsed total");
         if (split) {
             early_job.th.join();
@@ -1838,7 +2026,8 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
             items[i].channels = d.channels;
             items[i].samplerate = d.samplerate;
             items[i].frames = d.frames;
-            const float *plane = d.in_mp3_plane ? (const float *)owner->mp3_plane.p : (const float *)src->plane.p;
+            const float *plane = d.in_mp3_plane ? (const float *)owner->mp3_plane.p
+                                 : d.in_opus_plane ? (const float *)owner->opus_plane.p : (const float *)src->plane.p;
             items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)plane + d.pcm_off : nullptr;
         }
         keep = std::move(guard);
@@ -1933,8 +2122,7 @@ int afg_batch_decode_ex(const uint8_t *const *data, const size_t *length, int n_
                 load[best] += length[f] + 1;
             }
             for (auto &v : mine) std::sort(v.begin(), v.end());
-            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            const unsigned total_threads = n_threads > 0 ? (unsigned)n_threads : (hw >= 16 ? hw / 2 : hw);
+            const unsigned total_threads = n_threads > 0 ? (unsigned)n_threads : default_threads();
             const int per_dev_threads = (int)std::max<unsigned>(1u, total_threads / (unsigned)nd);
             owner->parts.resize(nd);
             struct Part {

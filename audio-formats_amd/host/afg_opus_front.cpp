@@ -1470,11 +1470,19 @@ struct Reader::Impl {
         // every audio packet's TOC: refuse what cannot be decoded here, before anything is delivered
         PacketWalk scan = walk;
         std::vector<uint8_t> tmp;
-        bool any = false;
+        bool any = false, counting = true;
         while (scan.next(pkt, len, tmp)) {
             if (!any && scan.page_granule() < (uint64_t)preskip) return kNotOpus;     // :8155
             any = true;
             if (len && (pkt[0] >> 3) < 16) return kUnsupported;
+            // what `more` will record: every frame up to the first packet it gives up on (same rules as there)
+            PacketLayout L;
+            if (counting && parse_packet(pkt, (int)len, L) && !(nch == 2 && L.frame_count * L.frame_samples > 2880)) {
+                meta.bound_frames += (size_t)L.frame_count;
+                meta.bound_coeffs += (size_t)L.frame_count * (size_t)L.frame_samples * (size_t)nch;
+            } else {
+                counting = false;
+            }
         }
         if (!any) return kNotOpus;                   // opusOpen needs one packet behind the tags (:8147)
         celt.reset(nch);
@@ -1486,6 +1494,7 @@ struct Reader::Impl {
     {
         out.frames.clear();
         out.coeffs.clear();
+        out.n_frames = out.n_coeffs = 0;
         out.pcm_frames = 0;
         out.error = false;
         if (failed) return false;
@@ -1508,7 +1517,7 @@ struct Reader::Impl {
                 celt.decode(rc, L.stereo + 1, L.frame_samples, k_celt_band_end[L.bandwidth], info);
                 afg_celt_frame r;
                 std::memset(&r, 0, sizeof(r));
-                r.coef_off = out.coeffs.size();
+                r.coef_off = out.n_coeffs;
                 r.out_off = out.pcm_frames * (uint64_t)channels;
                 r.out_stride = (uint32_t)channels;
                 r.frame_size = (uint16_t)L.frame_samples;
@@ -1516,10 +1525,24 @@ struct Reader::Impl {
                 r.pf_period_new = info.pf_period;
                 std::memcpy(r.pf_gains_new, info.pf_gains, sizeof(r.pf_gains_new));
                 r.imdct_scale = info.imdct_scale;
-                out.frames.push_back(r);
-                for (int c = 0; c < channels; c++) out.coeffs.insert(out.coeffs.end(), celt.coeffs(c), celt.coeffs(c) + L.frame_samples);
+                const size_t nco = (size_t)L.frame_samples * (size_t)channels;
+                if (out.ext_frames) {
+                    if (out.n_frames + 1 > out.ext_frames_cap || out.n_coeffs + nco > out.ext_coeffs_cap) {
+                        out.overflow = failed = true;
+                        break;
+                    }
+                    out.ext_frames[out.n_frames] = r;
+                    for (int c = 0; c < channels; c++)
+                        std::memcpy(out.ext_coeffs + out.n_coeffs + (size_t)c * L.frame_samples, celt.coeffs(c), (size_t)L.frame_samples * sizeof(float));
+                } else {
+                    out.frames.push_back(r);
+                    for (int c = 0; c < channels; c++) out.coeffs.insert(out.coeffs.end(), celt.coeffs(c), celt.coeffs(c) + L.frame_samples);
+                }
+                out.n_frames++;
+                out.n_coeffs += nco;
                 out.pcm_frames += (uint64_t)L.frame_samples;
             }
+            if (out.overflow) break;
         }
         return taken > 0;
     }
@@ -1529,6 +1552,20 @@ Reader::Reader() : p(new Impl) {}
 Reader::~Reader() { delete p; }
 Status Reader::open(const uint8_t *data, size_t size, File &meta) { return p->open(data, size, meta); }
 bool Reader::more(File &out, int max_packets) { return p->more(out, max_packets); }
+
+Status parse_file_into(const uint8_t *data, size_t size, File &out, afg_celt_frame *frames, size_t frames_cap, float *coeffs, size_t coeffs_cap)
+{
+    Reader r;
+    const Status st = r.open(data, size, out);
+    if (st != kOpened) return st;
+    // the whole stream in one pass of the chunked reader, straight into the caller's storage
+    out.ext_frames = frames;
+    out.ext_coeffs = coeffs;
+    out.ext_frames_cap = frames_cap;
+    out.ext_coeffs_cap = coeffs_cap;
+    r.more(out, 0x7fffffff);
+    return kOpened;
+}
 
 Status parse_file(const uint8_t *data, size_t size, File &out)
 {
@@ -1547,6 +1584,8 @@ Status parse_file(const uint8_t *data, size_t size, File &out)
         out.pcm_frames += chunk.pcm_frames;
         if (chunk.error) { out.error = true; break; }
     }
+    out.n_frames = out.frames.size();
+    out.n_coeffs = out.coeffs.size();
     return kOpened;
 }
 
