@@ -82,3 +82,35 @@ def test_hip_reproduces_flac_fixture(gpu):
     torch.cuda.synchronize()
     assert (d_i.cpu().numpy() == g["out_i32"]).all()                   # bit-exact int32
     assert same_bits(d_f.cpu().numpy(), g["out_f32"])
+
+
+def test_oracle_reproduces_opus_file_fixture():
+    g = load("opus_file.npz")
+    rec = oraclelib.opus_decode_file(g["data"].tobytes())
+    assert rec["gain_i"] == int(g["gain_i"]) and rec["declared_frames"] == int(g["declared"])
+    assert same_bits(rec["coeffs"], g["coeffs"]) and rec["frames"].tobytes() == g["frames"].tobytes()
+    assert same_bits(oraclelib.opus_file_pcm(rec), g["pcm"])
+
+
+def test_product_front_end_reproduces_opus_file_fixture():
+    import afgpu
+    g = load("opus_file.npz")
+    got = afgpu.opus_parse(g["data"].tobytes())
+    assert same_bits(got["coeffs"], g["coeffs"]) and got["frames"].tobytes() == g["frames"].tobytes()
+
+
+def test_oracle_reproduces_layer2_file_fixture():
+    g = load("mp2_file.npz")
+    want = oraclelib.mp3_decode_file(g["data"].tobytes())
+    assert want["layer"] == 2 and (want["channels"], want["hz"], want["declared_samples"]) == (int(g["channels"]), int(g["hz"]), int(g["declared"]))
+    assert same_bits(want["pcm"], g["pcm"]) and len(g["pcm"]) > 0
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_opus_and_layer2_file_fixtures(gpu):
+    import afgpu
+    o, m = load("opus_file.npz"), load("mp2_file.npz")
+    res = afgpu.batch_decode([o["data"].tobytes(), m["data"].tobytes()])
+    assert [r["status"] for r in res] == [0, 0]
+    assert same_bits(res[0]["pcm"], o["pcm"])
+    assert same_bits(res[1]["pcm"].reshape(-1), m["pcm"])
