@@ -257,6 +257,7 @@ class Part:
     kernel = ""
     samples = 0                 # decoded samples per launch
     alg_bytes = 0               # algorithmic bytes per launch
+    survey_bytes = None         # the same at SURVEY 8(d)'s per-unit figure, where the launch's input format moves fewer
     units = 0
 
     def launch(self, stream):   # pragma: no cover - interface
@@ -379,7 +380,8 @@ class VorbisPart(Part):
 class FlacPart(Part):
     name, kernel = "flac", "flac_restore_kernel"
 
-    def __init__(self, seed, frames_per_file, device, block_size=4096, file_ids=None, host=False):
+    def __init__(self, seed, frames_per_file, device, block_size=4096, file_ids=None, host=False, res16=None):
+        import os
         import torch
         fpf = np.asarray(frames_per_file, np.int64)
         self.frames_per_file = fpf
@@ -387,8 +389,30 @@ class FlacPart(Part):
         self.n_frames = len(self.frames_np)
         total = self.n_frames * 2 * block_size
         self.block_size = block_size
+        # residual rows as int16 (AFG_FLAC_ROW16): what a 16-bit file's residuals fit into; the same values as
+        # the int32 planes of round 1 (AFG_FLAC_RES32=1 keeps those for an A/B)
+        self.res16 = (not os.environ.get("AFG_FLAC_RES32")) if res16 is None else bool(res16)
+        if self.res16:
+            assert block_size % 8 == 0
+            self.frames_np["res16"] = 1            # in_off (2 * block_size per frame) now counts int16 elements
         if host:
-            self.res = torch.from_numpy(flac_residuals_numpy(seed, fpf, file_ids, block_size)).to(device)
+            r = flac_residuals_numpy(seed, fpf, file_ids, block_size)
+            if self.res16:
+                assert np.abs(r).max(initial=0) < 32768
+                r = r.astype(np.int16).view(np.int32)
+            self.res = torch.from_numpy(r).to(device)
+        elif self.res16:
+            gen = torch.Generator(device=device)
+            gen.manual_seed(int(seed))
+            r16 = torch.empty(total, dtype=torch.int16, device=device)
+            chunk = 1 << 28
+            for o in range(0, total, chunk):
+                k = min(chunk, total - o)
+                e = torch.empty(k, dtype=torch.float32, device=device).exponential_(1.0 / 32.0, generator=gen)
+                sgn = torch.empty(k, dtype=torch.float32, device=device).uniform_(-1.0, 1.0, generator=gen).sign_()
+                r16[o:o + k] = (e * sgn).round_().clamp_(-32767, 32767).to(torch.int16)
+                del e, sgn
+            self.res = r16.view(torch.int32)
         else:
             gen = torch.Generator(device=device)
             gen.manual_seed(int(seed))
@@ -405,7 +429,10 @@ class FlacPart(Part):
         self.out = torch.empty(total, dtype=torch.int32, device=device)
         self.units = self.n_frames * 2
         self.samples = total
-        self.alg_bytes = 8 * total + self.n_frames * FLAC_BYTES_PER_FRAME_REC
+        # int32 residual + int32 output = 8 B / sample; int16 residual rows make it 6 B / sample, and that is
+        # what the roofline is priced on (the 8 B figure is kept beside it, not used for `frac`)
+        self.survey_bytes = 8 * total + self.n_frames * FLAC_BYTES_PER_FRAME_REC
+        self.alg_bytes = (6 if self.res16 else 8) * total + self.n_frames * FLAC_BYTES_PER_FRAME_REC
 
     def launch(self, stream):
         flac_transform(self.n_frames, self.d_frames, self.d_sub, self.res, self.out, None, stream)
@@ -419,7 +446,8 @@ class FlacPart(Part):
     def check(self, checker, n_files=2):
         nchk = int(self.frames_per_file[:n_files].sum())
         cnt = nchk * 2 * self.block_size
-        want = checker.flac_transform(self.frames_np[:nchk], self.sub_np[:2 * nchk], self.res[:cnt].cpu().numpy(), cnt)
+        words = cnt // 2 if self.res16 else cnt
+        want = checker.flac_transform(self.frames_np[:nchk], self.sub_np[:2 * nchk], self.res[:words].cpu().numpy(), cnt)
         got = self.out[:cnt].cpu().numpy()
         bad = int((got != want).sum())
         return {"samples": int(cnt), "mismatches": bad, "rms_error": 0.0 if bad == 0 else None, "max_abs_error": 0.0 if bad == 0 else None}

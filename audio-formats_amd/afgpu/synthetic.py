@@ -185,7 +185,7 @@ def flac_batch(seed, n_frames, block_size=4096, channels=2, bps=16, orders=(8, 1
     for f in range(n_frames):
         bs = int(block_size if not vary_block else rng.choice([192, 576, 1152, 4096, 4608, 1000]))
         asg = int(rng.choice(assignments, p=assignment_p)) if channels == 2 else FLAC_INDEPENDENT
-        frames[f] = (in_off, out_off, bs, f * channels, channels, asg, bps, [0] * 5)
+        frames[f] = (in_off, out_off, bs, f * channels, channels, asg, bps, 0, [0] * 4)
         for c in range(channels):
             side = (asg in (FLAC_LEFT_SIDE, FLAC_MID_SIDE) and c == 1) or (asg == FLAC_RIGHT_SIDE and c == 0)
             wasted = int(rng.integers(1, 3)) if rng.random() < wasted_p else 0
@@ -206,6 +206,37 @@ def flac_batch(seed, n_frames, block_size=4096, channels=2, bps=16, orders=(8, 1
         in_off += bs * channels
         out_off += bs * channels
     return frames, subframes, np.concatenate(res_parts), out_off
+
+
+def flac_pack16(frames, res, every=1):
+    """The int16 storage of residual rows (AFG_FLAC_ROW16, include/afg.h): every `every`-th frame whose values all fit
+    16 bits is rewritten as int16 rows padded to 8, the others stay int32; returns (frames, res int32 array holding both)."""
+    frames = frames.copy()
+    out = []
+    words = 0
+    for f in range(len(frames)):
+        fr = frames[f]
+        bs, C, off = int(fr["block_size"]), int(fr["channels"]), int(fr["in_off"])
+        plane = res[off:off + bs * C]
+        if f % every == 0 and bs >= 8 and np.abs(plane.astype(np.int64)).max(initial=0) < 32768:
+            row = (bs + 7) & ~7
+            packed = np.zeros(C * row, np.int16)
+            for c in range(C):
+                packed[c * row:c * row + bs] = plane[c * bs:(c + 1) * bs]
+            pad = (-words) % 4                                    # 16-byte aligned start: in_off a multiple of 8 int16
+            out.append(np.zeros(pad, np.int32))
+            words += pad
+            frames["in_off"][f] = 2 * words
+            frames["res16"][f] = 1
+            w = np.zeros((C * row + 1) // 2, np.int32)
+            w.view(np.int16)[:C * row] = packed
+            out.append(w)
+            words += len(w)
+        else:
+            frames["in_off"][f] = words
+            out.append(plane.astype(np.int32))
+            words += bs * C
+    return frames, (np.concatenate(out) if out else np.zeros(0, np.int32))
 
 
 # ------------------------------------------------- device-resident BASELINE workloads ------

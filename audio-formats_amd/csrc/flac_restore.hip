@@ -37,7 +37,7 @@ struct RowMeta {                       // what the load/store phases need to kno
     uint64_t in_off;
     uint64_t out_off;
     uint32_t bs;
-    uint32_t info;                     // channels | assignment << 8 | bps << 16
+    uint32_t info;                     // channels | assignment << 8 | bps << 16 | res16 << 24
 };
 
 __device__ __forceinline__ int wave_max(int v)
@@ -130,12 +130,36 @@ __device__ __forceinline__ void restore_tile2(int32_t *tile, int row, int t0,
     }
 }
 
-// Issue the 16-byte loads of one tile step: instruction i covers row-chunks 16i .. 16i+15,
-// row-chunk rc = (row rc>>1, channel slot rc&1), lane&3 = 16-byte piece of the 64-byte chunk.
+// Residual rows come as int32 or, for frames whose values all fit 16 bits, as int16 (afg_flac_frame.res16).  A
+// wavefront's 64 frames are nearly always of one kind, so the walk is instantiated three times: MODE 0 all int32 (round 1's
+// code), MODE 1 all int16 (half the bytes, half the load instructions), MODE 2 a mix (file boundaries inside a wavefront).
+//
+// Issue the 16-byte loads of one tile step.  int32: instruction i covers row-chunks 16i .. 16i+15, row-chunk rc = (row rc>>1,
+// channel slot rc&1), lane&3 (kT = 16) or lane&7 = 16-byte piece of the chunk.
+template <int MODE>
 __device__ __forceinline__ void load_tile(int4 (&nxt)[kLoads], const RowMeta *meta, const int32_t *__restrict__ res,
                                           int pair, int t0)
 {
     const int lane = threadIdx.x;
+    if (MODE == 1) {
+        // int16 rows (AFG_FLAC_ROW16: padded to 16 bytes, so a piece of 8 samples is always there): kLoads / 2 instructions,
+        // lane % (kPieces / 2) = piece of 8 samples; widened by park_tile once the load has landed
+        constexpr int P16 = kPieces / 2;
+#pragma unroll
+        for (int i = 0; i < kLoads / 2; i++) {
+            const int rc = (64 / P16) * i + lane / P16;
+            const int row = rc >> 1, slot = rc & 1, p = lane % P16;
+            const RowMeta m = meta[row];
+            const int C = (int)(m.info & 0xff);
+            const int cidx = 2 * pair + slot;
+            const int t = t0 + 8 * p;
+            int4 v = make_int4(0, 0, 0, 0);
+            if (cidx < C && t < (int)m.bs)
+                v = *(const int4 *)((const int16_t *)res + m.in_off + (uint64_t)cidx * (((uint64_t)m.bs + 7u) & ~(uint64_t)7u) + (uint64_t)t);
+            nxt[i] = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < kLoads; i++) {
         const int rc = (64 / kPieces) * i + lane / kPieces;
@@ -145,7 +169,13 @@ __device__ __forceinline__ void load_tile(int4 (&nxt)[kLoads], const RowMeta *me
         const int cidx = 2 * pair + slot;
         const int t = t0 + 4 * p;
         int4 v = make_int4(0, 0, 0, 0);
-        if (cidx < C && t < (int)m.bs) {
+        if (MODE == 2 && cidx < C && t < (int)m.bs && (m.info >> 24)) {
+            // an int16 row in a mixed wavefront: the lane's four samples are 8 bytes, parked raw in .x / .y
+            const int16_t *src = (const int16_t *)res + m.in_off + (uint64_t)cidx * (((uint64_t)m.bs + 7u) & ~(uint64_t)7u) + (uint64_t)t;
+            const int2 w = *(const int2 *)src;
+            v.x = w.x;
+            v.y = w.y;
+        } else if (cidx < C && t < (int)m.bs) {
             const int32_t *src = res + m.in_off + (uint64_t)cidx * m.bs + (uint64_t)t;
             if (t + 3 < (int)m.bs) {
                 v = *(const int4 *)src;                              // may be 4-byte aligned only (odd block sizes)
@@ -159,13 +189,29 @@ __device__ __forceinline__ void load_tile(int4 (&nxt)[kLoads], const RowMeta *me
     }
 }
 
-__device__ __forceinline__ void park_tile(int32_t *tile, const int4 (&nxt)[kLoads])
+template <int MODE>
+__device__ __forceinline__ void park_tile(int32_t *tile, const RowMeta *meta, const int4 (&nxt)[kLoads])
 {
     const int lane = threadIdx.x;
+    if (MODE == 1) {
+        constexpr int P16 = kPieces / 2;
+#pragma unroll
+        for (int i = 0; i < kLoads / 2; i++) {
+            const int rc = (64 / P16) * i + lane / P16;
+            const int piece = (rc & 1) * kPieces + 2 * (lane % P16);
+            const int4 v = nxt[i];
+            *(int4 *)(tile + piece_off(rc >> 1, piece)) = make_int4((int)(int16_t)v.x, v.x >> 16, (int)(int16_t)v.y, v.y >> 16);
+            *(int4 *)(tile + piece_off(rc >> 1, piece + 1)) = make_int4((int)(int16_t)v.z, v.z >> 16, (int)(int16_t)v.w, v.w >> 16);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < kLoads; i++) {
         const int rc = (64 / kPieces) * i + lane / kPieces;
-        *(int4 *)(tile + piece_off(rc >> 1, (rc & 1) * kPieces + lane % kPieces)) = nxt[i];
+        int4 v = nxt[i];
+        if (MODE == 2 && (meta[rc >> 1].info >> 24))                 // int16 row: four samples in two dwords
+            v = make_int4((int)(int16_t)v.x, v.x >> 16, (int)(int16_t)v.y, v.y >> 16);
+        *(int4 *)(tile + piece_off(rc >> 1, (rc & 1) * kPieces + lane % kPieces)) = v;
     }
 }
 
@@ -228,7 +274,7 @@ __device__ __forceinline__ void store_tile(const int32_t *tile, const RowMeta *m
     }
 }
 
-template <int MAXORD, bool WIDE_A, bool WIDE_B>
+template <int MAXORD, bool WIDE_A, bool WIDE_B, int MODE>
 __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, const RowMeta &me, bool valid,
                                            const afg_flac_subframe *__restrict__ subframes, uint32_t sf_index,
                                            const int32_t *__restrict__ res, int32_t *__restrict__ out_i32,
@@ -261,11 +307,11 @@ __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, c
         }
 
         int4 nxt[kLoads];
-        load_tile(nxt, meta, res, pair, 0);
-        park_tile(tile, nxt);
+        load_tile<MODE>(nxt, meta, res, pair, 0);
+        park_tile<MODE>(tile, meta, nxt);
         __syncthreads();
         for (int t0 = 0; t0 < max_bs; t0 += kT) {
-            if (t0 + kT < max_bs) load_tile(nxt, meta, res, pair, t0 + kT);   // in flight during the recurrence
+            if (t0 + kT < max_bs) load_tile<MODE>(nxt, meta, res, pair, t0 + kT);   // in flight during the recurrence
 
             if (t0 < (int)me.bs) {
                 restore_tile2<MAXORD, WIDE_A, WIDE_B>(tile, lane, t0, order0, shift0, u0, c0, h0,
@@ -275,11 +321,11 @@ __device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, c
             // Make the prefetched residuals resident *here*: loads and stores share one in-order counter on this
             // hardware, so the wait park_tile would need after the stores below would also wait for them to drain.
 #pragma unroll
-            for (int i = 0; i < kLoads; i++)
+            for (int i = 0; i < (MODE == 1 ? kLoads / 2 : kLoads); i++)
                 asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y), "+v"(nxt[i].z), "+v"(nxt[i].w) : : "memory");
             store_tile(tile, meta, row_shift, out_i32, out_f32, pair, t0);
             __syncthreads();
-            if (t0 + kT < max_bs) park_tile(tile, nxt);
+            if (t0 + kT < max_bs) park_tile<MODE>(tile, meta, nxt);
             __syncthreads();
         }
     }
@@ -324,7 +370,7 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(
         me.in_off = fr.in_off;
         me.out_off = fr.out_off;
         me.bs = fr.block_size;
-        me.info = (uint32_t)fr.channels | ((uint32_t)fr.assignment << 8) | ((uint32_t)fr.bps << 16);
+        me.info = (uint32_t)fr.channels | ((uint32_t)fr.assignment << 8) | ((uint32_t)fr.bps << 16) | ((uint32_t)(fr.res16 != 0) << 24);
         for (int c = 0; c < 8; c++) {
             uint32_t sh = 0;
             if (c < (int)fr.channels) sh = (32u - fr.bps) + subframes[sf_index + c].wasted;   // drflac.d:2883, :2894
@@ -338,8 +384,13 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(
 
     const int max_bs = wave_max((int)me.bs);
     const int max_pairs = wave_max(((int)(me.info & 0xff) + 1) >> 1);
-    run_frames<MAXORD, WIDE_A, WIDE_B>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32,
-                             max_bs, max_pairs, row_shift);
+    const bool any16 = __any(valid && (me.info >> 24) != 0), any32 = __any(valid && (me.info >> 24) == 0);
+    if (!any16)
+        run_frames<MAXORD, WIDE_A, WIDE_B, 0>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
+    else if (!any32)
+        run_frames<MAXORD, WIDE_A, WIDE_B, 1>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
+    else
+        run_frames<MAXORD, WIDE_A, WIDE_B, 2>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
 }
 
 }  // namespace

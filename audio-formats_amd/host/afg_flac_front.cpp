@@ -269,6 +269,24 @@ bool flac_frame(BitReader &br, const FlacInfo &fi, FlacRecords &rec)
     br.align();
     br.bits(16);                                                   // CRC-16, not verified (drflac.d:108, :1673)
     if (br.fail) return false;
+    if (rec.pack16 && bs >= 8 && (fr.in_off & 3) == 0) {
+        uint32_t seen = 0;
+        const size_t n = (size_t)bs * C;
+        for (size_t i = 0; i < n; i++) seen |= (uint32_t)(plane[i] ^ (plane[i] >> 31));
+        if (seen < 32768u) {
+            // forward in place: the int16 rows (padded to 8) never overtake the int32 words still to be read (bs >= 8)
+            int16_t *rows = (int16_t *)plane;
+            const size_t row = (size_t)AFG_FLAC_ROW16(bs);
+            for (uint32_t c = 0; c < C; c++) {
+                const int32_t *src = plane + (size_t)c * bs;
+                int16_t *dst = rows + (size_t)c * row;
+                for (uint32_t i = 0; i < bs; i++) dst[i] = (int16_t)src[i];
+                for (size_t i = bs; i < row; i++) dst[i] = 0;
+            }
+            fr.res16 = 1;
+            fr.in_off *= 2;
+        }
+    }
     rec.frames.push_back(fr);
     rec.out_samples += (uint64_t)bs * C;
     return true;

@@ -24,6 +24,10 @@ struct FlacRecords {
     int32_t *ext_res = nullptr;
     size_t ext_cap = 0, n_res = 0;
     bool overflow = false;
+    // pack16 (set before parsing): a frame whose residuals and warm-up samples all fit 16 bits is rewritten in place as
+    // int16 rows (afg_flac_frame.res16, AFG_FLAC_ROW16): the device then reads half the bytes.  The frame keeps the words
+    // it was parsed into (the second half is unused); the plane itself must start on a 16-byte boundary.
+    bool pack16 = false;
     size_t res_size() const { return ext_res ? n_res : res.size(); }
     const int32_t *res_data() const { return ext_res ? ext_res : res.data(); }
     int32_t *res_grow(size_t words)          // room for `words` more residuals, or nullptr (external buffer full)

@@ -78,7 +78,12 @@ struct DeviceBuf {
         hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
         if (e != hipSuccess) { p = nullptr; afg::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return AFG_ERR_OOM; }
         // AFG_POISON_ALLOC=1 (tests): fresh device buffers hold NaN patterns, so that a stage that reads what nobody wrote shows
-        if (bytes && std::getenv("AFG_POISON_ALLOC")) (void)hipMemset(p, 0xff, bytes);
+        // (hipMemset runs on the null stream and returns early; the stages copy on non-blocking streams, which do not wait
+        // for it: without the synchronisation the fill can land on top of an upload)
+        if (bytes && std::getenv("AFG_POISON_ALLOC")) {
+            (void)hipMemset(p, 0xff, bytes);
+            (void)hipStreamSynchronize(nullptr);
+        }
         return AFG_OK;
     }
 };
@@ -464,6 +469,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
     for (size_t i = 0; i < nf; i++) {
         Parsed &p = parsed[i];
         if (fmt_of(p) != AFG_FORMAT_FLAC) continue;
+        if (!flac_staged) res_total = (res_total + 3) & ~(size_t)3;     // 16-byte aligned planes (int16 rows: afg_flac_frame.res16)
         res_base[i] = flac_staged ? flac_stage->base[i] : res_total; fr_base[i] = fr_total; sf_base[i] = sf_total;
         out.files[i].pcm_off = flac_out;
         res_total += p.flac.res_size(); fr_total += p.flac.frames.size(); sf_total += p.flac.subframes.size();
@@ -688,7 +694,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                     if (fmt_of(p) != AFG_FORMAT_FLAC) return;
                     for (size_t q = 0; q < p.flac.frames.size(); q++) {
                         afg_flac_frame f = p.flac.frames[q];
-                        f.in_off += res_base[i]; f.out_off += out.files[i].pcm_off; f.sf_index += (uint32_t)sf_base[i];
+                        f.in_off += (f.res16 ? 2 : 1) * (uint64_t)res_base[i]; f.out_off += out.files[i].pcm_off; f.sf_index += (uint32_t)sf_base[i];
                         hf[fr_base[i] + q] = f;
                     }
                     std::memcpy(hs + sf_base[i], p.flac.subframes.data(), p.flac.subframes.size() * sizeof(afg_flac_subframe));
@@ -701,7 +707,8 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 const size_t sf0 = sf_base[first], sf1 = sf_base[last] + parsed[last].flac.subframes.size();
                 const size_t r0 = res_base[first];
                 size_t r1 = r0;
-                for (size_t q = fr0; q < fr1; q++) r1 = std::max<size_t>(r1, hf[q].in_off + (size_t)hf[q].channels * hf[q].block_size);
+                for (size_t q = fr0; q < fr1; q++)                           // (a packed frame keeps the words it was parsed into)
+                    r1 = std::max<size_t>(r1, (size_t)(hf[q].res16 ? hf[q].in_off / 2 : hf[q].in_off) + (size_t)hf[q].channels * hf[q].block_size);
                 const size_t o0 = out.files[first].pcm_off, o1 = out.files[last].pcm_off + parsed[last].flac.out_samples;
                 e = hipMemcpyAsync((void *)(df + fr0), hf + fr0, (fr1 - fr0) * sizeof(afg_flac_frame), hipMemcpyHostToDevice, up);
                 if (e == hipSuccess) e = hipMemcpyAsync((void *)(ds + sf0), hs + sf0, (sf1 - sf0) * sizeof(afg_flac_subframe), hipMemcpyHostToDevice, up);
@@ -1144,6 +1151,7 @@ struct afg_stream {
         } else if (format == AFG_FORMAT_FLAC) {
             bool done = false;
             p.fi = fi;
+            p.flac.pack16 = true;
             const int got = flac_parse_frames(bytes.data(), bytes.size(), fi, p.flac, &flac_pos, kFlacFrames, &done);
             if (done) ended = true;
             if (!got) { ended = true; return false; }
@@ -1672,6 +1680,7 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 if (st == afg_opus::kUnsupported) { p.opus_mode = true; return; }
             }
             if ((flac_bound[i] = flac_res_bound(data[i], length[i])) != 0) return;                    // parsed in pass 1b
+            p.flac.pack16 = true;
             if (flac_parse(data[i], length[i], p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
             p.flac = FlacRecords();
             if (qoa_parse(data[i], length[i], p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
@@ -1698,9 +1707,11 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 Parsed &p = parsed[i];
                 bool ok = false;
                 try {
+                    p.flac.pack16 = true;
                     ok = flac_parse_into(data[i], length[i], p.fi, p.flac, res0 + flac_base[i], flac_bound[i]);
                     if (ok && p.flac.overflow) {                 // more audio than STREAMINFO declares: the file's own buffer
                         p.flac = FlacRecords();
+                        p.flac.pack16 = true;
                         ok = flac_parse(data[i], length[i], p.fi, p.flac);
                         lost = true;
                     }

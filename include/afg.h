@@ -182,15 +182,22 @@ typedef struct afg_flac_subframe {
     uint8_t use64;      /* subframe bitsPerSample > 16 -> 64-bit accumulator (drflac.d:1308) */
 } afg_flac_subframe;     /* 68 bytes */
 
+/* Residual rows of a frame whose residuals and warm-up samples all fit 16 bits may be stored as int16 (half
+ * the bytes on the bus and in HBM): rows padded to 16 bytes. */
+#define AFG_FLAC_ROW16(block_size) (((uint64_t)(block_size) + 7u) & ~(uint64_t)7u)
+
 typedef struct afg_flac_frame {
-    uint64_t in_off;      /* int32 index of channel 0's residual plane; channel c at in_off + c*block_size */
+    uint64_t in_off;      /* res16 == 0: int32 index of channel 0's residual row; channel c at in_off + c*block_size.
+                             res16 == 1: int16 index (d_res viewed as int16_t), a multiple of 8; channel c at
+                             in_off + c*AFG_FLAC_ROW16(block_size); the row padding is read, never used */
     uint64_t out_off;     /* int32 index of the interleaved output (block_size*channels samples) */
     uint32_t block_size;
     uint32_t sf_index;    /* index of channel 0's afg_flac_subframe; channel c at sf_index + c */
     uint8_t  channels;    /* 1..8 */
     uint8_t  assignment;  /* AFG_FLAC_* */
     uint8_t  bps;         /* STREAMINFO bitsPerSample */
-    uint8_t  pad[5];
+    uint8_t  res16;       /* 0: int32 residual rows, 1: int16 rows */
+    uint8_t  pad[4];
 } afg_flac_frame;         /* 32 bytes */
 
 /* d_out_i32 and/or d_out_f32 may be NULL (at least one must be given). */

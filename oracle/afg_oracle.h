@@ -191,7 +191,8 @@ typedef struct afgo_flac_frame {
     uint8_t  channels;    /* 1..8 */
     uint8_t  assignment;  /* 0 independent, 8 left/side, 9 right/side, 10 mid/side (drflac.d channelAssignment) */
     uint8_t  bps;         /* STREAMINFO bitsPerSample (pFlac.bitsPerSample) */
-    uint8_t  pad[5];
+    uint8_t  res16;       /* 1: the frame's residual rows are int16 (in_off an int16 index, rows padded to 8: include/afg.h) */
+    uint8_t  pad[4];
 } afgo_flac_frame;
 
 #define AFGO_FLAC_INDEPENDENT 0

@@ -63,7 +63,15 @@ void afgo_flac_transform(uint64_t n_frames, const afgo_flac_frame *frames,
         unsigned C = fr->channels;
         uint64_t sf_base = fr->sf_index;
         int32_t *dec = (int32_t *)malloc(sizeof(int32_t) * (size_t)bs * C);
-        memcpy(dec, res + fr->in_off, sizeof(int32_t) * (size_t)bs * C);
+        if (fr->res16) {                                                     /* int16 rows (a storage format of this project, not the
+                                                                                reference's: include/afg.h) widened back */
+            const int16_t *r16 = (const int16_t *)res + fr->in_off;
+            const size_t row = ((size_t)bs + 7u) & ~(size_t)7u;
+            for (unsigned c = 0; c < C; c++)
+                for (uint32_t i = 0; i < bs; i++) dec[(size_t)c * bs + i] = r16[(size_t)c * row + i];
+        } else {
+            memcpy(dec, res + fr->in_off, sizeof(int32_t) * (size_t)bs * C);
+        }
         for (unsigned c = 0; c < C; c++)
             afgo_flac_restore_subframe(&subframes[sf_base + c], dec + (size_t)c * bs, bs);
 

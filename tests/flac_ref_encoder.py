@@ -85,7 +85,7 @@ def encode(pcm, bps, block_size, orders=(8, 12), assignments=(MID_SIDE, LEFT_SID
         else:
             chans = [blk[:, c] for c in range(C)]
             extra = [0] * C
-        frames[f] = (in_off, out_off, bs, f * C, C, asg, bps, [0] * 5)
+        frames[f] = (in_off, out_off, bs, f * C, C, asg, bps, 0, [0] * 4)
         for c, s in enumerate(chans):
             w = wasted_bits(s)
             s = s >> w

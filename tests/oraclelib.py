@@ -43,7 +43,7 @@ FLAC_SUBFRAME_DTYPE = np.dtype([("coef", np.int16, (32,)), ("order", np.uint8), 
                                 ("wasted", np.uint8), ("use64", np.uint8)], align=True)
 FLAC_FRAME_DTYPE = np.dtype([("in_off", np.uint64), ("out_off", np.uint64), ("block_size", np.uint32),
                              ("sf_index", np.uint32), ("channels", np.uint8), ("assignment", np.uint8),
-                             ("bps", np.uint8), ("pad", np.uint8, (5,))], align=True)
+                             ("bps", np.uint8), ("res16", np.uint8), ("pad", np.uint8, (4,))], align=True)
 assert FLAC_SUBFRAME_DTYPE.itemsize == 68 and FLAC_FRAME_DTYPE.itemsize == 32
 
 CELT_FRAME_DTYPE = np.dtype([("coef_off", np.uint64), ("out_off", np.uint64), ("out_stride", np.uint32),

@@ -68,3 +68,25 @@ def test_flac_float_only_output(gpu):
     assert (d_f32.cpu().numpy().view(np.uint32) == want_f.view(np.uint32)).all()
     with pytest.raises(afgpu.AfgError):
         afgpu.flac_transform(len(frames), d_frames, d_sub, d_res, None, None)
+
+
+@pytest.mark.parametrize("kw,every", [
+    (dict(n_frames=130, block_size=4096, orders=(8, 12)), 1),                 # every frame packed
+    (dict(n_frames=150, block_size=4096, orders=(8, 12)), 3),                 # packed and unpacked frames inside one wavefront
+    (dict(n_frames=200, vary_block=True, orders=(2, 8, 12, 31)), 2),           # odd block sizes: rows padded to 8
+    (dict(n_frames=33, block_size=576, channels=1, orders=(8, 12)), 1),
+    (dict(n_frames=20, block_size=500, channels=6, orders=(4, 8)), 1),
+    (dict(n_frames=40, block_size=4096, bps=24, orders=(8, 12), residual_scale=3000.0), 1),   # hardly any frame fits
+])
+def test_flac_int16_residual_rows(gpu, kw, every):
+    """afg_flac_frame.res16: the same samples from int16 rows as from the int32 planes"""
+    frames, subframes, res, total = synthetic.flac_batch(23, **kw)
+    want_i, want_f = oraclelib.flac_transform(frames, subframes, res, total, want_float=True)
+    pf, pres = synthetic.flac_pack16(frames, res, every)
+    assert pf["res16"].any() or kw.get("bps") == 24
+    assert len(pres) < len(res) or not pf["res16"].any()
+    oi, of = oraclelib.flac_transform(pf, subframes, pres, total, want_float=True)         # the oracle reads both forms alike
+    assert (oi == want_i).all() and (of.view(np.uint32) == want_f.view(np.uint32)).all()
+    got_i, got_f = run_gpu(gpu, pf, subframes, pres, total)
+    assert (got_i == want_i).all(), f"{int((got_i != want_i).sum())} int32 mismatches"
+    assert (got_f.view(np.uint32) == want_f.view(np.uint32)).all()

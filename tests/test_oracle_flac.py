@@ -60,3 +60,13 @@ def test_prediction_accumulators():
         w64 = (((exact >> shift) + 2 ** 31) % 2 ** 32) - 2 ** 31
         assert L.afgo_flac_prediction_64(3, shift, coef.ctypes.data, p) == w64
     assert L.afgo_flac_prediction_32(0, 3, coef.ctypes.data, p) == 0
+
+
+def test_int16_residual_rows_are_the_same_samples():
+    """the int16 storage of residual rows (include/afg.h AFG_FLAC_ROW16) is a storage format only"""
+    from afgpu import synthetic
+    frames, subframes, res, total = synthetic.flac_batch(5, n_frames=40, vary_block=True, orders=(0, 3, 8, 12))
+    want = oraclelib.flac_transform(frames, subframes, res, total)
+    pf, pres = synthetic.flac_pack16(frames, res, 2)
+    assert pf["res16"].sum() >= 15 and (pf["in_off"][pf["res16"] == 1] % 8 == 0).all()
+    assert (oraclelib.flac_transform(pf, subframes, pres, total) == want).all()

@@ -35,6 +35,53 @@ template <int ROWS, int T, int TILED = 0> __global__ __launch_bounds__(64) void 
         __builtin_amdgcn_wave_barrier();
     }
 }
+// Variant: residuals as int16: per step ROWS*2 reads of 2T bytes (16-byte loads of 8 samples), widened into the
+// same LDS tile, writes unchanged (8T bytes per row).
+template <int ROWS, int T> __global__ __launch_bounds__(64) void k16(const short *__restrict__ in, int *__restrict__ out)
+{
+    constexpr int PIECES = T / 8;                       // 16-byte pieces (8 samples) per row-channel chunk
+    constexpr int LOADS = ROWS * 2 * PIECES / 64;
+    constexpr int STORES = ROWS * 2 * (T / 4) / 64;
+    __shared__ __attribute__((aligned(16))) int tile[ROWS * 2 * T];
+    const int lane = threadIdx.x;
+    const size_t f0 = (size_t)blockIdx.x * ROWS;
+    i4 nxt[LOADS];
+    auto load = [&](int t0) {
+        for (int i = 0; i < LOADS; i++) {
+            const int e = lane + 64 * i, rc = e / PIECES, p = e % PIECES;
+            nxt[i] = *(const i4 *)(in + (2 * f0 + rc) * 4096 + t0 + 8 * p);
+        }
+    };
+    load(0);
+    for (int t0 = 0; t0 < 4096; t0 += T) {
+        for (int i = 0; i < LOADS; i++) {
+            const int e = lane + 64 * i;
+            const i4 v = nxt[i];
+            ((i4 *)tile)[2 * e] = i4{ (v.x << 16) >> 16, v.x >> 16, (v.y << 16) >> 16, v.y >> 16 };
+            ((i4 *)tile)[2 * e + 1] = i4{ (v.z << 16) >> 16, v.z >> 16, (v.w << 16) >> 16, v.w >> 16 };
+        }
+        if (t0 + T < 4096) load(t0 + T);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < LOADS; i++) asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y), "+v"(nxt[i].z), "+v"(nxt[i].w) : : "memory");
+        for (int i = 0; i < STORES; i++) {
+            const int e = lane + 64 * i, r = e / (2 * (T / 4)), q = e % (2 * (T / 4));
+            const i4 v = ((const i4 *)tile)[e];
+            *(i4 *)(out + (f0 + r) * 8192 + 2 * t0 + 4 * q) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+template <int ROWS, int T> void run16(const int *in, int *out, size_t frames, const char *name)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k16<ROWS, T>), dim3(frames / ROWS), dim3(64), 0, 0, (const short *)in, out);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("%-28s %.3f ms  (%.2f TB/s of 6 B per sample)\n", name, ms, 1.5 * frames * 8192 * 4 / ms / 1e9);
+    }
+}
 template <int ROWS, int T, int TILED = 0> void run(const int *in, int *out, size_t frames, const char *name)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -61,5 +108,7 @@ int main()
     run<64, 32, 1>(in, out, frames, "64 x 128 B, tiled reads");
     run<64, 16, 1>(in, out, frames, "64 x 64 B, tiled reads");
     run<64, 32, 2>(in, out, frames, "64 x 128 B, tiled both");
+    run16<64, 32>(in, out, frames, "int16 in: 64 x 64 B reads");
+    run16<64, 64>(in, out, frames, "int16 in: 64 x 128 B reads");
     return 0;
 }
