@@ -84,9 +84,11 @@ struct afg_flac_frame
     ubyte channels;
     ubyte assignment;
     ubyte bps;
-    ubyte[5] pad;
+    ubyte res16;          // 1: the frame's residual rows are int16 (in_off counts int16 elements, rows of AFG_FLAC_ROW16)
+    ubyte[4] pad;
 }
 static assert(afg_flac_frame.sizeof == 32);
+ulong AFG_FLAC_ROW16(ulong block_size) { return (block_size + 7) & ~7UL; }
 
 int afg_flac_transform_hip(ulong n_frames, const(afg_flac_frame)* d_frames,
                            const(afg_flac_subframe)* d_subframes, const(int)* d_res,
