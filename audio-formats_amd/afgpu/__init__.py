@@ -22,6 +22,9 @@ FLAC_INDEPENDENT, FLAC_LEFT_SIDE, FLAC_RIGHT_SIDE, FLAC_MID_SIDE = 0, 8, 9, 10
 
 FLAC_SUBFRAME_DTYPE = np.dtype([("coef", np.int16, (32,)), ("order", np.uint8), ("shift", np.uint8),
                                 ("wasted", np.uint8), ("use64", np.uint8)], align=True)
+VORBIS_FLOOR_PACKET_DTYPE = np.dtype([("spec_off", np.uint64), ("n2", np.uint32), ("channels", np.uint32), ("curve_index", np.uint32),
+                                      ("step_off", np.uint32), ("n_steps", np.uint32), ("pad", np.uint32)])
+VORBIS_FLOOR_CURVE_DTYPE = np.dtype([("point_off", np.uint32), ("n_points", np.uint32)])
 FLAC_FRAME_DTYPE = np.dtype([("in_off", np.uint64), ("out_off", np.uint64), ("block_size", np.uint32),
                              ("sf_index", np.uint32), ("channels", np.uint8), ("assignment", np.uint8),
                              ("bps", np.uint8), ("res16", np.uint8), ("pad", np.uint8, (4,))], align=True)
@@ -47,7 +50,7 @@ ABI_SYMBOLS = [
     "afg_mp3_transform_hip", "afg_mp3_requant_hip", "afg_mp3_parse_q", "afg_mp3_parsed_q_free", "afg_mp3_qtables",
     "afg_vorbis_plan_create", "afg_vorbis_plan_destroy", "afg_vorbis_plan_packets",
     "afg_vorbis_plan_spec_floats", "afg_vorbis_plan_out_floats", "afg_vorbis_plan_offsets",
-    "afg_vorbis_transform_hip",
+    "afg_vorbis_transform_hip", "afg_vorbis_floor_hip", "afg_vorbis_parse_r", "afg_vorbis_parsed_r_free",
     "afg_flac_transform_hip",
     "afg_qoa_transform_hip",
     "afg_celt_transform_hip", "afg_celt_transform_streams_hip",
@@ -105,6 +108,11 @@ class VorbisParsed(C.Structure):
                 ("total_samples", C.c_uint32), ("n_packets", C.c_uint64), ("spec_floats", C.c_uint64),
                 ("pcm_frames", C.c_uint64), ("pflags", C.c_void_p), ("spec", C.c_void_p), ("take_from", C.c_void_p),
                 ("take_count", C.c_void_p), ("owner", C.c_void_p)]
+
+
+class VorbisParsedR(C.Structure):
+    _fields_ = [("base", VorbisParsed), ("n_curves", C.c_uint64), ("n_points", C.c_uint64), ("n_steps", C.c_uint64),
+                ("packets", C.c_void_p), ("curves", C.c_void_p), ("points", C.c_void_p), ("steps", C.c_void_p)]
 
 
 class OpusParsed(C.Structure):
@@ -186,6 +194,7 @@ def lib():
         fn.restype = u64
     L.afg_vorbis_plan_offsets.argtypes = [vp, vp, vp]
     L.afg_vorbis_transform_hip.argtypes = [vp, vp, vp, vp]
+    L.afg_vorbis_floor_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
     L.afg_flac_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
     L.afg_qoa_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp]
     L.afg_celt_transform_hip.argtypes = [u32, vp, vp, vp, vp, vp, vp]
@@ -220,6 +229,9 @@ def lib():
     L.afg_vorbis_parse.argtypes = [vp, C.c_size_t, C.POINTER(VorbisParsed)]
     L.afg_vorbis_parsed_free.argtypes = [C.POINTER(VorbisParsed)]
     L.afg_vorbis_parsed_free.restype = None
+    L.afg_vorbis_parse_r.argtypes = [vp, C.c_size_t, C.POINTER(VorbisParsedR)]
+    L.afg_vorbis_parsed_r_free.argtypes = [C.POINTER(VorbisParsedR)]
+    L.afg_vorbis_parsed_r_free.restype = None
     L.afg_qoa_parse.argtypes = [vp, C.c_size_t, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, C.c_size_t,
                                 C.POINTER(C.c_size_t)]
     L.afg_batch_decode.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(BatchResult)]
@@ -532,6 +544,38 @@ def vorbis_parse(file_bytes):
                 "take_from": view(out.take_from, n, np.int32), "take_count": view(out.take_count, n, np.int32)}
     finally:
         lib().afg_vorbis_parsed_free(C.byref(out))
+
+
+def vorbis_parse_r(file_bytes):
+    """afg_vorbis_parse_r: vorbis_parse's dict with `spec` holding residue vectors, plus the inputs of vorbis_floor:
+    fl_packets (VORBIS_FLOOR_PACKET_DTYPE), fl_curves (VORBIS_FLOOR_CURVE_DTYPE), fl_points int32 [n, 2], fl_steps uint8 [n, 2]."""
+    buf = bytes(file_bytes)
+    out = VorbisParsedR()
+    check(lib().afg_vorbis_parse_r(buf, len(buf), C.byref(out)))
+    try:
+        def view(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype)
+            raw = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(raw, dtype=dtype, count=count).copy()
+        b = out.base
+        n = int(b.n_packets)
+        return {"channels": b.channels, "sample_rate": b.sample_rate, "blocksize0": b.blocksize0,
+                "blocksize1": b.blocksize1, "total_samples": int(b.total_samples), "pcm_frames": int(b.pcm_frames),
+                "pflags": view(b.pflags, n, np.uint8), "spec": view(b.spec, int(b.spec_floats), np.float32),
+                "take_from": view(b.take_from, n, np.int32), "take_count": view(b.take_count, n, np.int32),
+                "fl_packets": view(out.packets, n, VORBIS_FLOOR_PACKET_DTYPE),
+                "fl_curves": view(out.curves, int(out.n_curves), VORBIS_FLOOR_CURVE_DTYPE),
+                "fl_points": view(out.points, 2 * int(out.n_points), np.int32).reshape(-1, 2),
+                "fl_steps": view(out.steps, 2 * int(out.n_steps), np.uint8).reshape(-1, 2)}
+    finally:
+        lib().afg_vorbis_parsed_r_free(C.byref(out))
+
+
+def vorbis_floor(n_packets, d_packets, d_curves, d_points, d_steps, d_spec, stream=None):
+    """afg_vorbis_floor_hip: inverse coupling + floor curves in place on the residue plane (device tensors; records as uint8
+    views of the dtypes above)."""
+    check(lib().afg_vorbis_floor_hip(int(n_packets), _ptr(d_packets), _ptr(d_curves), _ptr(d_points), _ptr(d_steps), _ptr(d_spec), _stream(stream)))
 
 
 def opus_parse(file_bytes):

@@ -70,6 +70,9 @@ struct Parsed {
     const uint32_t *mp3_flags() const { return mp3.ext_flags ? mp3.ext_flags : mp3.flags.data(); }
 };
 
+// Vorbis: inverse coupling and floor curves on the device (default) or in the host parser (AFG_VORBIS_HOST_FLOOR=1)
+static bool vorbis_floor_on_device() { return std::getenv("AFG_VORBIS_HOST_FLOOR") == nullptr; }
+
 struct DeviceBuf {
     void *p = nullptr;
     ~DeviceBuf() { if (p) (void)hipFree(p); }
@@ -899,9 +902,63 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
             int rc = AFG_OK;
-            for (OggChunk &c : ogg.v) {
+            // Files parsed with the floor left to the device: their packets' coupling / floor records go up
+            // with the chunk (one page-locked block: packets, curves, points, steps of chunk after chunk) and
+            // afg_vorbis_floor_hip turns the residue vectors into spectra in place, in front of the transform.
+            std::vector<size_t> f_pk(nf + 1, 0), f_cv(nf + 1, 0), f_pt(nf + 1, 0), f_st(nf + 1, 0);
+            for (size_t i = 0; i < nf; i++) {
+                const bool on = fmt_of(parsed[i]) == AFG_FORMAT_OGG && parsed[i].ogg.device_floor;
+                f_pk[i + 1] = f_pk[i] + (on ? parsed[i].ogg.fl_packets.size() : 0);
+                f_cv[i + 1] = f_cv[i] + (on ? parsed[i].ogg.fl_curves.size() : 0);
+                f_pt[i + 1] = f_pt[i] + (on ? parsed[i].ogg.fl_points.size() / 2 : 0);
+                f_st[i + 1] = f_st[i] + (on ? parsed[i].ogg.fl_steps.size() / 2 : 0);
+            }
+            const size_t fl_pk_bytes = f_pk[nf] * sizeof(afg_vorbis_floor_packet), fl_cv_bytes = f_cv[nf] * sizeof(afg_vorbis_floor_curve),
+                         fl_pt_bytes = f_pt[nf] * 8, fl_st_bytes = f_st[nf] * 2;
+            const size_t fl_bytes = fl_pk_bytes + fl_cv_bytes + fl_pt_bytes + fl_st_bytes;
+            StagingPool::Lease h_fl;
+            DeviceBuf d_fl;
+            if (f_pk[nf]) {
+                if (int rc2 = g_staging.take(fl_bytes, h_fl)) return rc2;
+                if (int rc2 = d_fl.alloc(fl_bytes)) return rc2;
+            }
+            auto fl_at = [&](void *base0, int which, size_t index) -> uint8_t * {   // 0 packets, 1 curves, 2 points, 3 steps
+                uint8_t *b = (uint8_t *)base0;
+                if (which == 0) return b + index * sizeof(afg_vorbis_floor_packet);
+                if (which == 1) return b + fl_pk_bytes + index * sizeof(afg_vorbis_floor_curve);
+                if (which == 2) return b + fl_pk_bytes + fl_cv_bytes + index * 8;
+                return b + fl_pk_bytes + fl_cv_bytes + fl_pt_bytes + index * 2;
+            };
+            for (size_t ci = 0; ci < ogg.v.size(); ci++) {
+                OggChunk &c = ogg.v[ci];
                 if (rc || e != hipSuccess) break;
                 const float *hs = ogg_staged ? ogg_stage->spec + c.spec0 : (const float *)h_spec.p + c.spec0;
+                const size_t npk_c = f_pk[c.f1] - f_pk[c.f0];
+                if (npk_c) {
+                    parallel_for(c.f1 - c.f0, threads, [&](size_t k) {
+                        const size_t i = c.f0 + k;
+                        const Parsed &p = parsed[i];
+                        if (f_pk[i + 1] == f_pk[i]) return;
+                        // chunk-local indices (the kernel gets the chunk's slices), absolute spectrum offsets
+                        const size_t spec_base = ogg_staged ? ogg_stage->base[i] : c.spec0 + c.spec_at[k];
+                        afg_vorbis_floor_packet *pk = (afg_vorbis_floor_packet *)fl_at(h_fl.p, 0, f_pk[i]);
+                        for (size_t q = 0; q < p.ogg.fl_packets.size(); q++) {
+                            afg_vorbis_floor_packet r = p.ogg.fl_packets[q];
+                            r.spec_off += spec_base;
+                            r.curve_index += (uint32_t)(f_cv[i] - f_cv[c.f0]);
+                            r.step_off += (uint32_t)(f_st[i] - f_st[c.f0]);
+                            pk[q] = r;
+                        }
+                        afg_vorbis_floor_curve *cv = (afg_vorbis_floor_curve *)fl_at(h_fl.p, 1, f_cv[i]);
+                        for (size_t q = 0; q < p.ogg.fl_curves.size(); q++) {
+                            afg_vorbis_floor_curve r = p.ogg.fl_curves[q];
+                            r.point_off += (uint32_t)(f_pt[i] - f_pt[c.f0]);
+                            cv[q] = r;
+                        }
+                        if (!p.ogg.fl_points.empty()) std::memcpy(fl_at(h_fl.p, 2, f_pt[i]), p.ogg.fl_points.data(), p.ogg.fl_points.size() * sizeof(int32_t));
+                        if (!p.ogg.fl_steps.empty()) std::memcpy(fl_at(h_fl.p, 3, f_st[i]), p.ogg.fl_steps.data(), p.ogg.fl_steps.size());
+                    });
+                }
                 if (!ogg_staged) {
                     float *hw = (float *)h_spec.p + c.spec0;
                     parallel_for(c.f1 - c.f0, threads, [&](size_t k) {
@@ -913,6 +970,20 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 }
                 e = hipMemcpyAsync((float *)d_spec.p + c.spec0, hs, c.spec_n * sizeof(float), hipMemcpyHostToDevice, up);
                 if (e != hipSuccess) break;
+                if (npk_c) {
+                    const struct { int which; size_t i0, i1, unit; } part[4] = {
+                        { 0, f_pk[c.f0], f_pk[c.f1], sizeof(afg_vorbis_floor_packet) }, { 1, f_cv[c.f0], f_cv[c.f1], sizeof(afg_vorbis_floor_curve) },
+                        { 2, f_pt[c.f0], f_pt[c.f1], 8 }, { 3, f_st[c.f0], f_st[c.f1], 2 } };
+                    for (const auto &pt : part) {
+                        if (pt.i1 == pt.i0 || e != hipSuccess) continue;
+                        e = hipMemcpyAsync(fl_at(d_fl.p, pt.which, pt.i0), fl_at(h_fl.p, pt.which, pt.i0), (pt.i1 - pt.i0) * pt.unit, hipMemcpyHostToDevice, up);
+                    }
+                    if (e != hipSuccess) break;
+                    rc = afg_vorbis_floor_hip(npk_c, (const afg_vorbis_floor_packet *)fl_at(d_fl.p, 0, f_pk[c.f0]),
+                                              (const afg_vorbis_floor_curve *)fl_at(d_fl.p, 1, f_cv[c.f0]), (const int32_t *)fl_at(d_fl.p, 2, f_pt[c.f0]),
+                                              (const uint8_t *)fl_at(d_fl.p, 3, f_st[c.f0]), (float *)d_spec.p, up);
+                    if (rc) break;
+                }
                 // a staged plan addresses the staging layout from float 0; a gathered one is packed from its chunk's start
                 rc = afg_vorbis_transform_hip(c.plan, (const float *)d_spec.p + (ogg_staged ? 0 : c.spec0), (float *)d_pcm.p + c.out0, up);
                 if (rc) break;
@@ -1119,7 +1190,7 @@ struct afg_stream {
         if (format == AFG_FORMAT_OGG) {
             afg_vorbis::File meta;
             ogg.reset(new afg_vorbis::Reader);
-            return ogg->open(bytes.data(), bytes.size(), meta);
+            return ogg->open(bytes.data(), bytes.size(), meta, vorbis_floor_on_device());
         }
         return true;
     }
@@ -1244,7 +1315,7 @@ afg_stream *afg_open_from_memory(const uint8_t *data, size_t length)
             s->channels = (int)s->qi.channels;
             s->samplerate = (float)s->qi.samplerate;
             s->declared_frames = (int64_t)s->qi.samples;
-        } else if ((s->ogg.reset(new afg_vorbis::Reader), s->ogg->open(d, length, og))) {
+        } else if ((s->ogg.reset(new afg_vorbis::Reader), s->ogg->open(d, length, og, vorbis_floor_on_device()))) {
             s->format = AFG_FORMAT_OGG;
             s->channels = og.channels;
             s->samplerate = (float)og.sample_rate;
@@ -1497,7 +1568,7 @@ void afg_mp3_parsed_q_free(afg_mp3_parsed_q *p)
     std::memset(p, 0, sizeof(*p));
 }
 
-int afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out)
+static int vorbis_parse_any(const uint8_t *data, size_t length, afg_vorbis_parsed *out, bool device_floor)
 {
     try {
         if (!out) return AFG_ERR_INVALID;
@@ -1505,7 +1576,7 @@ int afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out)
         if (!data) return AFG_ERR_INVALID;
         auto *own = new (std::nothrow) afg_vorbis::File;
         if (!own) return AFG_ERR_OOM;
-        if (!afg_vorbis::parse_file(data, length, *own)) {
+        if (!afg_vorbis::parse_file(data, length, *own, device_floor)) {
             delete own;
             afg::set_error("afg_vorbis_parse: not an Ogg Vorbis I stream");
             return AFG_ERR_UNSUPPORTED;
@@ -1530,10 +1601,35 @@ int afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out)
     }
 }
 
+int afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out) { return vorbis_parse_any(data, length, out, false); }
+
 void afg_vorbis_parsed_free(afg_vorbis_parsed *p)
 {
     if (!p) return;
     delete (afg_vorbis::File *)p->owner;
+    std::memset(p, 0, sizeof(*p));
+}
+
+int afg_vorbis_parse_r(const uint8_t *data, size_t length, afg_vorbis_parsed_r *out)
+{
+    if (!out) return AFG_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    if (int rc = vorbis_parse_any(data, length, &out->base, true)) return rc;
+    afg_vorbis::File *own = (afg_vorbis::File *)out->base.owner;
+    out->n_curves = own->fl_curves.size();
+    out->n_points = own->fl_points.size() / 2;
+    out->n_steps = own->fl_steps.size() / 2;
+    out->packets = own->fl_packets.data();
+    out->curves = own->fl_curves.data();
+    out->points = own->fl_points.data();
+    out->steps = own->fl_steps.data();
+    return AFG_OK;
+}
+
+void afg_vorbis_parsed_r_free(afg_vorbis_parsed_r *p)
+{
+    if (!p) return;
+    afg_vorbis_parsed_free(&p->base);
     std::memset(p, 0, sizeof(*p));
 }
 
@@ -2000,9 +2096,9 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 Parsed &p = parsed[i];
                 bool ok = false;
                 try {
-                    ok = afg_vorbis::parse_file_into(data[i], length[i], p.ogg, spec0 + ogg_base[i], ogg_bound[i]);
+                    ok = afg_vorbis::parse_file_into(data[i], length[i], p.ogg, spec0 + ogg_base[i], ogg_bound[i], vorbis_floor_on_device());
                     if (ok && p.ogg.overflow) {                  // cannot happen; be safe: the file's own buffer
-                        ok = afg_vorbis::parse_file(data[i], length[i], p.ogg);
+                        ok = afg_vorbis::parse_file(data[i], length[i], p.ogg, vorbis_floor_on_device());
                         lost = true;
                     }
                 } catch (...) { ok = false; }

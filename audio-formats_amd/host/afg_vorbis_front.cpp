@@ -325,6 +325,7 @@ struct Residue {
 };
 struct Mapping {
     int coupling = 0, submaps = 1;
+    uint32_t step_off = 0;                   // where this mapping's coupling steps sit in File::fl_steps
     uint8_t mag[256], ang[256], mux[16];
     uint8_t floor_of[16], residue_of[16];
 };
@@ -615,6 +616,11 @@ struct Scratch {
     std::vector<float> spec;                 // channels * n/2
     std::vector<int16_t> y;                  // channels * 256
     std::vector<int> cls;                    // residue classifications of the submap being decoded
+    // device floor: what the packet leaves to afg_vorbis_floor_hip
+    bool device_floor = false;
+    int mapping = 0;
+    std::vector<uint32_t> n_points;          // per channel; 0 = really_zero_channel
+    std::vector<int32_t> points;             // (x, y) pairs, channel after channel
 };
 
 // returns false when the packet cannot be decoded at all (not an audio packet / bad mode); `flags` and the window
@@ -806,6 +812,30 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
         }
     }
 
+    if (sc.device_floor) {
+        // the tail below as records: the floor points do_floor walks (:2262-2272), in its order, y scaled
+        sc.mapping = mode.mapping;
+        sc.n_points.assign((size_t)C, 0);
+        sc.points.clear();
+        for (int i = 0; i < C; i++) {
+            if (really_zero[i]) continue;
+            const Floor1 &g = st.floors[map.floor_of[map.mux[i]]];
+            const int16_t *Y = sc.y.data() + (size_t)i * 256;
+            sc.points.push_back(0);
+            sc.points.push_back(Y[0] * g.multiplier);
+            uint32_t np = 1;
+            for (int q = 1; q < g.values; q++) {
+                const int j = g.order[q];
+                if (Y[j] >= 0) {
+                    sc.points.push_back(g.x[j]);
+                    sc.points.push_back(Y[j] * g.multiplier);
+                    np++;
+                }
+            }
+            sc.n_points[(size_t)i] = np;
+        }
+        return true;
+    }
     // inverse coupling (:2493-2514)
     for (int i = map.coupling - 1; i >= 0; --i) {
         float *m = sc.spec.data() + (size_t)map.mag[i] * (size_t)n, *a = sc.spec.data() + (size_t)map.ang[i] * (size_t)n;
@@ -964,6 +994,14 @@ bool open_stream(const uint8_t *data, size_t size, File &f, Demux &dm, Setup &st
         if (!read_setup(br, st)) return false;
         if (!p.complete) return false;
     }
+    f.fl_steps.clear();
+    for (Mapping &m : st.mappings) {
+        m.step_off = (uint32_t)(f.fl_steps.size() / 2);
+        for (int i = m.coupling - 1; i >= 0; --i) {
+            f.fl_steps.push_back(m.mag[i]);
+            f.fl_steps.push_back(m.ang[i]);
+        }
+    }
     return true;
 }
 
@@ -980,7 +1018,7 @@ size_t max_spec_floats(const uint8_t *data, size_t size)
     return (dm.packets.size() - 3 + 1) * (size_t)f.channels * (size_t)(f.blocksize1 / 2);
 }
 
-bool parse_file(const uint8_t *data, size_t size, File &f) { return parse_file_into(data, size, f, nullptr, 0); }
+bool parse_file(const uint8_t *data, size_t size, File &f, bool device_floor) { return parse_file_into(data, size, f, nullptr, 0, device_floor); }
 
 namespace {
 
@@ -1001,6 +1039,29 @@ struct Walk {
     std::vector<float> last_spec;
     unsigned last_flags = 0;
     bool have_last = false;
+    int last_mapping = 0;
+    std::vector<uint32_t> last_n_points;
+    std::vector<int32_t> last_points;
+
+    // one packet's floor records appended to `f` (its spectrum starts at f.n_spec)
+    void add_floor_records(File &f, int n2, int mapping, const std::vector<uint32_t> &n_points, const std::vector<int32_t> &points) const
+    {
+        afg_vorbis_floor_packet r;
+        std::memset(&r, 0, sizeof(r));
+        r.spec_off = f.n_spec;
+        r.n2 = (uint32_t)n2;
+        r.channels = (uint32_t)f.channels;
+        r.curve_index = (uint32_t)f.fl_curves.size();
+        r.step_off = st.mappings[(size_t)mapping].step_off;
+        r.n_steps = (uint32_t)st.mappings[(size_t)mapping].coupling;
+        f.fl_packets.push_back(r);
+        uint32_t at = (uint32_t)(f.fl_points.size() / 2);
+        for (uint32_t np : n_points) {
+            f.fl_curves.push_back(afg_vorbis_floor_curve{ at, np });
+            at += np;
+        }
+        f.fl_points.insert(f.fl_points.end(), points.begin(), points.end());
+    }
 
     // Decodes packet k into `f`; false: the stream ends here (nothing recorded).  `recorded` tells whether a record was
     // appended (non-audio packets are skipped).
@@ -1071,6 +1132,7 @@ struct Walk {
         // record
         if (f.ext_spec && f.n_spec + (size_t)f.channels * (size_t)n2 > f.ext_cap) { f.overflow = true; return false; }
         f.pflags.push_back((uint8_t)flags);
+        if (sc.device_floor) add_floor_records(f, n2, sc.mapping, sc.n_points, sc.points);
         if (f.ext_spec) {
             for (int c = 0; c < f.channels; c++)
                 std::memcpy(f.ext_spec + f.n_spec + (size_t)c * (size_t)n2, sc.spec.data() + (size_t)c * (size_t)n, (size_t)n2 * sizeof(float));
@@ -1084,6 +1146,11 @@ struct Walk {
                 std::memcpy(last_spec.data() + (size_t)c * (size_t)n2, sc.spec.data() + (size_t)c * (size_t)n, (size_t)n2 * sizeof(float));
             last_flags = flags;
             have_last = true;
+            if (sc.device_floor) {
+                last_mapping = sc.mapping;
+                last_n_points = sc.n_points;
+                last_points = sc.points;
+            }
         }
         f.n_spec += (size_t)f.channels * (size_t)n2;
         int r = std::min(right_start, len);
@@ -1101,13 +1168,14 @@ struct Walk {
 
 }  // namespace
 
-bool parse_file_into(const uint8_t *data, size_t size, File &f, float *spec_dst, size_t cap)
+bool parse_file_into(const uint8_t *data, size_t size, File &f, float *spec_dst, size_t cap, bool device_floor)
 {
     f = File();
     Walk w;
     if (!open_stream(data, size, f, w.dm, w.st)) { f = File(); return false; }
     w.data = data;
     w.size = size;
+    f.device_floor = w.sc.device_floor = device_floor;
     f.ext_spec = spec_dst;
     f.ext_cap = cap;
     bool recorded = false;
@@ -1125,13 +1193,14 @@ struct Reader::Impl {
 Reader::Reader() : p(new Impl) {}
 Reader::~Reader() { delete p; }
 
-bool Reader::open(const uint8_t *data, size_t size, File &meta)
+bool Reader::open(const uint8_t *data, size_t size, File &meta, bool device_floor)
 {
     *p = Impl();
     p->meta = File();
     if (!open_stream(data, size, p->meta, p->w.dm, p->w.st)) return false;
     p->w.data = data;
     p->w.size = size;
+    p->meta.device_floor = p->w.sc.device_floor = device_floor;
     p->meta.total_samples = stream_length(data, size, p->w.dm.first_audio_page);
     meta = p->meta;
     return true;
@@ -1145,9 +1214,15 @@ bool Reader::more(File &out, int max_packets)
     out.blocksize1 = p->meta.blocksize1;
     out.sample_rate = p->meta.sample_rate;
     out.total_samples = p->meta.total_samples;
+    out.device_floor = p->meta.device_floor;
+    out.fl_steps = p->meta.fl_steps;
     Walk &w = p->w;
     if (w.have_last) {                                     // the predecessor of this chunk's first packet: primes the overlap only
         out.pflags.push_back((uint8_t)w.last_flags);
+        if (out.device_floor) {
+            const int n2 = ((w.last_flags & AFG_VORBIS_LONG) ? out.blocksize1 : out.blocksize0) >> 1;
+            w.add_floor_records(out, n2, w.last_mapping, w.last_n_points, w.last_points);
+        }
         out.spec = w.last_spec;
         out.n_spec = out.spec.size();
         out.take_from.push_back(0);

@@ -161,6 +161,31 @@ int      afg_vorbis_plan_offsets(const afg_vorbis_plan *plan, uint64_t *spec_off
 
 int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, float *d_out, void *hip_stream);
 
+/* Vorbis inverse coupling and floor curve on the device: replaces stb_vorbis2.d:2493-2514 (inverse coupling),
+ * :2516-2523 / :2255-2284 (do_floor, silent channels) and :1534-1563 (draw_line) between the host's residue decode and the
+ * transform above.  d_spec holds the decoded *residue* vectors in the transform's layout ([channel][n2] per packet) and is
+ * rewritten in place with the spectra.
+ * A curve is the list of floor-1 points that survive step 2 (finalY >= 0), in sorted_order, as int32 pairs
+ * (x = Xlist[j], y = finalY[j] * floor1_multiplier), the first one at x = 0.  n_points == 0: really_zero_channel.
+ * Coupling steps are byte pairs (magnitude channel, angle channel) in the order they are applied (coupling_steps-1 .. 0). */
+typedef struct afg_vorbis_floor_packet {
+    uint64_t spec_off;     /* float index of channel 0's n2 values; channel c at spec_off + c*n2 */
+    uint32_t n2;           /* blocksize / 2, a multiple of 4 */
+    uint32_t channels;
+    uint32_t curve_index;  /* channel 0's afg_vorbis_floor_curve; channel c at curve_index + c */
+    uint32_t step_off;     /* first coupling step: bytes d_steps[2*step_off], d_steps[2*step_off + 1] */
+    uint32_t n_steps;
+    uint32_t pad;
+} afg_vorbis_floor_packet; /* 32 bytes */
+
+typedef struct afg_vorbis_floor_curve {
+    uint32_t point_off;    /* first point: d_points[2*point_off] = x, d_points[2*point_off + 1] = y */
+    uint32_t n_points;
+} afg_vorbis_floor_curve;  /* 8 bytes */
+
+int afg_vorbis_floor_hip(uint64_t n_packets, const afg_vorbis_floor_packet *d_packets, const afg_vorbis_floor_curve *d_curves,
+                         const int32_t *d_points, const uint8_t *d_steps, float *d_spec, void *hip_stream);
+
 /* ========================================================================== *
  *  FLAC sample restore
  *  replaces drflac.d:1235 (residual + drflac__calculate_prediction_32/_64,
@@ -390,6 +415,19 @@ typedef struct afg_vorbis_parsed {
 
 int  afg_vorbis_parse(const uint8_t *data, size_t length, afg_vorbis_parsed *out);   /* AFG_ERR_UNSUPPORTED: not Ogg Vorbis */
 void afg_vorbis_parsed_free(afg_vorbis_parsed *parsed);
+/* The same with the tail of the packet decode left to the device: base.spec holds the residue vectors and the records
+ * below are the inputs of afg_vorbis_floor_hip (spec_off counted from base.spec; steps per mapping, shared by its packets). */
+typedef struct afg_vorbis_parsed_r {
+    afg_vorbis_parsed base;
+    uint64_t n_curves, n_points, n_steps;
+    afg_vorbis_floor_packet *packets;  /* [base.n_packets] */
+    afg_vorbis_floor_curve  *curves;   /* [n_curves] = one per packet-channel */
+    int32_t *points;                   /* [2 * n_points] */
+    uint8_t *steps;                    /* [2 * n_steps] */
+} afg_vorbis_parsed_r;
+
+int  afg_vorbis_parse_r(const uint8_t *data, size_t length, afg_vorbis_parsed_r *out);
+void afg_vorbis_parsed_r_free(afg_vorbis_parsed_r *parsed);
 
 /* Ogg Opus front-end on its own, CELT-only packets: Ogg pages, OpusHead / OpusTags (dopus.d:7791-7829, :8120-8193; output
  * gain :1311-1316 with R128_TRACK_GAIN :8011-8059), packet framing (ff_opus_parse_packet, :1081-1258), the range decoder

@@ -167,6 +167,17 @@ int afgo_vorbis_decode_file(const uint8_t *data, size_t size, afgo_vorbis_file *
 int afgo_vorbis_decode_file_ex(const uint8_t *data, size_t size, afgo_vorbis_file *out, int seek_clears_eof);
 void afgo_vorbis_file_free(afgo_vorbis_file *f);
 
+/* The tail of the packet decode on records (same layouts as include/afg.h afg_vorbis_floor_packet / _curve): inverse
+ * coupling (stb_vorbis2.d:2493-2514), silent channels and do_floor (:2516-2523, :2255-2284) with draw_line (:1534-1563),
+ * in place on residue vectors.  Checker of afg_vorbis_floor_hip. */
+typedef struct afgo_vorbis_floor_packet {
+    uint64_t spec_off;
+    uint32_t n2, channels, curve_index, step_off, n_steps, pad;
+} afgo_vorbis_floor_packet;
+typedef struct afgo_vorbis_floor_curve { uint32_t point_off, n_points; } afgo_vorbis_floor_curve;
+void afgo_vorbis_floor(uint64_t n_packets, const afgo_vorbis_floor_packet *packets, const afgo_vorbis_floor_curve *curves,
+                       const int32_t *points, const uint8_t *steps, float *spec);
+
 /* ----------------------------------------------------------------- FLAC -- */
 
 /* drflac.d:1060-1140 */

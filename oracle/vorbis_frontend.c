@@ -1473,3 +1473,55 @@ void afgo_vorbis_file_free(afgo_vorbis_file *f)
     free(f->take_count);
     memset(f, 0, sizeof(*f));
 }
+
+/* ---- the same tail driven by records (checker of the device floor stage) ---- */
+void afgo_vorbis_floor(uint64_t n_packets, const afgo_vorbis_floor_packet *packets, const afgo_vorbis_floor_curve *curves,
+                       const int32_t *points, const uint8_t *steps, float *spec)
+{
+    uint64_t p;
+    for (p = 0; p < n_packets; ++p) {
+        const afgo_vorbis_floor_packet *k = packets + p;
+        const int n2 = (int)k->n2;
+        float *base = spec + k->spec_off;
+        uint32_t s, c;
+        int j;
+        /* INVERSE COUPLING, vb:2493-2514 (steps are stored in the order the loop visits them) */
+        for (s = 0; s < k->n_steps; ++s) {
+            float *m_ = base + (size_t)steps[2 * (k->step_off + s)] * (size_t)n2;
+            float *a = base + (size_t)steps[2 * (k->step_off + s) + 1] * (size_t)n2;
+            for (j = 0; j < n2; ++j) {
+                float a2, m2;
+                if (m_[j] > 0)
+                    if (a[j] > 0) { m2 = m_[j]; a2 = m_[j] - a[j]; }
+                    else { a2 = m_[j]; m2 = m_[j] + a[j]; }
+                else
+                    if (a[j] > 0) { m2 = m_[j]; a2 = m_[j] + a[j]; }
+                    else { a2 = m_[j]; m2 = m_[j] - a[j]; }
+                m_[j] = m2;
+                a[j] = a2;
+            }
+        }
+        /* finish decoding the floors, vb:2516-2523 with do_floor, vb:2255-2284 */
+        for (c = 0; c < k->channels; ++c) {
+            float *target = base + (size_t)c * (size_t)n2;
+            const afgo_vorbis_floor_curve *cv = curves + k->curve_index + c;
+            const int32_t *pt = points + 2 * (size_t)cv->point_off;
+            uint32_t q;
+            int lx, ly;
+            if (cv->n_points == 0) {
+                memset(target, 0, sizeof(float) * (size_t)n2);
+                continue;
+            }
+            lx = 0;
+            ly = pt[1];
+            for (q = 1; q < cv->n_points; ++q) {
+                const int hx = pt[2 * q], hy = pt[2 * q + 1];
+                if (lx != hx) draw_line(target, lx, ly, hx, hy, n2);
+                lx = hx;
+                ly = hy;
+            }
+            if (lx < n2)
+                for (j = lx; j < n2; ++j) target[j] *= f32(k_inverse_db_bits[ly & 255]);
+        }
+    }
+}

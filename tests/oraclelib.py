@@ -186,6 +186,21 @@ def vorbis_transform(npkt, nch, bs0, bs1, pflags, spec_off, out_off, spec, out_t
     return out
 
 
+def vorbis_floor(packets, curves, points, steps, spec):
+    """afgo_vorbis_floor: inverse coupling + floor curves on residue vectors; records in the product's dtypes.  Returns the spectra."""
+    out = np.ascontiguousarray(spec, np.float32).copy()
+    packets = np.ascontiguousarray(packets)
+    curves = np.ascontiguousarray(curves)
+    assert packets.dtype.itemsize == 32 and curves.dtype.itemsize == 8
+    points = np.ascontiguousarray(points, np.int32)
+    steps = np.ascontiguousarray(steps, np.uint8)
+    fn = lib().afgo_vorbis_floor
+    fn.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = None
+    fn(len(packets), packets.ctypes.data, curves.ctypes.data, points.ctypes.data, steps.ctypes.data, out.ctypes.data)
+    return out
+
+
 class _Mp3File(C.Structure):
     _fields_ = [("channels", C.c_int), ("hz", C.c_int), ("vbr_tag_found", C.c_int), ("start_delay", C.c_int),
                 ("detected_samples", C.c_uint64), ("samples", C.c_uint64), ("n_streams", C.c_uint32),

@@ -35,6 +35,9 @@ def test_record_layouts_match_the_header():
     assert afgpu.FLAC_SUBFRAME_DTYPE.itemsize == 68 and afgpu.FLAC_FRAME_DTYPE.itemsize == 32
     assert afgpu.FLAC_FRAME_DTYPE.fields["sf_index"][1] == 20 and afgpu.FLAC_FRAME_DTYPE.fields["channels"][1] == 24
     assert int(afgpu.mp3_flags(3, 2, 1)) == 3 | (2 << 8) | (2 << 16)
+    assert afgpu.FLAC_FRAME_DTYPE.fields["res16"][1] == 27
+    assert afgpu.VORBIS_FLOOR_PACKET_DTYPE.itemsize == 32 and afgpu.VORBIS_FLOOR_CURVE_DTYPE.itemsize == 8
+    assert afgpu.VORBIS_FLOOR_PACKET_DTYPE.fields["curve_index"][1] == 16 and afgpu.VORBIS_FLOOR_PACKET_DTYPE.fields["n_steps"][1] == 24
 
 
 def test_fails_loudly_without_a_device():

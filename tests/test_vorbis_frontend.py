@@ -147,3 +147,60 @@ def test_inconsistent_window_flags_end_the_stream():
         np.testing.assert_array_equal(got["pflags"], want["pflags"][:n])
         assert np.array_equal(got["spec"].view(np.uint32), want["spec"][:len(got["spec"])].view(np.uint32))
     assert hit >= 3
+
+
+# ---- the tail of the packet decode left to the device: records + residues instead of spectra ----
+def same_spectra_through_records(data):
+    """afg_vorbis_parse_r -> oracle restatement of coupling / do_floor on the records == afg_vorbis_parse's spectra"""
+    full = afgpu.vorbis_parse(data)
+    r = afgpu.vorbis_parse_r(data)
+    for k in ("channels", "sample_rate", "blocksize0", "blocksize1", "total_samples", "pcm_frames"):
+        assert r[k] == full[k], k
+    for k in ("pflags", "take_from", "take_count"):
+        np.testing.assert_array_equal(r[k], full[k], err_msg=k)
+    assert len(r["fl_packets"]) == len(full["pflags"]) and len(r["fl_curves"]) == len(full["pflags"]) * full["channels"]
+    assert r["spec"].shape == full["spec"].shape
+    got = oraclelib.vorbis_floor(r["fl_packets"], r["fl_curves"], r["fl_points"], r["fl_steps"], r["spec"])
+    assert np.array_equal(got.view(np.uint32), full["spec"].view(np.uint32))
+    # the records are what the header says: packets tile the plane, curves start at x = 0 with ascending x
+    at = 0
+    for k, fl in zip(r["fl_packets"], r["pflags"]):
+        n2 = (full["blocksize1"] if fl & 1 else full["blocksize0"]) // 2
+        assert (int(k["spec_off"]), int(k["n2"]), int(k["channels"])) == (at, n2, full["channels"])
+        at += n2 * full["channels"]
+    for c in r["fl_curves"]:
+        if c["n_points"]:
+            x = r["fl_points"][int(c["point_off"]):int(c["point_off"]) + int(c["n_points"]), 0]
+            assert x[0] == 0 and (np.diff(x) >= 0).all() and c["n_points"] >= 2
+    return r, full
+
+
+def test_residue_records_of_the_real_file():
+    r, full = same_spectra_through_records(open(OGG, "rb").read())
+    assert len(r["fl_steps"]) == 2 and all(tuple(s) == (0, 1) for s in r["fl_steps"])   # two mappings, one stereo coupling step each
+    assert not np.array_equal(r["spec"].view(np.uint32), full["spec"].view(np.uint32))
+    assert (r["fl_curves"]["n_points"] == 0).any()                                   # silent channels occur in the earcon's tail
+
+
+@pytest.mark.parametrize("channels,bs", [(1, (256, 2048)), (2, (256, 2048)), (2, (512, 512)), (3, (256, 1024)), (6, (1024, 4096)),
+                                         (2, (2048, 8192)), (16, (256, 256))])
+def test_residue_records_of_synthetic_streams(channels, bs):
+    import vorbis_bitstream as vb
+    steps = 0
+    for seed in range(6):
+        data = vb.make_file(100 * channels + seed, channels=channels, bs=bs, n_packets=20,
+                            residue_types=[(0, 1), (1, 2), (2, 0), (2, 2), (0, 0), (1, 1)][seed])
+        r, _ = same_spectra_through_records(data)
+        steps += int(r["fl_packets"]["n_steps"].sum())
+    assert channels == 1 or steps > 0                                               # coupled mappings were exercised
+
+
+def test_residue_records_of_damaged_files():
+    d = open(OGG, "rb").read()
+    rng = np.random.default_rng(11)
+    for trial in range(25):
+        v = bytearray(d)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(4000, len(v)))
+            v[pos] ^= 1 << int(rng.integers(0, 8))
+        same_spectra_through_records(bytes(v))
