@@ -73,6 +73,9 @@ struct Parsed {
 // Vorbis: inverse coupling and floor curves on the device (default) or in the host parser (AFG_VORBIS_HOST_FLOOR=1)
 static bool vorbis_floor_on_device() { return std::getenv("AFG_VORBIS_HOST_FLOOR") == nullptr; }
 
+// FLAC: residual rows that fit 16 bits are packed as int16 (default) or left as int32 (AFG_FLAC_HOST_RES32=1)
+static bool flac_rows_int16() { return std::getenv("AFG_FLAC_HOST_RES32") == nullptr; }
+
 struct DeviceBuf {
     void *p = nullptr;
     ~DeviceBuf() { if (p) (void)hipFree(p); }
@@ -1222,7 +1225,7 @@ struct afg_stream {
         } else if (format == AFG_FORMAT_FLAC) {
             bool done = false;
             p.fi = fi;
-            p.flac.pack16 = true;
+            p.flac.pack16 = flac_rows_int16();
             const int got = flac_parse_frames(bytes.data(), bytes.size(), fi, p.flac, &flac_pos, kFlacFrames, &done);
             if (done) ended = true;
             if (!got) { ended = true; return false; }
@@ -1776,7 +1779,7 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 if (st == afg_opus::kUnsupported) { p.opus_mode = true; return; }
             }
             if ((flac_bound[i] = flac_res_bound(data[i], length[i])) != 0) return;                    // parsed in pass 1b
-            p.flac.pack16 = true;
+            p.flac.pack16 = flac_rows_int16();
             if (flac_parse(data[i], length[i], p.fi, p.flac)) { p.format = AFG_FORMAT_FLAC; return; }
             p.flac = FlacRecords();
             if (qoa_parse(data[i], length[i], p.qi, p.qoa)) { p.format = AFG_FORMAT_QOA; return; }
@@ -1803,11 +1806,11 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 Parsed &p = parsed[i];
                 bool ok = false;
                 try {
-                    p.flac.pack16 = true;
+                    p.flac.pack16 = flac_rows_int16();
                     ok = flac_parse_into(data[i], length[i], p.fi, p.flac, res0 + flac_base[i], flac_bound[i]);
                     if (ok && p.flac.overflow) {                 // more audio than STREAMINFO declares: the file's own buffer
                         p.flac = FlacRecords();
-                        p.flac.pack16 = true;
+                        p.flac.pack16 = flac_rows_int16();
                         ok = flac_parse(data[i], length[i], p.fi, p.flac);
                         lost = true;
                     }

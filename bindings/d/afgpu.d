@@ -62,6 +62,17 @@ int afg_vorbis_plan_offsets(const(afg_vorbis_plan)* plan, ulong* spec_off, ulong
 int afg_vorbis_transform_hip(const(afg_vorbis_plan)* plan, const(float)* d_spec, float* d_out,
                              void* hip_stream);
 
+// inverse coupling + floor curves on the device (replaces stb_vorbis2.d:2493-2523 with do_floor :2255-2284 / draw_line :1534-1563)
+struct afg_vorbis_floor_packet
+{
+    ulong spec_off;
+    uint n2, channels, curve_index, step_off, n_steps, pad;
+}
+static assert(afg_vorbis_floor_packet.sizeof == 32);
+struct afg_vorbis_floor_curve { uint point_off, n_points; }
+int afg_vorbis_floor_hip(ulong n_packets, const(afg_vorbis_floor_packet)* d_packets, const(afg_vorbis_floor_curve)* d_curves,
+                         const(int)* d_points, const(ubyte)* d_steps, float* d_spec, void* hip_stream);
+
 // ---- FLAC (replaces drflac.d:1235 prediction half + :2885-2941, optionally stream.d:505-511) --
 enum AFG_FLAC_INDEPENDENT = 0, AFG_FLAC_LEFT_SIDE = 8, AFG_FLAC_RIGHT_SIDE = 9, AFG_FLAC_MID_SIDE = 10;
 
@@ -226,6 +237,17 @@ struct afg_vorbis_parsed
 }
 int afg_vorbis_parse(const(ubyte)* data, size_t length, afg_vorbis_parsed* parsed);
 void afg_vorbis_parsed_free(afg_vorbis_parsed* parsed);
+struct afg_vorbis_parsed_r
+{
+    afg_vorbis_parsed base;          // base.spec: residue vectors
+    ulong n_curves, n_points, n_steps;
+    afg_vorbis_floor_packet* packets;
+    afg_vorbis_floor_curve* curves;
+    int* points;
+    ubyte* steps;
+}
+int afg_vorbis_parse_r(const(ubyte)* data, size_t length, afg_vorbis_parsed_r* parsed);
+void afg_vorbis_parsed_r_free(afg_vorbis_parsed_r* parsed);
 
 struct afg_opus_parsed
 {
