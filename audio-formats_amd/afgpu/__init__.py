@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "afg_vorbis_plan_create", "afg_vorbis_plan_destroy", "afg_vorbis_plan_packets",
     "afg_vorbis_plan_spec_floats", "afg_vorbis_plan_out_floats", "afg_vorbis_plan_offsets",
     "afg_vorbis_transform_hip", "afg_vorbis_floor_hip", "afg_vorbis_parse_r", "afg_vorbis_parsed_r_free",
-    "afg_flac_transform_hip",
+    "afg_flac_transform_hip", "afg_flac_variants", "afg_flac_transform_variants_hip",
     "afg_qoa_transform_hip",
     "afg_celt_transform_hip", "afg_celt_transform_streams_hip",
     "afg_open_from_memory", "afg_is_error", "afg_error_message", "afg_get_format", "afg_get_num_channels",
@@ -196,6 +196,9 @@ def lib():
     L.afg_vorbis_transform_hip.argtypes = [vp, vp, vp, vp]
     L.afg_vorbis_floor_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
     L.afg_flac_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp, vp]
+    L.afg_flac_variants.argtypes = [u64, vp, vp]
+    L.afg_flac_variants.restype = u32
+    L.afg_flac_transform_variants_hip.argtypes = [u64, vp, vp, vp, vp, vp, u32, vp]
     L.afg_qoa_transform_hip.argtypes = [u64, vp, vp, vp, vp, vp]
     L.afg_celt_transform_hip.argtypes = [u32, vp, vp, vp, vp, vp, vp]
     L.afg_celt_transform_streams_hip.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp]
@@ -348,11 +351,25 @@ class VorbisPlan:
             pass
 
 
-def flac_transform(n_frames, d_frames, d_subframes, d_res, d_out_i32=None, d_out_f32=None, stream=None):
+def flac_transform(n_frames, d_frames, d_subframes, d_res, d_out_i32=None, d_out_f32=None, stream=None, variants=None):
     """Enqueue the FLAC restore (afg_flac_transform_hip).  Records are uint8 CUDA tensors holding
-    FLAC_FRAME_DTYPE / FLAC_SUBFRAME_DTYPE arrays."""
-    check(lib().afg_flac_transform_hip(int(n_frames), _ptr(d_frames), _ptr(d_subframes), _ptr(d_res),
-                                       _ptr(d_out_i32), _ptr(d_out_f32), _stream(stream)))
+    FLAC_FRAME_DTYPE / FLAC_SUBFRAME_DTYPE arrays.  `variants`: the mask flac_variants() computed from the host records
+    (afg_flac_transform_variants_hip: only the populated instantiations are launched, side by side)."""
+    if variants is None:
+        check(lib().afg_flac_transform_hip(int(n_frames), _ptr(d_frames), _ptr(d_subframes), _ptr(d_res),
+                                           _ptr(d_out_i32), _ptr(d_out_f32), _stream(stream)))
+    else:
+        check(lib().afg_flac_transform_variants_hip(int(n_frames), _ptr(d_frames), _ptr(d_subframes), _ptr(d_res),
+                                                    _ptr(d_out_i32), _ptr(d_out_f32), int(variants), _stream(stream)))
+
+
+def flac_variants(frames, subframes):
+    """afg_flac_variants on host record arrays (FLAC_FRAME_DTYPE / FLAC_SUBFRAME_DTYPE): bit mask of the kernel
+    instantiations the batch populates."""
+    frames = np.ascontiguousarray(frames)
+    subframes = np.ascontiguousarray(subframes)
+    assert frames.dtype.itemsize == 32 and subframes.dtype.itemsize == 68
+    return int(lib().afg_flac_variants(len(frames), frames.ctypes.data, subframes.ctypes.data))
 
 
 def qoa_frames(file_bytes, out_base=0, byte_base=0):

@@ -12,7 +12,7 @@ walks its shard in waves of at most 8192 files so that a wave's planes fit one M
 import numpy as np
 
 from . import (CELT_FRAME_DTYPE, FLAC_FRAME_DTYPE, FLAC_INDEPENDENT, FLAC_LEFT_SIDE, FLAC_MID_SIDE,
-               FLAC_SUBFRAME_DTYPE, VORBIS_LONG, Mp3Plan, VorbisPlan, celt_transform, flac_transform, sharding, synthetic)
+               FLAC_SUBFRAME_DTYPE, VORBIS_LONG, Mp3Plan, VorbisPlan, celt_transform, flac_transform, flac_variants, sharding, synthetic)
 
 KIND_MP3, KIND_VORBIS, KIND_FLAC, KIND_CELT = 0, 1, 2, 3
 KIND_NAMES = ["mp3", "vorbis", "flac", "celt"]
@@ -426,6 +426,9 @@ class FlacPart(Part):
                 del e, sgn
         self.d_frames = torch.from_numpy(self.frames_np.view(np.uint8).copy()).to(device)
         self.d_sub = torch.from_numpy(self.sub_np.view(np.uint8).copy()).to(device)
+        # which instantiations of the restore kernel these records populate: known from the host copy of the records, as
+        # a parser knows it (AFG_FLAC_ALL_VARIANTS=1: the plain entry, all 16 launched on one stream)
+        self.variants = None if os.environ.get("AFG_FLAC_ALL_VARIANTS") else flac_variants(self.frames_np, self.sub_np)
         self.out = torch.empty(total, dtype=torch.int32, device=device)
         self.units = self.n_frames * 2
         self.samples = total
@@ -435,7 +438,7 @@ class FlacPart(Part):
         self.alg_bytes = (6 if self.res16 else 8) * total + self.n_frames * FLAC_BYTES_PER_FRAME_REC
 
     def launch(self, stream):
-        flac_transform(self.n_frames, self.d_frames, self.d_sub, self.res, self.out, None, stream)
+        flac_transform(self.n_frames, self.d_frames, self.d_sub, self.res, self.out, None, stream, variants=self.variants)
 
     def out_plane(self):
         return self.out

@@ -23,6 +23,8 @@
 //     leave as interleaved 16-byte stores with the decorrelation done on the way.
 #include "afg_common.h"
 
+#include <mutex>
+
 namespace {
 
 #ifndef AFG_FLAC_TILE
@@ -395,9 +397,19 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(
 
 }  // namespace
 
-extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
-                                      const afg_flac_subframe *d_subframes, const int32_t *d_res,
-                                      int32_t *d_out_i32, float *d_out_f32, void *hip_stream)
+namespace {
+
+// second stream + fork / join events of a device: populated instantiations of one call run side by side (each is a few
+// waves of long-lived wavefronts per SIMD with its own tail; together they share one).  One enqueue sequence at a time.
+struct SideLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+std::mutex g_side_mu;
+SideLane g_side[16];
+
+int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg_flac_subframe *d_subframes, const int32_t *d_res,
+                    int32_t *d_out_i32, float *d_out_f32, uint32_t variants, hipStream_t stream)
 {
     if (n_frames == 0) return AFG_OK;
     if (!d_frames || !d_subframes || !d_res || (!d_out_i32 && !d_out_f32)) {
@@ -410,9 +422,36 @@ extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d
         afg::set_error("afg_flac_transform_hip: too many frames in one call");
         return AFG_ERR_INVALID;
     }
-#define AFG_FLAC_LAUNCH1(LO, HI, WA, WB)                                                                      \
-    hipLaunchKernelGGL((flac_restore_kernel<LO, HI, WA, WB>), dim3((uint32_t)groups), dim3(64), 0,             \
-                       (hipStream_t)hip_stream, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, n_frames)
+    variants &= 0xffffu;
+    if (!variants) return AFG_OK;
+    // a known set of two or more: alternate between the caller's stream and the device's side stream
+    const bool two = variants != 0xffffu && (variants & (variants - 1)) != 0;
+    std::unique_lock<std::mutex> lk(g_side_mu, std::defer_lock);
+    SideLane *side = nullptr;
+    if (two) {
+        int dev = 0;
+        AFG_HIP_CHECK(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 16) {
+            lk.lock();
+            side = &g_side[dev];
+            if (!side->stream) {
+                AFG_HIP_CHECK(hipStreamCreateWithFlags(&side->stream, hipStreamNonBlocking));
+                AFG_HIP_CHECK(hipEventCreateWithFlags(&side->fork, hipEventDisableTiming));
+                AFG_HIP_CHECK(hipEventCreateWithFlags(&side->join, hipEventDisableTiming));
+            }
+            AFG_HIP_CHECK(hipEventRecord(side->fork, stream));
+            AFG_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+        }
+    }
+    int idx = 0, used = 0;
+#define AFG_FLAC_LAUNCH1(LO, HI, WA, WB)                                                                              \
+    if (variants & (1u << idx)) {                                                                                      \
+        hipLaunchKernelGGL((flac_restore_kernel<LO, HI, WA, WB>), dim3((uint32_t)groups), dim3(64), 0,                 \
+                           (side && (used & 1)) ? side->stream : stream, d_frames, d_subframes, d_res, d_out_i32,      \
+                           d_out_f32, n_frames);                                                                       \
+        used++;                                                                                                        \
+    }                                                                                                                  \
+    idx++
 #define AFG_FLAC_LAUNCH(LO, HI)            \
     AFG_FLAC_LAUNCH1(LO, HI, false, false); \
     AFG_FLAC_LAUNCH1(LO, HI, false, true);  \
@@ -424,6 +463,46 @@ extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d
     AFG_FLAC_LAUNCH(12, 32);
 #undef AFG_FLAC_LAUNCH1
 #undef AFG_FLAC_LAUNCH
+    if (side) {
+        AFG_HIP_CHECK(hipEventRecord(side->join, side->stream));
+        AFG_HIP_CHECK(hipStreamWaitEvent(stream, side->join, 0));
+    }
     AFG_HIP_CHECK(hipGetLastError());
     return AFG_OK;
+}
+
+}  // namespace
+
+// The instantiation a wavefront's 64 frames run in, exactly as flac_restore_kernel decides it: bucket of the largest LPC
+// order (<= 4, <= 8, <= 12, <= 32), any 64-bit subframe in an even / odd channel slot.  Bit = bucket * 4 + wide_even * 2 + wide_odd.
+extern "C" uint32_t afg_flac_variants(uint64_t n_frames, const afg_flac_frame *frames, const afg_flac_subframe *subframes)
+{
+    uint32_t mask = 0;
+    if (!frames || !subframes) return 0xffffu;
+    for (uint64_t g = 0; g < n_frames; g += 64) {
+        int order = 0, wa = 0, wb = 0;
+        for (uint64_t f = g; f < n_frames && f < g + 64; f++)
+            for (int c = 0; c < (int)frames[f].channels && c < 8; c++) {
+                const afg_flac_subframe &sf = subframes[frames[f].sf_index + c];
+                if (sf.order > order) order = sf.order;
+                if (c & 1) wb |= sf.use64 != 0; else wa |= sf.use64 != 0;
+            }
+        const int bucket = order <= 4 ? 0 : order <= 8 ? 1 : order <= 12 ? 2 : 3;
+        mask |= 1u << (bucket * 4 + wa * 2 + wb);
+    }
+    return mask;
+}
+
+extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
+                                      const afg_flac_subframe *d_subframes, const int32_t *d_res,
+                                      int32_t *d_out_i32, float *d_out_f32, void *hip_stream)
+{
+    return launch_variants(n_frames, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, 0xffffu, (hipStream_t)hip_stream);
+}
+
+extern "C" int afg_flac_transform_variants_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
+                                               const afg_flac_subframe *d_subframes, const int32_t *d_res,
+                                               int32_t *d_out_i32, float *d_out_f32, uint32_t variants, void *hip_stream)
+{
+    return launch_variants(n_frames, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, variants, (hipStream_t)hip_stream);
 }

@@ -720,7 +720,9 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 if (e == hipSuccess) e = hipMemcpyAsync((void *)(ds + sf0), hs + sf0, (sf1 - sf0) * sizeof(afg_flac_subframe), hipMemcpyHostToDevice, up);
                 if (e == hipSuccess) e = hipMemcpyAsync((void *)(dr + r0), hres + r0, (r1 - r0) * 4, hipMemcpyHostToDevice, up);
                 if (e != hipSuccess) break;
-                rc = afg_flac_transform_hip(fr1 - fr0, df + fr0, ds, dr, nullptr, (float *)d_out.p, up);
+                // (the records are still here in host memory: only the populated instantiations are launched)
+                rc = afg_flac_transform_variants_hip(fr1 - fr0, df + fr0, ds, dr, nullptr, (float *)d_out.p,
+                                                     afg_flac_variants(fr1 - fr0, hf + fr0, hs), up);
                 if (rc) break;
                 hipEvent_t done = nullptr;
                 e = hipEventCreateWithFlags(&done, hipEventDisableTiming);

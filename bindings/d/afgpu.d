@@ -104,6 +104,10 @@ ulong AFG_FLAC_ROW16(ulong block_size) { return (block_size + 7) & ~7UL; }
 int afg_flac_transform_hip(ulong n_frames, const(afg_flac_frame)* d_frames,
                            const(afg_flac_subframe)* d_subframes, const(int)* d_res,
                            int* d_out_i32, float* d_out_f32, void* hip_stream);
+uint afg_flac_variants(ulong n_frames, const(afg_flac_frame)* frames, const(afg_flac_subframe)* subframes);   // host records
+int afg_flac_transform_variants_hip(ulong n_frames, const(afg_flac_frame)* d_frames,
+                                    const(afg_flac_subframe)* d_subframes, const(int)* d_res,
+                                    int* d_out_i32, float* d_out_f32, uint variants, void* hip_stream);
 
 // ---- QOA (replaces the slice loop of qoa_decode_frame, qoa.d:489-530, and qoa.d:831-838) --------
 struct afg_qoa_frame

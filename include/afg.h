@@ -230,6 +230,18 @@ int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
                            const afg_flac_subframe *d_subframes, const int32_t *d_res,
                            int32_t *d_out_i32, float *d_out_f32, void *hip_stream);
 
+/* The restore kernel exists in 16 instantiations (LPC-order bucket <= 4 / 8 / 12 / 32 x 64-bit accumulator in the even / odd
+ * channel slot, so that each gets the registers it needs and no more); a wavefront of 64 consecutive frames runs in the
+ * one its largest order and widest subframe select.  afg_flac_transform_hip launches all 16, the ones nobody selects exit
+ * at once.  A caller that still holds the records in host memory can say which are populated:
+ * afg_flac_variants (host pointers, pure host code) returns the set as a bit mask, and afg_flac_transform_variants_hip
+ * launches only those -- two or more of them side by side on the caller's stream and an internal one, joined before
+ * the call returns to the stream's order.  Frames of an instantiation missing from `variants` are NOT decoded. */
+uint32_t afg_flac_variants(uint64_t n_frames, const afg_flac_frame *frames, const afg_flac_subframe *subframes);
+int afg_flac_transform_variants_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
+                                    const afg_flac_subframe *d_subframes, const int32_t *d_res,
+                                    int32_t *d_out_i32, float *d_out_f32, uint32_t variants, void *hip_stream);
+
 /* ========================================================================== *
  *  QOA frame decode (LMS predict / dequantise / clamp / update)
  *  replaces the slice loop of qoa_decode_frame (qoa.d:489-530, qoa_lms_predict /

@@ -90,3 +90,42 @@ def test_flac_int16_residual_rows(gpu, kw, every):
     got_i, got_f = run_gpu(gpu, pf, subframes, pres, total)
     assert (got_i == want_i).all(), f"{int((got_i != want_i).sum())} int32 mismatches"
     assert (got_f.view(np.uint32) == want_f.view(np.uint32)).all()
+
+
+def test_flac_variant_mask_launches_the_same_samples(gpu):
+    """afg_flac_variants on the host records + afg_flac_transform_variants_hip (only the populated instantiations, two
+    streams) against the plain entry and the oracle: mixed orders and accumulator widths so that several instantiations
+    are populated; a mask that leaves one out leaves exactly that instantiation's frames unwritten."""
+    import torch
+    groups = [((2, 3), 16), ((8, 6), 16), ((12, 9), 16), ((32, 20), 16), ((8, 8), 24), ((1, 12), 24)]
+    frs, sfs, rss, in_off, sf_off = [], [], [], 0, 0
+    for i, (orders, bps) in enumerate(groups):                 # 64 frames each: every group lands in one instantiation
+        fr, sf, res, total = synthetic.flac_batch(770 + i, 64, block_size=192, orders=orders, bps=bps)
+        fr["in_off"] += np.uint64(in_off)
+        fr["out_off"] += np.uint64(in_off)
+        fr["sf_index"] += np.uint32(sf_off)
+        frs.append(fr); sfs.append(sf); rss.append(res)
+        in_off += total
+        sf_off += len(sf)
+    frames, subs, res, total = np.concatenate(frs), np.concatenate(sfs), np.concatenate(rss), in_off
+    mask = afgpu.flac_variants(frames, subs)
+    assert bin(mask).count("1") >= 4
+    want = oraclelib.flac_transform(frames, subs, res, total)
+    d_fr = torch.from_numpy(frames.view(np.uint8).copy()).to(gpu)
+    d_sf = torch.from_numpy(subs.view(np.uint8).copy()).to(gpu)
+    d_res = torch.from_numpy(res).to(gpu)
+    for variants in (None, mask, 0xffff):
+        out = torch.full((total,), -7, dtype=torch.int32, device=gpu)
+        afgpu.flac_transform(len(frames), d_fr, d_sf, d_res, out, None, None, variants=variants)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+    # drop the lowest populated bit: its frames keep the fill value, everything else is decoded
+    low = mask & -mask
+    out = torch.full((total,), -7, dtype=torch.int32, device=gpu)
+    afgpu.flac_transform(len(frames), d_fr, d_sf, d_res, out, None, None, variants=mask & ~low)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    untouched = got == -7
+    assert untouched.any() and np.array_equal(got[~untouched], want[~untouched])
+    share = untouched.reshape(len(groups), -1).mean(axis=1)
+    assert ((share < 0.01) | (share > 0.99)).all() and (share > 0.99).sum() >= 1           # whole groups or nothing
