@@ -23,7 +23,9 @@ FLAC_BYTES_PER_FRAME_REC = 32 + 2 * 68          # one frame record + two subfram
 CELT_BYTES_PER_REC = 48
 
 C5_FILES = 65536
-C5_WAVE_FILES = 8192
+# files resident at once on one GPU: a third of the corpus is ~200 GB of planes (the Opus members' serial per-stream chains
+# take as long for 800 streams as for 2500, so fewer, larger waves pay: 8192 -> 24576 files took C5 from 304 to 200 ms)
+C5_WAVE_FILES = 24576
 C5_SEED = 0xC5
 
 

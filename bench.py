@@ -16,7 +16,7 @@ A *step* is one pass of the hot path over the device-resident batches of the con
   --config c2 | c3 | c4    one of them alone.
   --config c5              configs[4]: the 65 536-file mixed MP3 / Vorbis / FLAC / Opus-CELT corpus sharded by file
                            over the ranks (strong scaling: the same corpus at every N), walked in waves of
-                           <= 8192 files that fit one GPU; a step is one pass over the rank's whole shard.
+                           <= 24576 files that fit one GPU; a step is one pass over the rank's whole shard.
 
 Rank 0 prints ONE JSON line with `roofline` (per-kernel event times measured on the launch stream
 inside the timed region; the dominant kernel at the top level) and `cpu_baseline` (the CPU oracle, a
@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-full-fetch", action="store_true", help="skip the MP3 leg that fetches all 32 subbands")
+    ap.add_argument("--c5-wave-files", type=int, default=0, help="files per resident wave of --config c5 (0 = the corpus default)")
     ap.add_argument("--only", default="", help="development: restrict --config c5 to these codecs (comma list)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: ranks beyond the visible devices share them (rank % devices); the line says so")
@@ -282,7 +283,7 @@ def run_rank(args, world, rank, local_rank):
     parity, cpu, extra = {}, None, {}
     if args.config == "c5":
         man = corpus.c5_manifest(args.c5_files)
-        waves = corpus.c5_shard_waves(man, rank, world)
+        waves = corpus.c5_shard_waves(man, rank, world, args.c5_wave_files or corpus.C5_WAVE_FILES)
         elapsed, my_samples = 0.0, 0
         for wi, ids in enumerate(waves):
             wl = corpus.build_c5_wave(man, ids, dev)
@@ -307,7 +308,7 @@ def run_rank(args, world, rank, local_rank):
         scaling = "strong"
         workload = (f"{args.c5_files}-file mixed corpus (40% MP3 / 25% Ogg Vorbis / 25% FLAC / 10% Opus-CELT, durations "
                     f"log-uniform 4-30 s, seed {corpus.C5_SEED:#x}) file-sharded over {world} GPU(s) by LPT on frames x channels, "
-                    f"{len(waves)} wave(s) of <= {corpus.C5_WAVE_FILES} files per GPU, device-resident records -> PCM")
+                    f"{len(waves)} wave(s) of <= {args.c5_wave_files or corpus.C5_WAVE_FILES} files per GPU, device-resident records -> PCM")
         cfg_extra = {"files": args.c5_files, "waves_per_gpu": len(waves), "files_this_gpu": int(sum(len(w) for w in waves)),
                      "lpt_imbalance": corpus.sharding.imbalance(man["work"], world)}
     else:
