@@ -988,6 +988,163 @@ __device__ __forceinline__ void deemph_rows(float *xs, float *__restrict__ out, 
     }
 }
 
+// The same pass as a pair of wavefronts (few, long sequences: the chain's latency is the whole run time).  In the
+// single-wavefront form above a step is write-to-LDS, chain, read-from-LDS-and-store, one after the other: the chain lanes
+// sit out most of it (measured: 35 cycles per sample against the chain's own 14).  Here wavefront 0 only moves (row
+// loads D steps ahead, LDS writes of step g+1, LDS reads + scale + stores of step g-1) and wavefront 1 only chains
+// (step g), on three LDS step buffers, one workgroup barrier per step: the chain never waits for a transpose.
+template <int STRIDE, int SEQ, int GROUP, int D>
+__device__ __forceinline__ void deemph_rows_duo(float *xs2, float *__restrict__ out, bool have, uint64_t off, uint64_t off_next,
+                                                int n, float &m, f32x4 (&ring)[D][(SEQ * GROUP / 4 + 63) / 64], bool primed,
+                                                bool chain_next, int role)
+{
+    constexpr int PITCH = GROUP + 4;                          // floats; rows stay 16-byte aligned
+    constexpr int BUF = SEQ * PITCH;                          // floats per step buffer
+    constexpr int QUADS = SEQ * GROUP / 4;                    // float4 per step
+    constexpr int LOADS = (QUADS + 63) / 64;                  // float4 per lane per step
+    constexpr int F = GROUP / 4 * STRIDE;                     // float4 per row per step
+    constexpr int GS = GROUP * STRIDE;                        // floats a row advances per step
+    constexpr int CH = (GROUP / 4) % 10 == 0 ? 10 : GROUP / 4;   // float4 per chain chunk held in registers
+    static_assert((GROUP / 4) % CH == 0, "chunking");
+    const int lane = threadIdx.x & 63;
+    float *ptr[LOADS];
+    const float *lptr[LOADS], *lptr_n[LOADS];
+    int lds_at[LOADS];
+    bool valid[LOADS];
+    if (role == 0) {                                          // (the chainer needs none of the addresses)
+    const int lead0 = __ffsll((unsigned long long)__ballot(have)) - 1;
+    const uint64_t safe = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off >> 32), lead0) << 32) | (uint32_t)__shfl((int)(uint32_t)off, lead0);
+#pragma unroll
+    for (int i = 0; i < LOADS; i++) {
+        const int idx = lane + 64 * i;
+        const int row = idx / F, q = idx - row * F;
+        const int lead = (row * STRIDE) & 63;                // first chain lane of the row
+        const uint32_t lo = __shfl((uint32_t)off, lead), hi = __shfl((uint32_t)(off >> 32), lead);
+        const uint32_t nlo = __shfl((uint32_t)off_next, lead), nhi = __shfl((uint32_t)(off_next >> 32), lead);
+        valid[i] = idx < QUADS && __shfl((int)have, lead) != 0;
+        ptr[i] = out + (((uint64_t)hi << 32) | lo) + 4 * q;
+        lptr[i] = valid[i] ? ptr[i] : out + safe;
+        lptr_n[i] = (valid[i] && chain_next) ? out + (((uint64_t)nhi << 32) | nlo) + 4 * q : lptr[i];
+        lds_at[i] = STRIDE == 1 ? row * PITCH + 4 * q : (2 * row) * PITCH + 2 * q;
+    }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) { ptr[i] = out; lptr[i] = lptr_n[i] = out; lds_at[i] = 0; valid[i] = false; }
+    }
+    const int groups = n / GROUP;
+    if (role == 0 && !primed) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int g = d < groups ? d : groups - 1;
+#pragma unroll
+            for (int i = 0; i < LOADS; i++) ring[d][i] = __builtin_nontemporal_load((const f32x4 *)(lptr[i] + (size_t)g * GS));
+        }
+    }
+    // Three LDS step buffers (step g in buffer g % 3): while the chainer works on step g the mover first fills step g+1's
+    // (rows that were loaded D steps ago) and then empties step g-1's.  In that order, and with every load issued
+    // unconditionally (the slot keeps its value by a select when there is nothing to fetch), the wait in front of the
+    // LDS writes counts exactly the operations issued since those loads -- with the stores first, or a branch around
+    // the loads, the compiler has to drain the stores of the same phase every time (one in-order memory counter).
+    auto feed = [&](f32x4 (&b)[LOADS], int g, bool more) {
+        float *xs = xs2 + (g % 3) * BUF;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < LOADS; i++) {
+                if (QUADS % 64 != 0 && lane + 64 * i >= QUADS) continue;
+                if (STRIDE == 1) {
+                    *(f32x4 *)(xs + lds_at[i]) = b[i];
+                } else {
+                    *(f32x2 *)(xs + lds_at[i]) = f32x2{ b[i].x, b[i].z };
+                    *(f32x2 *)(xs + lds_at[i] + PITCH) = f32x2{ b[i].y, b[i].w };
+                }
+            }
+        }
+        const int gn = g + D;
+        const bool here = more && gn < groups;
+        const bool ahead = more && !here && chain_next;      // the next frame's first steps (same slots)
+        const size_t at = (size_t)(here ? gn : (ahead ? gn - groups : (g < groups ? g : groups - 1))) * GS;   // else: a harmless re-read
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) {
+            const f32x4 t = __builtin_nontemporal_load((const f32x4 *)((ahead ? lptr_n[i] : lptr[i]) + at));
+            b[i] = more ? t : b[i];
+        }
+    };
+    // mover: step g's chained rows out of buffer g % 3, scaled, to memory (g = -1: nothing is stored)
+    auto drain = [&](int g) {
+        const float *xs = xs2 + ((g + 3) % 3) * BUF;
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) {
+            f32x4 o;
+            if (QUADS % 64 != 0 && lane + 64 * i >= QUADS) continue;
+            if (STRIDE == 1) {
+                o = *(const f32x4 *)(xs + lds_at[i]);
+            } else {
+                const f32x2 l = *(const f32x2 *)(xs + lds_at[i]), r = *(const f32x2 *)(xs + lds_at[i] + PITCH);
+                o = f32x4{ l.x, r.x, l.y, r.y };
+            }
+            o *= (1.0f / 32768.0f);                                                // tmp / 32768. (exact)
+            if (valid[i] && g >= 0) *(f32x4 *)(ptr[i] + (size_t)(g >= 0 ? g : 0) * GS) = o;
+        }
+    };
+    // chainer: step g in buffer g % 3
+    auto chain_step = [&](int g) {
+        if (lane < SEQ && have) {
+            f32x4 *row = (f32x4 *)(xs2 + (g % 3) * BUF + lane * PITCH);
+            auto chain = [&](f32x4 (&c)[CH], int k0) {
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float t = c[k][e] + m;
+                        m = t * 0.85000610f;
+                        c[k][e] = t;
+                    }
+                    row[k0 + k] = c[k];
+                }
+            };
+            auto fill = [&](f32x4 (&c)[CH], int k0) {
+#pragma unroll
+                for (int k = 0; k < CH; k++) c[k] = row[k0 + k];
+            };
+            constexpr int NCH = GROUP / 4 / CH;
+            f32x4 ca[CH], cb[CH];
+            fill(ca, 0);
+            if (NCH == 1) {
+                chain(ca, 0);
+            } else {
+#pragma unroll 1
+                for (int k0 = 0; k0 < GROUP / 4; k0 += 2 * CH) {
+                    const bool two = k0 + CH < GROUP / 4;
+                    if (two) fill(cb, k0 + CH);
+                    chain(ca, k0);
+                    if (k0 + 2 * CH < GROUP / 4) fill(ca, k0 + 2 * CH);
+                    if (two) chain(cb, k0 + CH);
+                }
+            }
+        }
+    };
+    // The ring slot of step s is s % D (a frame that is chained to the next one has groups % D == 0, so the next frame's
+    // step 0 finds its rows in slot 0 again).
+    if (role == 0) feed(ring[0], 0, true);
+    __syncthreads();
+    for (int g = 0; g < groups; g += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int gg = g + d;
+            if (gg < groups) {
+                if (role == 0) {
+                    feed(ring[(d + 1) % D], gg + 1, gg + 1 < groups);
+                    drain(gg - 1);
+                } else {
+                    chain_step(gg);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (role == 0) drain(groups - 1);
+}
+
 template <int SEQ, int GROUP>
 __global__ __launch_bounds__(64) void celt_deemph_kernel(
     const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs, float *__restrict__ out,
@@ -1082,6 +1239,102 @@ __global__ __launch_bounds__(64) void celt_deemph_kernel(
     if (st) st[2056] = m;
 }
 
+// two wavefronts per SEQ sequences: see deemph_rows_duo
+template <int SEQ, int GROUP>
+__global__ __launch_bounds__(128) void celt_deemph_duo_kernel(
+    const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs, float *__restrict__ out,
+    float *__restrict__ states, uint32_t n_chan)
+{
+    constexpr int D = (960 / GROUP) >= 4 ? 4 : 2;            // steps in flight (divides the steps of a 20 ms frame)
+    constexpr int LOADS = (SEQ * GROUP / 4 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float xs[3 * SEQ * (GROUP + 4)];
+    const int role = threadIdx.x >> 6;                        // 0 moves, 1 chains
+    __builtin_amdgcn_s_setprio(3);                            // a serial chain: its instructions go first whenever ready
+    const int lane = threadIdx.x & 63;
+    const uint32_t chan = blockIdx.x * (uint32_t)SEQ + (uint32_t)lane;
+    const bool mine = lane < SEQ && chan < n_chan;
+    const uint32_t chan_c = chan < n_chan ? chan : n_chan - 1;
+    float *st = (states && mine) ? states + (size_t)chan * AFG_CELT_STATE_FLOATS : nullptr;
+    float m = st ? st[2056] : 0.0f;
+    const uint64_t total = rec_base[n_chan];                  // records in the batch
+    if (total == 0) return;
+    uint64_t r = rec_base[chan_c];
+    const uint64_t r_end = mine ? rec_base[chan_c + 1] : r;
+    struct Rec { uint32_t n, stride; uint64_t off; };
+    static_assert(offsetof(afg_celt_frame, out_off) == 8 && offsetof(afg_celt_frame, out_stride) == 16 &&
+                  offsetof(afg_celt_frame, frame_size) == 20, "record layout");
+    auto fetch = [&](uint64_t idx) -> Rec {                   // always a valid record: the fields of one past the end are unused
+        const uint64_t *p = (const uint64_t *)(recs + (idx < total ? idx : total - 1));
+        const uint64_t a = p[1], b = p[2];
+        return Rec{ (uint32_t)(b >> 32) & 0xffffu, (uint32_t)b, a };
+    };
+    // can a step of the SEQ sequences be walked as rows?  Geometry of the first lane that still has a record
+    // (sequences of a wavefront may end at different frames: the finished ones sit the step out)
+    auto rows_ok = [&](const Rec &rc, bool hv, int &n0, int &s0) -> bool {
+        const unsigned long long bal = __ballot(hv);
+        n0 = s0 = 0;
+        if (!bal) return false;
+        const int first = __ffsll(bal) - 1;
+        n0 = __shfl((int)rc.n, first);
+        s0 = __shfl((int)rc.stride, first);
+        bool bad = false;
+        const bool p_have = __shfl_xor((int)hv, 1) != 0;
+        const uint32_t plo = __shfl_xor((uint32_t)rc.off, 1), phi = __shfl_xor((uint32_t)(rc.off >> 32), 1);
+        const uint64_t p_off = ((uint64_t)phi << 32) | plo;
+        if (lane < SEQ) {
+            if (hv) bad = (int)rc.n != n0 || (int)rc.stride != s0;
+            if (s0 == 2) {
+                if (hv != p_have) bad = true;
+                else if (hv) bad = bad || ((lane & 1) ? rc.off != p_off + 1 : (rc.off & 3) != 0);
+            } else if (hv) {
+                bad = bad || (rc.off & 3) != 0;
+            }
+        }
+        return (s0 == 1 || s0 == 2) && n0 > 0 && n0 % GROUP == 0 && !__any(bad);
+    };
+    Rec cur = fetch(r), nxt = fetch(r + 1);
+    bool have = r < r_end;
+    bool primed = false;
+    f32x4 ring[D][LOADS];
+    while (__any(have)) {
+        const Rec nn = fetch(r + 2);                          // lands while this frame is chained
+        const bool have_n = r + 1 < r_end;
+        int n0, s0, n1, s1;
+        const bool rows = rows_ok(cur, have, n0, s0);
+        const bool rows_n = rows_ok(nxt, have_n, n1, s1);
+        const bool chain_next = rows && rows_n && n1 == n0 && s1 == s0 && __ballot(have_n) == __ballot(have) && (n0 / GROUP) % D == 0;
+        if (rows) {
+            if (s0 == 2) deemph_rows_duo<2, SEQ, GROUP, D>(xs, out, have, cur.off, nxt.off, n0, m, ring, primed, chain_next, role);
+            else deemph_rows_duo<1, SEQ, GROUP, D>(xs, out, have, cur.off, nxt.off, n0, m, ring, primed, chain_next, role);
+            primed = chain_next;
+        } else {
+            primed = false;
+            if (have && role == 1) {
+                const int n = (int)cur.n, stride = (int)cur.stride;
+                float *o = out + cur.off;
+                for (int j0 = 0; j0 < n; j0 += 8) {
+                    float x[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) x[k] = j0 + k < n ? o[(size_t)(j0 + k) * stride] : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (j0 + k < n) {
+                            const float t = x[k] + m;
+                            m = t * 0.85000610f;
+                            o[(size_t)(j0 + k) * stride] = t * (1.0f / 32768.0f);
+                        }
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        nxt = nn;
+        r++;
+        have = r < r_end;
+    }
+    if (st && role == 1) st[2056] = m;
+}
+
 // Sequences per wavefront from the number of sequences: the most chain lanes per wavefront that still leaves about a
 // wavefront per two SIMDs (512 wavefronts; measured: 16384 sequences run at the pass's memory rate with 32 per
 // wavefront).  AFG_CELT_DE_SEQ overrides (tests run every instantiation).
@@ -1099,7 +1352,23 @@ int deemph_seq_for(uint32_t n_chan)
 void launch_deemph(const uint64_t *d_rec_base, const afg_celt_frame *d_recs, float *d_out, float *d_states, uint32_t n_chan,
                    hipStream_t stream)
 {
-    const int seq = deemph_seq_for(n_chan);
+    int seq = deemph_seq_for(n_chan);
+    // Few, long sequences (fewer than 16384: not enough for 512 wavefronts of 32 chains, the form that runs at memory rate): the
+    // pass is as long as its longest chain, so the chain gets a wavefront of its own (celt_deemph_duo_kernel).
+    // AFG_CELT_DE_DUO=0 / 1 overrides (tests run both forms of every instantiation).
+    bool duo = seq < 32;
+    if (const char *e = getenv("AFG_CELT_DE_DUO")) duo = atoi(e) != 0;
+    if (duo) {
+        if (!getenv("AFG_CELT_DE_SEQ")) seq = 8;             // 120-sample steps: every CELT frame size walks as rows
+        if (seq > 8) seq = 8;
+        const dim3 grid((n_chan + (uint32_t)seq - 1) / (uint32_t)seq), block(128);
+        switch (seq) {
+        case 8:  hipLaunchKernelGGL((celt_deemph_duo_kernel<8, 120>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;
+        case 4:  hipLaunchKernelGGL((celt_deemph_duo_kernel<4, 240>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;
+        default: hipLaunchKernelGGL((celt_deemph_duo_kernel<2, 480>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;
+        }
+        return;
+    }
     const dim3 grid((n_chan + (uint32_t)seq - 1) / (uint32_t)seq), block(64);
     switch (seq) {
     case 32: hipLaunchKernelGGL((celt_deemph_kernel<32, 40>), grid, block, 0, stream, d_rec_base, d_recs, d_out, d_states, n_chan); break;

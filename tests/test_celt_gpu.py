@@ -81,12 +81,13 @@ def test_celt_many_streams_row_path(gpu):
     assert check(got, want) == 0
 
 
-@pytest.mark.parametrize("seq", [2, 4, 8, 16, 32])
-def test_celt_deemph_sequences_per_wavefront(gpu, monkeypatch, seq):
-    """Every instantiation of the de-emphasis pass (2 ... 32 chain lanes per wavefront; the host picks one from the
-    number of sequences) on streams of different lengths -- lanes whose sequence has ended sit the later steps out --
-    with mixed frame sizes in one stream and a mono / stereo mix."""
+@pytest.mark.parametrize("seq,duo", [(2, 0), (4, 0), (8, 0), (16, 0), (32, 0), (2, 1), (4, 1), (8, 1)])
+def test_celt_deemph_sequences_per_wavefront(gpu, monkeypatch, seq, duo):
+    """Every instantiation of the de-emphasis pass (2 ... 32 chain lanes per wavefront, as one wavefront or as a mover /
+    chainer pair; the host picks one from the number of sequences) on streams of different lengths -- lanes whose sequence
+    has ended sit the later steps out -- with mixed frame sizes in one stream and a mono / stereo mix."""
     monkeypatch.setenv("AFG_CELT_DE_SEQ", str(seq))
+    monkeypatch.setenv("AFG_CELT_DE_DUO", str(duo))
     fps = [3, 9, 5, 9, 2, 7, 4, 11, 6, 3, 8, 5, 10, 4, 7, 6, 9, 3, 5]
     rec_base, recs, coeffs, total = synthetic.celt_batch(31 + seq, fps, [2] * 15 + [1] * 4, p_postfilter=0.5, p_transient=0.3)
     want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
