@@ -388,6 +388,8 @@ def run_rank(args, world, rank, local_rank):
         if k.get("survey_bytes") and k["survey_bytes"] != k["alg_bytes"]:
             # FLAC with int16 residual rows: the launch reads 2 B / sample where SURVEY 8(d) counts 4.  `frac` above is
             # priced on the bytes this input format moves; the 8 B / sample figure is shown for comparison with round 1 only.
+            kernels[-1]["launch"] = ("the populated instantiations of flac_restore_kernel (here LPC order <= 8 and <= 12) run side by side on two "
+                                     "streams: a kernel trace lists each with about this duration, and they overlap")
             kernels[-1]["input_rows"] = "int16 residual rows (6 B / sample moved)"
             kernels[-1]["bytes_at_8B_per_sample"] = int(k["survey_bytes"])
             kernels[-1]["frac_at_8B_per_sample"] = k["survey_bytes"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

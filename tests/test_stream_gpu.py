@@ -386,3 +386,30 @@ def test_seeks_across_decode_chunks(gpu, kind):
         assert s.tellPosition() == min(target, total) + got
     assert not s.seekPosition(-1) and not s.seekPosition(int(length) + 1)
     s.cleanUp()
+
+
+@pytest.mark.parametrize("seed", [5, 13, 30, 45, 52])
+def test_vorbis_streams_whose_delivery_starts_late(gpu, seed):
+    """Streams whose first delivered frame is not the start of a packet's output (a long first block with a short next
+    window: the deferred discard of stb_vorbis2.d:2551-2560) or comes after packets that deliver nothing: the stream API,
+    the batch entry and the oracle agree sample for sample (the result plane offset of such a file is not zero)."""
+    import vorbis_bitstream as vb
+    data = vb.make_file(seed)
+    rec = afgpu.vorbis_parse(data)
+    first = next(i for i, c in enumerate(rec["take_count"]) if c > 0)
+    assert rec["take_from"][first] > 0 or first > 1
+    want = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(data))
+    item = afgpu.batch_decode([data])[0]
+    assert item["status"] == 0 and item["frames"] == len(want)
+    assert np.array_equal(item["pcm"].view(np.uint32), want.view(np.uint32))
+    for chunk in (100, 4096):
+        s = afgpu.AudioStream()
+        s.openFromMemory(data)
+        assert not s.isError(), s.errorMessage()
+        got = read_all(s, s.getNumChannels(), chunk)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert s.seekPosition(7) and s.tellPosition() == 7
+        buf = np.zeros(50 * want.shape[1], np.float32)
+        assert s.readSamplesFloat(buf) == min(50, len(want) - 7)
+        assert np.array_equal(buf[:min(50, len(want) - 7) * want.shape[1]].view(np.uint32), want[7:57].reshape(-1).view(np.uint32))
+        s.cleanUp()
