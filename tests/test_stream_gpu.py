@@ -408,8 +408,11 @@ def test_vorbis_streams_whose_delivery_starts_late(gpu, seed):
         assert not s.isError(), s.errorMessage()
         got = read_all(s, s.getNumChannels(), chunk)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-        assert s.seekPosition(7) and s.tellPosition() == 7
-        buf = np.zeros(50 * want.shape[1], np.float32)
-        assert s.readSamplesFloat(buf) == min(50, len(want) - 7)
-        assert np.array_equal(buf[:min(50, len(want) - 7) * want.shape[1]].view(np.uint32), want[7:57].reshape(-1).view(np.uint32))
+        if s.getLengthInFrames() > 0:                      # (a stream without a last-page granule has no length: no seeking, as in the reference)
+            assert s.seekPosition(7) and s.tellPosition() == 7
+            buf = np.zeros(50 * want.shape[1], np.float32)
+            assert s.readSamplesFloat(buf) == min(50, len(want) - 7)
+            assert np.array_equal(buf[:min(50, len(want) - 7) * want.shape[1]].view(np.uint32), want[7:57].reshape(-1).view(np.uint32))
+        else:
+            assert not s.seekPosition(7)
         s.cleanUp()
