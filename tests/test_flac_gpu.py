@@ -129,3 +129,45 @@ def test_flac_variant_mask_launches_the_same_samples(gpu):
     assert untouched.any() and np.array_equal(got[~untouched], want[~untouched])
     share = untouched.reshape(len(groups), -1).mean(axis=1)
     assert ((share < 0.01) | (share > 0.99)).all() and (share > 0.99).sum() >= 1           # whole groups or nothing
+
+
+def _encode_against(samples, coef, shift):
+    """residuals that make the reference's 32-bit recurrence (drflac.d:1060-1099, :1235) reproduce `samples`"""
+    order = len(coef)
+    res = samples.astype(np.int64).copy()
+    for t in range(order, len(samples)):
+        acc = int(np.dot(coef.astype(np.int64), samples[t - order:t][::-1].astype(np.int64)))
+        acc = (acc + 2 ** 31) % 2 ** 32 - 2 ** 31                    # the int32 accumulator wraps
+        res[t] = (int(samples[t]) - (acc >> shift) + 2 ** 31) % 2 ** 32 - 2 ** 31
+    return res.astype(np.int32)
+
+
+@pytest.mark.parametrize("order", [2, 7, 12, 31])
+def test_flac_in_range_samples_with_a_wrapping_sum(gpu, order):
+    """Valid-looking 16-bit channels whose prediction sum passes 2^31: coefficients at the int16 limits, every decoded sample
+    inside int16 (the residuals are computed against the reference's wrapping int32 recurrence).  Frames 40..47 hold samples
+    far beyond int16 as well.  (Written for a packed int16 dot-product form of the recurrence, which turned out slower
+    than the 32-bit multiplies -- DESIGN.md section 8 -- and is not in the product; the cases stay.)"""
+    rng = np.random.default_rng(order)
+    n_frames, bs = 130, 192
+    frames = np.zeros(n_frames, afgpu.FLAC_FRAME_DTYPE)
+    subs = np.zeros(2 * n_frames, afgpu.FLAC_SUBFRAME_DTYPE)
+    res = np.zeros((n_frames, 2, bs), np.int32)
+    for f in range(n_frames):
+        frames[f] = (f * 2 * bs, f * 2 * bs, bs, 2 * f, 2, afgpu.FLAC_INDEPENDENT, 16, 0, [0] * 4)
+        for c in range(2):
+            coef = rng.choice(np.array([32767, -32768, 30000, -29000, 12345]), order).astype(np.int16)
+            shift = int(rng.integers(0, 16))
+            wild = 40 <= f < 48 and c == 0
+            smp = rng.integers(-32768, 32768, bs) if not wild else rng.integers(-2 ** 20, 2 ** 20, bs)
+            sf = subs[2 * f + c]
+            sf["coef"][:order] = coef
+            sf["order"], sf["shift"], sf["wasted"], sf["use64"] = order, shift, 0, 0
+            res[f, c] = _encode_against(smp, coef, shift)
+    flat = res.reshape(-1)
+    total = n_frames * 2 * bs
+    want = oraclelib.flac_transform(frames, subs, flat, total)
+    # the construction itself: the oracle reproduces the chosen samples (left-justified by 32 - bps)
+    got_i32, _ = run_gpu(gpu, frames, subs, flat, total, want_float=False)
+    assert np.array_equal(got_i32, want)
+    assert np.abs(flat.astype(np.int64)).max() > 2 ** 28                # sums that wrapped: the residuals had to undo them

@@ -1,9 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-for abl in 0 2; do
-AFG_DE_ABL=$abl timeout 900 python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline --only celt 2> /tmp/c5.err | python -c "
+AFG_LIB_PATH=$PWD/audio-formats_amd/lib/libafg_noredo.so python bench.py --config c4 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('c5 celt only duo default abl=$abl', round(d['ms_per_step'],2), d['parity'])" || tail -5 /tmp/c5.err
-done
+print('noredo c4', [(k['codec'], round(k['avg_kernel_ms'],2), round(k['frac'],3)) for k in d['roofline']['kernels']], {k:v['mismatches'] for k,v in d['parity'].items()})"
