@@ -373,13 +373,14 @@ def run_rank(args, world, rank, local_rank):
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
     # passes over the same full-size batch, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_collect.sh): only
     # for the kernels and batch sizes those passes were taken on
-    pmc_file = {"mp3": "r02_pmc_mp3_transform_kernel.json", "vorbis": "r02_pmc_vorbis_wave_kernel.json"}
+    pmc_file = {"mp3": "r02_pmc_mp3_transform_kernel.json", "vorbis": "r02_pmc_vorbis_wave_kernel.json",
+                "flac": "r02_pmc_flac_restore_kernel.json"}      # (FLAC: counters calibrated on its own access pattern, both instantiations)
     kernels = []
     for name, k in kern.items():
         avg_ms = sum(k["ms"]) / len(k["ms"])
         ach = k["alg_bytes"] / (avg_ms * 1e-3) / 1e9
         tb = None
-        if args.config in ("c234", "c2", "c3") and args.files == 1024 and name in pmc_file:
+        if args.config in ("c234", "c2", "c3", "c4") and args.files == 1024 and name in pmc_file:
             tb = ((load_traffic(pmc_file[name]) or {}).get("derived") or {}).get("hbm_bytes_per_launch")
         kernels.append({"codec": name, "kernel": k["kernel"], "avg_kernel_ms": avg_ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": int(k["alg_bytes"]), "units_per_launch": int(k["units"]),

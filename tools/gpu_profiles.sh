@@ -12,7 +12,18 @@ python tools/export_kernel_stats.py gpurun_out/r02_prof/stats gpurun_out/r02_pro
 find gpurun_out/r02_prof/stats -name "*.db" -delete
 bash tools/pmc_collect.sh r02_pmc_mp3_transform_kernel mp3_transform_kernel bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-full-fetch > /dev/null
 bash tools/pmc_collect.sh r02_pmc_vorbis_wave_kernel vorbis_wave_kernel bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
-bash tools/pmc_collect.sh r02_pmc_flac_restore_kernel "flac_restore_kernelILi8ELi12ELb0ELb1" bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
+# FLAC: counters calibrated on the kernel's own access pattern (known bytes), then both populated instantiations together
+bash tools/pmc_calib_flac.sh > /dev/null 2>&1
+eval $(python3 - <<'PY'
+import json
+c = json.load(open("gpurun_out/calib_flac/calib.json"))
+f = sum(c["FETCH_SIZE_kb_per_launch"]) / len(c["FETCH_SIZE_kb_per_launch"]) * 1024
+w = sum(c["WRITE_SIZE_kb_per_launch"]) / len(c["WRITE_SIZE_kb_per_launch"]) * 1024
+print(f"export AFG_PMC_FETCH_FACTOR={c['known_read_bytes'] / f:.4f} AFG_PMC_WRITE_FACTOR={c['known_write_bytes'] / w:.4f} AFG_PMC_DISPATCHES_PER_LAUNCH=2")
+PY
+)
+bash tools/pmc_collect.sh r02_pmc_flac_restore_kernel "flac_restore_kernel" bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
+unset AFG_PMC_FETCH_FACTOR AFG_PMC_WRITE_FACTOR AFG_PMC_DISPATCHES_PER_LAUNCH
 bash tools/pmc_collect.sh r02_pmc_celt_stream_kernel celt_stream_kernel tools/bench_codecs.py --codec celt --steps 3 > /dev/null
 bash tools/pmc_collect.sh r02_pmc_celt_deemph_kernel celt_deemph_kernel tools/bench_codecs.py --codec celt --steps 3 > /dev/null
 bash tools/pmc_collect.sh r02_pmc_qoa_decode_kernel qoa_decode_kernel tools/bench_codecs.py --codec qoa --steps 3 > /dev/null

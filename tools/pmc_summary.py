@@ -64,11 +64,18 @@ def main():
     if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         # MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B; on gfx950 the
         # derived FETCH_SIZE counts 64-byte requests as 32 bytes: doubled here
-        f = c.get("FETCH_SIZE", 0.0) * 1024 * 2
-        wv = c.get("WRITE_SIZE", 0.0) * 1024
+        # A kernel whose access width the guide does not list brings its own factors, measured on its access pattern with
+        # known byte counts (FLAC: tools/pmc_calib_flac.sh -> profiles/r02_pmc_calib_flac.json), and says how many of the
+        # averaged dispatches make one launch of the library entry (FLAC: the two populated instantiations).
+        ff = float(os.environ.get("AFG_PMC_FETCH_FACTOR", "2.0"))
+        wf = float(os.environ.get("AFG_PMC_WRITE_FACTOR", "1.0"))
+        per_launch = float(os.environ.get("AFG_PMC_DISPATCHES_PER_LAUNCH", "1"))
+        f = c.get("FETCH_SIZE", 0.0) * 1024 * ff * per_launch
+        wv = c.get("WRITE_SIZE", 0.0) * 1024 * wf * per_launch
         derived["hbm_fetch_bytes_per_launch"] = f
         derived["hbm_write_bytes_per_launch"] = wv
         derived["hbm_bytes_per_launch"] = f + wv
+        derived["hbm_counter_factors"] = {"fetch": ff, "write": wf, "dispatches_per_launch": per_launch}
     res = {"kernel_name_contains": needle,
            "how": "tools/pmc_collect.sh: separate `rocprofv3 --pmc <set> -- python3 <program>` passes (counters only), means over the "
                   "dispatches after the first; SQ_* cycle counters are in quad-cycles (MI355X_MICROARCH.md)",

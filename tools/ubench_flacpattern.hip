@@ -93,11 +93,16 @@ template <int ROWS, int T, int TILED = 0> void run(const int *in, int *out, size
         printf("%-28s %.3f ms  %.2f TB/s\n", name, ms, 2.0 * frames * 8192 * 4 / ms / 1e9);
     }
 }
-int main()
+int main(int argc, char **argv)
 {
     const size_t frames = 4096 * 323 / 64 * 64;          // the C4 batch: 1.32M frames, 43 GB each way
     int *in, *out; hipMalloc(&in, frames * 8192 * 4); hipMalloc(&out, frames * 8192 * 4);
     hipMemset(in, 0, frames * 8192 * 4);
+    if (argc > 1) {                                      // calibration of FETCH_SIZE / WRITE_SIZE on the restore kernel's pattern:
+        run16<64, 32>(in, out, frames, "int16 in: 64 x 64 B reads");   // known bytes: 2 B read + 4 B written per sample
+        printf("known bytes per launch: read %zu write %zu\n", frames * 8192 * 2, frames * 8192 * 4);
+        return 0;
+    }
     run<64, 16>(in, out, frames, "64 rows x 64 B (kernel)");
     run<64, 32>(in, out, frames, "64 rows x 128 B");
     run<32, 32>(in, out, frames, "32 rows x 128 B");
