@@ -2,7 +2,9 @@
 # FETCH_SIZE / WRITE_SIZE on the FLAC restore kernel's access pattern with known byte counts (tools/ubench_flacpattern.hip calib):
 # the calibration MI355X_MICROARCH.md asks for before trusting the counters on an access width it does not list.
 R="$GRAFT_REPO_ROOT"; [ -z "$R" ] && R=/root/repo
-export TMPDIR=/tmp; cd /tmp
+export TMPDIR=/tmp
+[ -x "$R/tools/ubench_flacpattern.bin" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o "$R/tools/ubench_flacpattern.bin" "$R/tools/ubench_flacpattern.hip" 2>/dev/null
+cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p "$R/gpurun_out/calib_flac/$c"
   rocprofv3 --pmc $c -d "$R/gpurun_out/calib_flac/$c" -- "$R/tools/ubench_flacpattern.bin" calib > "$R/gpurun_out/calib_flac/$c.log" 2>&1
