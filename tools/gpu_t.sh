@@ -1,11 +1,13 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-for r in 0 1; do
-AFG_CELT_ROUNDS=$r timeout 600 python tools/bench_codecs.py --codec celt --steps 6 --warmup 2 2>/dev/null | tail -1 | python -c "
+for v in t64; do
+AFG_LIB_PATH=$PWD/audio-formats_amd/lib/libafg_$v.so python bench.py --config c4 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read())['celt']; print('rounds=$r', round(d['avg_kernel_ms'],2), d['frac'], d['bitwise_mismatches'])"
+d=json.loads(sys.stdin.read())
+print('$v c4', [(k['codec'], round(k['avg_kernel_ms'],2), round(k['frac'],3)) for k in d['roofline']['kernels']], {k:v['mismatches'] for k,v in d['parity'].items()})"
+AFG_FLAC_RES32=1 AFG_LIB_PATH=$PWD/audio-formats_amd/lib/libafg_$v.so python bench.py --config c4 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$v c4 int32 rows', [(k['codec'], round(k['avg_kernel_ms'],2), round(k['frac'],3)) for k in d['roofline']['kernels']], {k:v['mismatches'] for k,v in d['parity'].items()})"
 done
-AFG_CELT_DE_DUO=0 timeout 600 python tools/bench_codecs.py --codec celt --steps 6 --warmup 2 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())['celt']; print('rounds=1 duo=0', round(d['avg_kernel_ms'],2), d['frac'], d['bitwise_mismatches'])"
