@@ -298,6 +298,19 @@ struct afg_mp3_sdesc { ubyte[40] type; float[40] fl; float[40] fr; }
 static assert(afg_mp3_qgranule.sizeof == 344 && afg_mp3_sdesc.sizeof == 360);
 int afg_mp3_requant_hip(ulong n_granules, const(afg_mp3_qgranule)* d_granules, const(short)* d_q,
                         const(afg_mp3_sdesc)* d_sdesc, float* d_coef, void* hip_stream);
+
+struct afg_mp3_parsed_q
+{
+    afg_mp3_parsed base;             // base.coef is null
+    ulong n_granules, n_sdesc;
+    short* q;                        // n_blocks * 576 quantised lines
+    afg_mp3_qgranule* granules;
+    afg_mp3_sdesc* sdesc;
+}
+int afg_mp3_parse_q(const(ubyte)* data, size_t length, afg_mp3_parsed_q* parsed);
+void afg_mp3_parsed_q_free(afg_mp3_parsed_q* parsed);
+void afg_mp3_qtables(ubyte* band_of_line /* [24][576] */, ushort* dst_of_src /* [24][576] */, float* pow43 /* [145] */);
+int afg_lds_fill_probe_hip(uint word, void* hip_stream);   // test aid: fills the LDS of every CU with `word`
 int afg_celt_transform_streams_hip(uint n_chan, const(ulong)* d_rec_base, const(afg_celt_frame)* d_recs, const(float)* d_coeffs,
                                    float* d_out, float* d_states, void* hip_stream, void* hip_tail_stream);
 alias afg_rand_fn = extern(C) int function(void* user) nothrow @nogc;
