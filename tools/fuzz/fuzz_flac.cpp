@@ -42,6 +42,32 @@ int main(int argc, char **argv)
                                  (r2.n_res && memcmp(dst, rec.res.data(), r2.n_res * sizeof(int32_t))))) { printf("staged parse differs\n"); return 1; }
             free(dst);
         }
+        // int16 residual rows: the packed parse must describe the same residuals (rows widened back), inside the same words
+        if (is_flac) {
+            afg_front::FlacInfo f3; afg_front::FlacRecords r3;
+            r3.pack16 = true;
+            if (!afg_front::flac_parse(p, v.size(), f3, r3) || r3.frames.size() != rec.frames.size() || r3.res.size() != rec.res.size()) {
+                printf("packed parse differs in shape\n"); return 1;
+            }
+            for (size_t i = 0; i < rec.frames.size(); i++) {
+                const afg_flac_frame &a = rec.frames[i], &b = r3.frames[i];
+                if (a.block_size != b.block_size || a.channels != b.channels || a.res16) { printf("packed parse: frame differs\n"); return 1; }
+                for (unsigned c = 0; c < a.channels; c++) {
+                    const int32_t *want = rec.res.data() + a.in_off + (size_t)c * a.block_size;
+                    for (uint32_t k = 0; k < a.block_size; k++) {
+                        int32_t got;
+                        if (b.res16) {
+                            const size_t at = b.in_off + (size_t)c * AFG_FLAC_ROW16(b.block_size) + k;      // int16 index
+                            if ((b.in_off & 7) || at / 2 >= r3.res.size()) { printf("packed row out of range\n"); return 1; }
+                            got = ((const int16_t *)r3.res.data())[at];
+                        } else {
+                            got = r3.res[b.in_off + (size_t)c * b.block_size + k];
+                        }
+                        if (got != want[k]) { printf("packed parse: residual differs\n"); return 1; }
+                    }
+                }
+            }
+        }
         afg_front::QoaInfo qi; std::vector<afg_qoa_frame> q;
         afg_front::qoa_parse(p, v.size(), qi, q);
         free(p);
