@@ -114,3 +114,29 @@ def test_hip_reproduces_opus_and_layer2_file_fixtures(gpu):
     assert [r["status"] for r in res] == [0, 0]
     assert same_bits(res[0]["pcm"], o["pcm"])
     assert same_bits(res[1]["pcm"].reshape(-1), m["pcm"])
+
+
+def floor_fixture():
+    import afgpu
+    g = load("vorbis_floor.npz")
+    return (g["packets"].view(afgpu.VORBIS_FLOOR_PACKET_DTYPE), g["curves"].view(afgpu.VORBIS_FLOOR_CURVE_DTYPE), g["points"], g["steps"],
+            g["residue"], g["spec"])
+
+
+def test_oracle_reproduces_vorbis_floor_fixture():
+    """records of the product's parser + oracle restatement of coupling / do_floor == the oracle front-end's spectra (real file)"""
+    pk, cv, pt, st, residue, spec = floor_fixture()
+    assert len(pk) == 7 and (cv["n_points"] == 0).any() and not same_bits(residue, spec)
+    assert same_bits(oraclelib.vorbis_floor(pk, cv, pt, st, residue), spec)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_vorbis_floor_fixture(gpu):
+    import torch
+    import afgpu
+    pk, cv, pt, st, residue, spec = floor_fixture()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(gpu)
+    d_spec = torch.from_numpy(residue.copy()).to(gpu)
+    afgpu.vorbis_floor(len(pk), t(pk), t(cv), t(pt), t(st), d_spec)
+    torch.cuda.synchronize()
+    assert same_bits(d_spec.cpu().numpy(), spec)
