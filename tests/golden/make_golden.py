@@ -47,9 +47,22 @@ def vorbis_floor_fixture():
                         points=np.concatenate(pts), steps=r["fl_steps"], residue=np.concatenate(res), spec=np.concatenate(spec))
 
 
+def flac_rows16_fixture():
+    """The committed FLAC fixture with every second frame's residual rows stored as int16 (afg_flac_frame.res16):
+    same records otherwise, same expected samples."""
+    g = np.load(os.path.join(HERE, "flac_restore.npz"))
+    from afgpu import FLAC_FRAME_DTYPE
+    frames, res = synthetic.flac_pack16(g["frames"].view(FLAC_FRAME_DTYPE), g["res"], every=2)
+    assert frames["res16"].any() and not frames["res16"].all()
+    np.savez_compressed(os.path.join(HERE, "flac_rows16.npz"), frames=frames.view(np.uint8), res=res)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "vorbis_floor":
         vorbis_floor_fixture()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "flac_rows16":
+        flac_rows16_fixture()
         return
     vorbis_floor_fixture()
     # MP3: stereo + mono stream, block switching incl. mixed blocks
@@ -77,6 +90,7 @@ def main():
     out_i, out_f = oraclelib.flac_transform(frames, subframes, res, total, want_float=True)
     np.savez_compressed(os.path.join(HERE, "flac_restore.npz"), frames=frames.view(np.uint8),
                         subframes=subframes.view(np.uint8), res=res, out_i32=out_i, out_f32=out_f)
+    flac_rows16_fixture()
     # Whole files of the two front-ends added in round 2: generated bytes (tests/opus_bitstream.py, tests/mp3_l12_bitstream.py)
     # and what the oracle's reference-shaped drive delivers for them
     import opus_bitstream as ob

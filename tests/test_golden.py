@@ -140,3 +140,31 @@ def test_hip_reproduces_vorbis_floor_fixture(gpu):
     afgpu.vorbis_floor(len(pk), t(pk), t(cv), t(pt), t(st), d_spec)
     torch.cuda.synchronize()
     assert same_bits(d_spec.cpu().numpy(), spec)
+
+
+def rows16_fixture():
+    g, p = load("flac_restore.npz"), load("flac_rows16.npz")
+    return (p["frames"].view(oraclelib.FLAC_FRAME_DTYPE), g["subframes"].view(oraclelib.FLAC_SUBFRAME_DTYPE), p["res"], g["out_i32"], g["out_f32"])
+
+
+def test_oracle_reproduces_flac_fixture_from_int16_rows():
+    frames, sub, res, want_i, want_f = rows16_fixture()
+    assert frames["res16"].any() and not frames["res16"].all()
+    oi, of = oraclelib.flac_transform(frames, sub, res, want_i.size, want_float=True)
+    assert (oi == want_i).all() and same_bits(of, want_f)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_flac_fixture_from_int16_rows(gpu):
+    import torch
+    import afgpu
+    frames, sub, res, want_i, want_f = rows16_fixture()
+    d_i = torch.zeros(want_i.size, dtype=torch.int32, device=gpu)
+    d_f = torch.zeros(want_i.size, dtype=torch.float32, device=gpu)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(gpu)
+    d_res = torch.from_numpy(res.copy()).to(gpu)
+    for variants in (None, afgpu.flac_variants(frames, sub)):
+        d_i.zero_(); d_f.zero_()
+        afgpu.flac_transform(len(frames), dev(frames), dev(sub), d_res, d_i, d_f, None, variants=variants)
+        torch.cuda.synchronize()
+        assert (d_i.cpu().numpy() == want_i).all() and same_bits(d_f.cpu().numpy(), want_f)
