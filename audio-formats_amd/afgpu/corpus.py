@@ -328,6 +328,14 @@ class Mp3Part(Part):
         got = self.pcm[:nb * 576].cpu().numpy()
         return _float_parity(got, want)
 
+    def check_file(self, checker, f):
+        """file f on its own (any position in the plane: the last files of a full-size batch sit beyond 2^32 bytes)"""
+        b0 = int(self.granules[:f].astype(np.int64).sum()) * 2
+        nb = int(self.granules[f]) * 2
+        want = checker.mp3_transform(self.granules[f:f + 1], self.channels[f:f + 1], self.coef[b0 * 576:(b0 + nb) * 576].cpu().numpy(),
+                                     self.flags[b0:b0 + nb].cpu().numpy().view(np.uint32))
+        return _float_parity(self.pcm[b0 * 576:(b0 + nb) * 576].cpu().numpy(), want)
+
 
 class VorbisPart(Part):
     name, kernel = "vorbis", "vorbis_wave_kernel"
@@ -377,6 +385,18 @@ class VorbisPart(Part):
         want = checker.vorbis_transform(p.packets[:n_files], p.channels[:n_files], p.bs0[:n_files], p.bs1[:n_files],
                                           p.pflags[:npk], so[:npk], oo[:npk], self.spec[:s_end].cpu().numpy(), o_end)
         return _float_parity(self.out[:o_end].cpu().numpy(), want)
+
+    def check_file(self, checker, f):
+        p = self.plan
+        so, oo = p.offsets()
+        k0 = int(p.packets[:f].astype(np.int64).sum())
+        k1 = k0 + int(p.packets[f])
+        s0, o0 = int(so[k0]), int(oo[k0])
+        s1 = int(so[k1]) if p.total_packets > k1 else p.spec_floats
+        o1 = int(oo[k1]) if p.total_packets > k1 else p.out_floats
+        want = checker.vorbis_transform(p.packets[f:f + 1], p.channels[f:f + 1], p.bs0[f:f + 1], p.bs1[f:f + 1], p.pflags[k0:k1],
+                                        so[k0:k1] - np.uint64(s0), oo[k0:k1] - np.uint64(o0), self.spec[s0:s1].cpu().numpy(), o1 - o0)
+        return _float_parity(self.out[o0:o1].cpu().numpy(), want)
 
 
 class FlacPart(Part):
@@ -454,6 +474,21 @@ class FlacPart(Part):
         words = cnt // 2 if self.res16 else cnt
         want = checker.flac_transform(self.frames_np[:nchk], self.sub_np[:2 * nchk], self.res[:words].cpu().numpy(), cnt)
         got = self.out[:cnt].cpu().numpy()
+        bad = int((got != want).sum())
+        return {"samples": int(cnt), "mismatches": bad, "rms_error": 0.0 if bad == 0 else None, "max_abs_error": 0.0 if bad == 0 else None}
+
+    def check_file(self, checker, f):
+        fr0 = int(self.frames_per_file[:f].sum())
+        nfr = int(self.frames_per_file[f])
+        frames = self.frames_np[fr0:fr0 + nfr].copy()
+        w0, o0 = int(frames["in_off"][0]), int(frames["out_off"][0])
+        cnt = nfr * 2 * self.block_size
+        frames["in_off"] -= np.uint64(w0)
+        frames["out_off"] -= np.uint64(o0)
+        frames["sf_index"] -= np.uint32(2 * fr0)
+        res = (self.res[w0 // 2:(w0 + cnt) // 2] if self.res16 else self.res[w0:w0 + cnt]).cpu().numpy()   # in_off: int16 / int32 units
+        want = checker.flac_transform(frames, self.sub_np[2 * fr0:2 * (fr0 + nfr)], res, cnt)
+        got = self.out[o0:o0 + cnt].cpu().numpy()
         bad = int((got != want).sum())
         return {"samples": int(cnt), "mismatches": bad, "rms_error": 0.0 if bad == 0 else None, "max_abs_error": 0.0 if bad == 0 else None}
 
