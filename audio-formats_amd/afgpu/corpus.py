@@ -540,6 +540,18 @@ class CeltPart(Part):
         want = checker.celt_transform(rb, self.recs_np[:nrec], self.coef[:nrec * 960].cpu().numpy(), nrec * 960)
         return _float_parity(self.out[:nrec * 960].cpu().numpy(), want)
 
+    def check_file(self, checker, f):
+        """stereo file f on its own: its two channel sequences, records re-based to the file's first coefficient / sample"""
+        r0, r1 = int(self.rb_np[2 * f]), int(self.rb_np[2 * f + 2])
+        recs = self.recs_np[r0:r1].copy()
+        c0, o0 = int(recs["coef_off"].min()), int(recs["out_off"].min())
+        recs["coef_off"] -= np.uint64(c0)
+        recs["out_off"] -= np.uint64(o0)
+        rb = (self.rb_np[2 * f:2 * f + 3] - np.uint64(r0)).astype(np.uint64)
+        n = (r1 - r0) * 960
+        want = checker.celt_transform(rb, recs, self.coef[c0:c0 + n].cpu().numpy(), n)
+        return _float_parity(self.out[o0:o0 + n].cpu().numpy(), want)
+
 
 def _float_parity(got, want):
     diff = got.astype(np.float64) - want.astype(np.float64)

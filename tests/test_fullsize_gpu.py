@@ -43,3 +43,27 @@ def test_full_size_batch(gpu, codec, need_gb):
         assert torch.equal(first, out)
     del first, out, part, wl
     torch.cuda.empty_cache()
+
+
+def test_full_size_celt_batch(gpu):
+    """8192 stereo CELT streams of 200 frames (the stream-walk path, every wavefront slot taken four times over): first,
+    middle and last stream against the oracle, everything written, deterministic."""
+    import torch
+    if free_bytes() < 60e9:
+        pytest.skip("not enough free device memory")
+    part = corpus.CeltPart(0xCE17, np.full(8192, 200), gpu)
+    out = part.out_plane()
+    out.fill_(float("nan"))
+    stream = torch.cuda.current_stream()
+    part.launch(stream.cuda_stream)
+    torch.cuda.synchronize()
+    for f in (0, 4097, 8191):
+        r = part.check_file(oraclelib, f)
+        assert r["samples"] == 200 * 960 * 2 and r["mismatches"] == 0, (f, r)
+    assert bool(torch.isfinite(out).all())
+    first = out.clone()
+    part.launch(stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(first, out)
+    del first, out, part
+    torch.cuda.empty_cache()
