@@ -13,7 +13,10 @@ pytestmark = pytest.mark.gpu
 
 
 def free_bytes():
+    import gc
     import torch
+    gc.collect()
+    torch.cuda.empty_cache()                               # what earlier tests left in torch's caching allocator
     return torch.cuda.mem_get_info()[0]
 
 
