@@ -322,7 +322,8 @@ def run_rank(args, world, rank, local_rank):
         total_samples = float(my_samples) * world
         scaling = "weak"
         names = {"mp3": f"{args.files} x MP3 CBR-128k stereo 60 s (C2)", "vorbis": f"{args.files} x Ogg Vorbis 2048/256 stereo, 2584 packets (C3)",
-                 "flac": f"{4 * args.files} x FLAC 16-bit stereo, 323 frames of 4096, LPC order 8/12 (C4)"}
+                 "flac": f"{4 * args.files} x FLAC 16-bit stereo, 323 frames of 4096, LPC order 8/12 (C4"
+                         + ("; residual rows int32" if os.environ.get("AFG_FLAC_RES32") else "; residual rows int16, as the host parser packs 16-bit material") + ")"}
         workload = " + ".join(names[w] for w in which) + " per GPU, resident together; device-resident transform-stage records -> PCM"
         cfg_extra = {"files_per_gpu": {w: (4 * args.files if w == "flac" else args.files) for w in which}}
         if rank == 0:
