@@ -413,6 +413,12 @@ __device__ __forceinline__ void load_spectrum(float4 (&x)[4], const float *__res
 #ifndef AFG_VORBIS_TW_REGS
 #define AFG_VORBIS_TW_REGS 1
 #endif
+// Step 2 and the first two butterfly stages without the LDS round trip between them: half-iteration `it` of step 2 makes the
+// points n8-1-it and n4-1-it; with it = 63 - lane + 64 r these are j + 64 (3 - r) and n4/2 + j + 64 (3 - r) for j = lane, i.e.
+// exactly the eight points lane j combines in stages 0 and 1 -- they stay in registers.
+#ifndef AFG_VORBIS_FUSE12
+#define AFG_VORBIS_FUSE12 1
+#endif
 constexpr int kLaneTw = 14;                          // lane-constant twiddles per lane
 constexpr int kTabBase = kNL / 2 + kNL / 2 + kNL / 4 + kNL / 2;      // A B C window of n = 2048 (floats)
 constexpr int kTabFloats = kTabBase + (AFG_VORBIS_TW_REGS ? 0 : kLaneTw * 64 * 2);   // + the lane-major twiddle copy
@@ -421,7 +427,11 @@ __device__ __forceinline__ int lane_twiddle_index(int i, int lane)
 {
     constexpr int n4 = kNL / 4;
     const int jp = lane & 7;
+#if AFG_VORBIS_FUSE12
+    if (i < 4) return n4 - 2 - 2 * ((63 - lane) + 64 * i);      // step 2:      A[n2-4-2o], o = 2 it, it = 63 - lane + 64 r (below)
+#else
     if (i < 4) return n4 - 2 - 2 * (lane + 64 * i);             // step 2:      A[n2-4-2o], o = 2 (lane + 64 r)
+#endif
     if (i == 4) return 4 * lane;                                // stages 0, 1: A[j << 3]
     if (i == 5) return 4 * (lane + 64);                         //              A[(j+64) << 3]
     if (i == 6) return 8 * lane;                                //              A[j << 4]
@@ -488,9 +498,16 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
 
 #if !(AFG_VORBIS_ABL & 4)
     // step 2 (:2006-2040): half-iteration `it` makes points n4-1-it and n8-1-it
+#if AFG_VORBIS_FUSE12
+    f2 s2[2][4];                                    // [half][r']: the points base + 64 r' of stages 0, 1
+#endif
 #pragma unroll
     for (int r = 0; r < 4; r++) {
+#if AFG_VORBIS_FUSE12
+        const int it = 63 - lane + 64 * r;
+#else
         const int it = lane + 64 * r;
+#endif
         const f2 e0 = V[n8 + it];                   // v[n4+o], v[n4+o+1], o = 2 it
         const f2 e1 = V[it];
         const f2 aa = tw.p1(r);                     // A[n2-4-2o], A[n2-3-2o]
@@ -498,11 +515,18 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         const f2 hi = pk_add_swap(e0, e1);          // (d0[1], d0[0])
         // lo.x = v41_21*aa.x - v40_20*aa.y (d1[1]), lo.y = v40_20*aa.x + v41_21*aa.y (d1[0])
         const f2 lo = pk_mul_hl_ll(df, aa) + pk_mul_nlh_hh(df, aa);
+#if AFG_VORBIS_FUSE12
+        s2[0][3 - r] = hi;
+        s2[1][3 - r] = lo;
+#else
         U[pad_e(n8 - 1 - it)] = hi;
         U[pad_e(n4 - 1 - it)] = lo;
+#endif
     }
+#if !AFG_VORBIS_FUSE12
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
+#endif
 
     // stages l = 0, 1 (:2053-2060): point sets {base + j + 64 r}, lane j, both halves
     {
@@ -515,7 +539,11 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
             const int base = hb * (n4 / 2) + j;
             f2 e[4];
 #pragma unroll
+#if AFG_VORBIS_FUSE12
+            for (int r = 0; r < 4; r++) e[r] = s2[hb][r];
+#else
             for (int r = 0; r < 4; r++) e[r] = U[pad_e(base + 64 * r)];
+#endif
             bfly2(e[0], e[2], w00);
             bfly2(e[1], e[3], w01);
             bfly2(e[0], e[1], w1);
@@ -856,7 +884,11 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
         for (int ch = 0; ch < 2; ch++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
+#if AFG_VORBIS_FUSE12
+                const int it = 63 - lane + 64 * r;
+#else
                 const int it = lane + 64 * r;
+#endif
                 e0[ch][r] = V0[ch * CS + n8 + it];
                 e1[ch][r] = V0[ch * CS + it];
             }
@@ -864,20 +896,29 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
         for (int ch = 0; ch < 2; ch++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int it = lane + 64 * r;
                 const f2 aa = tw.p1(r);
                 const f2 df = e0[ch][r] - e1[ch][r];
                 const f2 hi = pk_add_swap(e0[ch][r], e1[ch][r]);
                 const f2 lo = pk_mul_hl_ll(df, aa) + pk_mul_nlh_hh(df, aa);
+#if AFG_VORBIS_FUSE12
+                e0[ch][r] = hi;                                 // point j + 64 (3 - r) of the lower half (j = lane)
+                e1[ch][r] = lo;                                 // the same point of the upper half
+#else
+                const int it = lane + 64 * r;
                 U0[ch * CS + pad_e(n8 - 1 - it)] = hi;
                 U0[ch * CS + pad_e(n4 - 1 - it)] = lo;
+#endif
             }
+#if !AFG_VORBIS_FUSE12
     }
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
 
     // stages l = 0, 1 (:2053-2060)
     {
+#else
+        // stages l = 0, 1 (:2053-2060) on the registers step 2 left
+#endif
         const int j = lane;
         const f2 w00 = tw.pa(0), w01 = tw.pa(1), w1 = tw.pa(2);
 #pragma unroll
@@ -887,7 +928,11 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
 #pragma unroll
             for (int ch = 0; ch < 2; ch++)
 #pragma unroll
+#if AFG_VORBIS_FUSE12
+                for (int r = 0; r < 4; r++) e[ch][r] = hb ? e1[ch][3 - r] : e0[ch][3 - r];
+#else
                 for (int r = 0; r < 4; r++) e[ch][r] = U0[ch * CS + pad_e(base + 64 * r)];
+#endif
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 bfly2(e[ch][0], e[ch][2], w00);
