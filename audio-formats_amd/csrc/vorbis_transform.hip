@@ -419,6 +419,13 @@ __device__ __forceinline__ void load_spectrum(float4 (&x)[4], const float *__res
 #ifndef AFG_VORBIS_FUSE12
 #define AFG_VORBIS_FUSE12 1
 #endif
+// Stages 0-1 and stages 2-4 without the LDS round trip between them (stereo walk): after stages 0, 1 slot s of lane j holds
+// point 64 s + j; stages 2..4 want slot k of lane 8 g + jp to hold point 64 g + jp + 8 k -- an 8 x 8 transpose between the slot
+// index and lane bits [5:3], done in place with v_permlane32_swap (bit 5), v_permlane16_swap (bit 4) and a row_ror:8 DPP
+// move with two selects (bit 3): tools/ubench_lanetr.hip checks the exchange on its own.
+#ifndef AFG_VORBIS_FUSE23
+#define AFG_VORBIS_FUSE23 AFG_VORBIS_FUSE12
+#endif
 constexpr int kLaneTw = 14;                          // lane-constant twiddles per lane
 constexpr int kTabBase = kNL / 2 + kNL / 2 + kNL / 4 + kNL / 2;      // A B C window of n = 2048 (floats)
 constexpr int kTabFloats = kTabBase + (AFG_VORBIS_TW_REGS ? 0 : kLaneTw * 64 * 2);   // + the lane-major twiddle copy
@@ -465,6 +472,42 @@ __device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &t, const float 
     t.t = (const f2 *)lane_major + (threadIdx.x & 63);
 }
 #endif
+
+__device__ __forceinline__ void lane_swap32(float &x, float &y)      // x of lanes 32..63 <-> y of lanes 0..31
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void lane_swap16(float &x, float &y)      // x of the odd rows of 16 <-> y of the even rows
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void lane_swap8(float &x, float &y, bool hi)   // x of lanes with bit 3 set <-> y of their partners (lane ^ 8)
+{
+    const float send = hi ? x : y;
+    const float got = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(send), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    x = hi ? got : x;
+    y = hi ? y : got;
+}
+// slot s of lane 8 k + jp  <->  slot k of lane 8 s + jp
+__device__ __forceinline__ void transpose_slots_hi(f2 (&e)[8], bool hi8)
+{
+    float x[8], y[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { x[k] = e[k].x; y[k] = e[k].y; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { lane_swap32(x[k], x[k + 4]); lane_swap32(y[k], y[k + 4]); }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (!(k & 2)) { lane_swap16(x[k], x[k + 2]); lane_swap16(y[k], y[k + 2]); }
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) { lane_swap8(x[k], x[k + 1], hi8); lane_swap8(y[k], y[k + 1], hi8); }
+#pragma unroll
+    for (int k = 0; k < 8; k++) e[k] = f2{ x[k], y[k] };
+}
 
 template <typename AfterStep0>
 __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *smem, const LaneTwiddles &tw,
@@ -921,6 +964,29 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
 #endif
         const int j = lane;
         const f2 w00 = tw.pa(0), w01 = tw.pa(1), w1 = tw.pa(2);
+#if AFG_VORBIS_FUSE23
+        f2 e[2][8];                                             // slot 4 hb + r: point hb n4/2 + j + 64 r
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { e[ch][r] = e0[ch][3 - r]; e[ch][4 + r] = e1[ch][3 - r]; }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int hb = 0; hb < 8; hb += 4) {
+                bfly2(e[ch][hb + 0], e[ch][hb + 2], w00);
+                bfly2(e[ch][hb + 1], e[ch][hb + 3], w01);
+                bfly2(e[ch][hb + 0], e[ch][hb + 1], w1);
+                bfly2(e[ch][hb + 2], e[ch][hb + 3], w1);
+            }
+        // stages l = 2, 3, 4 (:2062-2083) want slot k of lane 8 g + jp to hold point 64 g + jp + 8 k
+        transpose_slots_hi(e[0], (j & 8) != 0);
+        transpose_slots_hi(e[1], (j & 8) != 0);
+        const int g = lane >> 3, jp = lane & 7;
+        const int base = 64 * g + jp;
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+#else
 #pragma unroll
         for (int hb = 0; hb < 2; hb++) {
             const int base = hb * (n4 / 2) + j;
@@ -958,6 +1024,7 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
             for (int k = 0; k < 8; k++) e[ch][k] = U0[ch * CS + pad_e(base + 8 * k)];
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
+#endif
 #pragma unroll
             for (int k = 0; k < 4; k++) bfly2(e[ch][k], e[ch][k + 4], tw.pb(k));
 #pragma unroll
