@@ -46,6 +46,7 @@ WAV_S8, WAV_S16LE, WAV_S24LE, WAV_FP32LE, WAV_FP64LE = range(5)
 # every symbol include/afg.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "afg_abi_version", "afg_status_string", "afg_last_error", "afg_device_count", "afg_device_name",
+    "afg_set_numeric_mode", "afg_get_numeric_mode",
     "afg_mp3_plan_create", "afg_mp3_plan_destroy", "afg_mp3_plan_blocks", "afg_mp3_plan_segments",
     "afg_mp3_transform_hip", "afg_mp3_requant_hip", "afg_mp3_parse_q", "afg_mp3_parsed_q_free", "afg_mp3_qtables",
     "afg_vorbis_plan_create", "afg_vorbis_plan_destroy", "afg_vorbis_plan_packets",
@@ -765,6 +766,22 @@ def copy_probe(d_dst, d_src, nbytes, stream=None):
 def lds_fill(word=0x7fc00000, stream=None):
     """Test aid (afg_lds_fill_probe_hip): leave `word` (default: NaN) in the LDS of every compute unit."""
     check(lib().afg_lds_fill_probe_hip(int(word), _stream(stream)))
+
+
+NUMERIC_EXACT, NUMERIC_TOLERANCE = 0, 1
+
+
+def set_numeric_mode(mode):
+    """afg_set_numeric_mode: NUMERIC_EXACT (the reference's expression trees, bit for bit) or NUMERIC_TOLERANCE (default:
+    within 1e-5 RMS; the Opus/CELT stage may re-associate).  Returns the previous mode."""
+    prev = lib().afg_set_numeric_mode(int(mode))
+    if prev < 0:
+        check(prev)
+    return prev
+
+
+def get_numeric_mode():
+    return int(lib().afg_get_numeric_mode())
 
 
 def device_count():

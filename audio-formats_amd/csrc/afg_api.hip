@@ -1,6 +1,7 @@
 // afg_api.hip -- status strings, device checks and small utilities of the C ABI.
 #include "afg_common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <string>
 
@@ -34,6 +35,29 @@ int require_device()
         return AFG_ERR_NO_DEVICE;
     }
     return AFG_OK;
+}
+
+int device_slot(int *dev, const char *who)
+{
+    *dev = 0;
+    AFG_HIP_CHECK(hipGetDevice(dev));
+    if (*dev < 0 || *dev >= AFG_MAX_DEVICES) {
+        set_error("%s: device index %d does not fit this library's per-device tables (AFG_MAX_DEVICES = %d)", who, *dev,
+                  AFG_MAX_DEVICES);
+        return AFG_ERR_INVALID;
+    }
+    return AFG_OK;
+}
+
+static std::atomic<int> g_numeric_mode{ -1 };                 // -1: not set by the caller, the environment decides
+
+int numeric_mode()
+{
+    const int m = g_numeric_mode.load(std::memory_order_relaxed);
+    if (m >= 0) return m;
+    const char *e = getenv("AFG_NUMERIC");
+    if (e && !strcmp(e, "exact")) return AFG_NUMERIC_EXACT;
+    return AFG_NUMERIC_TOLERANCE;
 }
 
 int DeviceArray::upload(const void *host, size_t nbytes)
@@ -79,6 +103,19 @@ const char *afg_status_string(int status)
 }
 
 const char *afg_last_error(void) { return afg::g_err; }
+
+int afg_get_numeric_mode(void) { return afg::numeric_mode(); }
+
+int afg_set_numeric_mode(int mode)
+{
+    if (mode != AFG_NUMERIC_EXACT && mode != AFG_NUMERIC_TOLERANCE) {
+        afg::set_error("afg_set_numeric_mode: unknown mode %d", mode);
+        return AFG_ERR_INVALID;
+    }
+    const int prev = afg::numeric_mode();
+    afg::g_numeric_mode.store(mode, std::memory_order_relaxed);
+    return prev;
+}
 
 int afg_device_count(void)
 {

@@ -16,6 +16,15 @@ void set_error(const char *fmt, ...);
 // Verifies a gfx950 device is present and selected; loud failure otherwise.
 int require_device();
 
+// Per-device state of the library (table copies, side streams, work counters) lives in arrays of this many slots --
+// 8 MI355X in CPX partition mode show up as 64 devices.  device_slot() returns the calling thread's current device
+// in *dev, or AFG_ERR_INVALID with a message naming the cap when its index does not fit.
+#define AFG_MAX_DEVICES 64
+int device_slot(int *dev, const char *who);
+
+// Numeric mode of the float transform stages (afg_set_numeric_mode; env AFG_NUMERIC=exact|tolerance until it is called).
+int numeric_mode();
+
 #define AFG_HIP_CHECK(expr)                                                              \
     do {                                                                                 \
         hipError_t e__ = (expr);                                                         \

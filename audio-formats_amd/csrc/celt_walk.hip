@@ -1,0 +1,566 @@
+// celt_walk.hip -- Opus/CELT transform stage on gfx950, tolerance mode (AFG_NUMERIC_TOLERANCE).
+//
+// The same seam as celt_transform.hip (the per-channel tail of ff_celt_decode_frame, dopus.d:3680-3702: imdct15_half
+// :1611-1637 + vector_fmul_window :230-243, celt_postfilter :3281-3378, de-emphasis / scaling :3695-3701), for callers
+// that accept north_star's tolerance (1e-5 RMS on the API scale) instead of bit-identity with the D expression trees.
+// Two things become possible, and both remove a serial chain:
+//
+//   * De-emphasis (tmp = x + m; m = tmp * 0.8500061; out = tmp / 32768, :3695-3701) is a one-pole IIR whose float
+//     rounding order the exact path must follow sample by sample -- a second pass over the PCM plane with one lane per
+//     channel sequence.  Re-associated it is a weighted prefix sum: here it runs on the 64 samples a wavefront holds
+//     for its coalesced store anyway (six DPP steps per row, the carry between rows through a scalar), *inside* the
+//     frame walk: the PCM plane is written once and never read.
+//   * The comb post-filter (:3281-3378) feeds on its own output, but only while a filter is live: a frame whose old,
+//     current and new gains are all zero is left untouched (:3294-3296, :3333).  Where the records show enough such
+//     frames in a row (the filter reaches back at most 1024 samples) everything after them is independent of
+//     everything before them, *exactly*.  A wavefront therefore walks a *segment* of a stream: it starts a few frames
+//     early (the warm-up: transform only, nothing stored) at such a cut and stops at the first cut behind its nominal
+//     range.  Cuts are found on the device from the records themselves, so the entry point keeps the device-only
+//     signature of afg_celt_transform_hip; a stream with a live filter throughout stays one serial walk.
+//     The de-emphasis memory a segment starts from is rebuilt by the warm-up (0.85^1026 < 1e-72).
+//
+// Launch shape: persistent workgroups (8 wavefronts sharing one LDS copy of the tables, one per CU) draw items from
+// an atomic counter; an item is a range of `seg_recs` records of the flat record array (or a whole channel pair when
+// seg_recs is 0), mapped to the channel pairs it overlaps by a search in rec_base.
+//
+// This file is compiled with -ffp-contract=fast (Makefile): multiply-adds of the transform fuse.
+#include "celt_core.h"
+
+#include <algorithm>
+#include <mutex>
+
+namespace {
+
+constexpr int kWWaves = 8;                                   // wavefronts per workgroup, sharing the tables
+constexpr int kWLdsFloats = kTabFloatsMax + 240 + kWWaves * 2 * 2048;
+constexpr float kDeemph = 0.85000610f;                       // CELT_DEEMPH_COEFF, dopus.d:1964
+
+struct PfW {
+    int period, period_old;
+    float g[3], g_old[3];
+};
+
+// ---- post-filter on the linear frame buffer (data = buf + 1024: CeltFrame.buf + 1024 of the reference) ------------------
+// celt_postfilter_apply_transition (dopus.d:3281-3324) on data[n0 .. n0 + 120)
+__device__ __forceinline__ void wpf_transition(float *data, const float *win2, int n0, const PfW &pf, int l, bool lane_on)
+{
+    const bool go = lane_on && !(pf.g[0] == 0.0f && pf.g_old[0] == 0.0f);
+    if (!__any(go)) return;
+    const int T0 = pf.period_old, T1 = pf.period;
+    // a filter whose gains are all zero contributes exact zeros whatever it reads (its period may still be 0 on a
+    // fresh decoder): only live filters bound the parallel step, and a dead filter's taps are not read
+    const bool live0 = pf.g_old[0] != 0.0f || pf.g_old[1] != 0.0f || pf.g_old[2] != 0.0f;
+    const bool live1 = pf.g[0] != 0.0f || pf.g[1] != 0.0f || pf.g[2] != 0.0f;
+    int step = 32;
+    if (go && live0) step = min(step, T0 - 2);
+    if (go && live1) step = min(step, T1 - 2);
+    step = max(step, 1);
+    step = min(__shfl(step, 0), __shfl(step, 32));
+    float *d = data + n0;
+    for (int i0 = 0; i0 < 120; i0 += step) {
+        const int i = i0 + l;
+        float v = 0.0f;
+        const bool on = go && l < step && i < 120;
+        if (on) {
+            const float w = win2[i];
+            const float x0 = live1 ? d[i - T1 + 2] : 0.0f, x1 = live1 ? d[i - T1 + 1] : 0.0f, x2 = live1 ? d[i - T1] : 0.0f,
+                        x3 = live1 ? d[i - T1 - 1] : 0.0f, x4 = live1 ? d[i - T1 - 2] : 0.0f;
+            const float y0 = live0 ? d[i - T0 + 2] : 0.0f, y1 = live0 ? d[i - T0 + 1] : 0.0f, y2 = live0 ? d[i - T0] : 0.0f,
+                        y3 = live0 ? d[i - T0 - 1] : 0.0f, y4 = live0 ? d[i - T0 - 2] : 0.0f;
+            const float u = 1.0f - w;
+            const float acc = u * (pf.g_old[0] * y2 + pf.g_old[1] * (y3 + y1) + pf.g_old[2] * (y4 + y0)) +
+                              w * (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
+            v = d[i] + acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (on) d[i] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// celt_postfilter_apply (dopus.d:3326-3355) on data[n0 .. n0 + len)
+__device__ __forceinline__ void wpf_apply(float *data, int n0, int len, const PfW &pf, int l, bool lane_on)
+{
+    const bool go = lane_on && pf.g[0] != 0.0f && len > 0;
+    if (!__any(go)) return;
+    const int T = pf.period;
+    // everything a step reads is at least T - 2 samples old: a lane takes samples l and l + 32 of a step when T allows
+    int step = go ? max(min(T - 2, 64), 1) : 64;
+    step = min(__shfl(step, 0), __shfl(step, 32));
+    float *d = data + n0;
+    if (step > 32) {
+        for (int i0 = 0; i0 < len; i0 += step) {
+            float v[2] = { 0.0f, 0.0f };
+            bool on[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = i0 + l + 32 * u;
+                on[u] = go && l + 32 * u < step && i < len;
+                if (on[u]) {
+                    const float x0 = d[i - T + 2], x1 = d[i - T + 1], x2 = d[i - T], x3 = d[i - T - 1], x4 = d[i - T - 2];
+                    v[u] = d[i] + (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (on[u]) d[i0 + l + 32 * u] = v[u];
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    for (int i0 = 0; i0 < len; i0 += step) {
+        const int i = i0 + l;
+        float v = 0.0f;
+        const bool on = go && l < step && i < len;
+        if (on) {
+            const float x0 = d[i - T + 2], x1 = d[i - T + 1], x2 = d[i - T], x3 = d[i - T - 1], x4 = d[i - T - 2];
+            v = d[i] + (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (on) d[i] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- de-emphasis as a weighted prefix sum over the 64 lanes of a row ----------------------------------------------------
+// y[j] = x[j] + c * y[j-1] over lanes j = 0..63, y[-1] = 0: doubling steps inside the rows of 16 (DPP row_shr), then the
+// two cross-row steps (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lanes out of range read 0.
+struct DeW {
+    float w16, w32, wc;                                      // c^((lane & 15) + 1), c^((lane & 31) + 1), c^lane
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp0(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+
+__device__ __forceinline__ float deemph_row(float x, const DeW &w)
+{
+    constexpr float c1 = kDeemph, c2 = c1 * c1, c4 = c2 * c2, c8 = c4 * c4;
+    float y = x;
+    y = __builtin_fmaf(c1, dpp0<0x111, 0xf>(y), y);          // row_shr:1
+    y = __builtin_fmaf(c2, dpp0<0x112, 0xf>(y), y);          // row_shr:2
+    y = __builtin_fmaf(c4, dpp0<0x114, 0xf>(y), y);          // row_shr:4
+    y = __builtin_fmaf(c8, dpp0<0x118, 0xf>(y), y);          // row_shr:8
+    y = __builtin_fmaf(w.w16, dpp0<0x142, 0xa>(y), y);       // row_bcast:15 -> rows 1, 3
+    y = __builtin_fmaf(w.w32, dpp0<0x143, 0xc>(y), y);       // row_bcast:31 -> rows 2, 3
+    return y;
+}
+
+__device__ __forceinline__ float lane_value(float v, int lane_uniform)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
+// ---- records ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool rec_dead(const afg_celt_frame *r)     // the frame installs a filter that does nothing
+{
+    return r->pf_gains_new[0] == 0.0f && r->pf_gains_new[1] == 0.0f && r->pf_gains_new[2] == 0.0f;
+}
+
+// Is frame q of the sequence at `seq` (cnt frames) a cut?  Returns the warm-up length W > 0 (walk frames q - W .. q - 1
+// without storing, from a zeroed buffer, then q onwards is exact), else 0.  Conditions: the records q - W - 1 .. q - 1 all
+// install dead filters -- so frames q - W .. q - 1 are left untouched by celt_postfilter apart from the first 120 samples
+// of frame q - W, and the filter state entering frame q - W + 1 .. q is dead -- and the warm-up frames hold at least
+// 120 + 1026 samples: the first 120 of a walk that starts from nothing lack the previous frame's overlap, the filter of
+// frame q reaches back 1022 + 2 samples (period <= 1022, dopus.d:3399-3407).
+__device__ __forceinline__ int cut_warmup(const afg_celt_frame *seq, uint64_t cnt, uint64_t q)
+{
+    if (q < 2 || q >= cnt) return 0;
+    int sum = 0;
+    for (int w = 1; w <= 12 && (uint64_t)w < q; w++) {
+        const afg_celt_frame *r = seq + (q - w);
+        if (!rec_dead(r)) return 0;
+        sum += r->frame_size;
+        if (sum >= 120 + 1026) return rec_dead(r - 1) ? w : 0;
+    }
+    return 0;
+}
+
+// first cut in [lo, hi) of a channel pair (seq1 == nullptr: of one sequence); W of each channel through w0 / w1
+__device__ __forceinline__ uint64_t first_cut(const afg_celt_frame *seq0, const afg_celt_frame *seq1, uint64_t cnt,
+                                              uint64_t lo, uint64_t hi, int lane, int &w0, int &w1)
+{
+    for (uint64_t q0 = lo; q0 < hi; q0 += 64) {
+        const uint64_t q = q0 + lane;
+        int a = 0, b = 0;
+        if (q < hi) {
+            a = cut_warmup(seq0, cnt, q);
+            b = (seq1 && a) ? cut_warmup(seq1, cnt, q) : a;
+        }
+        const unsigned long long hit = __ballot(a > 0 && b > 0);
+        if (hit) {
+            const int first = __ffsll(hit) - 1;
+            w0 = __shfl(a, first);
+            w1 = __shfl(b, first);
+            return q0 + first;
+        }
+    }
+    w0 = w1 = 0;
+    return hi;
+}
+
+// largest c in [0, n) with rec_base[c] <= x (rec_base is non-decreasing, rec_base[0] <= x): 64 probes per round
+__device__ __forceinline__ uint32_t find_seq(const uint64_t *__restrict__ rec_base, uint32_t n, uint64_t x, int lane)
+{
+    uint32_t lo = 0, hi = n;                                  // answer in [lo, hi)
+    while (hi - lo > 1) {
+        const uint32_t span = hi - lo;
+        const uint32_t stepw = (span + 63) / 64;
+        const uint32_t c = lo + (uint32_t)lane * stepw;
+        const bool le = c < hi && rec_base[c] <= x;
+        const unsigned long long m = __ballot(le);            // lanes are ordered: a prefix of ones
+        const int k = m ? 63 - __clzll(m) : 0;                // (lane 0 holds whenever rec_base[lo] <= x)
+        const uint32_t nlo = lo + (uint32_t)k * stepw;
+        const uint32_t nhi = min(hi, nlo + stepw);
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
+    const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs,
+    const float *__restrict__ coeffs, float *__restrict__ out, float *__restrict__ states,
+    const float *__restrict__ tables, CeltTables tb, uint32_t tab_floats, uint32_t n_chan, uint32_t seg_recs,
+    uint32_t *__restrict__ counter)
+{
+    extern __shared__ __attribute__((aligned(16))) float slds[];
+    float *ltab = slds, *lwin = slds + kTabFloatsMax, *win2 = lwin + 120;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, l = lane & 31;
+    const uint32_t pairs = (n_chan + 1) / 2;
+    const uint64_t total = rec_base[n_chan];
+    const uint64_t n_items = seg_recs ? (total + seg_recs - 1) / seg_recs : pairs;
+
+    auto draw = [&]() -> uint64_t {
+        uint32_t it = 0;
+        if (lane == 0) it = atomicAdd(counter, 1u);
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+    };
+    uint64_t item = draw();
+    // a workgroup none of whose wavefronts got an item leaves before it stages anything
+    if (!__syncthreads_or(item < n_items)) return;
+    for (uint32_t i = threadIdx.x; i < tab_floats; i += 64 * kWWaves) ltab[i] = tables[i];
+    if (threadIdx.x < 240) lwin[threadIdx.x] = tables[kCeltWinAt + threadIdx.x];
+    __syncthreads();
+
+    float *bufs = win2 + 120 + (size_t)wv * 2 * 2048;
+    DeW dw;
+    {
+        float p = 1.0f;                                       // c^lane by repeated products (once per wavefront)
+        float c16 = 0.0f, c32 = 0.0f, cl = 0.0f;
+        for (int k = 0; k < 64; k++) {
+            if (k == lane) cl = p;
+            p *= kDeemph;
+            if (k == (lane & 15)) c16 = p;
+            if (k == (lane & 31)) c32 = p;
+        }
+        dw.w16 = c16; dw.w32 = c32; dw.wc = cl;
+    }
+
+    // Walks frames [a, end) of one sequence (lanes 0..31) or of both sequences of a pair (lane half = channel);
+    // frames before `start` are the warm-up: transformed, nothing stored.
+    auto walk = [&](bool both, uint32_t chan_lo, uint32_t chan_hi, uint64_t base_lo, uint64_t base_hi, uint64_t cnt,
+                    uint64_t a, uint64_t start, uint64_t end) __attribute__((always_inline)) {
+        const bool act = both || h == 0;
+        const uint32_t my_chan = (both && h) ? chan_hi : chan_lo;
+        const uint64_t my_base = (both && h) ? base_hi : base_lo;
+        float *st = states ? states + (size_t)my_chan * AFG_CELT_STATE_FLOATS : nullptr;
+        float *buf = bufs + (both ? h : 0) * 2048;
+        cpx *z = (cpx *)(buf + 1024 + 60);
+        const float *b0 = bufs, *b1 = bufs + 2048;
+
+        PfW pf;
+        pf.period = pf.period_old = 0;
+        pf.g[0] = pf.g[1] = pf.g[2] = pf.g_old[0] = pf.g_old[1] = pf.g_old[2] = 0.0f;
+        float m = 0.0f;                                      // de-emphasis memory of this lane's channel (uniform per half)
+        const bool from_state = a == 0 && st != nullptr;
+        if (act) {
+            for (int i = l; i < 2048; i += 32) buf[i] = from_state ? st[i] : 0.0f;
+            if (from_state) {
+                pf.period = __float_as_int(st[2048]);
+                pf.g[0] = st[2049]; pf.g[1] = st[2050]; pf.g[2] = st[2051];
+                pf.period_old = __float_as_int(st[2052]);
+                pf.g_old[0] = st[2053]; pf.g_old[1] = st[2054]; pf.g_old[2] = st[2055];
+                m = st[2056];
+            } else if (a > 0) {
+                pf.period = pf.period_old = recs[my_base + a - 1].pf_period_new;   // dead filters: gains stay zero
+            }
+        }
+        float wi[2], wj[2];                                  // block-0 window taps of this lane
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = min(l + 32 * u, 59);
+            wi[u] = lwin[k];
+            wj[u] = lwin[119 - k];
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        afg_celt_frame fr = recs[my_base + a], fr_next = fr;
+        if (a + 1 < end) fr_next = recs[my_base + a + 1];
+        float xa[15], xb[15];
+        {
+            const Geo g0 = geo_of(fr);
+            if (is_960(g0)) load_inputs(xa, xb, coeffs, fr, geo_960(), l);
+            else load_inputs(xa, xb, coeffs, fr, g0, l);
+        }
+
+        for (uint64_t q = a; q < end; q++) {
+            const Geo g = geo_of(fr);
+            const int F = g.F;
+            const bool storing = q >= start;
+            afg_celt_frame fr_next2 = recs[my_base + (q + 2 < end ? q + 2 : end - 1)];
+            // iMDCT and overlap-add, dopus.d:3684-3690
+            if (is_960(g)) frame_fft(z, xa, xb, fr, geo_960(), ltab, lwin, tb, l, act);
+            else frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
+            {                                                // (the last frame's again at the end)
+                const Geo gn = geo_of(fr_next);
+                if (is_960(gn)) load_inputs(xa, xb, coeffs, fr_next, geo_960(), l);
+                else load_inputs(xa, xb, coeffs, fr_next, gn, l);
+            }
+            if (is_960(g)) frame_rest(z, fr, geo_960(), ltab, lwin, tb, l, act);
+            else frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+            if (act) {                                       // vector_fmul_window of block 0
+                float *d = buf + 1024;
+                float va[2], vb[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int k = l + 32 * u;
+                    if (k < 60) {
+                        const float s0 = d[k], s1 = d[119 - k];
+                        va[u] = s0 * wj[u] - s1 * wi[u];
+                        vb[u] = s0 * wi[u] + s1 * wj[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int k = l + 32 * u;
+                    if (k < 60) { d[k] = va[u]; d[119 - k] = vb[u]; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // celt_postfilter, dopus.d:3357-3378 (a no-op on warm-up frames: their filters are dead by construction)
+            wpf_transition(buf + 1024, win2, 0, pf, l, act);
+            pf.period_old = pf.period;
+            pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
+            pf.period = fr.pf_period_new;
+            pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
+            if (F > 120) {
+                wpf_transition(buf + 1024, win2, 120, pf, l, act);
+                wpf_apply(buf + 1024, 240, F - 240, pf, l, act);
+                pf.period_old = pf.period;
+                pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
+            }
+
+            // make the prefetched inputs resident before the stores enter the queue (one in-order memory counter)
+#pragma unroll
+            for (int i = 0; i < 15; i++) asm volatile("" : "+v"(xa[i]), "+v"(xb[i]) : : "memory");
+            settle_rec(fr_next2);
+            // de-emphasis + scaling on the rows as they leave (dopus.d:3695-3701, re-associated), coalesced stores
+            const int last = (F - 1) & 63;
+            if (both) {
+                // m of the two channels: lanes of half h carry channel h's; row lanes span both halves, so take scalars
+                float m0 = lane_value(m, 0), m1 = lane_value(m, 32);
+                f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
+                if (F == 960) {
+                    f32x2 v[15];
+#pragma unroll
+                    for (int i = 0; i < 15; i++) v[i] = f32x2{ b0[1024 + lane + 64 * i], b1[1024 + lane + 64 * i] };
+#pragma unroll
+                    for (int i = 0; i < 15; i++) { v[i].x = deemph_row(v[i].x, dw); v[i].y = deemph_row(v[i].y, dw); }
+#pragma unroll
+                    for (int i = 0; i < 15; i++) {
+                        v[i].x = __builtin_fmaf(dw.wc, m0, v[i].x);
+                        v[i].y = __builtin_fmaf(dw.wc, m1, v[i].y);
+                        m0 = kDeemph * lane_value(v[i].x, 63);
+                        m1 = kDeemph * lane_value(v[i].y, 63);
+                    }
+                    if (storing) {
+#pragma unroll
+                        for (int i = 0; i < 15; i++) o[lane + 64 * i] = v[i] * (1.0f / 32768.0f);
+                    }
+                } else {
+                    for (int p0 = 0; p0 < F; p0 += 64) {
+                        const int p = p0 + lane;
+                        const bool in = p < F;
+                        float x0 = in ? b0[1024 + p] : 0.0f, x1 = in ? b1[1024 + p] : 0.0f;
+                        x0 = __builtin_fmaf(dw.wc, m0, deemph_row(x0, dw));
+                        x1 = __builtin_fmaf(dw.wc, m1, deemph_row(x1, dw));
+                        const int lastl = p0 + 64 <= F ? 63 : last;
+                        m0 = kDeemph * lane_value(x0, lastl);
+                        m1 = kDeemph * lane_value(x1, lastl);
+                        if (in && storing) o[p] = f32x2{ x0, x1 } * (1.0f / 32768.0f);
+                    }
+                }
+                m = h ? m1 : m0;
+            } else {
+                float m0 = lane_value(m, 0);
+                float *o = out + __shfl(fr.out_off, 0);
+                const size_t stride = __shfl(fr.out_stride, 0);
+                for (int p0 = 0; p0 < F; p0 += 64) {
+                    const int p = p0 + lane;
+                    const bool in = p < F;
+                    float x0 = in ? b0[1024 + p] : 0.0f;
+                    x0 = __builtin_fmaf(dw.wc, m0, deemph_row(x0, dw));
+                    const int lastl = p0 + 64 <= F ? 63 : last;
+                    m0 = kDeemph * lane_value(x0, lastl);
+                    if (in && storing) o[(size_t)p * stride] = x0 * (1.0f / 32768.0f);
+                }
+                m = m0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // memmove(buf, buf + F, 1084 floats) (:3370): every read is issued before the first write
+            {
+                f32x4 mv[9];
+#pragma unroll
+                for (int u = 0; u < 9; u++)
+                    if (act && l + 32 * u < 271) mv[u] = *(const f32x4 *)(buf + F + 4 * (l + 32 * u));
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 9; u++)
+                    if (act && l + 32 * u < 271) *(f32x4 *)(buf + 4 * (l + 32 * u)) = mv[u];
+                __builtin_amdgcn_wave_barrier();
+            }
+            fr = fr_next;
+            fr_next = fr_next2;
+        }
+
+        if (st && act && end == cnt) {
+            for (int i = l; i < 2048; i += 32) st[i] = buf[i];
+            if (l == 0) {
+                st[2048] = __int_as_float(pf.period);
+                st[2049] = pf.g[0]; st[2050] = pf.g[1]; st[2051] = pf.g[2];
+                st[2052] = __int_as_float(pf.period_old);
+                st[2053] = pf.g_old[0]; st[2054] = pf.g_old[1]; st[2055] = pf.g_old[2];
+                st[2056] = m;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // One call site for the walk (so that it is inlined and its LDS pointers keep their address space): an item is
+    // broken into the channel pairs it overlaps, a pair into one run (two sequences of equal length, walked together when
+    // their records pair up) or two (sequences of different lengths), a run into one or two walks.
+    while (item < n_items) {
+        uint32_t p_lo = (uint32_t)item, p_hi = p_lo + 1;
+        uint64_t x0 = 0, x1 = 0;
+        if (seg_recs) {
+            x0 = item * seg_recs;
+            x1 = x0 + seg_recs < total ? x0 + seg_recs : total;
+            p_lo = find_seq(rec_base, n_chan, x0, lane) >> 1;
+            p_hi = pairs;
+        }
+        for (uint32_t p = p_lo; p < p_hi; p++) {
+            const uint32_t c0 = 2 * p, c1 = c0 + 1;
+            const uint64_t base0 = rec_base[c0], cnt0 = rec_base[c0 + 1] - base0;
+            if (seg_recs && base0 >= x1) break;
+            uint64_t base1 = base0 + cnt0, cnt1 = 0;
+            if (c1 < n_chan) { base1 = rec_base[c1]; cnt1 = rec_base[c1 + 1] - base1; }
+            const uint64_t span = cnt0 + cnt1, cmax = cnt0 > cnt1 ? cnt0 : cnt1;
+            if (span == 0) continue;
+            uint64_t qa = 0, qb = cmax;
+            if (seg_recs) {
+                const uint64_t lo = x0 > base0 ? x0 - base0 : 0, hi = (x1 < base0 + span ? x1 : base0 + span) - base0;
+                if (lo >= hi) continue;
+                // a monotone map of flat offsets onto frames of the longer sequence: consecutive items partition [0, cmax)
+                qa = (lo * cmax + span - 1) / span;
+                qb = (hi * cmax + span - 1) / span;
+            }
+            const bool equal = cnt0 == cnt1;
+            for (int r = 0; r < (equal ? 1 : 2); r++) {
+                // run r: frames [ra, rb) of one sequence, or of both sequences when they are equally long
+                const bool two = equal;
+                const uint32_t rc = r ? c1 : c0;
+                const uint64_t rbase = r ? base1 : base0, rcnt = r ? cnt1 : cnt0;
+                const uint64_t ra = qa < rcnt ? qa : rcnt, rb = qb < rcnt ? qb : rcnt;
+                if (ra >= rb) continue;
+                const afg_celt_frame *s0 = recs + rbase, *s1 = two ? recs + base1 : nullptr;
+                uint64_t start = 0, end = rcnt;
+                int w0 = 0, w1 = 0;
+                if (ra > 0) {
+                    start = first_cut(s0, s1, rcnt, ra, rb, lane, w0, w1);
+                    if (start >= rb) continue;               // no cut in the range: an earlier item walks through it
+                }
+                if (rb < rcnt) {
+                    int e0, e1;
+                    end = first_cut(s0, s1, rcnt, rb, rcnt, lane, e0, e1);
+                }
+                bool paired = two && w0 == w1;
+                if (paired) {
+                    bool bad = false;
+                    for (uint64_t q = start - w0 + lane; q < end; q += 64) bad = bad || !celt_pair_ok(s0[q], s1[q]);
+                    paired = !__any(bad);
+                }
+                for (int j = 0; j < ((two && !paired) ? 2 : 1); j++) {
+                    const uint32_t jc = j ? c1 : rc;
+                    const uint64_t jbase = j ? base1 : rbase;
+                    walk(paired, jc, jc + 1, jbase, base1, rcnt, start - (j ? w1 : w0), start, end);
+                }
+            }
+        }
+        item = draw();
+    }
+}
+
+std::mutex g_mu;
+uint32_t *g_counters[AFG_MAX_DEVICES] = {};
+uint32_t g_launches[AFG_MAX_DEVICES] = {};
+int g_cus[AFG_MAX_DEVICES] = {};
+
+}  // namespace
+
+// Records per item from the number of channel sequences.  Long streams are cut into 64-frame pieces (the warm-up of a
+// piece costs two frames of transform: 3 %); with thousands of streams the pieces only have to even out the tail.
+// AFG_CELT_SEG_RECS overrides (0: whole channel pairs).
+static uint32_t seg_recs_for(uint32_t n_chan)
+{
+    if (const char *e = getenv("AFG_CELT_SEG_RECS")) {
+        const long v = atol(e);
+        if (v >= 0 && v <= (1 << 24)) return (uint32_t)v;
+    }
+    return 128;
+}
+
+int afg::celt_walk_launch(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs, const float *d_coeffs,
+                          float *d_out, float *d_states, hipStream_t stream)
+{
+    const float *d_tables = nullptr;
+    CeltTables tb;
+    uint32_t tab_floats = 0;
+    if (int rc = afg::celt_tables_for_device(&d_tables, &tb, &tab_floats)) return rc;
+    int dev = 0;
+    AFG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= AFG_MAX_DEVICES) {
+        afg::set_error("afg_celt_transform_hip: device index %d is outside this library's table of %d devices", dev, AFG_MAX_DEVICES);
+        return AFG_ERR_INVALID;
+    }
+    uint32_t *counter = nullptr;
+    int cus = 0;
+    {
+        // work counters of the persistent kernel: launch k uses (and first clears, on its stream) counter k % 64, so
+        // launches in flight on different streams never share one
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_counters[dev]) {
+            AFG_HIP_CHECK(hipMalloc(&g_counters[dev], 64 * sizeof(uint32_t)));
+            AFG_HIP_CHECK(hipDeviceGetAttribute(&g_cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+            static_assert(kWLdsFloats * sizeof(float) <= 160 * 1024, "LDS budget");
+            AFG_HIP_CHECK(hipFuncSetAttribute((const void *)celt_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(kWLdsFloats * sizeof(float))));
+        }
+        counter = g_counters[dev] + (g_launches[dev]++ & 63u);
+        cus = g_cus[dev] > 0 ? g_cus[dev] : 256;
+    }
+    AFG_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
+    const uint32_t seg_recs = seg_recs_for(n_chan);
+    const uint32_t pairs = (n_chan + 1) / 2;
+    // one workgroup per CU (147 KB of LDS); with whole pairs as items never more wavefronts than pairs
+    uint32_t groups = (uint32_t)cus;
+    if (seg_recs == 0) groups = std::min<uint32_t>(groups, (pairs + kWWaves - 1) / kWWaves);
+    hipLaunchKernelGGL(celt_walk_kernel, dim3(groups), dim3(64 * kWWaves), kWLdsFloats * sizeof(float), stream, d_rec_base,
+                       d_recs, d_coeffs, d_out, d_states, d_tables, tb, tab_floats, n_chan, seg_recs, counter);
+    AFG_HIP_CHECK(hipGetLastError());
+    return AFG_OK;
+}

@@ -406,7 +406,7 @@ struct SideLane {
     hipEvent_t fork = nullptr, join = nullptr;
 };
 std::mutex g_side_mu;
-SideLane g_side[16];
+SideLane g_side[AFG_MAX_DEVICES];
 
 int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg_flac_subframe *d_subframes, const int32_t *d_res,
                     int32_t *d_out_i32, float *d_out_f32, uint32_t variants, hipStream_t stream)
@@ -430,8 +430,8 @@ int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg
     SideLane *side = nullptr;
     if (two) {
         int dev = 0;
-        AFG_HIP_CHECK(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 16) {
+        if (int rc = afg::device_slot(&dev, "afg_flac_transform_variants_hip")) return rc;
+        {
             lk.lock();
             side = &g_side[dev];
             if (!side->stream) {

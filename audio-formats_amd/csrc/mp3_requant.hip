@@ -88,13 +88,12 @@ __global__ __launch_bounds__(64) void mp3_requant_kernel(const afg_mp3_qgranule 
 }
 
 std::mutex g_mu;
-bool g_ready[16] = {};
+bool g_ready[AFG_MAX_DEVICES] = {};
 
 int ensure_tables()
 {
     int dev = 0;
-    AFG_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return AFG_ERR_INVALID;
+    if (int rc = afg::device_slot(&dev, "afg_mp3_requant_hip")) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_ready[dev]) {
         const afg_mp3::QTables &t = afg_mp3::qtables();

@@ -101,13 +101,12 @@ __global__ __launch_bounds__(256) void vorbis_floor_kernel(const afg_vorbis_floo
 }
 
 std::mutex g_mu;
-bool g_ready[16] = {};
+bool g_ready[AFG_MAX_DEVICES] = {};
 
 int ensure_table()
 {
     int dev = 0;
-    AFG_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return AFG_ERR_INVALID;
+    if (int rc = afg::device_slot(&dev, "afg_vorbis_floor_hip")) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_ready[dev]) {
         AFG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_inverse_db), k_inverse_db_bits, sizeof(k_inverse_db_bits)));

@@ -42,6 +42,20 @@ int         afg_abi_version(void);
 const char *afg_status_string(int status);
 const char *afg_last_error(void);          /* thread-local detail of the last failure, never NULL */
 int         afg_device_count(void);        /* number of HIP devices visible, <0 on error */
+
+/* Numeric mode of the float transform stages, process-wide.
+ *   AFG_NUMERIC_EXACT      every float32 result is produced by the reference's own expression tree (no fused
+ *                          multiply-adds, recurrences in the reference's order): bit-identical to the D decoders' arithmetic.
+ *   AFG_NUMERIC_TOLERANCE  (default) results within the 1e-5 RMS of the decoders' float output that drop-in use asks
+ *                          for; lets the Opus/CELT stage re-associate the de-emphasis recurrence (dopus.d:3695-3701) into a
+ *                          prefix sum inside the frame walk, fuse multiply-adds there, and cut a stream into independently
+ *                          walked segments wherever the post-filter is provably idle (dopus.d:3294-3296, :3333).
+ * MP3, Vorbis, FLAC and QOA compute the same bits in both modes.  The environment variable AFG_NUMERIC=exact|tolerance
+ * decides until afg_set_numeric_mode is called.  Returns the previous mode, AFG_ERR_INVALID for an unknown one. */
+#define AFG_NUMERIC_EXACT     0
+#define AFG_NUMERIC_TOLERANCE 1
+int         afg_set_numeric_mode(int mode);
+int         afg_get_numeric_mode(void);
 int         afg_device_name(int device, char *buf, size_t buflen);
 
 /* ========================================================================== *

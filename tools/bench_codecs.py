@@ -132,8 +132,11 @@ def bench_celt(dev, streams, frames_per_stream, steps, warmup):
     alg = 8 * tot1 * streams
     return {"workload": f"{streams} x Opus/CELT stereo, {frames_per_stream} frames of 960", "samples_per_step": tot1 * streams,
             "avg_kernel_ms": avg * 1e3, "samples_per_s": tot1 * streams / avg, "achieved_GBs": alg / avg / 1e9,
-            "frac": alg / avg / 1e9 / HBM_PEAK_GBS,
-            "bitwise_mismatches": int((got.view(np.uint32) != want.view(np.uint32)).sum())}
+            "frac": alg / avg / 1e9 / HBM_PEAK_GBS, "numeric_mode": ("exact", "tolerance")[afgpu.get_numeric_mode()],
+            "bitwise_mismatches": int((got.view(np.uint32) != want.view(np.uint32)).sum()),
+            "rms_vs_oracle": float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2))),
+            "rms_signal": float(np.sqrt(np.mean(want.astype(np.float64) ** 2))),
+            "int16_flip_rate": float((oraclelib.opus_output(got)[0] != oraclelib.opus_output(want)[0]).mean())}
 
 
 def bench_flac_e2e(files, frames_per_file, threads):
