@@ -28,6 +28,15 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
+
+#ifndef AFG_WALK_ABL
+#define AFG_WALK_ABL 0      // development ablations (tools/build_variant1.sh; timing only, results are wrong): 1 no de-emphasis scan,
+#endif                      // 2 no post-filter, 3 no memmove, 4 no radix / post-rotation, 5 no fft15, 6 no stores, 7 no input loads
+
+#ifndef AFG_WALK_PFU
+#define AFG_WALK_PFU 8      // samples a lane takes per step of the steady-state comb filter (4 or 8)
+#endif
 
 namespace {
 
@@ -42,6 +51,41 @@ struct PfW {
 
 // ---- post-filter on the linear frame buffer (data = buf + 1024: CeltFrame.buf + 1024 of the reference) ------------------
 // celt_postfilter_apply_transition (dopus.d:3281-3324) on data[n0 .. n0 + 120)
+// Everything a step reads is at least min(T0, T1) - 2 samples old, so that many samples are independent: a lane (32 per
+// channel) takes U = 4, 2 or 1 of them per step -- all reads of a step are issued before its first write.
+template <int U>
+__device__ __forceinline__ void wpf_transition_steps(float *d, const float *win2, const PfW &pf, int l, bool go, bool live0,
+                                                     bool live1, int step)
+{
+    const int T0 = pf.period_old, T1 = pf.period;
+    for (int i0 = 0; i0 < 120; i0 += step) {
+        float v[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + l + 32 * u;
+            on[u] = go && l + 32 * u < step && i < 120;
+            v[u] = 0.0f;
+            if (on[u]) {
+                const float w = win2[i];
+                const float x0 = live1 ? d[i - T1 + 2] : 0.0f, x1 = live1 ? d[i - T1 + 1] : 0.0f, x2 = live1 ? d[i - T1] : 0.0f,
+                            x3 = live1 ? d[i - T1 - 1] : 0.0f, x4 = live1 ? d[i - T1 - 2] : 0.0f;
+                const float y0 = live0 ? d[i - T0 + 2] : 0.0f, y1 = live0 ? d[i - T0 + 1] : 0.0f, y2 = live0 ? d[i - T0] : 0.0f,
+                            y3 = live0 ? d[i - T0 - 1] : 0.0f, y4 = live0 ? d[i - T0 - 2] : 0.0f;
+                const float uw = 1.0f - w;
+                const float acc = uw * (pf.g_old[0] * y2 + pf.g_old[1] * (y3 + y1) + pf.g_old[2] * (y4 + y0)) +
+                                  w * (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
+                v[u] = d[i] + acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (on[u]) d[i0 + l + 32 * u] = v[u];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __device__ __forceinline__ void wpf_transition(float *data, const float *win2, int n0, const PfW &pf, int l, bool lane_on)
 {
     const bool go = lane_on && !(pf.g[0] == 0.0f && pf.g_old[0] == 0.0f);
@@ -51,83 +95,65 @@ __device__ __forceinline__ void wpf_transition(float *data, const float *win2, i
     // fresh decoder): only live filters bound the parallel step, and a dead filter's taps are not read
     const bool live0 = pf.g_old[0] != 0.0f || pf.g_old[1] != 0.0f || pf.g_old[2] != 0.0f;
     const bool live1 = pf.g[0] != 0.0f || pf.g[1] != 0.0f || pf.g[2] != 0.0f;
-    int step = 32;
+    int step = 128;
     if (go && live0) step = min(step, T0 - 2);
     if (go && live1) step = min(step, T1 - 2);
     step = max(step, 1);
     step = min(__shfl(step, 0), __shfl(step, 32));
     float *d = data + n0;
-    for (int i0 = 0; i0 < 120; i0 += step) {
-        const int i = i0 + l;
-        float v = 0.0f;
-        const bool on = go && l < step && i < 120;
-        if (on) {
-            const float w = win2[i];
-            const float x0 = live1 ? d[i - T1 + 2] : 0.0f, x1 = live1 ? d[i - T1 + 1] : 0.0f, x2 = live1 ? d[i - T1] : 0.0f,
-                        x3 = live1 ? d[i - T1 - 1] : 0.0f, x4 = live1 ? d[i - T1 - 2] : 0.0f;
-            const float y0 = live0 ? d[i - T0 + 2] : 0.0f, y1 = live0 ? d[i - T0 + 1] : 0.0f, y2 = live0 ? d[i - T0] : 0.0f,
-                        y3 = live0 ? d[i - T0 - 1] : 0.0f, y4 = live0 ? d[i - T0 - 2] : 0.0f;
-            const float u = 1.0f - w;
-            const float acc = u * (pf.g_old[0] * y2 + pf.g_old[1] * (y3 + y1) + pf.g_old[2] * (y4 + y0)) +
-                              w * (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
-            v = d[i] + acc;
+    if (step >= 120) wpf_transition_steps<4>(d, win2, pf, l, go, live0, live1, 128);
+    else if (step > 32) wpf_transition_steps<2>(d, win2, pf, l, go, live0, live1, min(step, 64));
+    else wpf_transition_steps<1>(d, win2, pf, l, go, live0, live1, step);
+}
+
+// celt_postfilter_apply (dopus.d:3326-3355) on data[n0 .. n0 + len): a lane takes up to U samples of a step of up to
+// T - 2 samples (everything a step reads is at least that old)
+template <int U>
+__device__ __forceinline__ void wpf_apply_steps(float *d, int len, const PfW &pf, int l, bool go, int step)
+{
+    const int T = pf.period;
+    for (int i0 = 0; i0 < len; i0 += step) {
+        float v[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + l + 32 * u;
+            on[u] = go && l + 32 * u < step && i < len;
+            v[u] = 0.0f;
+            if (on[u]) {
+                const float x0 = d[i - T + 2], x1 = d[i - T + 1], x2 = d[i - T], x3 = d[i - T - 1], x4 = d[i - T - 2];
+                v[u] = d[i] + (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        if (on) d[i] = v;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (on[u]) d[i0 + l + 32 * u] = v[u];
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-// celt_postfilter_apply (dopus.d:3326-3355) on data[n0 .. n0 + len)
 __device__ __forceinline__ void wpf_apply(float *data, int n0, int len, const PfW &pf, int l, bool lane_on)
 {
     const bool go = lane_on && pf.g[0] != 0.0f && len > 0;
     if (!__any(go)) return;
-    const int T = pf.period;
-    // everything a step reads is at least T - 2 samples old: a lane takes samples l and l + 32 of a step when T allows
-    int step = go ? max(min(T - 2, 64), 1) : 64;
+    int step = go ? max(min(pf.period - 2, 32 * AFG_WALK_PFU), 1) : 32 * AFG_WALK_PFU;
     step = min(__shfl(step, 0), __shfl(step, 32));
     float *d = data + n0;
-    if (step > 32) {
-        for (int i0 = 0; i0 < len; i0 += step) {
-            float v[2] = { 0.0f, 0.0f };
-            bool on[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int i = i0 + l + 32 * u;
-                on[u] = go && l + 32 * u < step && i < len;
-                if (on[u]) {
-                    const float x0 = d[i - T + 2], x1 = d[i - T + 1], x2 = d[i - T], x3 = d[i - T - 1], x4 = d[i - T - 2];
-                    v[u] = d[i] + (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-                if (on[u]) d[i0 + l + 32 * u] = v[u];
-            __builtin_amdgcn_wave_barrier();
-        }
-        return;
-    }
-    for (int i0 = 0; i0 < len; i0 += step) {
-        const int i = i0 + l;
-        float v = 0.0f;
-        const bool on = go && l < step && i < len;
-        if (on) {
-            const float x0 = d[i - T + 2], x1 = d[i - T + 1], x2 = d[i - T], x3 = d[i - T - 1], x4 = d[i - T - 2];
-            v = d[i] + (pf.g[0] * x2 + pf.g[1] * (x1 + x3) + pf.g[2] * (x0 + x4));
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (on) d[i] = v;
-        __builtin_amdgcn_wave_barrier();
-    }
+    if (AFG_WALK_PFU > 4 && step > 128) wpf_apply_steps<AFG_WALK_PFU>(d, len, pf, l, go, step);
+    else if (step > 64) wpf_apply_steps<4>(d, len, pf, l, go, step);
+    else if (step > 32) wpf_apply_steps<2>(d, len, pf, l, go, step);
+    else wpf_apply_steps<1>(d, len, pf, l, go, step);
 }
 
-// ---- de-emphasis as a weighted prefix sum over the 64 lanes of a row ----------------------------------------------------
-// y[j] = x[j] + c * y[j-1] over lanes j = 0..63, y[-1] = 0: doubling steps inside the rows of 16 (DPP row_shr), then the
-// two cross-row steps (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lanes out of range read 0.
+// ---- de-emphasis (dopus.d:3695-3701), re-associated ---------------------------------------------------------------------
+//   tmp = x[j] + m;  m = tmp * c;  out[j] = tmp / 32768          (c = 0.8500061)
+// A lane takes 15 consecutive samples of a channel (64 lanes x 15 = a 20 ms frame): the recurrence from a zero memory
+// in registers (t), then the memory each lane's run really starts from -- B[l+1] = c * t14[l] + c^15 * B[l], B[0] = m, a
+// weighted prefix sum over the lanes: doubling steps inside the rows of 16 (DPP row_shr), the two cross-row steps
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- and out[k] = (t[k] + c^k * B) / 32768.
 struct DeW {
-    float w16, w32, wc;                                      // c^((lane & 15) + 1), c^((lane & 31) + 1), c^lane
+    float w16, w32, wl;                                      // r^((lane & 15) + 1), r^((lane & 31) + 1), r^lane; r = c^15
 };
 
 template <int CTRL, int ROW_MASK>
@@ -136,22 +162,31 @@ __device__ __forceinline__ float dpp0(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
 
-__device__ __forceinline__ float deemph_row(float x, const DeW &w)
-{
-    constexpr float c1 = kDeemph, c2 = c1 * c1, c4 = c2 * c2, c8 = c4 * c4;
-    float y = x;
-    y = __builtin_fmaf(c1, dpp0<0x111, 0xf>(y), y);          // row_shr:1
-    y = __builtin_fmaf(c2, dpp0<0x112, 0xf>(y), y);          // row_shr:2
-    y = __builtin_fmaf(c4, dpp0<0x114, 0xf>(y), y);          // row_shr:4
-    y = __builtin_fmaf(c8, dpp0<0x118, 0xf>(y), y);          // row_shr:8
-    y = __builtin_fmaf(w.w16, dpp0<0x142, 0xa>(y), y);       // row_bcast:15 -> rows 1, 3
-    y = __builtin_fmaf(w.w32, dpp0<0x143, 0xc>(y), y);       // row_bcast:31 -> rows 2, 3
-    return y;
-}
+constexpr float cpow(float c, int n) { float p = 1.0f; for (int i = 0; i < n; i++) p *= c; return p; }
+constexpr float kR15 = cpow(kDeemph, 15);
 
 __device__ __forceinline__ float lane_value(float v, int lane_uniform)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
+// x[k]: sample 15 * lane + k of the frame (zeros on lanes >= n_act); returns the scaled outputs in x and the new memory
+__device__ __forceinline__ void deemph_chunk(float (&x)[15], float &m, const DeW &w, int n_act)
+{
+    constexpr float r1 = kR15, r2 = r1 * r1, r4 = r2 * r2, r8 = r4 * r4;
+#pragma unroll
+    for (int k = 1; k < 15; k++) x[k] = __builtin_fmaf(kDeemph, x[k - 1], x[k]);
+    float S = kDeemph * x[14];
+    S = __builtin_fmaf(r1, dpp0<0x111, 0xf>(S), S);          // row_shr:1
+    S = __builtin_fmaf(r2, dpp0<0x112, 0xf>(S), S);          // row_shr:2
+    S = __builtin_fmaf(r4, dpp0<0x114, 0xf>(S), S);          // row_shr:4
+    S = __builtin_fmaf(r8, dpp0<0x118, 0xf>(S), S);          // row_shr:8
+    S = __builtin_fmaf(w.w16, dpp0<0x142, 0xa>(S), S);       // row_bcast:15 -> rows 1, 3
+    S = __builtin_fmaf(w.w32, dpp0<0x143, 0xc>(S), S);       // row_bcast:31 -> rows 2, 3
+    const float B = __builtin_fmaf(w.wl, m, dpp0<0x138, 0xf>(S));             // wave_shr:1: lane 0 reads 0
+    m = lane_value(__builtin_fmaf(w.wl * r1, m, S), n_act - 1);
+#pragma unroll
+    for (int k = 0; k < 15; k++) x[k] = __builtin_fmaf(cpow(kDeemph, k), B, x[k]) * (1.0f / 32768.0f);
 }
 
 // ---- records ------------------------------------------------------------------------------------------------------------
@@ -249,22 +284,22 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
     float *bufs = win2 + 120 + (size_t)wv * 2 * 2048;
     DeW dw;
     {
-        float p = 1.0f;                                       // c^lane by repeated products (once per wavefront)
-        float c16 = 0.0f, c32 = 0.0f, cl = 0.0f;
+        float p = 1.0f, c16 = 0.0f, c32 = 0.0f, cl = 0.0f;   // r^lane by repeated products (once per wavefront)
         for (int k = 0; k < 64; k++) {
             if (k == lane) cl = p;
-            p *= kDeemph;
+            p *= kR15;
             if (k == (lane & 15)) c16 = p;
             if (k == (lane & 31)) c32 = p;
         }
-        dw.w16 = c16; dw.w32 = c32; dw.wc = cl;
+        dw.w16 = c16; dw.w32 = c32; dw.wl = cl;
     }
 
     // Walks frames [a, end) of one sequence (lanes 0..31) or of both sequences of a pair (lane half = channel);
     // frames before `start` are the warm-up: transformed, nothing stored.
-    auto walk = [&](bool both, uint32_t chan_lo, uint32_t chan_hi, uint64_t base_lo, uint64_t base_hi, uint64_t cnt,
+    auto walk = [&](bool both_rt, uint32_t chan_lo, uint32_t chan_hi, uint64_t base_lo, uint64_t base_hi, uint64_t cnt,
                     uint64_t a, uint64_t start, uint64_t end) __attribute__((always_inline)) {
-        const bool act = both || h == 0;
+        const bool act_rt = both_rt || h == 0;
+        const bool both = both_rt, act = act_rt;
         const uint32_t my_chan = (both && h) ? chan_hi : chan_lo;
         const uint64_t my_base = (both && h) ? base_hi : base_lo;
         float *st = states ? states + (size_t)my_chan * AFG_CELT_STATE_FLOATS : nullptr;
@@ -307,21 +342,28 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             else load_inputs(xa, xb, coeffs, fr, g0, l);
         }
 
-        for (uint64_t q = a; q < end; q++) {
-            const Geo g = geo_of(fr);
-            const int F = g.F;
-            const bool storing = q >= start;
-            afg_celt_frame fr_next2 = recs[my_base + (q + 2 < end ? q + 2 : end - 1)];
+        // one frame; K960: the hot case -- a stereo pair's dominant record (20 ms in one block) -- with the geometry and
+        // the lane roles as compile-time constants (no lane predicates, fixed trip counts, immediate offsets)
+        auto frame_step = [&](auto k960, bool storing, const afg_celt_frame &fr_next2) __attribute__((always_inline)) {
+            constexpr bool K960 = decltype(k960)::value;
+            const bool both = K960 ? true : both_rt;
+            const bool act = K960 ? true : act_rt;
+            const Geo g = K960 ? geo_960() : geo_of(fr);
+            const int F = K960 ? 960 : g.F;
             // iMDCT and overlap-add, dopus.d:3684-3690
-            if (is_960(g)) frame_fft(z, xa, xb, fr, geo_960(), ltab, lwin, tb, l, act);
-            else frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
+#if AFG_WALK_ABL != 5
+            frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
+#endif
+#if AFG_WALK_ABL != 7
             {                                                // (the last frame's again at the end)
                 const Geo gn = geo_of(fr_next);
                 if (is_960(gn)) load_inputs(xa, xb, coeffs, fr_next, geo_960(), l);
                 else load_inputs(xa, xb, coeffs, fr_next, gn, l);
             }
-            if (is_960(g)) frame_rest(z, fr, geo_960(), ltab, lwin, tb, l, act);
-            else frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+#endif
+#if AFG_WALK_ABL != 4
+            frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+#endif
             if (act) {                                       // vector_fmul_window of block 0
                 float *d = buf + 1024;
                 float va[2], vb[2];
@@ -343,14 +385,18 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             __builtin_amdgcn_wave_barrier();
 
             // celt_postfilter, dopus.d:3357-3378 (a no-op on warm-up frames: their filters are dead by construction)
+#if AFG_WALK_ABL != 2
             wpf_transition(buf + 1024, win2, 0, pf, l, act);
+#endif
             pf.period_old = pf.period;
             pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             pf.period = fr.pf_period_new;
             pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
             if (F > 120) {
+#if AFG_WALK_ABL != 2
                 wpf_transition(buf + 1024, win2, 120, pf, l, act);
                 wpf_apply(buf + 1024, 240, F - 240, pf, l, act);
+#endif
                 pf.period_old = pf.period;
                 pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             }
@@ -358,61 +404,62 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             // make the prefetched inputs resident before the stores enter the queue (one in-order memory counter)
 #pragma unroll
             for (int i = 0; i < 15; i++) asm volatile("" : "+v"(xa[i]), "+v"(xb[i]) : : "memory");
-            settle_rec(fr_next2);
-            // de-emphasis + scaling on the rows as they leave (dopus.d:3695-3701, re-associated), coalesced stores
-            const int last = (F - 1) & 63;
-            if (both) {
-                // m of the two channels: lanes of half h carry channel h's; row lanes span both halves, so take scalars
+            {
+                uint32_t *w = (uint32_t *)&fr_next2;
+#pragma unroll
+                for (int i = 0; i < 12; i++) asm volatile("" : : "v"(w[i]) : "memory");
+            }
+            // De-emphasis + scaling (dopus.d:3695-3701, re-associated: deemph_chunk), then coalesced stores.  The samples
+            // pass through buf[0, F) of their channel on the way: history the next frame's filter no longer reaches.
+            const int n_act = K960 ? 64 : F / 15;
+            {
                 float m0 = lane_value(m, 0), m1 = lane_value(m, 32);
+                float xs[15];
+#if AFG_WALK_ABL != 1
+                const int at = K960 ? 15 * lane : 15 * min(lane, n_act - 1);      // (idle lanes re-read the last run)
+                const bool in = K960 || lane < n_act;
+#pragma unroll
+                for (int k = 0; k < 15; k++) { const float t = b0[1024 + at + k]; xs[k] = in ? t : 0.0f; }
+                deemph_chunk(xs, m0, dw, n_act);
+                if (in) {
+#pragma unroll
+                    for (int k = 0; k < 15; k++) bufs[at + k] = xs[k];
+                }
+                if (both) {
+#pragma unroll
+                    for (int k = 0; k < 15; k++) { const float t = b1[1024 + at + k]; xs[k] = in ? t : 0.0f; }
+                    deemph_chunk(xs, m1, dw, n_act);
+                    if (in) {
+#pragma unroll
+                        for (int k = 0; k < 15; k++) bufs[2048 + at + k] = xs[k];
+                    }
+                }
+#endif
+                m = (both && h) ? m1 : m0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int so = AFG_WALK_ABL == 1 ? 1024 : 0;
+            if (both) {
                 f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
-                if (F == 960) {
+                if (K960) {
                     f32x2 v[15];
 #pragma unroll
-                    for (int i = 0; i < 15; i++) v[i] = f32x2{ b0[1024 + lane + 64 * i], b1[1024 + lane + 64 * i] };
+                    for (int i = 0; i < 15; i++) v[i] = f32x2{ b0[so + lane + 64 * i], b1[so + lane + 64 * i] };
+                    if (storing && AFG_WALK_ABL != 6) {
 #pragma unroll
-                    for (int i = 0; i < 15; i++) { v[i].x = deemph_row(v[i].x, dw); v[i].y = deemph_row(v[i].y, dw); }
-#pragma unroll
-                    for (int i = 0; i < 15; i++) {
-                        v[i].x = __builtin_fmaf(dw.wc, m0, v[i].x);
-                        v[i].y = __builtin_fmaf(dw.wc, m1, v[i].y);
-                        m0 = kDeemph * lane_value(v[i].x, 63);
-                        m1 = kDeemph * lane_value(v[i].y, 63);
+                        for (int i = 0; i < 15; i++) o[lane + 64 * i] = v[i];
                     }
-                    if (storing) {
-#pragma unroll
-                        for (int i = 0; i < 15; i++) o[lane + 64 * i] = v[i] * (1.0f / 32768.0f);
-                    }
-                } else {
-                    for (int p0 = 0; p0 < F; p0 += 64) {
-                        const int p = p0 + lane;
-                        const bool in = p < F;
-                        float x0 = in ? b0[1024 + p] : 0.0f, x1 = in ? b1[1024 + p] : 0.0f;
-                        x0 = __builtin_fmaf(dw.wc, m0, deemph_row(x0, dw));
-                        x1 = __builtin_fmaf(dw.wc, m1, deemph_row(x1, dw));
-                        const int lastl = p0 + 64 <= F ? 63 : last;
-                        m0 = kDeemph * lane_value(x0, lastl);
-                        m1 = kDeemph * lane_value(x1, lastl);
-                        if (in && storing) o[p] = f32x2{ x0, x1 } * (1.0f / 32768.0f);
-                    }
+                } else if (storing) {
+                    for (int p = lane; p < F; p += 64) o[p] = f32x2{ b0[so + p], b1[so + p] };
                 }
-                m = h ? m1 : m0;
-            } else {
-                float m0 = lane_value(m, 0);
+            } else if (storing) {
                 float *o = out + __shfl(fr.out_off, 0);
                 const size_t stride = __shfl(fr.out_stride, 0);
-                for (int p0 = 0; p0 < F; p0 += 64) {
-                    const int p = p0 + lane;
-                    const bool in = p < F;
-                    float x0 = in ? b0[1024 + p] : 0.0f;
-                    x0 = __builtin_fmaf(dw.wc, m0, deemph_row(x0, dw));
-                    const int lastl = p0 + 64 <= F ? 63 : last;
-                    m0 = kDeemph * lane_value(x0, lastl);
-                    if (in && storing) o[(size_t)p * stride] = x0 * (1.0f / 32768.0f);
-                }
-                m = m0;
+                for (int p = lane; p < F; p += 64) o[(size_t)p * stride] = b0[so + p];
             }
             __builtin_amdgcn_wave_barrier();
             // memmove(buf, buf + F, 1084 floats) (:3370): every read is issued before the first write
+#if AFG_WALK_ABL != 3
             {
                 f32x4 mv[9];
 #pragma unroll
@@ -424,6 +471,14 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                     if (act && l + 32 * u < 271) *(f32x4 *)(buf + 4 * (l + 32 * u)) = mv[u];
                 __builtin_amdgcn_wave_barrier();
             }
+#endif
+        };
+
+        for (uint64_t q = a; q < end; q++) {
+            afg_celt_frame fr_next2 = recs[my_base + (q + 2 < end ? q + 2 : end - 1)];
+            const Geo gq = geo_of(fr);
+            if (both && is_960(gq)) frame_step(std::true_type{}, q >= start, fr_next2);
+            else frame_step(std::false_type{}, q >= start, fr_next2);
             fr = fr_next;
             fr_next = fr_next2;
         }
@@ -554,7 +609,9 @@ int afg::celt_walk_launch(uint32_t n_chan, const uint64_t *d_rec_base, const afg
         cus = g_cus[dev] > 0 ? g_cus[dev] : 256;
     }
     AFG_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
-    const uint32_t seg_recs = seg_recs_for(n_chan);
+    // A carry state is read by the walk that starts at a sequence's first frame and rewritten, in place, by the one that
+    // ends at its last: with states every channel pair is one item, so that this is one wavefront, in that order.
+    const uint32_t seg_recs = d_states ? 0 : seg_recs_for(n_chan);
     const uint32_t pairs = (n_chan + 1) / 2;
     // one workgroup per CU (147 KB of LDS); with whole pairs as items never more wavefronts than pairs
     uint32_t groups = (uint32_t)cus;

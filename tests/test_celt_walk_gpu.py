@@ -100,6 +100,8 @@ def test_walk_short_period_postfilter(gpu):
 
 @pytest.mark.parametrize("seg", [0, 6])
 def test_walk_chunked_with_state_equals_whole(gpu, monkeypatch, seg):
+    """(With a carry state every channel pair is walked by one wavefront whatever the item size asked for: the state
+    is read at the first frame and rewritten in place after the last.)"""
     monkeypatch.setenv("AFG_CELT_SEG_RECS", str(seg))
     rec_base, recs, coeffs, total = synthetic.celt_batch(9, [40], [2], p_postfilter=0.3, p_transient=0.3)
     coeffs = (coeffs * 0.05).astype(np.float32)
