@@ -768,12 +768,13 @@ def lds_fill(word=0x7fc00000, stream=None):
     check(lib().afg_lds_fill_probe_hip(int(word), _stream(stream)))
 
 
-NUMERIC_EXACT, NUMERIC_TOLERANCE = 0, 1
+NUMERIC_FROM_ENV, NUMERIC_EXACT, NUMERIC_TOLERANCE = -1, 0, 1
 
 
 def set_numeric_mode(mode):
     """afg_set_numeric_mode: NUMERIC_EXACT (the reference's expression trees, bit for bit) or NUMERIC_TOLERANCE (default:
-    within 1e-5 RMS; the Opus/CELT stage may re-associate).  Returns the previous mode."""
+    within 1e-5 RMS; the Opus/CELT stage may re-associate); NUMERIC_FROM_ENV hands the choice back to AFG_NUMERIC.
+    Returns the mode that was in effect before."""
     prev = lib().afg_set_numeric_mode(int(mode))
     if prev < 0:
         check(prev)

@@ -108,7 +108,7 @@ int afg_get_numeric_mode(void) { return afg::numeric_mode(); }
 
 int afg_set_numeric_mode(int mode)
 {
-    if (mode != AFG_NUMERIC_EXACT && mode != AFG_NUMERIC_TOLERANCE) {
+    if (mode != AFG_NUMERIC_EXACT && mode != AFG_NUMERIC_TOLERANCE && mode != AFG_NUMERIC_FROM_ENV) {
         afg::set_error("afg_set_numeric_mode: unknown mode %d", mode);
         return AFG_ERR_INVALID;
     }

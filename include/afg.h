@@ -51,7 +51,9 @@ int         afg_device_count(void);        /* number of HIP devices visible, <0 
  *                          prefix sum inside the frame walk, fuse multiply-adds there, and cut a stream into independently
  *                          walked segments wherever the post-filter is provably idle (dopus.d:3294-3296, :3333).
  * MP3, Vorbis, FLAC and QOA compute the same bits in both modes.  The environment variable AFG_NUMERIC=exact|tolerance
- * decides until afg_set_numeric_mode is called.  Returns the previous mode, AFG_ERR_INVALID for an unknown one. */
+ * decides until afg_set_numeric_mode is called, and again after afg_set_numeric_mode(AFG_NUMERIC_FROM_ENV).  Returns the
+ * mode that was in effect before, AFG_ERR_INVALID for an unknown one. */
+#define AFG_NUMERIC_FROM_ENV  (-1)
 #define AFG_NUMERIC_EXACT     0
 #define AFG_NUMERIC_TOLERANCE 1
 int         afg_set_numeric_mode(int mode);

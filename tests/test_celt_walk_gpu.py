@@ -10,14 +10,14 @@ import afgpu
 import oraclelib
 from afgpu import synthetic
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.numeric_tolerance]
 
 TOL_RMS = 1e-5          # north_star: float output within 1e-5 RMS of the reference decoders
 
 
 @pytest.fixture(autouse=True)
-def tolerance_mode(monkeypatch):
-    monkeypatch.setenv("AFG_CELT_PATH", "walk")
+def no_path_override(monkeypatch):
+    monkeypatch.delenv("AFG_CELT_PATH", raising=False)          # the numeric mode (default: tolerance) picks the walk
 
 
 def run_gpu(gpu, rec_base, recs, coeffs, total, states=None):
@@ -126,7 +126,7 @@ def test_walk_state_blob_is_interchangeable_with_the_exact_paths(gpu, monkeypatc
     states = np.zeros((2, afgpu.CELT_STATE_FLOATS), np.float32)
     out = np.full(total, np.nan, np.float32)
     for path, (lo, hi) in zip(("stream", "walk", "split", "walk"), ((0, 3), (3, 6), (6, 9), (9, 12))):
-        monkeypatch.setenv("AFG_CELT_PATH", path)
+        monkeypatch.setenv("AFG_CELT_PATH", path)                   # stream / split: the bit-exact kernels
         sel = np.concatenate([np.arange(int(rec_base[c]) + lo, int(rec_base[c]) + hi) for c in range(2)])
         rb = np.array([0, hi - lo, 2 * (hi - lo)], np.uint64)
         got, st = run_gpu(gpu, rb, recs[sel].copy(), coeffs, total, states.reshape(-1).copy())
@@ -167,7 +167,6 @@ def test_walk_at_full_scale_amplitude(gpu):
 
 def test_numeric_mode_switch(gpu, monkeypatch):
     """afg_set_numeric_mode selects the path when AFG_CELT_PATH does not: exact -> bit-identical to the oracle."""
-    monkeypatch.delenv("AFG_CELT_PATH")
     rec_base, recs, coeffs, total = synthetic.celt_batch(3, [9, 5], [2, 1], p_postfilter=0.5)
     want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
     prev = afgpu.set_numeric_mode(afgpu.NUMERIC_EXACT)
@@ -178,5 +177,6 @@ def test_numeric_mode_switch(gpu, monkeypatch):
         afgpu.set_numeric_mode(afgpu.NUMERIC_TOLERANCE)
         got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
         check(got, want)
+        assert prev == afgpu.NUMERIC_TOLERANCE                      # the default
     finally:
-        afgpu.set_numeric_mode(prev)
+        afgpu.set_numeric_mode(afgpu.NUMERIC_FROM_ENV)
