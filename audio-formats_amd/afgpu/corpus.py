@@ -28,6 +28,10 @@ C5_FILES = 65536
 # take as long for 800 streams as for 2500, so fewer, larger waves pay: 8192 -> 24576 files took C5 from 304 to 200 ms)
 C5_WAVE_FILES = 24576
 C5_SEED = 0xC5
+# Device time per decoded sample, ns, by kind (MP3, Vorbis, FLAC, CELT): each codec's kernel alone over its C5 members on one
+# MI355X (profiles/r03_c5.json; round 2 sharded on samples, when a CELT sample cost 8 x an MP3 sample).  Only the ratios matter.
+C5_COST_NS_PER_SAMPLE = np.array([1.85e-3, 1.87e-3, 1.41e-3, 2.75e-3])
+C5_SPREAD_OPUS = 64             # the longest Opus files are dealt out evenly before the greedy pass (sharding.lpt_partition)
 
 
 # --------------------------------------------------------------------------- manifest
@@ -50,14 +54,35 @@ def c5_manifest(n_files=C5_FILES, seed=C5_SEED):
     per_unit = np.array([576, 1024, 4096, 960], np.int64)[kind]
     work = units * per_unit * 2
     work[kind == KIND_VORBIS] -= 1024 * 2                                                        # the first packet delivers nothing
-    return {"kind": kind, "seconds": seconds, "units": units, "work": work}
+    return with_cost({"kind": kind, "seconds": seconds, "units": units, "work": work})
+
+
+def with_cost(manifest):
+    """Adds what the partition balances: cost[i] = predicted device time of file i (ns) and spread = the C5_SPREAD_OPUS
+    longest Opus files (by frames), which no rank may collect."""
+    kind, work, units = manifest["kind"], manifest["work"], manifest["units"]
+    manifest["cost"] = work * C5_COST_NS_PER_SAMPLE[kind]
+    opus = np.flatnonzero(kind == KIND_CELT)
+    manifest["spread"] = opus[np.lexsort((opus, -units[opus]))][:C5_SPREAD_OPUS]
+    return manifest
+
+
+def c5_partition(manifest, world):
+    """rank_of[file]: LPT on predicted device time, the longest Opus files spread first (a manifest without `cost`:
+    on samples)."""
+    return sharding.lpt_partition(manifest.get("cost", manifest["work"]), world, manifest.get("spread"))
+
+
+def c5_imbalance(manifest, world):
+    """max / mean predicted device time over the ranks"""
+    return sharding.imbalance(manifest.get("cost", manifest["work"]), world, manifest.get("spread"))
 
 
 def c5_shard_waves(manifest, rank, world, wave_files=C5_WAVE_FILES):
     """File indices of `rank`'s shard, cut into waves of at most wave_files files (ascending file order).  Every rank
     gets the same number of waves (the partition is deterministic, so each rank derives it from all shards' sizes):
     the ranks meet in a barrier around every wave's timed region."""
-    rank_of = sharding.lpt_partition(manifest["work"], world)
+    rank_of = c5_partition(manifest, world)
     counts = np.bincount(rank_of, minlength=world)
     n_waves = max(1, int(-(-counts.max() // wave_files)))
     mine = np.flatnonzero(rank_of == rank)

@@ -307,10 +307,11 @@ def run_rank(args, world, rank, local_rank):
         total_samples = reduce_sum(float(my_samples))
         scaling = "strong"
         workload = (f"{args.c5_files}-file mixed corpus (40% MP3 / 25% Ogg Vorbis / 25% FLAC / 10% Opus-CELT, durations "
-                    f"log-uniform 4-30 s, seed {corpus.C5_SEED:#x}) file-sharded over {world} GPU(s) by LPT on frames x channels, "
+                    f"log-uniform 4-30 s, seed {corpus.C5_SEED:#x}) file-sharded over {world} GPU(s) by LPT on predicted device time, "
                     f"{len(waves)} wave(s) of <= {args.c5_wave_files or corpus.C5_WAVE_FILES} files per GPU, device-resident records -> PCM")
         cfg_extra = {"files": args.c5_files, "waves_per_gpu": len(waves), "files_this_gpu": int(sum(len(w) for w in waves)),
-                     "lpt_imbalance": corpus.sharding.imbalance(man["work"], world)}
+                     "lpt_imbalance": corpus.c5_imbalance(man, world),
+                     "partition": "LPT on predicted device time (samples x measured ns/sample per codec), the 64 longest Opus files dealt out first"}
     else:
         which = {"c234": ("mp3", "vorbis", "flac"), "c2": ("mp3",), "c3": ("vorbis",), "c4": ("flac",)}[args.config]
         wl = corpus.build_c234(dev, rank, which, args.files, args.seg)

@@ -32,7 +32,7 @@ def small_manifest(n_files=40, seed=0x5C5):
     m["units"] = np.maximum(2, m["units"] // 16)
     per_unit = np.array([576, 1024, 4096, 960], np.int64)[m["kind"]]
     m["work"] = m["units"] * per_unit * 2
-    return m
+    return corpus.with_cost(m)
 
 
 def oracle_file_outputs(part):
@@ -246,7 +246,7 @@ def test_two_rank_processes_decode_their_shards_with_the_library(gpu, tmp_path):
         gathered = pickle.load(fh)
     assert len(gathered) == 2 and all(len(g) > 0 for g in gathered)
     assert sorted(list(gathered[0]) + list(gathered[1])) == list(range(40))            # a partition: no file twice, none lost
-    rank_of = sharding.lpt_partition(man["work"], 2)
+    rank_of = corpus.c5_partition(man, 2)
     for r, g in enumerate(gathered):
         for fid, arr in g.items():
             assert rank_of[fid] == r

@@ -20,7 +20,7 @@ def manifest():
     m["units"] = np.maximum(2, m["units"] // 64)
     per_unit = np.array([576, 1024, 4096, 960], np.int64)[m["kind"]]
     m["work"] = m["units"] * per_unit * 2
-    return m
+    return corpus.with_cost(m)
 
 
 def decode_file(m, fid, seed=corpus.C5_SEED):
@@ -71,13 +71,22 @@ def test_partition_is_deterministic_and_balanced():
     assert 7.0e10 < m["work"].sum() < 8.0e10                                           # ~7.5e10 samples
     assert (corpus.c5_manifest()["units"] == m["units"]).all()                         # seeds fixed
     for world in (1, 2, 4, 8):
-        r = sharding.lpt_partition(m["work"], world)
-        assert (r == sharding.lpt_partition(m["work"], world)).all() and r.max() < world
+        r = corpus.c5_partition(m, world)
+        assert (r == corpus.c5_partition(m, world)).all() and r.max() < world
         waves = [corpus.c5_shard_waves(m, k, world) for k in range(world)]
         assert len({len(w) for w in waves}) == 1                                       # same wave count on every rank
         assert max(len(x) for w in waves for x in w) <= corpus.C5_WAVE_FILES
         assert sorted(np.concatenate([np.concatenate(w) for w in waves])) == list(range(65536))
-        assert sharding.imbalance(m["work"], world) < 1.001
+        # balanced on predicted device time (samples x the codec's measured time per sample), not on samples
+        assert corpus.c5_imbalance(m, world) < 1.02
+        time_of = np.bincount(r, weights=m["cost"], minlength=world)
+        assert time_of.max() / time_of.mean() < 1.02
+        # ... and no rank collects the long Opus files: a stream whose post-filter never idles is one serial walk
+        longest = m["spread"]
+        assert len(longest) == 64 and (m["kind"][longest] == corpus.KIND_CELT).all()
+        opus = np.flatnonzero(m["kind"] == corpus.KIND_CELT)
+        assert m["units"][longest].min() >= np.sort(m["units"][opus])[-64]
+        assert np.bincount(r[longest], minlength=world).max() <= -(-64 // world) + 1
 
 
 def test_file_inputs_do_not_depend_on_their_neighbours():
@@ -112,7 +121,7 @@ def test_two_ranks_equal_one_process_file_by_file():
         assert p.exitcode == 0
     assert n_waves >= 2 and len(gathered) == 2
     assert sorted(list(gathered[0]) + list(gathered[1])) == list(range(N_FILES))       # a partition of the corpus
-    rank_of = sharding.lpt_partition(m["work"], 2)
+    rank_of = corpus.c5_partition(m, 2)
     for r, g in enumerate(gathered):
         assert 0 < len(g) < N_FILES
         for fid, arr in g.items():

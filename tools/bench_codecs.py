@@ -17,6 +17,37 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
+def file_parity(items, want, tolerance=False):
+    """Parity block of an end-to-end batch: the first and the last file's delivered floats against the oracle's decode of
+    the same bytes (bit-identical, or -- Opus in the default numeric mode -- within one int16 step on < 1 % of the samples)."""
+    import oraclelib  # noqa: F401
+    want = np.ascontiguousarray(want, np.float32).reshape(-1)
+    rec = {"files_checked": 0, "samples": 0, "mismatches": 0, "rms_error": 0.0}
+    sq = 0.0
+    for it in (items[0], items[-1]):
+        got = np.ascontiguousarray(it["pcm"], np.float32).reshape(-1)
+        rec["files_checked"] += 1
+        if got.size != want.size:
+            rec["mismatches"] += max(got.size, want.size)
+            continue
+        d = got.astype(np.float64) - want
+        bits = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        rec["samples"] += int(got.size)
+        sq += float((d ** 2).sum())
+        if tolerance:
+            step = np.abs(d) * 32767.0
+            rec["bitwise_mismatches"] = rec.get("bitwise_mismatches", 0) + bits
+            rec["int16_flip_rate"] = float((step > 0).mean())
+            ok = step.max() <= 1.0001 and (step > 0).mean() < 0.01 and np.sqrt((d ** 2).mean()) <= 1e-5
+            rec["mismatches"] += 0 if ok else max(bits, 1)
+        else:
+            rec["mismatches"] += bits
+    rec["rms_error"] = float(np.sqrt(sq / max(rec["samples"], 1)))
+    if tolerance:
+        rec["mode"] = "tolerance: <= 1 int16 step, < 1 % of the samples, <= 1e-5 RMS"
+    return rec
+
+
 def time_launches(fn, steps, warmup):
     stream = torch.cuda.current_stream()
     for _ in range(warmup):
@@ -160,7 +191,7 @@ def bench_flac_e2e(files, frames_per_file, threads):
         job.run()                                     # the C call only: parse + H2D + kernel + D2H
         best = min(best, time.perf_counter() - t0)
     dt = best
-    out = [dict(o) for o in job.items]
+    out = [dict(o, pcm=o["pcm"].copy()) if k in (0, files - 1) else dict(o) for k, o in enumerate(job.items)]
     first = out[0]["pcm"][:8].copy()
     job.close()
     t0 = time.perf_counter()
@@ -169,8 +200,11 @@ def bench_flac_e2e(files, frames_per_file, threads):
     dt_parse = time.perf_counter() - t0
     ok = all(o["status"] == 0 and o["frames"] == n for o in out) and bool(np.isfinite(first).all())
     samples = 2 * n * files
+    import oraclelib
+    info, frames, subframes, res = afgpu.flac_parse(data)
+    want = oraclelib.flac_transform(frames, subframes, res, info["out_samples"], want_float=True)[1]
     return {"workload": f"{files} x FLAC 16-bit stereo, {frames_per_file} frames of 4096 ({len(data)} bytes each)",
-            "threads": threads, "all_ok": ok, "seconds": dt, "samples_per_s_end_to_end": samples / dt,
+            "threads": threads, "all_ok": ok, "parity": file_parity(out, want), "seconds": dt, "samples_per_s_end_to_end": samples / dt,
             "compressed_MBps": len(data) * files / dt / 1e6,
             "host_parse_one_thread_samples_per_s": samples / dt_parse}
 
@@ -190,14 +224,16 @@ def bench_mp3_e2e(files, frames_per_file, threads):
         t0 = time.perf_counter()
         job.run()
         best = min(best, time.perf_counter() - t0)
-    items = [dict(o) for o in job.items]
+    items = [dict(o, pcm=o["pcm"].copy()) if k in (0, files - 1) else dict(o) for k, o in enumerate(job.items)]
     n = items[0]["frames"]
     finite = bool(np.isfinite(items[0]["pcm"]).all())
     job.close()
     ok = all(o["status"] == 0 and o["frames"] == n for o in items) and finite
     samples = 2 * n * files
+    import oraclelib
+    want = oraclelib.mp3_decode_file(data)["pcm"]
     return {"workload": f"{files} x MP3 128 kbit/s joint stereo, {frames_per_file} frames ({len(data)} bytes each)",
-            "threads": threads, "all_ok": ok, "seconds": best, "samples_per_s_end_to_end": samples / best,
+            "threads": threads, "all_ok": ok, "parity": file_parity(items, want), "seconds": best, "samples_per_s_end_to_end": samples / best,
             "compressed_MBps": len(data) * files / best / 1e6}
 
 
@@ -252,16 +288,26 @@ def bench_mixed_e2e(files, threads):
         t0 = time.perf_counter()
         job.run()
         best = min(best, time.perf_counter() - t0)
-    items = [dict(o) for o in job.items]
+    items = [dict(o, pcm=o["pcm"].copy()) if k < len(kinds) else dict(o) for k, o in enumerate(job.items)]
     samples = sum(o["frames"] * o["channels"] for o in items)
     ok = all(o["status"] == 0 and o["frames"] > 0 for o in items)
+    fi, ff, fs, fr = afgpu.flac_parse(flac)
+    qf, qch, _, qtotal = afgpu.qoa_frames(qoa.tobytes())
+    wants = {"mp3": oraclelib.mp3_decode_file(mp3)["pcm"], "ogg": oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(ogg)),
+             "flac": oraclelib.flac_transform(ff, fs, fr, fi["out_samples"], want_float=True)[1],
+             "qoa": oraclelib.qoa_transform(qf, qoa, qtotal * qch)[1]}
+    parity = {}
+    for k in range(len(kinds)):
+        name = kinds[k][0]
+        if name not in parity:
+            parity[name] = file_parity([items[k]], wants[name])
     per = {}
     for i, o in enumerate(items):
         k = kinds[i % len(kinds)][0]
         per[k] = per.get(k, 0) + o["frames"] * o["channels"]
     job.close()
     return {"workload": f"{files} mixed files in one batch (MP3 {len(mp3)} B, OGG {len(ogg)} B, FLAC {len(flac)} B, QOA {len(qoa)} B)",
-            "threads": threads, "all_ok": ok, "seconds": best, "samples": samples, "samples_by_format": per,
+            "threads": threads, "all_ok": ok, "parity": parity, "seconds": best, "samples": samples, "samples_by_format": per,
             "samples_per_s_end_to_end": samples / best, "compressed_MBps": sum(len(b) for b in blobs) / best / 1e6}
 
 
@@ -280,15 +326,17 @@ def bench_vorbis_e2e(files, packets, threads):
         t0 = time.perf_counter()
         job.run()
         best = min(best, time.perf_counter() - t0)
-    items = [dict(o) for o in job.items]
+    items = [dict(o, pcm=o["pcm"].copy()) if k in (0, files - 1) else dict(o) for k, o in enumerate(job.items)]
     n = items[0]["frames"]
     ch = items[0]["channels"]
     finite = bool(np.isfinite(items[0]["pcm"]).all())
     job.close()
     ok = all(o["status"] == 0 and o["frames"] == n for o in items) and finite and n > 0
     samples = ch * n * files
+    import oraclelib
+    want = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(data))
     return {"workload": f"{files} x Ogg Vorbis stereo 2048/256, {packets} packets ({len(data)} bytes each)",
-            "threads": threads, "all_ok": ok, "seconds": best, "samples_per_s_end_to_end": samples / best,
+            "threads": threads, "all_ok": ok, "parity": file_parity(items, want), "seconds": best, "samples_per_s_end_to_end": samples / best,
             "compressed_MBps": len(data) * files / best / 1e6}
 
 
@@ -301,7 +349,7 @@ def bench_opus_e2e(files, packets, threads):
     import opus_bitstream as ob
     rng = np.random.default_rng(12)
     pkts = [ob.packet(rng, 31, True, 0, sizes=[160]) for _ in range(packets)]
-    data = ob.ogg_opus(pkts, 2, preskip=312, packets_per_page=50)
+    data = ob.ogg_opus(pkts, 2, preskip=312, packets_per_page=50, comments=(b"R128_TRACK_GAIN=-20000",))
     blobs = [data] * files
     afgpu.batch_decode(blobs[:2], threads)
     job = afgpu.BatchDecoded(blobs, threads)
@@ -310,14 +358,17 @@ def bench_opus_e2e(files, packets, threads):
         t0 = time.perf_counter()
         job.run()
         best = min(best, time.perf_counter() - t0)
-    items = [dict(o) for o in job.items]
+    items = [dict(o, pcm=o["pcm"].copy()) if k in (0, files - 1) else dict(o) for k, o in enumerate(job.items)]
     n = items[0]["frames"]
     ch = items[0]["channels"]
     job.close()
     ok = all(o["status"] == 0 and o["frames"] == n for o in items) and n > 0
     samples = ch * n * files
-    return {"workload": f"{files} x Ogg Opus CELT-only stereo, {packets} packets of 20 ms ({len(data)} bytes each)",
-            "threads": threads, "all_ok": ok, "seconds": best, "samples_per_s_end_to_end": samples / best,
+    import oraclelib
+    want = oraclelib.opus_file_pcm(oraclelib.opus_decode_file(data))
+    tol = afgpu.get_numeric_mode() == afgpu.NUMERIC_TOLERANCE
+    return {"workload": f"{files} x Ogg Opus CELT-only stereo, {packets} packets of 20 ms ({len(data)} bytes each; R128 gain -78 dB: programme level)",
+            "threads": threads, "all_ok": ok, "parity": file_parity(items, want, tol), "seconds": best, "samples_per_s_end_to_end": samples / best,
             "compressed_MBps": len(data) * files / best / 1e6}
 
 
@@ -361,6 +412,19 @@ def main():
     if args.codec in ("all", "celt"):
         torch.cuda.empty_cache()
         res["celt"] = bench_celt(dev, 8192, 200, args.steps, args.warmup)
+    if args.codec == "others":
+        # what bench.py appends to its line as `other_workloads` (besides the C5 run): the non-headline kernels on dense
+        # device-resident batches, and SURVEY 8d's (c) end-to-end rates -- file bytes in host memory -> floats in host memory
+        # through afg_batch_decode, PCIe-inclusive -- each with its parity block against the oracle
+        res["celt_dense"] = bench_celt(dev, 8192, 200, args.steps, args.warmup)
+        torch.cuda.empty_cache()
+        res["qoa"] = bench_qoa(dev, 4096, 4.0, args.steps, args.warmup)
+        torch.cuda.empty_cache()
+        res["mp3_e2e"] = bench_mp3_e2e(args.e2e_files, 60, args.e2e_threads)
+        res["vorbis_e2e"] = bench_vorbis_e2e(args.e2e_files, 128, args.e2e_threads)
+        res["flac_e2e"] = bench_flac_e2e(args.e2e_files, 8, args.e2e_threads)
+        res["opus_e2e"] = bench_opus_e2e(args.e2e_files, 250, args.e2e_threads)
+        res["mixed_e2e"] = bench_mixed_e2e(args.e2e_files * 2, args.e2e_threads)
     print(json.dumps(res))
 
 
