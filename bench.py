@@ -54,6 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-full-fetch", action="store_true", help="skip the MP3 leg that fetches all 32 subbands")
     ap.add_argument("--c5-wave-files", type=int, default=0, help="files per resident wave of --config c5 (0 = the corpus default)")
     ap.add_argument("--only", default="", help="development: restrict --config c5 to these codecs (comma list)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip `other_workloads` (the C5 corpus, dense CELT, QOA and the end-to-end batches, each in a child process "
+                         "after the headline measurement; only at N = 1 with the default config)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: ranks beyond the visible devices share them (rank % devices); the line says so")
     return ap.parse_args(argv)
@@ -209,6 +212,78 @@ def cpu_baseline(parts, seconds):
         "logical_cpus": cpus, "cgroup_cpu_quota": quota,
         "achieved_parallelism": cpu_s / wall, "parallel_efficiency_vs_single_thread": (samples / wall) / (single * threads),
     }
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# other workloads: everything SURVEY 8d asks for besides the headline step, under the same driver clock
+# ----------------------------------------------------------------------------------------------------------------
+def other_workloads(args):
+    """Run after the headline measurement has released the device, each in a child process (a fresh HIP context; the C5
+    waves need the memory the headline batches held):
+      c5          BASELINE configs[4] at full size on this one GPU: 65 536 mixed files in 3 resident waves (bench.py --config c5)
+      celt_dense  8192 x Opus/CELT stereo, 200 frames of 960: the CELT kernel on a device-filling batch
+      qoa         4096 x QOA stereo 4 s
+      *_e2e       SURVEY 8d (c): file bytes in host memory -> afg_batch_decode (host parse, H2D, kernels, D2H) -> floats in
+                  host memory; PCIe-inclusive, never `value`
+    Every entry carries its own parity block against the oracle."""
+    out = {}
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    def child(cmd, timeout):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable] + cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            return None, f"timed out after {timeout} s", time.perf_counter() - t0
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        if not lines:
+            return None, f"exit code {r.returncode}: {r.stderr.decode()[-400:]}", time.perf_counter() - t0
+        return json.loads(lines[-1]), (None if r.returncode == 0 else f"exit code {r.returncode}"), time.perf_counter() - t0
+
+    d, err, wall = child([os.path.abspath(__file__), "--config", "c5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--c5-files", str(args.c5_files)], 420)
+    if d is None:
+        out["c5"] = {"error": err}
+    else:
+        out["c5"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                     "steps": d["steps"], "samples_per_step": d["config"]["samples_per_step"], "waves": d["config"].get("waves_per_gpu"),
+                     "kernels": [{k: v for k, v in kk.items() if k in ("codec", "kernel", "avg_kernel_ms", "achieved", "frac", "samples_per_launch",
+                                                                       "algorithmic_bytes_per_launch")} for kk in d["roofline"]["kernels"]],
+                     "overlapped_on_a_second_stream": d["roofline"].get("overlapped_on_a_second_stream"),
+                     "parity": d["parity"], "wall_s": wall, "error": err}
+    d, err, wall = child([os.path.join(ROOT, "tools", "bench_codecs.py"), "--codec", "others", "--steps", "5"], 420)
+    if d is None:
+        out["codecs"] = {"error": err}
+    else:
+        for k, v in d.items():
+            out[k] = v
+        out["codecs_wall_s"] = wall
+    return out
+
+
+def other_parity_failures(others):
+    bad = []
+    for name, rec in others.items():
+        if not isinstance(rec, dict):
+            continue
+        if rec.get("error"):
+            bad.append(f"{name}: {rec['error']}")
+        par = rec.get("parity")
+        if isinstance(par, dict):
+            blocks = par.values() if all(isinstance(v, dict) for v in par.values()) else [par]
+            if any(b.get("mismatches") for b in blocks):
+                bad.append(f"{name}: parity")
+        for key in ("mismatches", "int32_mismatches"):
+            if rec.get(key):
+                bad.append(f"{name}: {key}")
+        if rec.get("numeric_mode") == "exact" and rec.get("bitwise_mismatches"):
+            bad.append(f"{name}: bitwise_mismatches")
+        if rec.get("numeric_mode") == "tolerance" and not rec.get("rms_vs_oracle", 0.0) <= 1e-5:
+            bad.append(f"{name}: rms_vs_oracle")
+        if rec.get("all_ok") is False:
+            bad.append(f"{name}: not all files decoded")
+    return bad
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -382,12 +457,15 @@ def run_rank(args, world, rank, local_rank):
         avg_ms = sum(k["ms"]) / len(k["ms"])
         ach = k["alg_bytes"] / (avg_ms * 1e-3) / 1e9
         tb = None
-        if args.config in ("c234", "c2", "c3", "c4") and args.files == 1024 and name in pmc_file:
+        # (only for the run those passes describe: full size, the product library, no input-format or segment overrides)
+        variant = args.seg or any(os.environ.get(v) for v in ("AFG_LIB_PATH", "AFG_FLAC_RES32", "AFG_MP3_FLOAT_UPLOAD", "AFG_NUMERIC"))
+        if args.config in ("c234", "c2", "c3", "c4") and args.files == 1024 and name in pmc_file and not variant:
             tb = ((load_traffic(pmc_file[name]) or {}).get("derived") or {}).get("hbm_bytes_per_launch")
         kernels.append({"codec": name, "kernel": k["kernel"], "avg_kernel_ms": avg_ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": int(k["alg_bytes"]), "units_per_launch": int(k["units"]),
                         "samples_per_launch": int(k["samples"]), "samples_per_s": k["samples"] / (avg_ms * 1e-3),
-                        "traffic": tb, "frac_by_traffic": (tb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None})
+                        "traffic": tb, "frac_by_traffic": (tb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None,
+                        "traffic_source": ("profiles/" + pmc_file[name]) if tb else None})
         if k.get("survey_bytes") and k["survey_bytes"] != k["alg_bytes"]:
             # FLAC with int16 residual rows: the launch reads 2 B / sample where SURVEY 8(d) counts 4.  `frac` above is
             # priced on the bytes this input format moves; the 8 B / sample figure is shown for comparison with round 1 only.
@@ -421,6 +499,14 @@ def run_rank(args, world, rank, local_rank):
     if args.oversubscribe and world > ndev:
         line["oversubscribed"] = f"{world} ranks on {ndev} device(s): a launcher test, not a scaling point"
     failed = [n for n, p in parity.items() if p["mismatches"]]
+    if world == 1 and args.config == "c234" and not args.no_others:
+        # release the headline batches (148 GB) first: the C5 waves need the room
+        wl = mp3 = p = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        line["other_workloads"] = other_workloads(args)
+        failed += other_parity_failures(line["other_workloads"])
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -70,3 +70,83 @@ def test_full_size_celt_batch(gpu):
     assert torch.equal(first, out)
     del first, out, part
     torch.cuda.empty_cache()
+
+
+@pytest.mark.numeric_tolerance
+def test_full_size_celt_batch_default_numeric_mode(gpu):
+    """The same batch through the product's default path (csrc/celt_walk.hip: persistent segment walk, de-emphasis as a
+    prefix sum): 1e-5 RMS against the oracle on the first, a middle and the last stream, < 1 % of the samples on a
+    neighbouring int16, everything written, and -- items are drawn from an atomic counter -- still deterministic."""
+    import torch
+    if free_bytes() < 60e9:
+        pytest.skip("not enough free device memory")
+    part = corpus.CeltPart(0xCE17, np.full(8192, 200), gpu)
+    out = part.out_plane()
+    out.fill_(float("nan"))
+    stream = torch.cuda.current_stream()
+    part.launch(stream.cuda_stream)
+    torch.cuda.synchronize()
+    for f in (0, 4097, 8191):
+        r = part.check_file(oraclelib, f)
+        assert r["mode"] == "tolerance" and r["samples"] == 200 * 960 * 2 and r["mismatches"] == 0, (f, r)
+        assert r["rms_error"] <= 1e-5 and r["int16_flip_rate"] < 0.01 and r["int16_max_step"] <= 1, (f, r)
+    assert bool(torch.isfinite(out).all())
+    first = out.clone()
+    part.launch(stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(first, out)
+    del first, out, part
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.numeric_tolerance
+def test_fullsize_c5_wave(gpu):
+    """BASELINE configs[4] at its real size: the first of the three resident waves of the 65 536-file mixed corpus on one GPU
+    (21 846 files: MP3 + Ogg Vorbis + FLAC + Opus-CELT planes resident together, the CELT walk on a second stream beside the
+    other codecs' kernels, long streams cut into segments) -- the first, a middle and the last file of every codec against
+    the oracle, every output written (the planes are pre-filled with NaN / INT_MIN), a second step bit-identical."""
+    import torch
+    if free_bytes() < 230e9:
+        pytest.skip("not enough free device memory for a full C5 wave")
+    man = corpus.c5_manifest()
+    waves = corpus.c5_shard_waves(man, 0, 1)
+    assert len(waves) == 3 and 20000 < len(waves[0]) <= corpus.C5_WAVE_FILES
+    wl = corpus.build_c5_wave(man, waves[0], gpu)
+    assert [p.name for p in wl.parts] == ["mp3", "vorbis", "flac", "celt"]
+    for p in wl.parts:
+        o = p.out_plane()
+        o.fill_(float("nan") if o.dtype == torch.float32 else -2 ** 31)
+    stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=gpu)
+    wl.step(stream, None, side)
+    torch.cuda.synchronize()
+    for p in wl.parts:
+        n_files = len(p.file_bounds()) - 1
+        assert n_files == len(p.file_ids) > 1000
+        for f in (0, n_files // 2 + 1, n_files - 1):
+            r = p.check_file(oraclelib, f)
+            assert r["samples"] > 0 and r["mismatches"] == 0, (p.name, f, r)
+            if p.name == "celt":
+                assert r["rms_error"] <= 1e-5 and r["int16_flip_rate"] < 0.01, (f, r)
+        o = p.out_plane()
+        if o.dtype == torch.float32:
+            assert bool(torch.isfinite(o).all()), p.name
+        else:
+            assert int((o == -2 ** 31).sum()) < o.numel() // 1000, p.name           # (INT_MIN is a legal FLAC sample, not a common one)
+    # the long-chain regime decides C5's time: the wave's longest Opus file (30 s = 1500 frames) is in this check
+    celt = wl.parts[3]
+    longest = int(np.argmax(celt.frames_per_file))
+    assert celt.frames_per_file[longest] >= 1400
+    r = celt.check_file(oraclelib, longest)
+    assert r["mismatches"] == 0 and r["rms_error"] <= 1e-5, r
+    for p in wl.parts:                                                               # determinism, one plane at a time
+        o = p.out_plane()
+        if free_bytes() < o.numel() * o.element_size() + (4 << 30):
+            continue
+        first = o.clone()
+        wl.step(stream, None, side)
+        torch.cuda.synchronize()
+        assert torch.equal(first, o), p.name
+        del first
+    del wl
+    torch.cuda.empty_cache()
