@@ -813,11 +813,26 @@ extern "C" uint32_t afg_flac_variants(uint64_t n_frames, const afg_flac_frame *f
     return mask;
 }
 
+// can the host read this device pointer (page-locked host memory mapped into the device, or managed memory)?
+static bool host_visible(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                                    // (an ordinary host pointer: not an error of this call)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged || a.isManaged;
+}
+
 extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
                                       const afg_flac_subframe *d_subframes, const int32_t *d_res,
                                       int32_t *d_out_i32, float *d_out_f32, void *hip_stream)
 {
-    return launch_variants(n_frames, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, 0xffffu, (hipStream_t)hip_stream);
+    // records the host can read: find the populated instantiations here instead of launching all of them
+    uint32_t variants = 0xffffu;
+    if (n_frames && d_frames && d_subframes && host_visible(d_frames) && host_visible(d_subframes))
+        variants = afg_flac_variants(n_frames, d_frames, d_subframes);
+    return launch_variants(n_frames, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, variants, (hipStream_t)hip_stream);
 }
 
 extern "C" int afg_flac_transform_variants_hip(uint64_t n_frames, const afg_flac_frame *d_frames,

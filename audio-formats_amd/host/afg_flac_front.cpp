@@ -275,13 +275,20 @@ bool flac_frame(BitReader &br, const FlacInfo &fi, FlacRecords &rec)
         for (size_t i = 0; i < n; i++) seen |= (uint32_t)(plane[i] ^ (plane[i] >> 31));
         if (seen < 32768u) {
             // forward in place: the int16 rows (padded to 8) never overtake the int32 words still to be read (bs >= 8)
-            int16_t *rows = (int16_t *)plane;
+            // (byte-wise copies: the int16 stores overlap int32 words of the same buffer, which plain typed accesses
+            // would leave to the optimiser's no-alias assumptions)
+            unsigned char *rows = (unsigned char *)plane;
             const size_t row = (size_t)AFG_FLAC_ROW16(bs);
             for (uint32_t c = 0; c < C; c++) {
-                const int32_t *src = plane + (size_t)c * bs;
-                int16_t *dst = rows + (size_t)c * row;
-                for (uint32_t i = 0; i < bs; i++) dst[i] = (int16_t)src[i];
-                for (size_t i = bs; i < row; i++) dst[i] = 0;
+                const unsigned char *src = (const unsigned char *)(plane + (size_t)c * bs);
+                unsigned char *dst = rows + (size_t)c * row * sizeof(int16_t);
+                for (uint32_t i = 0; i < bs; i++) {
+                    int32_t w;
+                    std::memcpy(&w, src + (size_t)i * sizeof(int32_t), sizeof(w));
+                    const int16_t h = (int16_t)w;
+                    std::memcpy(dst + (size_t)i * sizeof(int16_t), &h, sizeof(h));
+                }
+                std::memset(dst + (size_t)bs * sizeof(int16_t), 0, (row - bs) * sizeof(int16_t));
             }
             fr.res16 = 1;
             fr.in_off *= 2;

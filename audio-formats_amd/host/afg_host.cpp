@@ -1433,11 +1433,12 @@ int afg_flac_parse(const uint8_t *data, size_t length, afg_flac_parsed *out)
         if (!out) return AFG_ERR_INVALID;
         std::memset(out, 0, sizeof(*out));
         if (!data) return AFG_ERR_INVALID;
-        auto *own = new (std::nothrow) FlacParsedOwner;
+        std::unique_ptr<FlacParsedOwner> own_guard(new (std::nothrow) FlacParsedOwner);               // (freed if the parser throws)
+        auto *own = own_guard.get();
         if (!own) return AFG_ERR_OOM;
         FlacInfo fi;
         if (!flac_parse(data, length, fi, own->rec)) {
-            delete own;
+            own_guard.reset();
             afg::set_error("afg_flac_parse: not a native FLAC stream");
             return AFG_ERR_UNSUPPORTED;
         }
@@ -1453,7 +1454,7 @@ int afg_flac_parse(const uint8_t *data, size_t length, afg_flac_parsed *out)
         out->frames = own->rec.frames.data();
         out->subframes = own->rec.subframes.data();
         out->res = own->rec.res.data();
-        out->owner = own;
+        out->owner = own_guard.release();
         return AFG_OK;
     } catch (...) {
         afg::set_error("out of host memory");
@@ -1474,10 +1475,11 @@ int afg_mp3_parse(const uint8_t *data, size_t length, afg_mp3_parsed *out)
         if (!out) return AFG_ERR_INVALID;
         std::memset(out, 0, sizeof(*out));
         if (!data) return AFG_ERR_INVALID;
-        auto *own = new (std::nothrow) afg_mp3::File;
+        std::unique_ptr<afg_mp3::File> own_guard(new (std::nothrow) afg_mp3::File);               // (freed if the parser throws)
+        auto *own = own_guard.get();
         if (!own) return AFG_ERR_OOM;
         if (!afg_mp3::parse_file(data, length, *own)) {
-            delete own;
+            own_guard.reset();
             afg::set_error("afg_mp3_parse: no MPEG Layer III stream found");
             return AFG_ERR_UNSUPPORTED;
         }
@@ -1496,7 +1498,7 @@ int afg_mp3_parse(const uint8_t *data, size_t length, afg_mp3_parsed *out)
         out->coef = own->coef.data();
         out->flags = own->flags.data();
         out->copies = (afg_mp3_copy *)own->copies.data();
-        out->owner = own;
+        out->owner = own_guard.release();
         return AFG_OK;
     } catch (...) {
         afg::set_error("out of host memory");
@@ -1517,16 +1519,17 @@ int afg_mp3_parse_q(const uint8_t *data, size_t length, afg_mp3_parsed_q *out)
         if (!out) return AFG_ERR_INVALID;
         std::memset(out, 0, sizeof(*out));
         if (!data) return AFG_ERR_INVALID;
-        auto *own = new (std::nothrow) afg_mp3::File;
+        std::unique_ptr<afg_mp3::File> own_guard(new (std::nothrow) afg_mp3::File);               // (freed if the parser throws)
+        auto *own = own_guard.get();
         if (!own) return AFG_ERR_OOM;
         own->quantised = true;
         if (!afg_mp3::parse_file(data, length, *own)) {
-            delete own;
+            own_guard.reset();
             afg::set_error("afg_mp3_parse_q: no MPEG Layer III stream found");
             return AFG_ERR_UNSUPPORTED;
         }
         if (own->q_unsupported) {
-            delete own;
+            own_guard.reset();
             afg::set_error("afg_mp3_parse_q: the stream holds MPEG-2.5 8 kHz mixed blocks, which the device requantiser does not cover");
             return AFG_ERR_UNSUPPORTED;
         }
@@ -1545,12 +1548,13 @@ int afg_mp3_parse_q(const uint8_t *data, size_t length, afg_mp3_parsed_q *out)
         b.coef = nullptr;
         b.flags = own->flags.data();
         b.copies = (afg_mp3_copy *)own->copies.data();
-        b.owner = own;
+        b.owner = own;                                  // (released from the guard at the end)
         out->n_granules = own->qgr.size();
         out->n_sdesc = own->sdesc.size();
         out->q = own->q.data();
         out->granules = own->qgr.data();
         out->sdesc = own->sdesc.data();
+        own_guard.release();
         return AFG_OK;
     } catch (...) {
         afg::set_error("out of host memory");
@@ -1579,10 +1583,11 @@ static int vorbis_parse_any(const uint8_t *data, size_t length, afg_vorbis_parse
         if (!out) return AFG_ERR_INVALID;
         std::memset(out, 0, sizeof(*out));
         if (!data) return AFG_ERR_INVALID;
-        auto *own = new (std::nothrow) afg_vorbis::File;
+        std::unique_ptr<afg_vorbis::File> own_guard(new (std::nothrow) afg_vorbis::File);               // (freed if the parser throws)
+        auto *own = own_guard.get();
         if (!own) return AFG_ERR_OOM;
         if (!afg_vorbis::parse_file(data, length, *own, device_floor)) {
-            delete own;
+            own_guard.reset();
             afg::set_error("afg_vorbis_parse: not an Ogg Vorbis I stream");
             return AFG_ERR_UNSUPPORTED;
         }
@@ -1598,7 +1603,7 @@ static int vorbis_parse_any(const uint8_t *data, size_t length, afg_vorbis_parse
         out->spec = own->spec.data();
         out->take_from = own->take_from.data();
         out->take_count = own->take_count.data();
-        out->owner = own;
+        out->owner = own_guard.release();
         return AFG_OK;
     } catch (...) {
         afg::set_error("out of host memory");
@@ -1644,7 +1649,8 @@ int afg_opus_parse(const uint8_t *data, size_t length, afg_opus_parsed *out)
         if (!out) return AFG_ERR_INVALID;
         std::memset(out, 0, sizeof(*out));
         if (!data) return AFG_ERR_INVALID;
-        auto *own = new (std::nothrow) afg_opus::File;
+        std::unique_ptr<afg_opus::File> own_guard(new (std::nothrow) afg_opus::File);               // (freed if the parser throws)
+        auto *own = own_guard.get();
         if (!own) return AFG_ERR_OOM;
         const afg_opus::Status st = afg_opus::parse_file(data, length, *own);
         if (st != afg_opus::kOpened) {
@@ -1655,7 +1661,7 @@ int afg_opus_parse(const uint8_t *data, size_t length, afg_opus_parsed *out)
             } else {
                 afg::set_error("afg_opus_parse: not an Ogg Opus stream");
             }
-            delete own;
+            own_guard.reset();
             return AFG_ERR_UNSUPPORTED;
         }
         out->channels = own->channels;
@@ -1669,7 +1675,7 @@ int afg_opus_parse(const uint8_t *data, size_t length, afg_opus_parsed *out)
         out->n_coeffs = own->coeffs.size();
         out->frames = own->frames.data();
         out->coeffs = own->coeffs.data();
-        out->owner = own;
+        out->owner = own_guard.release();
         return AFG_OK;
     } catch (...) {
         afg::set_error("out of host memory");
@@ -2064,7 +2070,13 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                             ok = afg_mp3::parse_file(data[i], length[i], p.mp3);
                             lost = true;
                         }
-                    } catch (...) { ok = false; }
+                    } catch (...) {
+                        // the file may have left records with file-relative offsets in the staged plane: the chunk must not
+                        // be submitted as it stands (afg_mp3_requant_hip walks every slot with nch != 0)
+                        ok = false;
+                        if (qmode) std::memset(recs0 + base[i], 0, bound[i] * sizeof(afg_mp3_qgranule));
+                        lost = true;
+                    }
                     if (ok) p.format = AFG_FORMAT_MP3;
                     else p.mp3 = afg_mp3::File();
                 });
@@ -2264,10 +2276,15 @@ int afg_batch_decode_ex(const uint8_t *const *data, const size_t *length, int n_
                 }
             };
             {
-                std::vector<std::thread> th;
-                for (size_t k = 1; k < nd; k++) th.emplace_back(run_part, k);
+                // joins on every way out: a thread that cannot be created after others have started must not take the
+                // process down (std::terminate on a joinable std::thread) instead of returning AFG_ERR_OOM
+                struct Joiner {
+                    std::vector<std::thread> th;
+                    ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); }
+                } j;
+                j.th.reserve(nd);
+                for (size_t k = 1; k < nd; k++) j.th.emplace_back(run_part, k);
                 run_part(0);
-                for (auto &t : th) t.join();
             }
             (void)hipSetDevice(caller_dev);
             for (size_t k = 0; k < nd; k++)

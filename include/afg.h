@@ -246,13 +246,15 @@ int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
                            const afg_flac_subframe *d_subframes, const int32_t *d_res,
                            int32_t *d_out_i32, float *d_out_f32, void *hip_stream);
 
-/* The restore kernel exists in 16 instantiations (LPC-order bucket <= 4 / 8 / 12 / 32 x 64-bit accumulator in the even / odd
- * channel slot, so that each gets the registers it needs and no more); a wavefront of 64 consecutive frames runs in the
- * one its largest order and widest subframe select.  afg_flac_transform_hip launches all 16, the ones nobody selects exit
- * at once.  A caller that still holds the records in host memory can say which are populated:
+/* The restore kernel exists in 8 instantiations (LPC-order bucket <= 4 / 8 / 12 / 32 x 64-bit accumulator, so that each gets
+ * the registers it needs and no more); a wavefront of 32 consecutive frames -- a lane per subframe -- runs in the one its
+ * largest order and widest subframe select.  afg_flac_transform_hip launches only the populated ones when d_frames and
+ * d_subframes are host-visible (page-locked or managed memory: it reads the records itself), else all 8 -- the ones nobody
+ * selects exit at once.  A caller that still holds the records in host memory can say which are populated:
  * afg_flac_variants (host pointers, pure host code) returns the set as a bit mask, and afg_flac_transform_variants_hip
  * launches only those -- two or more of them side by side on the caller's stream and an internal one, joined before
- * the call returns to the stream's order.  Frames of an instantiation missing from `variants` are NOT decoded. */
+ * the call returns to the stream's order.  Frames of an instantiation missing from `variants` are NOT decoded.  The mask
+ * is only meaningful within the process that computed it. */
 uint32_t afg_flac_variants(uint64_t n_frames, const afg_flac_frame *frames, const afg_flac_subframe *subframes);
 int afg_flac_transform_variants_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
                                     const afg_flac_subframe *d_subframes, const int32_t *d_res,
@@ -332,10 +334,12 @@ int afg_opus_output_gain_hip(uint64_t n_samples, const float *d_in, float gain, 
 
 /* ========================================================================== *
  *  Outer surface: the AudioStream subset (stream.d:102-637) over the host front-ends
- *  that exist so far -- FLAC (native container, drflac.d:680-1695, :1887-2153), QOA
- *  (qoa.d:413-486, :703-851), MP3 Layer III (minimp3.d, minimp3_ex.d) and Ogg Vorbis (stb_vorbis2.d).
- *  Other formats report "unrecognized encoding" (Opus, WAV, MOD, XM).  The host parses the whole file into
- *  transform-stage records, the device restores the samples, the stream serves them.
+ *  -- FLAC (native container, drflac.d:680-1695, :1887-2153), QOA (qoa.d:413-486, :703-851), MP3 Layer I / II / III
+ *  (minimp3.d, minimp3_ex.d), Ogg Vorbis (stb_vorbis2.d) and Ogg Opus with CELT-only packets (dopus.d; a file that holds
+ *  SILK / hybrid packets is refused at open with this library's own message).  WAV, MOD and XM report "unrecognized
+ *  encoding".  Like the reference the stream decodes as the caller pulls: afg_open_from_memory parses the container only,
+ *  a read that finds the FIFO empty decodes the next chunk (64 MP3 frames / Vorbis or Opus packets, 16 FLAC or QOA frames)
+ *  on the device; afg_batch_decode parses whole files into transform-stage records and decodes them in one pass.
  * ========================================================================== */
 
 typedef enum afg_format {          /* AudioFileFormat, stream.d:36-47 */

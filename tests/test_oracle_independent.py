@@ -1,0 +1,94 @@
+"""The oracle against a decoder that was NOT written in this repository (tests/golden/independent_webaudio.npz, made by
+tests/golden/make_independent.py in the build container: the WebAudio decodeAudioData of the Chromium inside the image's
+`kaleido` package -- Chromium's FFmpeg build for MP3 / Vorbis / FLAC, libopus for Opus).
+
+It is not the reference (SURVEY 8c's pin needs the D decoders or vectors they made: the oracle's header still says "parity
+unpinned"), but it is evidence from other hands:
+  * MP3: minimp3's arithmetic (the oracle's restatement) and FFmpeg's mp3float are two float implementations of one
+    standard-defined decoder -- they must agree to float accuracy on every sample of the real file, with the same delay
+    / padding bookkeeping (same length, lag 0);
+  * Vorbis: stb_vorbis (restated) and FFmpeg's vorbis decoder, likewise;
+  * FLAC: bit-exact integers;
+  * Opus: the reference's decoder is a port of FFmpeg's native CELT decoder, the independent one is libopus, the codec's
+    normative implementation.  On the two committed files (60 fullband 20 ms frames of random payloads each) they agree
+    to 0.5 % RMS (stereo) and 6 % RMS (mono, a signal 80 dB below full scale whose silent stretches libopus flushes to
+    exact zeros).  That is gross agreement, not float accuracy: a slip anywhere in the range decoder, the band energies,
+    the bit allocation or the PVQ shapes turns the output into unrelated noise (100 % and more).  It is NOT uniform: on
+    other random files (other seeds, mixed frame sizes or bandwidths) single frames differ by tens of percent between the
+    two decoder lineages -- FFmpeg's CELT decoder is known not to track libopus on everything a random bitstream
+    exercises -- and without the reference's own output those differences cannot be assigned to either side.  The Opus
+    front-end therefore stays "parity unpinned" in DESIGN.md."""
+import os
+
+import numpy as np
+
+import oraclelib
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def vectors():
+    return np.load(os.path.join(GOLD, "independent_webaudio.npz"))
+
+
+def rms(x):
+    return float(np.sqrt(np.mean(np.asarray(x, np.float64) ** 2)))
+
+
+def test_mp3_file_agrees_with_ffmpeg():
+    data = open(os.path.join(GOLD, "mathjax_invalid_keypress.mp3"), "rb").read()
+    want = vectors()["mp3_pcm"]
+    got = oraclelib.mp3_decode_file(data)["pcm"].reshape(-1, 2)
+    assert got.shape == want.shape == (23087, 2)                     # same delay / padding trim, sample for sample
+    d = got.astype(np.float64) - want
+    assert rms(want) > 0.1
+    assert rms(d) <= 1e-5 and np.abs(d).max() <= 6e-5, (rms(d), np.abs(d).max())
+    # not a coincidence of levels: one sample of misalignment is three orders of magnitude worse
+    assert rms(got[1:].astype(np.float64) - want[:-1]) > 100 * rms(d)
+
+
+def test_vorbis_file_agrees_with_ffmpeg():
+    data = open(os.path.join(GOLD, "mathjax_invalid_keypress.ogg"), "rb").read()
+    want = vectors()["ogg_pcm"]                                       # WebAudio does not apply the last page's granule trim
+    got = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(data))
+    assert got.shape == (22050, 2) and want.shape[0] >= 22050
+    d = got.astype(np.float64) - want[:22050]
+    assert rms(d) <= 1e-7 and np.abs(d).max() <= 1e-6, (rms(d), np.abs(d).max())
+
+
+def test_flac_file_agrees_with_ffmpeg():
+    import afgpu
+    v = vectors()
+    data = v["flac_file"].tobytes()
+    info, frames, subframes, res = afgpu.flac_parse(data)             # (host parser; the restore below is the oracle's)
+    got = oraclelib.flac_transform(frames, subframes, res, info["out_samples"]).reshape(-1, 2) >> 16
+    assert np.array_equal(got, v["flac_source"])                      # lossless: the samples that were encoded
+    web = v["flac_pcm"].astype(np.float64)
+    # WebAudio hands FLAC over as int16 / 32768 for negative and / 32767 for positive values (its sample-format bridge)
+    back = np.where(web < 0, web * 32768.0, web * 32767.0)
+    assert np.abs(back - got).max() < 0.51 and np.array_equal(np.rint(back).astype(np.int64), got)
+
+
+def opus_case(tag, channels):
+    v = vectors()
+    rec = oraclelib.opus_decode_file(v[tag + "_file_gain0"].tobytes())
+    assert not isinstance(rec, int) and rec["channels"] == channels and len(rec["frames"]) == 60
+    base, recs = oraclelib.opus_channel_records(rec)
+    pcm = oraclelib.celt_transform(base, recs, rec["coeffs"], rec["pcm_frames"] * channels).reshape(-1, channels)
+    want = v[tag + "_pcm_m78dB"].astype(np.float64)                   # libopus: pre-skip dropped, header gain applied
+    got = pcm[312:].astype(np.float64) * 10.0 ** (-20000 / 256.0 / 20.0)
+    n = min(len(got), len(want))
+    assert n >= 57000
+    return got[:n], want[:n]
+
+
+def test_opus_stereo_agrees_with_libopus():
+    got, want = opus_case("opus_stereo", 2)
+    assert rms(got - want) <= 0.02 * rms(want), rms(got - want) / rms(want)
+    assert rms(got[1:] - want[:-1]) > 20 * rms(got - want)            # aligned to the sample
+
+
+def test_opus_mono_agrees_with_libopus():
+    got, want = opus_case("opus_mono", 1)
+    assert rms(got - want) <= 0.10 * rms(want), rms(got - want) / rms(want)
+    assert rms(got[1:] - want[:-1]) > 5 * rms(got - want)
