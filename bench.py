@@ -251,6 +251,7 @@ def other_workloads(args):
                      "kernels": [{k: v for k, v in kk.items() if k in ("codec", "kernel", "avg_kernel_ms", "achieved", "frac", "samples_per_launch",
                                                                        "algorithmic_bytes_per_launch")} for kk in d["roofline"]["kernels"]],
                      "overlapped_on_a_second_stream": d["roofline"].get("overlapped_on_a_second_stream"),
+                     "celt_alone": d["roofline"].get("celt_alone"),
                      "parity": d["parity"], "wall_s": wall, "error": err}
     d, err, wall = child([os.path.join(ROOT, "tools", "bench_codecs.py"), "--codec", "others", "--steps", "5"], 420)
     if d is None:
@@ -371,6 +372,19 @@ def run_rank(args, world, rank, local_rank):
                 k = kern.setdefault(p.name, {"kernel": p.kernel, "ms": [0.0] * args.steps, "samples": 0, "alg_bytes": 0, "units": 0})
                 k["ms"] = [a + b for a, b in zip(k["ms"], ms)]
                 k["samples"] += p.samples; k["alg_bytes"] += p.alg_bytes; k["units"] += p.units
+            # the Opus members on their own (in the step they run on a second stream beside the other codecs' kernels, so
+            # their event span there is the overlapped one)
+            for p in wl.parts:
+                if p.name == "celt":
+                    ms = []
+                    for i in range(3):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream); p.launch(stream); e1.record(stream)
+                        torch.cuda.synchronize()
+                        if i:
+                            ms.append(e0.elapsed_time(e1))
+                    extra["celt_alone_ms"] = extra.get("celt_alone_ms", 0.0) + sum(ms) / len(ms)
+                    extra["celt_alone_bytes"] = extra.get("celt_alone_bytes", 0) + p.alg_bytes
             if rank == 0 and wi == 0:
                 import oraclelib
                 parity = {p.name: p.check(oraclelib) for p in wl.parts}
@@ -487,6 +501,9 @@ def run_rank(args, world, rank, local_rank):
                 "whole_step": {"algorithmic_bytes": int(step_bytes), "kernel_ms": step_ms,
                                "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "measured_copy_GBs": extra.get("measured_copy_GBs"), "mp3_full_fetch": extra.get("mp3_full_fetch")}
+    if extra.get("celt_alone_ms"):
+        roofline["celt_alone"] = {"avg_kernel_ms": extra["celt_alone_ms"], "frac": extra["celt_alone_bytes"] / (extra["celt_alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "the Opus members of all waves launched on their own (no other kernel beside them), summed over the waves"}
     line = {
         "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
