@@ -34,6 +34,12 @@
 #define AFG_WALK_ABL 0      // development ablations (tools/build_variant1.sh; timing only, results are wrong): 1 no de-emphasis scan,
 #endif                      // 2 no post-filter, 3 no memmove, 4 no radix / post-rotation, 5 no fft15, 6 no stores, 7 no input loads
 
+#ifndef AFG_WALK_FFT_SIGN
+#define AFG_WALK_FFT_SIGN 1
+#endif
+#ifndef AFG_WALK_PFA
+#define AFG_WALK_PFA 1      // the 15-point base transform in prime-factor form (0: the reference's radix-3 x 5 form)
+#endif
 #ifndef AFG_WALK_PFU
 #define AFG_WALK_PFU 8      // samples a lane takes per step of the steady-state comb filter (4 or 8)
 #endif
@@ -48,6 +54,75 @@ struct PfW {
     int period, period_old;
     float g[3], g_old[3];
 };
+
+// ---- 15-point transform, prime-factor form ---------------------------------------------------------------------------------
+// imdct15's base transform (dopus.d:1552-1581) is a radix-3 step over three 5-point transforms, with a twiddle on two
+// thirds of the points: ~440 operations per lane.  15 = 3 x 5 with coprime factors, so the Good-Thomas index maps
+// n = (5 n1 + 3 n2) mod 15, k = (10 k1 + 6 k2) mod 15 turn it into three 5-point and five 3-point transforms with NO
+// twiddles in between (W15^(nk) = W3^(n1 k1) W5^(n2 k2)), each in its real-constant form: 178 operations.  Same sums,
+// another association: tolerance mode only.
+constexpr int kFftSign = AFG_WALK_FFT_SIGN;                // exponent sign of the reference's tables: e^(+2 pi i j / 15)
+
+__device__ __forceinline__ cpx mul_i(cpx a) { return kFftSign > 0 ? cpx{ -a.im, a.re } : cpx{ a.im, -a.re }; }   // a * (s i)
+
+__device__ __forceinline__ void fft5_pfa(cpx &X0, cpx &X1, cpx &X2, cpx &X3, cpx &X4, cpx x0, cpx x1, cpx x2, cpx x3, cpx x4)
+{
+    constexpr float c1 = 0.30901699437494745f, c2 = -0.80901699437494734f;     // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float s1 = 0.95105651629515353f, s2 = 0.58778525229247325f;      // sin(2 pi / 5), sin(4 pi / 5)
+    const cpx t1 = { x1.re + x4.re, x1.im + x4.im }, t2 = { x2.re + x3.re, x2.im + x3.im };
+    const cpx t3 = { x1.re - x4.re, x1.im - x4.im }, t4 = { x2.re - x3.re, x2.im - x3.im };
+    X0 = cpx{ x0.re + t1.re + t2.re, x0.im + t1.im + t2.im };
+    const cpx m1 = { x0.re + c1 * t1.re + c2 * t2.re, x0.im + c1 * t1.im + c2 * t2.im };
+    const cpx m2 = { x0.re + c2 * t1.re + c1 * t2.re, x0.im + c2 * t1.im + c1 * t2.im };
+    const cpx n1 = mul_i(cpx{ s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im });
+    const cpx n2 = mul_i(cpx{ s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im });
+    X1 = cpx{ m1.re + n1.re, m1.im + n1.im };
+    X4 = cpx{ m1.re - n1.re, m1.im - n1.im };
+    X2 = cpx{ m2.re + n2.re, m2.im + n2.im };
+    X3 = cpx{ m2.re - n2.re, m2.im - n2.im };
+}
+
+__device__ __forceinline__ void fft3_pfa(cpx &X0, cpx &X1, cpx &X2, cpx x0, cpx x1, cpx x2)
+{
+    constexpr float sn = 0.86602540378443865f;                                  // sin(2 pi / 3)
+    const cpx t = { x1.re + x2.re, x1.im + x2.im }, d = { x1.re - x2.re, x1.im - x2.im };
+    X0 = cpx{ x0.re + t.re, x0.im + t.im };
+    const cpx m = { x0.re - 0.5f * t.re, x0.im - 0.5f * t.im };
+    const cpx n = mul_i(cpx{ sn * d.re, sn * d.im });
+    X1 = cpx{ m.re + n.re, m.im + n.im };
+    X2 = cpx{ m.re - n.re, m.im - n.im };
+}
+
+__device__ __forceinline__ void fft15_pfa(cpx (&y)[15], const cpx (&x)[15])
+{
+    cpx A[3][5];
+#pragma unroll
+    for (int n1 = 0; n1 < 3; n1++)
+        fft5_pfa(A[n1][0], A[n1][1], A[n1][2], A[n1][3], A[n1][4], x[(5 * n1) % 15], x[(5 * n1 + 3) % 15], x[(5 * n1 + 6) % 15],
+                 x[(5 * n1 + 9) % 15], x[(5 * n1 + 12) % 15]);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; k2++)
+        fft3_pfa(y[(6 * k2) % 15], y[(10 + 6 * k2) % 15], y[(20 + 6 * k2) % 15], A[0][k2], A[1][k2], A[2][k2]);
+}
+
+// frame_fft of celt_core.h with the base transform above
+__device__ __forceinline__ void frame_fft_pfa(cpx *z, const float (&xa)[15], const float (&xb)[15], const Geo &g, const float *ltab,
+                                              int l, bool act)
+{
+    const cpx *tw = (const cpx *)(ltab + tw_off(g.N));
+    if (act && l < g.nb15) {
+        const int an = l & (g.nblk - 1);
+        const int a = (int)(__brev((unsigned)an) >> (32 - g.fft_n));
+        cpx x[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) x[k] = cmul(cpx{ xa[k], xb[k] }, tw[a + g.nblk * k]);
+        cpx y[15];
+        fft15_pfa(y, x);
+#pragma unroll
+        for (int m = 0; m < 15; m++) z[15 * l + m] = y[m];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ---- post-filter on the linear frame buffer (data = buf + 1024: CeltFrame.buf + 1024 of the reference) ------------------
 // celt_postfilter_apply_transition (dopus.d:3281-3324) on data[n0 .. n0 + 120)
@@ -352,7 +427,11 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             const int F = K960 ? 960 : g.F;
             // iMDCT and overlap-add, dopus.d:3684-3690
 #if AFG_WALK_ABL != 5
+#if AFG_WALK_PFA
+            frame_fft_pfa(z, xa, xb, g, ltab, l, act);
+#else
             frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
+#endif
 #endif
 #if AFG_WALK_ABL != 7
             {                                                // (the last frame's again at the end)
