@@ -40,6 +40,9 @@
 #ifndef AFG_WALK_PFA
 #define AFG_WALK_PFA 1      // the 15-point base transform in prime-factor form (0: the reference's radix-3 x 5 form)
 #endif
+#ifndef AFG_WALK_ST16
+#define AFG_WALK_ST16 1     // 16-byte PCM stores (two samples of both channels per lane); 0: 8-byte stores
+#endif
 #ifndef AFG_WALK_PFU
 #define AFG_WALK_PFU 8      // samples a lane takes per step of the steady-state comb filter (4 or 8)
 #endif
@@ -122,6 +125,21 @@ __device__ __forceinline__ void frame_fft_pfa(cpx *z, const float (&xa)[15], con
         for (int m = 0; m < 15; m++) z[15 * l + m] = y[m];
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// load_inputs of celt_core.h for the hot geometry (960 samples, one block): two base pointers per lane and compile-time
+// element offsets, so that the 30 loads carry their offsets as immediates instead of a 64-bit address each
+__device__ __forceinline__ void load_inputs_960(float (&xa)[15], float (&xb)[15], const float *__restrict__ coeffs,
+                                                const afg_celt_frame &fr, int l)
+{
+    const int a = (int)(__brev((unsigned)(l & 31)) >> 27);
+    const float *pb = coeffs + fr.coef_off + 2 * a;                  // x[2 i],        i = a + 32 k
+    const float *pa = coeffs + fr.coef_off + (959 - 2 * a);          // x[959 - 2 i]
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        xa[k] = AFG_CELT_LD(pa - 64 * k);
+        xb[k] = AFG_CELT_LD(pb + 64 * k);
+    }
 }
 
 // ---- post-filter on the linear frame buffer (data = buf + 1024: CeltFrame.buf + 1024 of the reference) ------------------
@@ -413,7 +431,7 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
         float xa[15], xb[15];
         {
             const Geo g0 = geo_of(fr);
-            if (is_960(g0)) load_inputs(xa, xb, coeffs, fr, geo_960(), l);
+            if (is_960(g0)) load_inputs_960(xa, xb, coeffs, fr, l);
             else load_inputs(xa, xb, coeffs, fr, g0, l);
         }
 
@@ -436,8 +454,12 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
 #if AFG_WALK_ABL != 7
             {                                                // (the last frame's again at the end)
                 const Geo gn = geo_of(fr_next);
-                if (is_960(gn)) load_inputs(xa, xb, coeffs, fr_next, geo_960(), l);
-                else load_inputs(xa, xb, coeffs, fr_next, gn, l);
+                if (is_960(gn)) {
+                    load_inputs_960(xa, xb, coeffs, fr_next, l);
+                    asm volatile("");                          // keeps the two branches' loads apart: merged into one block
+                } else {                                       // they take selected 64-bit addresses instead of immediates
+                    load_inputs(xa, xb, coeffs, fr_next, gn, l);
+                }
             }
 #endif
 #if AFG_WALK_ABL != 4
@@ -521,6 +543,21 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             if (both) {
                 f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
                 if (K960) {
+#if AFG_WALK_ST16
+                    // 16-byte stores: a lane takes two consecutive samples of both channels (8 x 1 KB rows per frame)
+                    f32x4 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int j = min(lane + 64 * i, 479);                   // sample pair (the last row is half full)
+                        const f32x2 a = *(const f32x2 *)(b0 + so + 2 * j), b = *(const f32x2 *)(b1 + so + 2 * j);
+                        v[i] = f32x4{ a.x, b.x, a.y, b.y };
+                    }
+                    if (storing && AFG_WALK_ABL != 6) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            if (i < 7 || lane < 32) *(f32x4 *)(o + 2 * (lane + 64 * i)) = v[i];
+                    }
+#else
                     f32x2 v[15];
 #pragma unroll
                     for (int i = 0; i < 15; i++) v[i] = f32x2{ b0[so + lane + 64 * i], b1[so + lane + 64 * i] };
@@ -528,6 +565,7 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
 #pragma unroll
                         for (int i = 0; i < 15; i++) o[lane + 64 * i] = v[i];
                     }
+#endif
                 } else if (storing) {
                     for (int p = lane; p < F; p += 64) o[p] = f32x2{ b0[so + p], b1[so + p] };
                 }
