@@ -426,7 +426,7 @@ class VorbisPart(Part):
 
 
 class FlacPart(Part):
-    name, kernel = "flac", "flac_restore_kernel"
+    name, kernel = "flac", "flac_restore1_kernel"
 
     def __init__(self, seed, frames_per_file, device, block_size=4096, file_ids=None, host=False, res16=None):
         import os

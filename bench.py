@@ -464,8 +464,8 @@ def run_rank(args, world, rank, local_rank):
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
     # passes over the same full-size batch, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_collect.sh): only
     # for the kernels and batch sizes those passes were taken on
-    pmc_file = {"mp3": "r02_pmc_mp3_transform_kernel.json", "vorbis": "r02_pmc_vorbis_wave_kernel.json",
-                "flac": "r02_pmc_flac_restore_kernel.json"}      # (FLAC: counters calibrated on its own access pattern, both instantiations)
+    pmc_file = {"mp3": "r03_pmc_mp3_transform_kernel.json", "vorbis": "r03_pmc_vorbis_wave_kernel.json",
+                "flac": "r03_pmc_flac_restore1_kernel.json"}     # (FLAC: counters calibrated on its own access pattern, both instantiations)
     kernels = []
     for name, k in kern.items():
         avg_ms = sum(k["ms"]) / len(k["ms"])
@@ -483,7 +483,7 @@ def run_rank(args, world, rank, local_rank):
         if k.get("survey_bytes") and k["survey_bytes"] != k["alg_bytes"]:
             # FLAC with int16 residual rows: the launch reads 2 B / sample where SURVEY 8(d) counts 4.  `frac` above is
             # priced on the bytes this input format moves; the 8 B / sample figure is shown for comparison with round 1 only.
-            kernels[-1]["launch"] = ("the populated instantiations of flac_restore_kernel (here LPC order <= 8 and <= 12) run side by side on two "
+            kernels[-1]["launch"] = ("the populated instantiations of flac_restore1_kernel (here LPC order <= 8 and <= 12) run side by side on two "
                                      "streams: a kernel trace lists each with about this duration, and they overlap")
             kernels[-1]["input_rows"] = "int16 residual rows (6 B / sample moved)"
             kernels[-1]["bytes_at_8B_per_sample"] = int(k["survey_bytes"])

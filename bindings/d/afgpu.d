@@ -24,6 +24,13 @@ int afg_abi_version();
 const(char)* afg_status_string(int status);
 const(char)* afg_last_error();
 int afg_device_count();
+
+/// Numeric mode of the float transform stages (afg.h): exact = the reference's expression trees bit for bit; tolerance
+/// (default) = within 1e-5 RMS, which lets the Opus/CELT stage re-associate.  AFG_NUMERIC_FROM_ENV hands the choice back to
+/// the environment variable AFG_NUMERIC.  Returns the mode in effect before.
+enum AFG_NUMERIC_FROM_ENV = -1, AFG_NUMERIC_EXACT = 0, AFG_NUMERIC_TOLERANCE = 1;
+int afg_set_numeric_mode(int mode);
+int afg_get_numeric_mode();
 int afg_device_name(int device, char* buf, size_t buflen);
 
 // ---- MP3 (replaces minimp3.d:1226-1228 + :1553) ------------------------------------------
