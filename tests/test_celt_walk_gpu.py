@@ -180,3 +180,42 @@ def test_numeric_mode_switch(gpu, monkeypatch):
         assert prev == afgpu.NUMERIC_TOLERANCE                      # the default
     finally:
         afgpu.set_numeric_mode(afgpu.NUMERIC_FROM_ENV)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_walk_random_batches_and_item_sizes(gpu, monkeypatch, seed):
+    """Random batch shapes -- empty sequences, one-frame streams, mono / stereo mixes, an odd channel at the end, frame-size
+    mixes -- under random item sizes (including ones that are not a multiple of anything): every segmentation must give the
+    bits of the unsegmented walk, which must be within tolerance of the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 40))
+    fps = [int(x) for x in rng.choice([0, 1, 2, 3, 5, 9, 17, 40, 90], n)]
+    if sum(fps) == 0:
+        fps[0] = 7
+    chans = [int(x) for x in rng.choice([1, 2, 2], n)]
+    sizes = (960,) if seed % 2 == 0 else (120, 240, 480, 960)
+    rec_base, recs, coeffs, total = synthetic.celt_batch(500 + seed, fps, chans, frame_sizes=sizes,
+                                                         p_postfilter=float(rng.choice([0.0, 0.1, 0.3])), p_transient=0.2)
+    coeffs = (coeffs * 0.05).astype(np.float32)
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    monkeypatch.setenv("AFG_CELT_SEG_RECS", "0")
+    whole, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    rms, rel, flips, step = check(whole, want)
+    assert rel < 1e-6 and flips < 0.01 and step <= 1, (rms, rel, flips, step)
+    for seg in [int(x) for x in rng.choice([1, 2, 3, 5, 7, 12, 31, 64, 100, 1000], 4, replace=False)]:
+        monkeypatch.setenv("AFG_CELT_SEG_RECS", str(seg))
+        got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+        assert np.array_equal(got.view(np.uint32), whole.view(np.uint32)), (seed, seg, int((got.view(np.uint32) != whole.view(np.uint32)).sum()))
+
+
+def test_walk_many_short_streams(gpu):
+    """20 000 channel sequences of 1-3 frames: the search in rec_base, items that span hundreds of channel pairs."""
+    rng = np.random.default_rng(77)
+    n = 10000
+    fps = [int(x) for x in rng.integers(1, 4, n)]
+    rec_base, recs, coeffs, total = synthetic.celt_batch(909, fps, [2] * n, p_postfilter=0.3)
+    coeffs = (coeffs * 0.05).astype(np.float32)
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    rms, rel, flips, step = check(got, want)
+    assert rel < 1e-6 and flips < 0.01 and step <= 1, (rms, rel, flips, step)
