@@ -365,7 +365,11 @@ __device__ __forceinline__ void mp3_segment(
         const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)g_first * nch) * 576) + lane * 9;
         const bool on = loads_of(g_first);
 #pragma unroll
-        for (int q = 0; q < 9; q++) pre[q] = on ? src[q] : f2{ 0.0f, 0.0f };
+        for (int q = 0; q < 9; q++) pre[q] = f2{ 0.0f, 0.0f };
+        if (on) {                                            // one predicated region for the nine loads, not nine
+#pragma unroll
+            for (int q = 0; q < 9; q++) pre[q] = src[q];
+        }
     }
 #pragma unroll
     for (int q = 0; q < 9; q++) asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y) : : "memory");
@@ -390,7 +394,11 @@ __device__ __forceinline__ void mp3_segment(
             const f2 *src = (const f2 *)(coef + (st.blk_base + (uint64_t)(g + 1) * nch) * 576) + lane * 9;
             const bool on = loads_of(g + 1);
 #pragma unroll
-            for (int q = 0; q < 9; q++) pre[q] = on ? src[q] : f2{ 0.0f, 0.0f };
+            for (int q = 0; q < 9; q++) pre[q] = f2{ 0.0f, 0.0f };
+            if (on) {
+#pragma unroll
+                for (int q = 0; q < 9; q++) pre[q] = src[q];
+            }
         }
 
         // C. alias reduction (minimp3.d:1002-1020), IMDCT (:1152-1168), frequency inversion (:1144-1150).  A block of subband
