@@ -30,6 +30,12 @@ namespace {
 #ifndef AFG_FLAC_TILE
 #define AFG_FLAC_TILE 32
 #endif
+#ifndef AFG_FLAC_STAGGER
+#define AFG_FLAC_STAGGER 0
+#endif
+#ifndef AFG_FLAC_ABL
+#define AFG_FLAC_ABL 0
+#endif
 #ifndef AFG_FLAC_MAD64
 #define AFG_FLAC_MAD64 0               // 1: one v_mad_i64_i32 per tap by inline assembly -- measured slower (14.6 vs 13.7 ms on C4), kept for A/B builds
 #endif
@@ -86,6 +92,14 @@ __device__ __forceinline__ void mad64(int64_t &acc, int32_t a, int32_t b)
 template <int MAXORD, bool WIDE>
 __device__ __forceinline__ int32_t predict(const int32_t (&c)[MAXORD], const int32_t (&h)[MAXORD], int shift, bool use64)
 {
+#ifdef AFG_FLAC_ABL_TAPS                                     // development ablation (timing only): AFG_FLAC_ABL_TAPS taps instead of MAXORD
+    {
+        uint32_t a = 0;
+#pragma unroll
+        for (int k = 0; k < AFG_FLAC_ABL_TAPS && k < MAXORD; k++) a += (uint32_t)c[k] * (uint32_t)h[k];
+        return (int32_t)a >> shift;
+    }
+#endif
     int64_t a0 = 0, a1 = 0;
 #pragma unroll
     for (int k = MAXORD - 1; k >= 1; k -= 2) {            // older taps first: they do not wait for the newest output
@@ -561,7 +575,11 @@ __device__ __forceinline__ void store_tile1(const int32_t *tile, const RowMeta *
         const bool second = (t + 1 < (int)m.bs);
         const double factor = 1.0 / 2147483647.0;                    // stream.d:507
         if (C == 2 && second) {
+#if AFG_FLAC_ABL == 5
+            const uint64_t o = (m.out_off + (uint64_t)t * 2) & 0x3ffffu;
+#else
             const uint64_t o = m.out_off + (uint64_t)t * 2;
+#endif
             if (out_i32) *(int4 *)(out_i32 + o) = make_int4(l0, r0, l1, r1);
             if (out_f32)
                 *(float4 *)(out_f32 + o) = make_float4((float)((double)l0 * factor), (float)((double)r0 * factor),
@@ -606,14 +624,22 @@ __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, 
         park_tile1<MODE>(tile, meta, nxt);
         __syncthreads();
         for (int t0 = 0; t0 < max_bs; t0 += kT) {
-            if (t0 + kT < max_bs) load_tile1<MODE>(nxt, meta, res, pair, t0 + kT);   // in flight during the recurrence
+#if AFG_FLAC_ABL != 2                                                               // (development ablations, timing only: 1 no stores,
+            if (t0 + kT < max_bs) load_tile1<MODE>(nxt, meta, res, pair, t0 + kT);   //  2 no row loads, 3 no recurrence, 4 no store phase at all)
+#endif
+#if AFG_FLAC_ABL != 3
             if (t0 < (int)me.bs) restore_tile1<MAXORD, WIDE>(tile, row, slot, t0, order, shift, u64, c, h);
+#endif
             __syncthreads();
             // make the prefetched residuals resident here: loads and stores share one in-order counter
 #pragma unroll
             for (int i = 0; i < Loads1<MODE>::n; i++)
                 asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y), "+v"(nxt[i].z), "+v"(nxt[i].w) : : "memory");
+#if AFG_FLAC_ABL == 1
+            store_tile1(tile, meta, row_shift, (int32_t *)nullptr, (float *)nullptr, pair, t0);
+#elif AFG_FLAC_ABL != 4
             store_tile1(tile, meta, row_shift, out_i32, out_f32, pair, t0);
+#endif
             __syncthreads();
             if (t0 + kT < max_bs) park_tile1<MODE>(tile, meta, nxt);
             __syncthreads();
@@ -677,6 +703,11 @@ __global__ __launch_bounds__(64, (MAXORD <= 12 ? AFG_FLAC_WAVES : 2)) void flac_
     const int max_bs = wave_max((int)me.bs);
     const int max_pairs = wave_max(((int)(me.info & 0xff) + 1) >> 1);
     const bool any16 = __any(valid && (me.info >> 24) != 0), any32 = __any(valid && (me.info >> 24) == 0);
+#if AFG_FLAC_STAGGER
+    // wavefronts of a CU start together and run the same program: a start offset of a fraction of a tile step keeps their
+    // store phases from falling into one another's
+    for (int k = 0; k < (int)(blockIdx.x % AFG_FLAC_STAGGER); k++) __builtin_amdgcn_s_sleep(127);
+#endif
     if (!any16)
         run_frames1<MAXORD, WIDE, 0>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
     else if (!any32)
