@@ -555,7 +555,7 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                     if (storing && AFG_WALK_ABL != 6) {
 #pragma unroll
                         for (int i = 0; i < 8; i++)
-                            if (i < 7 || lane < 32) *(f32x4 *)(o + 2 * (lane + 64 * i)) = v[i];
+                            if (i < 7 || lane < 32) __builtin_nontemporal_store(v[i], (f32x4 *)(o + 2 * (lane + 64 * i)));
                     }
 #else
                     f32x2 v[15];

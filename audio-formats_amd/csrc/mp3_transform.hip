@@ -25,6 +25,9 @@
 // Coefficients are read with fully coalesced 256-byte wave loads one granule
 // ahead of their use and staged through LDS into the (channel, subband) layout.
 #include "afg_common.h"
+#ifndef AFG_MP3_NT_STORE
+#define AFG_MP3_NT_STORE 1     // nontemporal PCM stores (0: plain stores -- A/B builds; measured 10.08 -> 9.95 ms on C2)
+#endif
 
 #include <vector>
 
@@ -548,7 +551,14 @@ __device__ __forceinline__ void mp3_segment(
 #pragma unroll
             for (int q = 0; q < 5; q++) {
                 const int idx = lane + 64 * q;
+#if AFG_MP3_NT_STORE
+                if (4 * idx < nval) {
+                    typedef float f32x4nt __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(((const f32x4nt *)H)[idx], (f32x4nt *)dst + idx);
+                }
+#else
                 if (4 * idx < nval) dst[idx] = ((const float4 *)H)[idx];
+#endif
             }
         }
         WAVE_SYNC();

@@ -170,9 +170,12 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
 #if AFG_QOA_ABL != 1 && AFG_QOA_ABL != 3
                         if (left >= 2) {
                             if (out_i16) *(short4 *)(out_i16 + o) = make_short4(l0, r0, l1, r1);
-                            if (out_f32)
-                                *(float4 *)(out_f32 + o) = make_float4((float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767),
-                                                                       (float)l1 * (1.0f / 32767), (float)r1 * (1.0f / 32767));
+                            if (out_f32) {
+                                typedef float f32x4nt __attribute__((ext_vector_type(4)));
+                                __builtin_nontemporal_store(f32x4nt{ (float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767),
+                                                                     (float)l1 * (1.0f / 32767), (float)r1 * (1.0f / 32767) },
+                                                            (f32x4nt *)(out_f32 + o));
+                            }
                         } else if (left == 1) {
                             if (out_i16) *(short2 *)(out_i16 + o) = make_short2(l0, r0);
                             if (out_f32) *(float2 *)(out_f32 + o) = make_float2((float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767));

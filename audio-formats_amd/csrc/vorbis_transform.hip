@@ -19,6 +19,14 @@
 //     rows; twiddle/window tables (host-computed exactly as :851-881) are
 //     shared by all workgroups and served from L2.
 #include "afg_common.h"
+#ifndef AFG_VORBIS_NT_STORE
+#define AFG_VORBIS_NT_STORE 1  // nontemporal PCM stores in the wave kernel (0: plain stores -- A/B builds)
+#endif
+#if AFG_VORBIS_NT_STORE
+#define AFG_VORBIS_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define AFG_VORBIS_ST(ptr, val) (*(ptr) = (val))
+#endif
 #include "afg_pk.h"
 
 #include <atomic>
@@ -1251,7 +1259,7 @@ __device__ __forceinline__ void vorbis_wave2_body(
                 for (int i = 0; i < 16; i++) {
                     const int jj = lane + 64 * i;
                     const float w0 = lwin[jj], w1 = lwin[1023 - jj];
-                    o[jj] = f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 };   // :2624-2626
+                    AFG_VORBIS_ST(o + jj, (f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 }));   // :2624-2626
                 }
             } else if (pn * 2 == kNL) {
 #pragma unroll
@@ -1259,7 +1267,7 @@ __device__ __forceinline__ void vorbis_wave2_body(
                     const int jj = lane + 64 * i;
                     if (jj < nwin) {
                         const float w0 = lwin[jj], w1 = lwin[1023 - jj];
-                        o[jj] = f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 };
+                        AFG_VORBIS_ST(o + jj, (f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 }));
                     }
                 }
             } else {
@@ -1269,11 +1277,11 @@ __device__ __forceinline__ void vorbis_wave2_body(
                     const int jj = lane + 64 * i;
                     if (jj < nwin) {
                         const float w0 = wt[jj], w1 = wt[pn - 1 - jj];
-                        o[jj] = f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 };
+                        AFG_VORBIS_ST(o + jj, (f2{ sm0[left + jj] * w0 + pv[0][i] * w1, sm1[left + jj] * w0 + pv[1][i] * w1 }));
                     }
                 }
             }
-            for (int jj = nwin + lane; jj < nout; jj += 64) o[jj] = f2{ sm0[left + jj], sm1[left + jj] };
+            for (int jj = nwin + lane; jj < nout; jj += 64) AFG_VORBIS_ST(o + jj, (f2{ sm0[left + jj], sm1[left + jj] }));
         }
 #if !(AFG_VORBIS_ABL & 32)
         if (plen == kNL / 2) {                                 // :2641-2643
