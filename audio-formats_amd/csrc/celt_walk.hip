@@ -7,9 +7,9 @@
 //
 //   * De-emphasis (tmp = x + m; m = tmp * 0.8500061; out = tmp / 32768, :3695-3701) is a one-pole IIR whose float
 //     rounding order the exact path must follow sample by sample -- a second pass over the PCM plane with one lane per
-//     channel sequence.  Re-associated it is a weighted prefix sum: here it runs on the 64 samples a wavefront holds
-//     for its coalesced store anyway (six DPP steps per row, the carry between rows through a scalar), *inside* the
-//     frame walk: the PCM plane is written once and never read.
+//     channel sequence.  Re-associated it is a weighted prefix sum: a lane takes 15 consecutive samples of a frame
+//     (the recurrence from a zero memory, in registers), the memories the lanes' runs start from come out of one
+//     six-step DPP scan per frame and channel, *inside* the frame walk: the PCM plane is written once and never read.
 //   * The comb post-filter (:3281-3378) feeds on its own output, but only while a filter is live: a frame whose old,
 //     current and new gains are all zero is left untouched (:3294-3296, :3333).  Where the records show enough such
 //     frames in a row (the filter reaches back at most 1024 samples) everything after them is independent of
@@ -23,7 +23,8 @@
 // an atomic counter; an item is a range of `seg_recs` records of the flat record array (or a whole channel pair when
 // seg_recs is 0), mapped to the channel pairs it overlaps by a search in rec_base.
 //
-// This file is compiled with -ffp-contract=fast (Makefile): multiply-adds of the transform fuse.
+// This file is compiled with -ffp-contract=fast (Makefile): multiply-adds of the transform fuse; the 15-point base
+// transform runs in prime-factor form (fft15_pfa) instead of the reference's radix-3 x 5 form.
 #include "celt_core.h"
 
 #include <algorithm>
