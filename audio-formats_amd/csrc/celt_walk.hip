@@ -25,6 +25,7 @@
 //
 // This file is compiled with -ffp-contract=fast (Makefile): multiply-adds of the transform fuse; the 15-point base
 // transform runs in prime-factor form (fft15_pfa) instead of the reference's radix-3 x 5 form.
+#define AFG_CELT_NT 0       // plain coefficient loads in this walk (measured 7.38 -> 7.30 ms against nontemporal ones)
 #include "celt_core.h"
 
 #include <algorithm>

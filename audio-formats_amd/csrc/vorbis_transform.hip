@@ -19,6 +19,9 @@
 //     rows; twiddle/window tables (host-computed exactly as :851-881) are
 //     shared by all workgroups and served from L2.
 #include "afg_common.h"
+#ifndef AFG_VORBIS_NT_LOAD
+#define AFG_VORBIS_NT_LOAD 1   // nontemporal spectrum loads (0: plain -- A/B builds)
+#endif
 #ifndef AFG_VORBIS_NT_STORE
 #define AFG_VORBIS_NT_STORE 1  // nontemporal PCM stores in the wave kernel (0: plain stores -- A/B builds)
 #endif
@@ -410,7 +413,11 @@ __device__ __forceinline__ void load_spectrum(float4 (&x)[4], const float *__res
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         typedef float v4f __attribute__((ext_vector_type(4)));
+#if AFG_VORBIS_NT_LOAD
         const v4f t = __builtin_nontemporal_load((const v4f *)X + lane + 64 * r);   // read once: keep L1 for the tables
+#else
+        const v4f t = *((const v4f *)X + lane + 64 * r);
+#endif
         x[r] = make_float4(t.x, t.y, t.z, t.w);
     }
 }
