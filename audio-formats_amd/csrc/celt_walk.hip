@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
     const uint64_t *__restrict__ rec_base, const afg_celt_frame *__restrict__ recs,
     const float *__restrict__ coeffs, float *__restrict__ out, float *__restrict__ states,
     const float *__restrict__ tables, CeltTables tb, uint32_t tab_floats, uint32_t n_chan, uint32_t seg_recs,
-    uint32_t *__restrict__ counter)
+    uint32_t whole_frames, uint32_t *__restrict__ counter)
 {
     extern __shared__ __attribute__((aligned(16))) float slds[];
     float *ltab = slds, *lwin = slds + kTabFloatsMax, *win2 = lwin + 120;
@@ -654,11 +654,16 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                 const afg_celt_frame *s0 = recs + rbase, *s1 = two ? recs + base1 : nullptr;
                 uint64_t start = 0, end = rcnt;
                 int w0 = 0, w1 = 0;
+                if (rcnt <= whole_frames) {
+                    // a short sequence is not worth a warm-up (two frames of transform per cut): the item that holds its
+                    // first frame walks all of it, the others pass
+                    if (ra > 0) continue;
+                } else
                 if (ra > 0) {
                     start = first_cut(s0, s1, rcnt, ra, rb, lane, w0, w1);
                     if (start >= rb) continue;               // no cut in the range: an earlier item walks through it
                 }
-                if (rb < rcnt) {
+                if (rb < rcnt && rcnt > whole_frames) {
                     int e0, e1;
                     end = first_cut(s0, s1, rcnt, rb, rcnt, lane, e0, e1);
                 }
@@ -731,12 +736,21 @@ int afg::celt_walk_launch(uint32_t n_chan, const uint64_t *d_rec_base, const afg
     // A carry state is read by the walk that starts at a sequence's first frame and rewritten, in place, by the one that
     // ends at its last: with states every channel pair is one item, so that this is one wavefront, in that order.
     const uint32_t seg_recs = d_states ? 0 : seg_recs_for(n_chan);
+    // With at least four channel pairs per wavefront slot (8 wavefronts x 256 CUs) sequences of up to 512 frames (10 s of 20 ms
+    // frames: a walk of 4.6 ms) are walked whole -- a cut costs two frames of warm-up, and there are enough sequences to even
+    // out the tail; with fewer every sequence is cut wherever it can be (the mixed corpus: 2 460 streams per wave, 22 ms against
+    // 29 ms with its short ones whole).  AFG_CELT_WHOLE_FRAMES overrides.
+    uint32_t whole_frames = (n_chan + 1) / 2 >= 4u * kWWaves * 256u ? 512 : 0;
+    if (const char *e = getenv("AFG_CELT_WHOLE_FRAMES")) {
+        const long v = atol(e);
+        if (v >= 0 && v <= (1 << 24)) whole_frames = (uint32_t)v;
+    }
     const uint32_t pairs = (n_chan + 1) / 2;
     // one workgroup per CU (147 KB of LDS); with whole pairs as items never more wavefronts than pairs
     uint32_t groups = (uint32_t)cus;
     if (seg_recs == 0) groups = std::min<uint32_t>(groups, (pairs + kWWaves - 1) / kWWaves);
     hipLaunchKernelGGL(celt_walk_kernel, dim3(groups), dim3(64 * kWWaves), kWLdsFloats * sizeof(float), stream, d_rec_base,
-                       d_recs, d_coeffs, d_out, d_states, d_tables, tb, tab_floats, n_chan, seg_recs, counter);
+                       d_recs, d_coeffs, d_out, d_states, d_tables, tb, tab_floats, n_chan, seg_recs, whole_frames, counter);
     AFG_HIP_CHECK(hipGetLastError());
     return AFG_OK;
 }

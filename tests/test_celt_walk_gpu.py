@@ -18,6 +18,9 @@ TOL_RMS = 1e-5          # north_star: float output within 1e-5 RMS of the refere
 @pytest.fixture(autouse=True)
 def no_path_override(monkeypatch):
     monkeypatch.delenv("AFG_CELT_PATH", raising=False)          # the numeric mode (default: tolerance) picks the walk
+    # (with thousands of channel pairs the library walks sequences of up to 512 frames whole; these batches are small, the
+    # setting only pins the policy the segmentation tests are written against)
+    monkeypatch.setenv("AFG_CELT_WHOLE_FRAMES", "0")
 
 
 def run_gpu(gpu, rec_base, recs, coeffs, total, states=None):
@@ -219,3 +222,18 @@ def test_walk_many_short_streams(gpu):
     got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
     rms, rel, flips, step = check(got, want)
     assert rel < 1e-6 and flips < 0.01 and step <= 1, (rms, rel, flips, step)
+
+
+def test_walk_default_policy_short_whole_long_cut(gpu, monkeypatch):
+    """Sequences of up to AFG_CELT_WHOLE_FRAMES frames walked whole, longer ones in segments (what the library does by itself
+    from 8192 channel pairs up) -- same bits as the unsegmented walk either way."""
+    rec_base, recs, coeffs, total = synthetic.celt_batch(4242, [700, 90, 513, 512, 30], [2, 2, 1, 2, 1], p_postfilter=0.2)
+    coeffs = (coeffs * 0.05).astype(np.float32)
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    monkeypatch.setenv("AFG_CELT_SEG_RECS", "0")
+    whole, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    monkeypatch.delenv("AFG_CELT_SEG_RECS")
+    monkeypatch.setenv("AFG_CELT_WHOLE_FRAMES", "512")
+    got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    check(got, want)
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
