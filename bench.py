@@ -221,6 +221,7 @@ def other_workloads(args):
     """Run after the headline measurement has released the device, each in a child process (a fresh HIP context; the C5
     waves need the memory the headline batches held):
       c5          BASELINE configs[4] at full size on this one GPU: 65 536 mixed files in 3 resident waves (bench.py --config c5)
+      flac_int32_rows  C4 with int32 residual rows (8 B per sample moved) beside the headline's int16 rows
       celt_dense  8192 x Opus/CELT stereo, 200 frames of 960: the CELT kernel on a device-filling batch
       qoa         4096 x QOA stereo 4 s
       *_e2e       SURVEY 8d (c): file bytes in host memory -> afg_batch_decode (host parse, H2D, kernels, D2H) -> floats in
@@ -253,6 +254,24 @@ def other_workloads(args):
                      "overlapped_on_a_second_stream": d["roofline"].get("overlapped_on_a_second_stream"),
                      "celt_alone": d["roofline"].get("celt_alone"),
                      "parity": d["parity"], "wall_s": wall, "error": err}
+    # C4 with the residual rows left as int32 (what material with 17-bit warm-up samples falls back to, frame by frame)
+    env32 = dict(env, AFG_FLAC_RES32="1")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "5", "--warmup", "1", "--no-cpu-baseline",
+                            "--no-others", "--files", str(args.files)], env=env32, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        d = json.loads(lines[-1]) if lines else None
+        err = None if (d is not None and r.returncode == 0) else f"exit code {r.returncode}: {r.stderr.decode()[-300:]}"
+    except subprocess.TimeoutExpired:
+        d, err = None, "timed out after 300 s"
+    if d is None:
+        out["flac_int32_rows"] = {"error": err}
+    else:
+        k = d["roofline"]["kernels"][0]
+        out["flac_int32_rows"] = {"workload": d["config"]["workload"], "avg_kernel_ms": k["avg_kernel_ms"], "achieved": k["achieved"], "frac": k["frac"],
+                                  "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "samples_per_s": k["samples_per_s"],
+                                  "parity": d["parity"], "wall_s": time.perf_counter() - t0, "error": err}
     d, err, wall = child([os.path.join(ROOT, "tools", "bench_codecs.py"), "--codec", "others", "--steps", "5"], 420)
     if d is None:
         out["codecs"] = {"error": err}
