@@ -64,3 +64,21 @@ def test_product_does_not_depend_on_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oraclelib" not in text and "liboracle" not in text, f
+
+
+def test_numeric_mode_switch_needs_no_device(monkeypatch):
+    """afg_set_numeric_mode / afg_get_numeric_mode (afg.h): tolerance by default, AFG_NUMERIC decides until the call, the call
+    wins afterwards, AFG_NUMERIC_FROM_ENV hands the choice back; an unknown mode is refused."""
+    import afgpu
+    lib = afgpu.lib()
+    monkeypatch.delenv("AFG_NUMERIC", raising=False)
+    assert afgpu.set_numeric_mode(afgpu.NUMERIC_FROM_ENV) in (afgpu.NUMERIC_EXACT, afgpu.NUMERIC_TOLERANCE)
+    assert afgpu.get_numeric_mode() == afgpu.NUMERIC_TOLERANCE
+    monkeypatch.setenv("AFG_NUMERIC", "exact")
+    assert afgpu.get_numeric_mode() == afgpu.NUMERIC_EXACT
+    assert afgpu.set_numeric_mode(afgpu.NUMERIC_TOLERANCE) == afgpu.NUMERIC_EXACT
+    assert afgpu.get_numeric_mode() == afgpu.NUMERIC_TOLERANCE                  # the call outranks the environment
+    assert lib.afg_set_numeric_mode(7) < 0 and b"unknown mode" in lib.afg_last_error()
+    assert afgpu.get_numeric_mode() == afgpu.NUMERIC_TOLERANCE
+    afgpu.set_numeric_mode(afgpu.NUMERIC_FROM_ENV)
+    assert afgpu.get_numeric_mode() == afgpu.NUMERIC_EXACT
