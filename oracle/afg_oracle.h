@@ -11,8 +11,12 @@
  * or on the GPU box, so the reference cannot be run (oracle/_ref is
  * unbuildable).  What pins this restatement instead is listed in DESIGN.md:
  * float64 textbook definitions of every transform (tests/test_oracle_*.py),
- * lossless FLAC/QOA encode->decode round trips, and frozen golden vectors
- * under tests/golden/.
+ * lossless FLAC/QOA encode->decode round trips, frozen golden vectors under
+ * tests/golden/, and -- the one check against code written elsewhere -- the
+ * whole-file decodes of the fixture files by Chromium's FFmpeg / libopus
+ * (tests/test_oracle_independent.py: MP3 8.9e-6 RMS, Vorbis 3e-8 RMS, FLAC
+ * exact, Opus 0.5 % / 6 % RMS).  That is not the reference either: the
+ * restatement stays unpinned in the sense above.
  *
  * Every function cites the reference file:line (relative to /root/reference)
  * whose arithmetic -- operation order, operand widths, constants -- it follows.
