@@ -1,0 +1,147 @@
+"""Vorbis transform stage in the default numeric mode (AFG_NUMERIC_TOLERANCE): the re-factored walk of
+csrc/vorbis_walk.hip (one 512-point complex FFT per 2048-sample block, window / overlap written on the DCT-IV) against
+the CPU oracle's restatement of stb_vorbis' inverse_mdct (stb_vorbis2.d:1941-2242) + vorbis_finish_frame (:2606-2657).
+The twin of test_vorbis_gpu.py: same cases, north_star's tolerance (1e-5 RMS on the API scale) instead of bit-identity,
+plus checks that the result does not depend on how a stream is cut into segments."""
+import numpy as np
+import pytest
+
+import oraclelib
+from afgpu import VorbisPlan, synthetic, VORBIS_LONG, VORBIS_PREV, VORBIS_NEXT
+
+pytestmark = [pytest.mark.gpu, pytest.mark.numeric_tolerance]
+
+FULL = VORBIS_LONG | VORBIS_PREV | VORBIS_NEXT
+
+
+def run_both(gpu, packets, channels, bs0, bs1, pflags, spec, seg=0):
+    import torch
+    plan = VorbisPlan(packets, channels, bs0, bs1, pflags, seg)
+    spec_off, out_off = plan.offsets()
+    want = oraclelib.vorbis_transform(packets, channels, bs0, bs1, pflags, spec_off, out_off, spec, plan.out_floats)
+    d_spec = torch.from_numpy(spec).to(gpu)
+    d_out = torch.full((max(plan.out_floats, 1),), float("nan"), dtype=torch.float32, device=gpu)
+    plan.transform(d_spec, d_out)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()[:plan.out_floats], want
+
+
+def check(got, want, limit=1e-5):
+    assert not np.isnan(got).any(), "unwritten output"
+    diff = got.astype(np.float64) - want.astype(np.float64)
+    rms = float(np.sqrt(np.mean(diff ** 2))) if diff.size else 0.0
+    assert rms <= limit, f"rms error {rms} over the tolerance {limit}"
+    sig = float(np.sqrt(np.mean(want.astype(np.float64) ** 2))) if want.size else 0.0
+    assert sig == 0 or rms <= 1e-6 * max(sig, 1.0), f"rms error {rms} for a signal of rms {sig}"
+    return rms, int((got.view(np.uint32) != want.view(np.uint32)).sum())
+
+
+def test_walk_is_the_path_under_test(gpu):
+    """The default mode must not be bit-identical on long blocks (it is a different factorisation); if it were, the exact
+    kernel ran and this file would test nothing."""
+    packets, channels = [12], [2]
+    pflags = np.full(12, FULL, np.uint8)
+    _, spec = synthetic.vorbis_batch(5, packets, channels, [256], [2048], p_short_run=0.0)
+    got, want = run_both(gpu, packets, channels, [256], [2048], pflags, spec, 4)
+    rms, differ = check(got, want)
+    assert differ > got.size // 10, "tolerance mode produced the exact kernel's bits"
+
+
+@pytest.mark.parametrize("seg", [1, 2, 5, 16, 1000])
+def test_walk_long_short_mix(gpu, seg):
+    packets = [40, 1, 2, 25, 70]
+    channels = [2, 2, 1, 2, 2]
+    bs0 = [256, 256, 256, 512, 256]
+    bs1 = [2048] * 5
+    pflags, spec = synthetic.vorbis_batch(7, packets, channels, bs0, bs1, p_short_run=0.2)
+    got, want = run_both(gpu, packets, channels, bs0, bs1, pflags, spec, seg)
+    check(got, want)
+
+
+def test_walk_every_window_shape(gpu):
+    """long after short, long before short, long between two shorts, short runs of every length, at both ends of a stream"""
+    L, S = True, False
+    shapes = [[L, L, L, L], [S, L, L, S], [L, S, L, S, L], [S, S, L, S, S], [L, L, S, S, S, L, L], [S] * 6, [L], [S],
+              [L, S], [S, L], [L, L, S], [S, L, L, L, S, L, S, S, L]]
+    packets, chans, flags = [], [], []
+    for sh in shapes:
+        n = len(sh)
+        pf = np.zeros(n, np.uint8)
+        for p in range(n):
+            if sh[p]:
+                prev_long = sh[p - 1] if p > 0 else True
+                next_long = sh[p + 1] if p + 1 < n else True
+                pf[p] = VORBIS_LONG | (VORBIS_PREV if prev_long else 0) | (VORBIS_NEXT if next_long else 0)
+        packets.append(n)
+        chans.append(2)
+        flags.append(pf)
+    pflags = np.concatenate(flags)
+    rng = np.random.default_rng(11)
+    spec = np.concatenate([rng.standard_normal(2 * (1024 if (f & VORBIS_LONG) else 128)).astype(np.float32) for f in pflags])
+    for seg in (1, 3, 64):
+        got, want = run_both(gpu, packets, chans, [256] * len(packets), [2048] * len(packets), pflags, spec, seg)
+        check(got, want)
+
+
+@pytest.mark.parametrize("bs0", [256, 512])
+def test_walk_segmentation_does_not_change_the_result(gpu, bs0):
+    packets, channels = [97, 33], [2, 2]
+    pflags, spec = synthetic.vorbis_batch(21, packets, channels, [bs0] * 2, [2048] * 2, p_short_run=0.1)
+    ref = None
+    for seg in (1, 7, 16, 200):
+        got, want = run_both(gpu, packets, channels, [bs0] * 2, [2048] * 2, pflags, spec, seg)
+        check(got, want)
+        if ref is None:
+            ref = got
+        else:
+            assert (got.view(np.uint32) == ref.view(np.uint32)).all(), "the segment length changed the samples"
+
+
+def test_walk_unaligned_planes_fall_back(gpu):
+    """16-byte PCM stores need an aligned plane: a caller's odd offset takes the bit-exact kernel, not a fault."""
+    import torch
+    packets, channels = [9], [2]
+    pflags = np.full(9, FULL, np.uint8)
+    _, spec = synthetic.vorbis_batch(2, packets, channels, [256], [2048], p_short_run=0.0)
+    plan = VorbisPlan(packets, channels, [256], [2048], pflags, 4)
+    so, oo = plan.offsets()
+    want = oraclelib.vorbis_transform(packets, channels, [256], [2048], pflags, so, oo, spec, plan.out_floats)
+    d_spec = torch.from_numpy(spec).to(gpu)
+    d_big = torch.full((plan.out_floats + 2,), float("nan"), dtype=torch.float32, device=gpu)
+    plan.transform(d_spec, d_big[2:])                     # 8 bytes off
+    torch.cuda.synchronize()
+    got = d_big.cpu().numpy()[2:]
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_walk_tdac_reconstruction(gpu):
+    """forward MDCT with the Vorbis window, then this path: the signal comes back (independent of the oracle)"""
+    n, npk = 2048, 8
+    rng = np.random.default_rng(1)
+    sig = rng.standard_normal((npk + 1) * (n // 2)).astype(np.float64)
+    w = oraclelib.vorbis_tables(n)["window"].astype(np.float64)
+    win = np.concatenate([w, w[::-1]])
+    m = np.arange(n)[:, None]
+    k = np.arange(n // 2)[None, :]
+    basis = np.cos(np.pi / (2 * n) * (2 * m + 1 + n / 2) * (2 * k + 1))
+    spec = np.zeros((npk, 2, n // 2), np.float32)
+    for p in range(npk):
+        blk = sig[p * n // 2:p * n // 2 + n] * win
+        spec[p, 0] = (blk @ basis * (2.0 / (n // 2))).astype(np.float32)
+        spec[p, 1] = -spec[p, 0]
+    pflags = np.full(npk, FULL, np.uint8)
+    got, want = run_both(gpu, [npk], [2], [256], [n], pflags, spec.reshape(-1), 3)
+    check(got, want)
+    ref = sig[n // 2:n // 2 + got.size // 2]
+    assert np.abs(got[0::2] - ref).max() < 2e-4 and np.abs(got[1::2] + ref).max() < 2e-4
+
+
+def test_walk_amplitude_range(gpu):
+    """programme level (rms 0.1) and 30 dB over full scale: the error scales with the signal"""
+    packets, channels = [20], [2]
+    for amp in (0.02, 30.0):
+        pflags, spec = synthetic.vorbis_batch(4, packets, channels, [256], [2048], p_short_run=0.1, amplitude=amp)
+        got, want = run_both(gpu, packets, channels, [256], [2048], pflags, spec, 6)
+        diff = got.astype(np.float64) - want.astype(np.float64)
+        rms, sig = np.sqrt(np.mean(diff ** 2)), np.sqrt(np.mean(want.astype(np.float64) ** 2))
+        assert rms <= 1e-6 * sig, (amp, rms, sig)
