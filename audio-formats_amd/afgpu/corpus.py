@@ -364,7 +364,9 @@ class Mp3Part(Part):
 
 
 class VorbisPart(Part):
-    name, kernel = "vorbis", "vorbis_wave_kernel"
+    name = "vorbis"
+    kernel = ("vorbis_walk_kernel (tolerance mode: IMDCT-2048 as one radix 8 x 8 x 8 FFT, csrc/vorbis_walk.hip; exact mode: vorbis_wave_kernel, "
+              "the reference's 8-step algorithm)")
 
     def __init__(self, seed, packets_per_file, device, seg=0, bs0=256, bs1=2048, file_ids=None, host=False):
         import torch
@@ -410,7 +412,7 @@ class VorbisPart(Part):
         o_end = int(oo[npk]) if p.total_packets > npk else p.out_floats
         want = checker.vorbis_transform(p.packets[:n_files], p.channels[:n_files], p.bs0[:n_files], p.bs1[:n_files],
                                           p.pflags[:npk], so[:npk], oo[:npk], self.spec[:s_end].cpu().numpy(), o_end)
-        return _float_parity(self.out[:o_end].cpu().numpy(), want)
+        return _float_parity(self.out[:o_end].cpu().numpy(), want, get_numeric_mode() == NUMERIC_TOLERANCE)
 
     def check_file(self, checker, f):
         p = self.plan
@@ -422,7 +424,7 @@ class VorbisPart(Part):
         o1 = int(oo[k1]) if p.total_packets > k1 else p.out_floats
         want = checker.vorbis_transform(p.packets[f:f + 1], p.channels[f:f + 1], p.bs0[f:f + 1], p.bs1[f:f + 1], p.pflags[k0:k1],
                                         so[k0:k1] - np.uint64(s0), oo[k0:k1] - np.uint64(o0), self.spec[s0:s1].cpu().numpy(), o1 - o0)
-        return _float_parity(self.out[o0:o1].cpu().numpy(), want)
+        return _float_parity(self.out[o0:o1].cpu().numpy(), want, get_numeric_mode() == NUMERIC_TOLERANCE)
 
 
 class FlacPart(Part):

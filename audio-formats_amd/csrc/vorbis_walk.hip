@@ -434,6 +434,7 @@ __device__ __forceinline__ void walk_body(
     (void)carry_u;
 }
 
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void vorbis_walk_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES) void vorbis_walk_kernel(
 }
 
 #ifndef AFG_VORBIS_WALK_WAVES
-#define AFG_VORBIS_WALK_WAVES 12
+#define AFG_VORBIS_WALK_WAVES 8
 #endif
 constexpr int kWalkWaves = AFG_VORBIS_WALK_WAVES;
 constexpr size_t kWalkLds = sizeof(float) * (kTabFloats + (size_t)kWalkWaves * 2 * kWaveF2);

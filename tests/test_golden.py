@@ -70,6 +70,22 @@ def test_hip_reproduces_vorbis_fixture(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.numeric_tolerance
+def test_hip_reproduces_vorbis_fixture_within_tolerance(gpu):
+    """the default numeric mode: the re-factored inverse MDCT of csrc/vorbis_walk.hip against the frozen oracle output"""
+    import torch
+    from afgpu import VorbisPlan
+    g = load("vorbis_transform.npz")
+    plan = VorbisPlan(g["packets"], g["channels"], g["bs0"], g["bs1"], g["pflags"], 3)
+    d_out = torch.full((g["out"].size,), float("nan"), dtype=torch.float32, device=gpu)
+    plan.transform(torch.from_numpy(g["spec"]).to(gpu), d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert float(np.sqrt(np.mean((got.astype(np.float64) - g["out"]) ** 2))) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_hip_reproduces_flac_fixture(gpu):
     import torch
     import afgpu
