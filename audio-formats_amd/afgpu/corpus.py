@@ -170,7 +170,10 @@ _LPC_POOL = {}
 
 def _lpc_pool(seed):
     if seed not in _LPC_POOL:
-        _LPC_POOL[seed] = {o: ([synthetic._quantised_lpc(np.random.default_rng([seed, o, i]), o) for i in range(64)]) for o in (8, 12)}
+        # quantised LPC of a STABLE AR(order) process -- with the residual clamp below every decoded sample stays
+        # inside 16 bits per subframe (synthetic.stable_quantised_lpc: sum |h| <= 24, |residual| <= 1023)
+        _LPC_POOL[seed] = {o: ([synthetic.stable_quantised_lpc(np.random.default_rng([seed, o, i]), o) for i in range(64)]) for o in (8, 12)}
+        assert synthetic.FLAC_C4_L1_MAX * (synthetic.FLAC_C4_RESIDUAL_CLAMP + 1) < 32768
     return _LPC_POOL[seed]
 
 
@@ -215,7 +218,8 @@ def flac_records(seed, frames_per_file, file_ids=None, block_size=4096, bps=16):
 
 def flac_residuals_numpy(seed, frames_per_file, file_ids=None, block_size=4096):
     ids = _ids(len(frames_per_file), file_ids)
-    out = [np.rint(np.random.default_rng([seed, int(ids[k]), 6]).laplace(0.0, 32.0, int(nf) * 2 * block_size)).astype(np.int32)
+    lim = synthetic.FLAC_C4_RESIDUAL_CLAMP
+    out = [np.clip(np.rint(np.random.default_rng([seed, int(ids[k]), 6]).laplace(0.0, 32.0, int(nf) * 2 * block_size)), -lim, lim).astype(np.int32)
            for k, nf in enumerate(frames_per_file)]
     return np.concatenate(out) if out else np.zeros(0, np.int32)
 
@@ -460,7 +464,7 @@ class FlacPart(Part):
                 k = min(chunk, total - o)
                 e = torch.empty(k, dtype=torch.float32, device=device).exponential_(1.0 / 32.0, generator=gen)
                 sgn = torch.empty(k, dtype=torch.float32, device=device).uniform_(-1.0, 1.0, generator=gen).sign_()
-                r16[o:o + k] = (e * sgn).round_().clamp_(-32767, 32767).to(torch.int16)
+                r16[o:o + k] = (e * sgn).round_().clamp_(-synthetic.FLAC_C4_RESIDUAL_CLAMP, synthetic.FLAC_C4_RESIDUAL_CLAMP).to(torch.int16)
                 del e, sgn
             self.res = r16.view(torch.int32)
         else:
@@ -472,7 +476,7 @@ class FlacPart(Part):
                 k = min(chunk, total - o)
                 e = torch.empty(k, dtype=torch.float32, device=device).exponential_(1.0 / 32.0, generator=gen)
                 sgn = torch.empty(k, dtype=torch.float32, device=device).uniform_(-1.0, 1.0, generator=gen).sign_()
-                self.res[o:o + k] = (e * sgn).round_().to(torch.int32)
+                self.res[o:o + k] = (e * sgn).round_().clamp_(-synthetic.FLAC_C4_RESIDUAL_CLAMP, synthetic.FLAC_C4_RESIDUAL_CLAMP).to(torch.int32)
                 del e, sgn
         self.d_frames = torch.from_numpy(self.frames_np.view(np.uint8).copy()).to(device)
         self.d_sub = torch.from_numpy(self.sub_np.view(np.uint8).copy()).to(device)
@@ -503,7 +507,11 @@ class FlacPart(Part):
         want = checker.flac_transform(self.frames_np[:nchk], self.sub_np[:2 * nchk], self.res[:words].cpu().numpy(), cnt)
         got = self.out[:cnt].cpu().numpy()
         bad = int((got != want).sum())
-        return {"samples": int(cnt), "mismatches": bad, "rms_error": 0.0 if bad == 0 else None, "max_abs_error": 0.0 if bad == 0 else None}
+        # a stable AR process -- every sample (left-justified 16-bit PCM) inside 17 bits, as in a real file
+        peak = int(np.abs(want.astype(np.int64) >> (32 - int(self.frames_np["bps"][0]))).max(initial=0))
+        assert peak < (1 << 16), f"C4 generator: decoded sample magnitude {peak} is outside 17 bits"
+        return {"samples": int(cnt), "mismatches": bad, "rms_error": 0.0 if bad == 0 else None, "max_abs_error": 0.0 if bad == 0 else None,
+                "peak_sample_magnitude": peak}
 
     def check_file(self, checker, f):
         fr0 = int(self.frames_per_file[:f].sum())

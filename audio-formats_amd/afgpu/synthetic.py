@@ -172,6 +172,41 @@ def _quantised_lpc(rng, order, precision=12):
     return q.astype(np.int16), shift
 
 
+FLAC_C4_RESIDUAL_CLAMP = 1023      # C4 / C5 residuals: Laplacian of scale 2^5 (Rice k ~ 5), clamped here
+FLAC_C4_L1_MAX = 24.0              # bound on sum |h| of a C4 predictor's synthesis filter 1 / A(z)
+
+
+def stable_quantised_lpc(rng, order, precision=12, l1_max=FLAC_C4_L1_MAX):
+    """A quantised AR(order) predictor as SURVEY 8d specifies it for C4: STABLE after quantisation, with a bounded gain --
+    the impulse response h of the synthesis filter 1 / A_q(z) satisfies sum |h| <= l1_max, so residuals of magnitude
+    <= R decode to samples of magnitude <= l1_max * R (+ the floor-shift rounding, < l1_max): with R = 1023 every sample
+    stays inside 16 bits per subframe, 17 after mid / side decorrelation.  (Round 1-3's pool put pole pairs at up to
+    0.97: a quarter of its filters were unstable once quantised and their samples wrapped around int32.)"""
+    for _ in range(1000):
+        npairs = order // 2
+        poles = []
+        for _ in range(npairs):
+            r = rng.uniform(0.3, 0.9)
+            th = rng.uniform(0.05, np.pi * 0.9)
+            poles += [r * np.exp(1j * th), r * np.exp(-1j * th)]
+        if order % 2:
+            poles.append(rng.uniform(-0.8, 0.8))
+        lpc = -np.real(np.poly(poles))[1:]
+        cmax = np.abs(lpc).max()
+        shift = int(np.clip(precision - 1 - int(np.floor(np.log2(cmax))) - 1, 0, 15))
+        q = np.clip(np.round(lpc * (1 << shift)), -(1 << (precision - 1)), (1 << (precision - 1)) - 1).astype(np.int64)
+        # impulse response of s[t] = d[t] + sum_k (q[k] / 2^shift) s[t-1-k]
+        h = np.zeros(2048)
+        h[0] = 1.0
+        a = q / float(1 << shift)
+        for t in range(1, len(h)):
+            k = min(t, order)
+            h[t] = np.dot(a[:k], h[t - 1::-1][:k])
+        if np.abs(h).sum() <= l1_max and np.abs(h[-256:]).max() < 1e-6:
+            return q.astype(np.int16), shift
+    raise RuntimeError("no stable predictor found")
+
+
 def flac_batch(seed, n_frames, block_size=4096, channels=2, bps=16, orders=(8, 12),
                assignments=(FLAC_MID_SIDE, FLAC_LEFT_SIDE, FLAC_RIGHT_SIDE, FLAC_INDEPENDENT),
                assignment_p=(0.55, 0.2, 0.1, 0.15), residual_scale=32.0, wasted_p=0.05,

@@ -18,9 +18,6 @@
 #include "celt_core.h"
 #include "celt_tables.h"
 
-#ifndef AFG_CELT_ABL
-#define AFG_CELT_ABL 0      // development ablations (tools/build_variant.sh): 2 no post-filter, 5 no steady-state comb filter, 6 no iMDCT, 7 no radix/post-rotation
-#endif
 
 #include <algorithm>
 #include <cmath>
@@ -337,20 +334,14 @@ __global__ __launch_bounds__(64) void celt_postfilter_kernel(
         __builtin_amdgcn_wave_barrier();
 
         // celt_postfilter, dopus.d:3357-3378
-#if AFG_CELT_ABL != 2
         pf_transition(ring, win2, n0, pf, l, lane_on);
-#endif
         pf.period_old = pf.period;
         pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
         pf.period = fr.pf_period_new;
         pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
         if (F > 120) {
-#if AFG_CELT_ABL != 2
             pf_transition(ring, win2, n0 + 120, pf, l, lane_on);
-#if AFG_CELT_ABL != 5
             pf_apply(ring, n0 + 240, F - 240, pf, l, lane_on);
-#endif
-#endif
             pf.period_old = pf.period;
             pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
         }
@@ -474,21 +465,15 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
             const int F = g.F;
             afg_celt_frame fr_next2 = recs[my_base + (q + 2 < cnt ? q + 2 : cnt - 1)];
             // iMDCT and overlap-add, dopus.d:3684-3690
-#if AFG_CELT_ABL != 6 && AFG_CELT_ABL != 9
             if (is_960(g)) frame_fft(z, xa, xb, fr, geo_960(), ltab, lwin, tb, l, act);
             else frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
-#endif
-#if AFG_CELT_ABL != 8 && AFG_CELT_ABL != 9
             {                                                // (the last frame's again at the end)
                 const Geo gn = geo_of(fr_next);
                 if (is_960(gn)) load_inputs(xa, xb, coeffs, fr_next, geo_960(), l);
                 else load_inputs(xa, xb, coeffs, fr_next, gn, l);
             }
-#endif
-#if AFG_CELT_ABL != 6 && AFG_CELT_ABL != 7 && AFG_CELT_ABL != 9
             if (is_960(g)) frame_rest(z, fr, geo_960(), ltab, lwin, tb, l, act);
             else frame_rest(z, fr, g, ltab, lwin, tb, l, act);
-#endif
             if (act) {                                       // vector_fmul_window of block 0
                 float *d = buf + 1024;
                 float a[2], b[2];
@@ -510,18 +495,14 @@ __global__ __launch_bounds__(64 * kSWaves) void celt_stream_kernel(
             __builtin_amdgcn_wave_barrier();
 
             // celt_postfilter, dopus.d:3357-3378
-#if AFG_CELT_ABL != 2
             pf_transition(buf, win2, 1024, pf, l, act);
-#endif
             pf.period_old = pf.period;
             pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             pf.period = fr.pf_period_new;
             pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
             if (F > 120) {
-#if AFG_CELT_ABL != 2
                 pf_transition(buf, win2, 1024 + 120, pf, l, act);
                 pf_apply(buf, 1024 + 240, F - 240, pf, l, act);
-#endif
                 pf.period_old = pf.period;
                 pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             }

@@ -32,10 +32,6 @@
 #include <mutex>
 #include <type_traits>
 
-#ifndef AFG_WALK_ABL
-#define AFG_WALK_ABL 0      // development ablations (tools/build_variant1.sh; timing only, results are wrong): 1 no de-emphasis scan,
-#endif                      // 2 no post-filter, 3 no memmove, 4 no radix / post-rotation, 5 no fft15, 6 no stores, 7 no input loads
-
 #ifndef AFG_WALK_FFT_SIGN
 #define AFG_WALK_FFT_SIGN 1
 #endif
@@ -446,14 +442,11 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             const Geo g = K960 ? geo_960() : geo_of(fr);
             const int F = K960 ? 960 : g.F;
             // iMDCT and overlap-add, dopus.d:3684-3690
-#if AFG_WALK_ABL != 5
 #if AFG_WALK_PFA
             frame_fft_pfa(z, xa, xb, g, ltab, l, act);
 #else
             frame_fft(z, xa, xb, fr, g, ltab, lwin, tb, l, act);
 #endif
-#endif
-#if AFG_WALK_ABL != 7
             {                                                // (the last frame's again at the end)
                 const Geo gn = geo_of(fr_next);
                 if (is_960(gn)) {
@@ -463,10 +456,7 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                     load_inputs(xa, xb, coeffs, fr_next, gn, l);
                 }
             }
-#endif
-#if AFG_WALK_ABL != 4
             frame_rest(z, fr, g, ltab, lwin, tb, l, act);
-#endif
             if (act) {                                       // vector_fmul_window of block 0
                 float *d = buf + 1024;
                 float va[2], vb[2];
@@ -488,18 +478,14 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             __builtin_amdgcn_wave_barrier();
 
             // celt_postfilter, dopus.d:3357-3378 (a no-op on warm-up frames: their filters are dead by construction)
-#if AFG_WALK_ABL != 2
             wpf_transition(buf + 1024, win2, 0, pf, l, act);
-#endif
             pf.period_old = pf.period;
             pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             pf.period = fr.pf_period_new;
             pf.g[0] = fr.pf_gains_new[0]; pf.g[1] = fr.pf_gains_new[1]; pf.g[2] = fr.pf_gains_new[2];
             if (F > 120) {
-#if AFG_WALK_ABL != 2
                 wpf_transition(buf + 1024, win2, 120, pf, l, act);
                 wpf_apply(buf + 1024, 240, F - 240, pf, l, act);
-#endif
                 pf.period_old = pf.period;
                 pf.g_old[0] = pf.g[0]; pf.g_old[1] = pf.g[1]; pf.g_old[2] = pf.g[2];
             }
@@ -518,7 +504,6 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             {
                 float m0 = lane_value(m, 0), m1 = lane_value(m, 32);
                 float xs[15];
-#if AFG_WALK_ABL != 1
                 const int at = K960 ? 15 * lane : 15 * min(lane, n_act - 1);      // (idle lanes re-read the last run)
                 const bool in = K960 || lane < n_act;
 #pragma unroll
@@ -537,14 +522,15 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                         for (int k = 0; k < 15; k++) bufs[2048 + at + k] = xs[k];
                     }
                 }
-#endif
                 m = (both && h) ? m1 : m0;
             }
             __builtin_amdgcn_wave_barrier();
-            const int so = AFG_WALK_ABL == 1 ? 1024 : 0;
+            constexpr int so = 0;
             if (both) {
                 f32x2 *o = (f32x2 *)(out + __shfl(fr.out_off, 0));
-                if (K960) {
+                // (celt_pair_ok guarantees an even out_off, i.e. 8-byte alignment; a pair whose frames start 2 mod 4 floats
+                // into the plane -- an odd number of stereo frames in front of it -- takes the 8-byte stores below)
+                if (K960 && ((uintptr_t)o & 15) == 0) {
 #if AFG_WALK_ST16
                     // 16-byte stores: a lane takes two consecutive samples of both channels (8 x 1 KB rows per frame)
                     f32x4 v[8];
@@ -554,7 +540,7 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                         const f32x2 a = *(const f32x2 *)(b0 + so + 2 * j), b = *(const f32x2 *)(b1 + so + 2 * j);
                         v[i] = f32x4{ a.x, b.x, a.y, b.y };
                     }
-                    if (storing && AFG_WALK_ABL != 6) {
+                    if (storing) {
 #pragma unroll
                         for (int i = 0; i < 8; i++)
                             if (i < 7 || lane < 32) __builtin_nontemporal_store(v[i], (f32x4 *)(o + 2 * (lane + 64 * i)));
@@ -563,7 +549,7 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                     f32x2 v[15];
 #pragma unroll
                     for (int i = 0; i < 15; i++) v[i] = f32x2{ b0[so + lane + 64 * i], b1[so + lane + 64 * i] };
-                    if (storing && AFG_WALK_ABL != 6) {
+                    if (storing) {
 #pragma unroll
                         for (int i = 0; i < 15; i++) o[lane + 64 * i] = v[i];
                     }
@@ -578,7 +564,6 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             }
             __builtin_amdgcn_wave_barrier();
             // memmove(buf, buf + F, 1084 floats) (:3370): every read is issued before the first write
-#if AFG_WALK_ABL != 3
             {
                 f32x4 mv[9];
 #pragma unroll
@@ -590,7 +575,6 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                     if (act && l + 32 * u < 271) *(f32x4 *)(buf + 4 * (l + 32 * u)) = mv[u];
                 __builtin_amdgcn_wave_barrier();
             }
-#endif
         };
 
         for (uint64_t q = a; q < end; q++) {
@@ -711,23 +695,30 @@ int afg::celt_walk_launch(uint32_t n_chan, const uint64_t *d_rec_base, const afg
     uint32_t tab_floats = 0;
     if (int rc = afg::celt_tables_for_device(&d_tables, &tb, &tab_floats)) return rc;
     int dev = 0;
-    AFG_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= AFG_MAX_DEVICES) {
-        afg::set_error("afg_celt_transform_hip: device index %d is outside this library's table of %d devices", dev, AFG_MAX_DEVICES);
-        return AFG_ERR_INVALID;
-    }
+    if (int rc = afg::device_slot(&dev, "afg_celt_transform_hip")) return rc;
     uint32_t *counter = nullptr;
     int cus = 0;
     {
-        // work counters of the persistent kernel: launch k uses (and first clears, on its stream) counter k % 64, so
-        // launches in flight on different streams never share one
+        // work counters of the persistent kernel: launch k uses (and first clears, on its stream) counter k % 64, so up to
+        // 64 launches in flight on different streams never share one (a 65th would: the ring is the documented limit)
         std::lock_guard<std::mutex> lk(g_mu);
         if (!g_counters[dev]) {
-            AFG_HIP_CHECK(hipMalloc(&g_counters[dev], 64 * sizeof(uint32_t)));
-            AFG_HIP_CHECK(hipDeviceGetAttribute(&g_cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+            // published only when every step succeeded: a half-initialised slot would fail every later launch
+            uint32_t *ring = nullptr;
+            int n_cus = 0;
             static_assert(kWLdsFloats * sizeof(float) <= 160 * 1024, "LDS budget");
-            AFG_HIP_CHECK(hipFuncSetAttribute((const void *)celt_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)(kWLdsFloats * sizeof(float))));
+            hipError_t e = hipMalloc(&ring, 64 * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void *)celt_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(kWLdsFloats * sizeof(float)));
+            if (e != hipSuccess) {
+                if (ring) (void)hipFree(ring);
+                afg::set_error("afg_celt_transform_hip: device set-up failed: %s", hipGetErrorString(e));
+                return AFG_ERR_HIP;
+            }
+            g_cus[dev] = n_cus;
+            g_counters[dev] = ring;
         }
         counter = g_counters[dev] + (g_launches[dev]++ & 63u);
         cus = g_cus[dev] > 0 ? g_cus[dev] : 256;

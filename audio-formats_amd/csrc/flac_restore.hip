@@ -6,21 +6,17 @@
 // drflac_read_s32 (drflac.d:2885-2941), optionally followed by the int32 -> float
 // conversion of stream.d:505-511.  Integer results are bit-exact by construction:
 //
-//   * the LPC recurrence is serial inside a subframe (floor shift: not a scan),
-//     so the parallel axis is frames: one lane owns one frame and runs the
-//     recurrence of its channels (two at a time) with the last `order` samples
-//     and the coefficients in registers;
-//   * prediction_32 is a wrapping int32 sum: v_mul_lo_u32 + add per tap.  When a
-//     wavefront holds `use64` subframes the sum is kept in int64 instead; its low
-//     32 bits are exactly the wrapping sum, so the flag only selects which bits
+//   * the LPC recurrence is serial inside a subframe (floor shift: not a scan), so the parallel axis is subframes: a
+//     wavefront takes 32 consecutive frames and a lane ONE channel of a frame, with the last `order` samples and the
+//     coefficients in registers;
+//   * prediction_32 is a wrapping int32 sum: v_mul_lo_u32 + add per tap.  When a wavefront holds `use64` subframes the
+//     sum is kept in int64 instead; its low 32 bits are exactly the wrapping sum, so the flag only selects which bits
 //     are shifted (drflac.d:1098 vs :1139);
-//   * residual planes are subframe-major in HBM (what the Rice decoder writes),
-//     so a wavefront moves 64 frames x 2 channels x 16 samples per step through
-//     an LDS tile.  The next step's rows are already in flight (16-byte loads
-//     parked in registers) while the current step runs its recurrence; the tile
-//     is stored as 16-byte pieces rotated by row/2, which makes the
-//     one-row-per-lane 16-byte accesses of the recurrence conflict-free; outputs
-//     leave as interleaved 16-byte stores with the decorrelation done on the way.
+//   * residual planes are subframe-major in HBM (what the Rice decoder writes, as int32 or -- 16-bit material -- int16
+//     rows), so a wavefront moves 32 frames x 2 channels x 32 samples per step through an 8 KB LDS tile.  The next step's
+//     rows are already in flight (16-byte loads parked in registers) while the current step runs its recurrence; the
+//     tile is stored as 16-byte pieces rotated by the row, which makes the one-row-per-lane 16-byte accesses of the
+//     recurrence conflict-free; outputs leave as interleaved 16-byte stores with the decorrelation done on the way.
 #include "afg_common.h"
 
 #include <mutex>
@@ -29,15 +25,6 @@ namespace {
 
 #ifndef AFG_FLAC_TILE
 #define AFG_FLAC_TILE 32
-#endif
-#ifndef AFG_FLAC_STAGGER
-#define AFG_FLAC_STAGGER 0
-#endif
-#ifndef AFG_FLAC_ABL
-#define AFG_FLAC_ABL 0
-#endif
-#ifndef AFG_FLAC_MAD64
-#define AFG_FLAC_MAD64 0               // 1: one v_mad_i64_i32 per tap by inline assembly -- measured slower (14.6 vs 13.7 ms on C4), kept for A/B builds
 #endif
 constexpr int kT = AFG_FLAC_TILE;      // samples per tile step (16 or 32)
 constexpr int kRowWords = 2 * kT;      // LDS row: [channel A | channel B], 2*kT/4 pieces of 4 words
@@ -79,37 +66,14 @@ __device__ __forceinline__ int32_t shl32(int32_t v, unsigned sh) { return (int32
 // no branches, so the unrolled history shift is pure register renaming.
 // prediction of one sample from the history h (h[k] = s[t-1-k]); two independent partial sums
 // halve the dependent multiply-add chain (integer sums are associative: same bits).
-// acc += a * b in 64 bits as ONE instruction.  Written as assembly because the compiler narrows the 64-bit form back to
-// v_mul_lo_u32 + v_add_u32 wherever only the low word is consumed -- which is the 32-bit prediction -- and this kernel is
-// bound by vector issue (profiles/r03_pmc_flac*.json): a multiply costs the same 4.7 cycles in every flavour
-// (tools/ubench_imul2.hip), the separate add 2.7 more per tap.  The low word of the 64-bit sum IS the wrapping 32-bit sum.
-__device__ __forceinline__ void mad64(int64_t &acc, int32_t a, int32_t b)
-{
-    uint64_t carry;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "v"(b));
-}
-
 template <int MAXORD, bool WIDE>
 __device__ __forceinline__ int32_t predict(const int32_t (&c)[MAXORD], const int32_t (&h)[MAXORD], int shift, bool use64)
 {
-#ifdef AFG_FLAC_ABL_TAPS                                     // development ablation (timing only): AFG_FLAC_ABL_TAPS taps instead of MAXORD
-    {
-        uint32_t a = 0;
-#pragma unroll
-        for (int k = 0; k < AFG_FLAC_ABL_TAPS && k < MAXORD; k++) a += (uint32_t)c[k] * (uint32_t)h[k];
-        return (int32_t)a >> shift;
-    }
-#endif
     int64_t a0 = 0, a1 = 0;
 #pragma unroll
     for (int k = MAXORD - 1; k >= 1; k -= 2) {            // older taps first: they do not wait for the newest output
-#if AFG_FLAC_MAD64
-        mad64(a1, c[k], h[k]);
-        mad64(a0, c[k - 1], h[k - 1]);
-#else
         a1 += (int64_t)c[k] * (int64_t)h[k];
         a0 += (int64_t)c[k - 1] * (int64_t)h[k - 1];
-#endif
     }
     if (WIDE) {
         const int64_t acc = a0 + a1;
@@ -120,312 +84,11 @@ __device__ __forceinline__ int32_t predict(const int32_t (&c)[MAXORD], const int
     return (int32_t)((uint32_t)(uint64_t)a0 + (uint32_t)(uint64_t)a1) >> shift;
 }
 
-// One tile of the (up to) two channels of this lane's frame, interleaved so that the two serial
-// recurrences overlap: kT steps of
-//   s[t] = r[t] + (sum_k coef[k]*s[t-1-k]) >> shift        (drflac.d:1235)
-// for t >= order, verbatim warm-up below (drflac.d:1406-1410, :1419-1423).
-// Coefficients past `order` are zero, values past the end of the block are never stored:
-// no branches, so the unrolled history shift is pure register renaming.  An absent channel runs
-// with zero coefficients on zero residuals.
-template <int MAXORD, bool WIDE_A, bool WIDE_B>
-__device__ __forceinline__ void restore_tile2(int32_t *tile, int row, int t0,
-                                              int order0, int shift0, bool u0, const int32_t (&c0)[MAXORD], int32_t (&h0)[MAXORD],
-                                              int order1, int shift1, bool u1, const int32_t (&c1)[MAXORD], int32_t (&h1)[MAXORD])
-{
-#pragma unroll
-    for (int q = 0; q < kT / 4; q++) {
-        int4 *pa = (int4 *)(tile + piece_off(row, q));
-        int4 *pb = (int4 *)(tile + piece_off(row, kPieces + q));
-        const int4 va = *pa, vb = *pb;
-        int32_t ra[4] = { va.x, va.y, va.z, va.w }, rb[4] = { vb.x, vb.y, vb.z, vb.w };
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int t = t0 + 4 * q + e;
-            const int32_t pA = predict<MAXORD, WIDE_A>(c0, h0, shift0, u0);
-            const int32_t pB = predict<MAXORD, WIDE_B>(c1, h1, shift1, u1);
-            const int32_t sA = (t >= order0) ? (int32_t)((uint32_t)ra[e] + (uint32_t)pA) : ra[e];
-            const int32_t sB = (t >= order1) ? (int32_t)((uint32_t)rb[e] + (uint32_t)pB) : rb[e];
-            ra[e] = sA;
-            rb[e] = sB;
-#pragma unroll
-            for (int k = MAXORD - 1; k >= 1; k--) { h0[k] = h0[k - 1]; h1[k] = h1[k - 1]; }
-            h0[0] = sA;
-            h1[0] = sB;
-        }
-        *pa = make_int4(ra[0], ra[1], ra[2], ra[3]);
-        *pb = make_int4(rb[0], rb[1], rb[2], rb[3]);
-    }
-}
-
-// Residual rows come as int32 or, for frames whose values all fit 16 bits, as int16 (afg_flac_frame.res16).  A
-// wavefront's 64 frames are nearly always of one kind, so the walk is instantiated three times: MODE 0 all int32 (round 1's
-// code), MODE 1 all int16 (half the bytes, half the load instructions), MODE 2 a mix (file boundaries inside a wavefront).
-//
-// Issue the 16-byte loads of one tile step.  int32: instruction i covers row-chunks 16i .. 16i+15, row-chunk rc = (row rc>>1,
-// channel slot rc&1), lane&3 (kT = 16) or lane&7 = 16-byte piece of the chunk.
-template <int MODE>
-__device__ __forceinline__ void load_tile(int4 (&nxt)[kLoads], const RowMeta *meta, const int32_t *__restrict__ res,
-                                          int pair, int t0)
-{
-    const int lane = threadIdx.x;
-    if (MODE == 1) {
-        // int16 rows (AFG_FLAC_ROW16: padded to 16 bytes, so a piece of 8 samples is always there): kLoads / 2 instructions,
-        // lane % (kPieces / 2) = piece of 8 samples; widened by park_tile once the load has landed
-        constexpr int P16 = kPieces / 2;
-#pragma unroll
-        for (int i = 0; i < kLoads / 2; i++) {
-            const int rc = (64 / P16) * i + lane / P16;
-            const int row = rc >> 1, slot = rc & 1, p = lane % P16;
-            const RowMeta m = meta[row];
-            const int C = (int)(m.info & 0xff);
-            const int cidx = 2 * pair + slot;
-            const int t = t0 + 8 * p;
-            int4 v = make_int4(0, 0, 0, 0);
-            if (cidx < C && t < (int)m.bs)
-                v = *(const int4 *)((const int16_t *)res + m.in_off + (uint64_t)cidx * (((uint64_t)m.bs + 7u) & ~(uint64_t)7u) + (uint64_t)t);
-            nxt[i] = v;
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < kLoads; i++) {
-        const int rc = (64 / kPieces) * i + lane / kPieces;
-        const int row = rc >> 1, slot = rc & 1, p = lane % kPieces;
-        const RowMeta m = meta[row];
-        const int C = (int)(m.info & 0xff);
-        const int cidx = 2 * pair + slot;
-        const int t = t0 + 4 * p;
-        int4 v = make_int4(0, 0, 0, 0);
-        if (MODE == 2 && cidx < C && t < (int)m.bs && (m.info >> 24)) {
-            // an int16 row in a mixed wavefront: the lane's four samples are 8 bytes, parked raw in .x / .y
-            const int16_t *src = (const int16_t *)res + m.in_off + (uint64_t)cidx * (((uint64_t)m.bs + 7u) & ~(uint64_t)7u) + (uint64_t)t;
-            const int2 w = *(const int2 *)src;
-            v.x = w.x;
-            v.y = w.y;
-        } else if (cidx < C && t < (int)m.bs) {
-            const int32_t *src = res + m.in_off + (uint64_t)cidx * m.bs + (uint64_t)t;
-            if (t + 3 < (int)m.bs) {
-                v = *(const int4 *)src;                              // may be 4-byte aligned only (odd block sizes)
-            } else {
-                v.x = src[0];
-                if (t + 1 < (int)m.bs) v.y = src[1];
-                if (t + 2 < (int)m.bs) v.z = src[2];
-            }
-        }
-        nxt[i] = v;
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ void park_tile(int32_t *tile, const RowMeta *meta, const int4 (&nxt)[kLoads])
-{
-    const int lane = threadIdx.x;
-    if (MODE == 1) {
-        constexpr int P16 = kPieces / 2;
-#pragma unroll
-        for (int i = 0; i < kLoads / 2; i++) {
-            const int rc = (64 / P16) * i + lane / P16;
-            const int piece = (rc & 1) * kPieces + 2 * (lane % P16);
-            const int4 v = nxt[i];
-            *(int4 *)(tile + piece_off(rc >> 1, piece)) = make_int4((int)(int16_t)v.x, v.x >> 16, (int)(int16_t)v.y, v.y >> 16);
-            *(int4 *)(tile + piece_off(rc >> 1, piece + 1)) = make_int4((int)(int16_t)v.z, v.z >> 16, (int)(int16_t)v.w, v.w >> 16);
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < kLoads; i++) {
-        const int rc = (64 / kPieces) * i + lane / kPieces;
-        int4 v = nxt[i];
-        if (MODE == 2 && (meta[rc >> 1].info >> 24))                 // int16 row: four samples in two dwords
-            v = make_int4((int)(int16_t)v.x, v.x >> 16, (int)(int16_t)v.y, v.y >> 16);
-        *(int4 *)(tile + piece_off(rc >> 1, (rc & 1) * kPieces + lane % kPieces)) = v;
-    }
-}
-
-// decorrelate (drflac.d:2885-2941), shift, interleave, convert; 8 rows per instruction
-__device__ __forceinline__ void store_tile(const int32_t *tile, const RowMeta *meta, const uint32_t *row_shift,
-                                           int32_t *__restrict__ out_i32, float *__restrict__ out_f32,
-                                           int pair, int t0)
-{
-    const int lane = threadIdx.x;
-#pragma unroll 2
-    for (int i = 0; i < kT / 2; i++) {
-        const int row = (128 / kT) * i + lane / (kT / 2);
-        const int q = lane % (kT / 2);                               // samples 2q, 2q+1 of the tile
-        const RowMeta m = meta[row];
-        const int C = (int)(m.info & 0xff);
-        const int asg = (int)((m.info >> 8) & 0xff);
-        const int t = t0 + 2 * q;
-        if (2 * pair >= C || t >= (int)m.bs) continue;
-        const int2 a = *(const int2 *)(tile + piece_off(row, q >> 1) + 2 * (q & 1));
-        const int2 b = *(const int2 *)(tile + piece_off(row, kPieces + (q >> 1)) + 2 * (q & 1));
-        const bool two = (C - 2 * pair) >= 2;
-        int32_t l0, r0, l1, r1;
-        if (asg == AFG_FLAC_LEFT_SIDE) {                             // :2886-2897
-            l0 = a.x; r0 = (int32_t)((uint32_t)a.x - (uint32_t)b.x);
-            l1 = a.y; r1 = (int32_t)((uint32_t)a.y - (uint32_t)b.y);
-        } else if (asg == AFG_FLAC_RIGHT_SIDE) {                     // :2899-2909
-            l0 = (int32_t)((uint32_t)b.x + (uint32_t)a.x); r0 = b.x;
-            l1 = (int32_t)((uint32_t)b.y + (uint32_t)a.y); r1 = b.y;
-        } else if (asg == AFG_FLAC_MID_SIDE) {                       // :2911-2920
-            const int32_t m0 = (int32_t)(((uint32_t)a.x << 1) | (uint32_t)(b.x & 1));
-            const int32_t m1 = (int32_t)(((uint32_t)a.y << 1) | (uint32_t)(b.y & 1));
-            l0 = (int32_t)((uint32_t)m0 + (uint32_t)b.x) >> 1; r0 = (int32_t)((uint32_t)m0 - (uint32_t)b.x) >> 1;
-            l1 = (int32_t)((uint32_t)m1 + (uint32_t)b.y) >> 1; r1 = (int32_t)((uint32_t)m1 - (uint32_t)b.y) >> 1;
-        } else {                                                     // :2922-2940
-            l0 = a.x; r0 = b.x; l1 = a.y; r1 = b.y;
-        }
-        const unsigned shA = row_shift[row * 8 + 2 * pair];
-        const unsigned shB = row_shift[row * 8 + ((2 * pair + 1) & 7)];
-        l0 = shl32(l0, shA); l1 = shl32(l1, shA);
-        r0 = shl32(r0, shB); r1 = shl32(r1, shB);
-        const bool second = (t + 1 < (int)m.bs);
-        const double factor = 1.0 / 2147483647.0;                    // stream.d:507
-        if (C == 2 && second) {
-            const uint64_t o = m.out_off + (uint64_t)t * 2;
-            if (out_i32) *(int4 *)(out_i32 + o) = make_int4(l0, r0, l1, r1);
-            if (out_f32)
-                *(float4 *)(out_f32 + o) = make_float4((float)((double)l0 * factor), (float)((double)r0 * factor),
-                                                       (float)((double)l1 * factor), (float)((double)r1 * factor));
-        } else {
-            const int32_t vals[4] = { l0, r0, l1, r1 };
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int smp = e >> 1, slot = e & 1;
-                if ((slot && !two) || (smp && !second)) continue;
-                const uint64_t o = m.out_off + (uint64_t)(t + smp) * C + (2 * pair + slot);
-                if (out_i32) out_i32[o] = vals[e];
-                if (out_f32) out_f32[o] = (float)((double)vals[e] * factor);
-            }
-        }
-    }
-}
-
-template <int MAXORD, bool WIDE_A, bool WIDE_B, int MODE>
-__device__ __forceinline__ void run_frames(int32_t *tile, const RowMeta *meta, const RowMeta &me, bool valid,
-                                           const afg_flac_subframe *__restrict__ subframes, uint32_t sf_index,
-                                           const int32_t *__restrict__ res, int32_t *__restrict__ out_i32,
-                                           float *__restrict__ out_f32, int max_bs, int max_pairs,
-                                           const uint32_t *row_shift /* LDS [64][8] */)
-{
-    const int lane = threadIdx.x;
-    const int my_ch = valid ? (int)(me.info & 0xff) : 0;
-
-    for (int pair = 0; pair < max_pairs; pair++) {
-        // this lane's two subframes of the pair
-        int32_t c0[MAXORD], c1[MAXORD];
-        int32_t h0[MAXORD], h1[MAXORD];
-        int order0 = 0, order1 = 0, shift0 = 0, shift1 = 0;
-        bool u0 = false, u1 = false;
-        const int chA = 2 * pair, chB = 2 * pair + 1;
-#pragma unroll
-        for (int k = 0; k < MAXORD; k++) { c0[k] = c1[k] = 0; h0[k] = h1[k] = 0; }
-        if (chA < my_ch) {
-            const afg_flac_subframe *sf = subframes + sf_index + chA;
-            order0 = sf->order; shift0 = sf->shift; u0 = sf->use64 != 0;
-#pragma unroll
-            for (int k = 0; k < MAXORD; k++) c0[k] = (k < order0) ? (int32_t)sf->coef[k] : 0;
-        }
-        if (chB < my_ch) {
-            const afg_flac_subframe *sf = subframes + sf_index + chB;
-            order1 = sf->order; shift1 = sf->shift; u1 = sf->use64 != 0;
-#pragma unroll
-            for (int k = 0; k < MAXORD; k++) c1[k] = (k < order1) ? (int32_t)sf->coef[k] : 0;
-        }
-
-        int4 nxt[kLoads];
-        load_tile<MODE>(nxt, meta, res, pair, 0);
-        park_tile<MODE>(tile, meta, nxt);
-        __syncthreads();
-        for (int t0 = 0; t0 < max_bs; t0 += kT) {
-            if (t0 + kT < max_bs) load_tile<MODE>(nxt, meta, res, pair, t0 + kT);   // in flight during the recurrence
-
-            if (t0 < (int)me.bs) {
-                restore_tile2<MAXORD, WIDE_A, WIDE_B>(tile, lane, t0, order0, shift0, u0, c0, h0,
-                                                      order1, shift1, u1, c1, h1);
-            }
-            __syncthreads();
-            // Make the prefetched residuals resident *here*: loads and stores share one in-order counter on this
-            // hardware, so the wait park_tile would need after the stores below would also wait for them to drain.
-#pragma unroll
-            for (int i = 0; i < (MODE == 1 ? kLoads / 2 : kLoads); i++)
-                asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y), "+v"(nxt[i].z), "+v"(nxt[i].w) : : "memory");
-            store_tile(tile, meta, row_shift, out_i32, out_f32, pair, t0);
-            __syncthreads();
-            if (t0 + kT < max_bs) park_tile<MODE>(tile, meta, nxt);
-            __syncthreads();
-        }
-    }
-}
-
-// One kernel per (order bucket, accumulator width of the even / odd channel slot): a wavefront only runs in the instantiation
-// that matches the largest LPC order / widest accumulator among its 64 frames and leaves the
-// others at once, so every instantiation gets its own (small) register allocation.
-template <int LO, int MAXORD, bool WIDE_A, bool WIDE_B>
-__global__ __launch_bounds__(64) void flac_restore_kernel(
-    const afg_flac_frame *__restrict__ frames, const afg_flac_subframe *__restrict__ subframes,
-    const int32_t *__restrict__ res, int32_t *__restrict__ out_i32, float *__restrict__ out_f32,
-    uint64_t n_frames)
-{
-    __shared__ __attribute__((aligned(16))) int32_t tile[64 * kRowWords];
-    __shared__ RowMeta meta[64];
-    __shared__ uint32_t row_shift[64 * 8];
-
-    const int lane = threadIdx.x;
-    const uint64_t f = (uint64_t)blockIdx.x * 64 + lane;
-    const bool valid = f < n_frames;
-
-    RowMeta me;
-    me.in_off = 0; me.out_off = 0; me.bs = 0; me.info = 0;
-    uint32_t sf_index = 0;
-    int my_order = 0, my_wide_a = 0, my_wide_b = 0;    // even / odd channel slots
-    afg_flac_frame fr;
-    if (valid) {
-        fr = frames[f];
-        sf_index = fr.sf_index;
-        for (int c = 0; c < (int)fr.channels && c < 8; c++) {
-            const afg_flac_subframe *sf = subframes + sf_index + c;
-            my_order = sf->order > my_order ? sf->order : my_order;
-            if (c & 1) my_wide_b |= sf->use64; else my_wide_a |= sf->use64;
-        }
-    }
-    const int max_order = wave_max(my_order);
-    const bool wide_a = wave_max(my_wide_a) != 0, wide_b = wave_max(my_wide_b) != 0;
-    if (!(max_order > LO && max_order <= MAXORD && wide_a == WIDE_A && wide_b == WIDE_B)) return;
-
-    if (valid) {
-        me.in_off = fr.in_off;
-        me.out_off = fr.out_off;
-        me.bs = fr.block_size;
-        me.info = (uint32_t)fr.channels | ((uint32_t)fr.assignment << 8) | ((uint32_t)fr.bps << 16) | ((uint32_t)(fr.res16 != 0) << 24);
-        for (int c = 0; c < 8; c++) {
-            uint32_t sh = 0;
-            if (c < (int)fr.channels) sh = (32u - fr.bps) + subframes[sf_index + c].wasted;   // drflac.d:2883, :2894
-            row_shift[lane * 8 + c] = sh;
-        }
-    } else {
-        for (int c = 0; c < 8; c++) row_shift[lane * 8 + c] = 0;
-    }
-    meta[lane] = me;
-    __syncthreads();
-
-    const int max_bs = wave_max((int)me.bs);
-    const int max_pairs = wave_max(((int)(me.info & 0xff) + 1) >> 1);
-    const bool any16 = __any(valid && (me.info >> 24) != 0), any32 = __any(valid && (me.info >> 24) == 0);
-    if (!any16)
-        run_frames<MAXORD, WIDE_A, WIDE_B, 0>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
-    else if (!any32)
-        run_frames<MAXORD, WIDE_A, WIDE_B, 1>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
-    else
-        run_frames<MAXORD, WIDE_A, WIDE_B, 2>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
-// Lane = subframe (round 3).  The walk above gives a lane a frame and interleaves its two channels' recurrences: 48
+// Lane = subframe (round 3).  Round 2 gave a lane a whole frame and interleaved its two channels' recurrences: 48
 // coefficient / history registers and a 16 KB tile per wavefront -- two wavefronts per SIMD, each parked at a memory
-// wait a third of the time (profiles/r02_pmc_flac_restore_kernel.json).  Here a wavefront takes 32 frames and a lane
-// ONE channel of a frame (lane = 2 * frame row + channel slot): half the registers, an 8 KB tile, so four wavefronts per
+// wait a third of the time (profiles/r02_pmc_flac_restore_kernel.json; that walk is in the history of this file).  Here a
+// wavefront takes 32 frames and a lane ONE channel of a frame (lane = 2 * frame row + channel slot): half the registers, an 8 KB tile, so four wavefronts per
 // SIMD share the same rows-per-step memory pattern (64-byte residual pieces in, 256-byte interleaved pieces out) with
 // twice the bytes in flight.  The tile keeps its layout -- row = frame, [slot A | slot B], 16-byte pieces rotated by the
 // row -- which is conflict-free for this lane mapping as well (a 16-lane LDS group holds 8 rows x 2 slots).
@@ -575,11 +238,7 @@ __device__ __forceinline__ void store_tile1(const int32_t *tile, const RowMeta *
         const bool second = (t + 1 < (int)m.bs);
         const double factor = 1.0 / 2147483647.0;                    // stream.d:507
         if (C == 2 && second) {
-#if AFG_FLAC_ABL == 5
-            const uint64_t o = (m.out_off + (uint64_t)t * 2) & 0x3ffffu;
-#else
             const uint64_t o = m.out_off + (uint64_t)t * 2;
-#endif
             if (out_i32) *(int4 *)(out_i32 + o) = make_int4(l0, r0, l1, r1);
             if (out_f32)
                 *(float4 *)(out_f32 + o) = make_float4((float)((double)l0 * factor), (float)((double)r0 * factor),
@@ -624,22 +283,14 @@ __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, 
         park_tile1<MODE>(tile, meta, nxt);
         __syncthreads();
         for (int t0 = 0; t0 < max_bs; t0 += kT) {
-#if AFG_FLAC_ABL != 2                                                               // (development ablations, timing only: 1 no stores,
             if (t0 + kT < max_bs) load_tile1<MODE>(nxt, meta, res, pair, t0 + kT);   //  2 no row loads, 3 no recurrence, 4 no store phase at all)
-#endif
-#if AFG_FLAC_ABL != 3
             if (t0 < (int)me.bs) restore_tile1<MAXORD, WIDE>(tile, row, slot, t0, order, shift, u64, c, h);
-#endif
             __syncthreads();
             // make the prefetched residuals resident here: loads and stores share one in-order counter
 #pragma unroll
             for (int i = 0; i < Loads1<MODE>::n; i++)
                 asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y), "+v"(nxt[i].z), "+v"(nxt[i].w) : : "memory");
-#if AFG_FLAC_ABL == 1
-            store_tile1(tile, meta, row_shift, (int32_t *)nullptr, (float *)nullptr, pair, t0);
-#elif AFG_FLAC_ABL != 4
             store_tile1(tile, meta, row_shift, out_i32, out_f32, pair, t0);
-#endif
             __syncthreads();
             if (t0 + kT < max_bs) park_tile1<MODE>(tile, meta, nxt);
             __syncthreads();
@@ -703,11 +354,6 @@ __global__ __launch_bounds__(64, (MAXORD <= 12 ? AFG_FLAC_WAVES : 2)) void flac_
     const int max_bs = wave_max((int)me.bs);
     const int max_pairs = wave_max(((int)(me.info & 0xff) + 1) >> 1);
     const bool any16 = __any(valid && (me.info >> 24) != 0), any32 = __any(valid && (me.info >> 24) == 0);
-#if AFG_FLAC_STAGGER
-    // wavefronts of a CU start together and run the same program: a start offset of a fraction of a tile step keeps their
-    // store phases from falling into one another's
-    for (int k = 0; k < (int)(blockIdx.x % AFG_FLAC_STAGGER); k++) __builtin_amdgcn_s_sleep(127);
-#endif
     if (!any16)
         run_frames1<MAXORD, WIDE, 0>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
     else if (!any32)
@@ -729,14 +375,6 @@ struct SideLane {
 std::mutex g_side_mu;
 SideLane g_side[AFG_MAX_DEVICES];
 
-// AFG_FLAC_LANE=frame selects round 2's walk (a lane owns a frame, 64 frames per wavefront) for A/B runs; the default is the
-// lane-per-subframe walk (32 frames per wavefront).  afg_flac_variants and the launch agree on the choice.
-bool lane_per_subframe()
-{
-    const char *e = getenv("AFG_FLAC_LANE");
-    return !(e && !strcmp(e, "frame"));
-}
-
 int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg_flac_subframe *d_subframes, const int32_t *d_res,
                     int32_t *d_out_i32, float *d_out_f32, uint32_t variants, hipStream_t stream)
 {
@@ -746,13 +384,12 @@ int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg
         return AFG_ERR_INVALID;
     }
     if (int rc = afg::require_device()) return rc;
-    const uint64_t groups = (n_frames + 63) / 64;
-    if (groups > 0x3fffffffull) {
+    const uint64_t groups1 = (n_frames + kFpw - 1) / kFpw;
+    if (groups1 > 0x7fffffffull) {
         afg::set_error("afg_flac_transform_hip: too many frames in one call");
         return AFG_ERR_INVALID;
     }
-    const uint32_t all = lane_per_subframe() ? 0xffu : 0xffffu;
-    if (variants == 0xffffu) variants = all;                         // "every instantiation"
+    const uint32_t all = 0xffu;                                      // eight instantiations: (order bucket, accumulator width)
     variants &= all;
     if (!variants) return AFG_OK;
     // a known set of two or more: alternate between the caller's stream and the device's side stream
@@ -775,8 +412,6 @@ int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg
         }
     }
     int idx = 0, used = 0;
-    if (lane_per_subframe()) {
-        const uint64_t groups1 = (n_frames + kFpw - 1) / kFpw;
 #define AFG_FLAC_LAUNCH2(LO, HI, W)                                                                                    \
     if (variants & (1u << idx)) {                                                                                      \
         hipLaunchKernelGGL((flac_restore1_kernel<LO, HI, W>), dim3((uint32_t)groups1), dim3(64), 0,                    \
@@ -785,32 +420,11 @@ int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg
         used++;                                                                                                        \
     }                                                                                                                  \
     idx++
-        AFG_FLAC_LAUNCH2(-1, 4, false);  AFG_FLAC_LAUNCH2(-1, 4, true);
-        AFG_FLAC_LAUNCH2(4, 8, false);   AFG_FLAC_LAUNCH2(4, 8, true);
-        AFG_FLAC_LAUNCH2(8, 12, false);  AFG_FLAC_LAUNCH2(8, 12, true);
-        AFG_FLAC_LAUNCH2(12, 32, false); AFG_FLAC_LAUNCH2(12, 32, true);
+    AFG_FLAC_LAUNCH2(-1, 4, false);  AFG_FLAC_LAUNCH2(-1, 4, true);
+    AFG_FLAC_LAUNCH2(4, 8, false);   AFG_FLAC_LAUNCH2(4, 8, true);
+    AFG_FLAC_LAUNCH2(8, 12, false);  AFG_FLAC_LAUNCH2(8, 12, true);
+    AFG_FLAC_LAUNCH2(12, 32, false); AFG_FLAC_LAUNCH2(12, 32, true);
 #undef AFG_FLAC_LAUNCH2
-    } else {
-#define AFG_FLAC_LAUNCH1(LO, HI, WA, WB)                                                                              \
-    if (variants & (1u << idx)) {                                                                                      \
-        hipLaunchKernelGGL((flac_restore_kernel<LO, HI, WA, WB>), dim3((uint32_t)groups), dim3(64), 0,                 \
-                           (side && (used & 1)) ? side->stream : stream, d_frames, d_subframes, d_res, d_out_i32,      \
-                           d_out_f32, n_frames);                                                                       \
-        used++;                                                                                                        \
-    }                                                                                                                  \
-    idx++
-#define AFG_FLAC_LAUNCH(LO, HI)            \
-    AFG_FLAC_LAUNCH1(LO, HI, false, false); \
-    AFG_FLAC_LAUNCH1(LO, HI, false, true);  \
-    AFG_FLAC_LAUNCH1(LO, HI, true, false);  \
-    AFG_FLAC_LAUNCH1(LO, HI, true, true)
-    AFG_FLAC_LAUNCH(-1, 4);
-    AFG_FLAC_LAUNCH(4, 8);
-    AFG_FLAC_LAUNCH(8, 12);
-    AFG_FLAC_LAUNCH(12, 32);
-#undef AFG_FLAC_LAUNCH1
-#undef AFG_FLAC_LAUNCH
-    }
     if (side) {
         AFG_HIP_CHECK(hipEventRecord(side->join, side->stream));
         AFG_HIP_CHECK(hipStreamWaitEvent(stream, side->join, 0));
@@ -821,49 +435,35 @@ int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg
 
 }  // namespace
 
-// The instantiations a batch populates, exactly as the kernels decide it per wavefront (32 frames; 64 with AFG_FLAC_LANE=frame):
-// bucket of the largest LPC order (<= 4, <= 8, <= 12, <= 32) and whether any subframe needs the 64-bit accumulator.  The mask
-// is only meaningful to afg_flac_transform_variants_hip of the same process.
+// The instantiations a batch populates, exactly as the kernels decide it per wavefront (32 frames): bucket of the largest LPC
+// order (<= 4, <= 8, <= 12, <= 32) and whether any subframe needs the 64-bit accumulator -- bit 2 * bucket + wide.
 extern "C" uint32_t afg_flac_variants(uint64_t n_frames, const afg_flac_frame *frames, const afg_flac_subframe *subframes)
 {
     uint32_t mask = 0;
-    if (!frames || !subframes) return 0xffffu;
-    const bool sub = lane_per_subframe();
-    const uint64_t per = sub ? kFpw : 64;
-    for (uint64_t g = 0; g < n_frames; g += per) {
-        int order = 0, wa = 0, wb = 0;
-        for (uint64_t f = g; f < n_frames && f < g + per; f++)
+    if (!frames || !subframes) return 0xffu;
+    for (uint64_t g = 0; g < n_frames; g += kFpw) {
+        int order = 0, wide = 0;
+        for (uint64_t f = g; f < n_frames && f < g + kFpw; f++)
             for (int c = 0; c < (int)frames[f].channels && c < 8; c++) {
                 const afg_flac_subframe &sf = subframes[frames[f].sf_index + c];
                 if (sf.order > order) order = sf.order;
-                if (c & 1) wb |= sf.use64 != 0; else wa |= sf.use64 != 0;
+                wide |= sf.use64 != 0;
             }
         const int bucket = order <= 4 ? 0 : order <= 8 ? 1 : order <= 12 ? 2 : 3;
-        mask |= sub ? 1u << (bucket * 2 + (wa | wb)) : 1u << (bucket * 4 + wa * 2 + wb);
+        mask |= 1u << (bucket * 2 + wide);
     }
     return mask;
 }
 
-// can the host read this device pointer (page-locked host memory mapped into the device, or managed memory)?
-static bool host_visible(const void *p)
-{
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();                                    // (an ordinary host pointer: not an error of this call)
-        return false;
-    }
-    return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged || a.isManaged;
-}
-
+// Stream-ordered: the records are read on the device when `hip_stream` gets there, never on the host at enqueue time (they
+// may be the product of earlier work on the stream), so every instantiation is launched and the unpopulated ones leave at
+// once.  A caller that still holds the records in host memory names the populated ones: afg_flac_variants +
+// afg_flac_transform_variants_hip.
 extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
                                       const afg_flac_subframe *d_subframes, const int32_t *d_res,
                                       int32_t *d_out_i32, float *d_out_f32, void *hip_stream)
 {
-    // records the host can read: find the populated instantiations here instead of launching all of them
-    uint32_t variants = 0xffffu;
-    if (n_frames && d_frames && d_subframes && host_visible(d_frames) && host_visible(d_subframes))
-        variants = afg_flac_variants(n_frames, d_frames, d_subframes);
-    return launch_variants(n_frames, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, variants, (hipStream_t)hip_stream);
+    return launch_variants(n_frames, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, 0xffu, (hipStream_t)hip_stream);
 }
 
 extern "C" int afg_flac_transform_variants_hip(uint64_t n_frames, const afg_flac_frame *d_frames,

@@ -12,9 +12,6 @@
 // Integer results are bit-exact (int arithmetic wraps exactly as in D).
 #include "afg_common.h"
 
-#ifndef AFG_QOA_ABL
-#define AFG_QOA_ABL 0      // development ablations: 1 no global stores, 2 no LMS chain, 3 no staging either
-#endif
 #ifndef AFG_QOA_STEP
 #define AFG_QOA_STEP 8
 #endif
@@ -128,10 +125,6 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
                 float outv[kSliceLen];
 #pragma unroll
                 for (int k = 0; k < kSliceLen; k++) {
-#if AFG_QOA_ABL >= 2
-                    outv[k] = (float)(int)((slice >> (3 * k)) & 7) + (float)(w0 + h0);
-                    continue;
-#endif
                     // qoa_lms_predict (:231-239): wrapping int sum, arithmetic shift
                     const int pred = (int)((unsigned)w0 * (unsigned)h0 + (unsigned)w1 * (unsigned)h1 +
                                            (unsigned)w2 * (unsigned)h2 + (unsigned)w3 * (unsigned)h3) >> 13;
@@ -167,7 +160,6 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
                         const short l0 = (short)(v.x & 0xffff), r0 = (short)(v.x >> 16), l1 = (short)(v.y & 0xffff), r1 = (short)(v.y >> 16);
                         const int left = min((int)m.samples - first, have) - k;               // pairs of this row still to write from k
                         const uint64_t o = m.out_off + (uint64_t)(first + k) * 2;
-#if AFG_QOA_ABL != 1 && AFG_QOA_ABL != 3
                         if (left >= 2) {
                             if (out_i16) *(short4 *)(out_i16 + o) = make_short4(l0, r0, l1, r1);
                             if (out_f32) {
@@ -180,9 +172,6 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
                             if (out_i16) *(short2 *)(out_i16 + o) = make_short2(l0, r0);
                             if (out_f32) *(float2 *)(out_f32 + o) = make_float2((float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767));
                         }
-#else
-                        if (l0 == 12345 && out_f32 && left > 0) out_f32[o] = (float)r1;
-#endif
                     }
                     __builtin_amdgcn_wave_barrier();
                     continue;

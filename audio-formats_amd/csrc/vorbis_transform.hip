@@ -289,7 +289,6 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     f2 *const V = (f2 *)(smem + kUFloats);
     const f2 *A2p = (const f2 *)A;
 
-#if !(AFG_VORBIS_ABL & 64)
     // step 0 (:1972-1994): item q and the mirrored item n8-1-q share one 16-byte load
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -304,12 +303,10 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
         const f2 g = pk_mul_nhh_nhl(xb, a1) + pk_mul_nhl_hh(xa, a1);
         V[q] = g;                                   // buf2[n4-2-2q'] = buf2[2q]
     }
-#endif
     __builtin_amdgcn_wave_barrier();
     after_step0();                                  // the spectrum registers are free from here on
     lane = fresh_lane();
 
-#if !(AFG_VORBIS_ABL & 4)
     // step 2 (:2006-2040): half-iteration `it` makes points n4-1-it and n8-1-it
 #if AFG_VORBIS_FUSE12
     f2 s2[2][4];                                    // [half][r']: the points base + 64 r' of stages 0, 1
@@ -444,8 +441,6 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
 
-#endif
-#if !(AFG_VORBIS_ABL & 16)
     // step 7 (:2133-2175) fused with step 8 (:2187-2238).  Item s works on pairs v2[s] and
     // v2[n4-1-s]; the results feed step-8 items x = n4-1-s and x = s.  All of buf2 is read
     // before the first output is written (the output aliases it).
@@ -493,18 +488,12 @@ __device__ __forceinline__ void imdct_2048_wave(const float4 (&xin)[4], float *s
             }
         }
     }
-#endif
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
 }
 
 #ifndef AFG_VORBIS_MIN_WAVES
 #define AFG_VORBIS_MIN_WAVES 2
-#endif
-// Development ablations (tools/build_variant.sh <name> -DAFG_VORBIS_ABL=<bits>): 1 = no PCM stores, 2 = no spectrum
-// loads, 4 = no butterfly passes (step 2 .. bit-reverse), 8 = no window / overlap arithmetic.  Results are wrong by design.
-#ifndef AFG_VORBIS_ABL
-#define AFG_VORBIS_ABL 0
 #endif
 // Make the prefetched spectrum resident *here*: the wait this forces only covers loads that were
 // issued a whole transform ago.  (Loads and stores share one in-order counter on gfx9-class hardware;
@@ -573,7 +562,6 @@ __device__ __forceinline__ void vorbis_wave_body(
     // and are waited for (settle) just before the PCM stores of transform k enter the queue.
     float4 xin[4];
     auto issue = [&](int p) {
-        if ((AFG_VORBIS_ABL & 2) && p != p_first) return;
         if (p < p_end && (flags_of(p) & AFG_VORBIS_LONG))
             load_spectrum(xin, spec + lane64(so_reg, p) + c * (kNL / 2));
     };
@@ -591,7 +579,7 @@ __device__ __forceinline__ void vorbis_wave_body(
         const float *T = tables + (which ? tab1 : tab0);            // (a runtime index into the struct would put it in scratch memory)
         const float *A = T, *B = T + n2, *Ct = T + n;
         const float *src = spec + lane64(so_reg, p);
-        const bool emit = (p >= (int)seg.p0) && previous_length > 0 && (!(AFG_VORBIS_ABL & 1) || spec == nullptr);
+        const bool emit = (p >= (int)seg.p0) && previous_length > 0;
         const int pn = previous_length;
         const int nout = right - left, plen = right_end - right;
         float *o = out + lane64(oo_reg, p);
@@ -633,7 +621,6 @@ __device__ __forceinline__ void vorbis_wave_body(
                 }
                 for (int jj = nwin + lane; jj < nout; jj += 64) o[jj * C + c] = smem[left + jj];
             }
-#if !(AFG_VORBIS_ABL & 32)
             if (plen == kNL / 2) {                                                     // :2641-2643; the long-long case:
 #pragma unroll
                 for (int i = 0; i < 16; i++) pv[i] = smem[right + lane + 64 * i];      // sixteen reads, no conditions
@@ -641,7 +628,6 @@ __device__ __forceinline__ void vorbis_wave_body(
                 pv[0] = smem[right + lane];
                 if (plen > 64) pv[1] = smem[right + lane + 64];
             }
-#endif
             __builtin_amdgcn_wave_barrier();
         }
         previous_length = plen;
@@ -668,7 +654,6 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
     constexpr int CS = kDualStride / 2;             // channel stride in f2
     const f2 *A2p = (const f2 *)A;
 
-#if !(AFG_VORBIS_ABL & 64)
     // step 0 (:1972-1994)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -684,12 +669,10 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
             V0[ch * CS + q] = g;
         }
     }
-#endif
     __builtin_amdgcn_wave_barrier();
     after_step0();                                  // the spectrum registers are free from here on
     lane = fresh_lane();
 
-#if !(AFG_VORBIS_ABL & 4)
     // step 2 (:2006-2040)
     {
         f2 e0[2][4], e1[2][4];
@@ -867,8 +850,6 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
 
-#endif
-#if !(AFG_VORBIS_ABL & 16)
     // step 7 (:2133-2175) fused with step 8 (:2187-2238); all of buf2 is read before the first output is written
     {
         const f2 *const C2 = (const f2 *)C;
@@ -916,7 +897,6 @@ __device__ __forceinline__ void imdct_2048_wave2(const float4 (&xin)[2][4], floa
             }
         }
     }
-#endif
     __builtin_amdgcn_wave_barrier();
     lane = fresh_lane();
 }
@@ -974,7 +954,6 @@ __device__ __forceinline__ void vorbis_wave2_body(
 
     float4 xin[2][4];
     auto issue = [&](int p) {
-        if ((AFG_VORBIS_ABL & 2) && p != p_first) return;
         if (p < p_end && (flags_of(p) & AFG_VORBIS_LONG)) {
             const float *src = spec + lane64(so_reg, p);
             load_spectrum(xin[0], src);
@@ -994,7 +973,7 @@ __device__ __forceinline__ void vorbis_wave2_body(
         const float *T = tables + (which ? tab1 : tab0);            // (a runtime index into the struct would put it in scratch memory)
         const float *A = T, *B = T + n2, *Ct = T + n;
         const float *src = spec + lane64(so_reg, p);
-        const bool emit = (p >= (int)seg.p0) && previous_length > 0 && (!(AFG_VORBIS_ABL & 1) || spec == nullptr);
+        const bool emit = (p >= (int)seg.p0) && previous_length > 0;
         const int pn = previous_length;
         const int nout = right - left, plen = right_end - right;
         f2 *o = (f2 *)(out + lane64(oo_reg, p));           // interleaved frames: one (L, R) pair per frame, 8-byte aligned
@@ -1045,7 +1024,6 @@ __device__ __forceinline__ void vorbis_wave2_body(
             }
             for (int jj = nwin + lane; jj < nout; jj += 64) AFG_VORBIS_ST(o + jj, (f2{ sm0[left + jj], sm1[left + jj] }));
         }
-#if !(AFG_VORBIS_ABL & 32)
         if (plen == kNL / 2) {                                 // :2641-2643
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -1060,7 +1038,6 @@ __device__ __forceinline__ void vorbis_wave2_body(
                 pv[1][1] = sm1[right + lane + 64];
             }
         }
-#endif
         __builtin_amdgcn_wave_barrier();
         previous_length = plen;
     }

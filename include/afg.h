@@ -49,8 +49,11 @@ int         afg_device_count(void);        /* number of HIP devices visible, <0 
  *   AFG_NUMERIC_TOLERANCE  (default) results within the 1e-5 RMS of the decoders' float output that drop-in use asks
  *                          for; lets the Opus/CELT stage re-associate the de-emphasis recurrence (dopus.d:3695-3701) into a
  *                          prefix sum inside the frame walk, fuse multiply-adds there, and cut a stream into independently
- *                          walked segments wherever the post-filter is provably idle (dopus.d:3294-3296, :3333).
- * MP3, Vorbis, FLAC and QOA compute the same bits in both modes.  The environment variable AFG_NUMERIC=exact|tolerance
+ *                          walked segments wherever the post-filter is provably idle (dopus.d:3294-3296, :3333); lets the
+ *                          Vorbis stage compute inverse_mdct (stb_vorbis2.d:1941-2242) of 2048-sample blocks of stereo streams
+ *                          as ONE 512-point complex FFT with fused multiply-adds instead of scheduling the reference's 8-step
+ *                          algorithm, and write window + overlap (:2606-2657) on the transform's DCT-IV (csrc/vorbis_walk.hip).
+ * MP3, FLAC and QOA compute the same bits in both modes.  The environment variable AFG_NUMERIC=exact|tolerance
  * decides until afg_set_numeric_mode is called, and again after afg_set_numeric_mode(AFG_NUMERIC_FROM_ENV).  Returns the
  * mode that was in effect before, AFG_ERR_INVALID for an unknown one. */
 #define AFG_NUMERIC_FROM_ENV  (-1)
@@ -248,9 +251,9 @@ int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
 
 /* The restore kernel exists in 8 instantiations (LPC-order bucket <= 4 / 8 / 12 / 32 x 64-bit accumulator, so that each gets
  * the registers it needs and no more); a wavefront of 32 consecutive frames -- a lane per subframe -- runs in the one its
- * largest order and widest subframe select.  afg_flac_transform_hip launches only the populated ones when d_frames and
- * d_subframes are host-visible (page-locked or managed memory: it reads the records itself), else all 8 -- the ones nobody
- * selects exit at once.  A caller that still holds the records in host memory can say which are populated:
+ * largest order and widest subframe select.  afg_flac_transform_hip is stream-ordered -- the records are read by the
+ * device when hip_stream gets there, never by the host at the call -- so it launches all 8; the ones nobody selects exit
+ * at once.  A caller that still holds the FINAL records in host memory can say which are populated:
  * afg_flac_variants (host pointers, pure host code) returns the set as a bit mask, and afg_flac_transform_variants_hip
  * launches only those -- two or more of them side by side on the caller's stream and an internal one, joined before
  * the call returns to the stream's order.  Frames of an instantiation missing from `variants` are NOT decoded.  The mask
@@ -318,7 +321,8 @@ int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const af
  * they occupy a fraction of the device for the length of the longest sequence.  Here the record-parallel transform is
  * queued on hip_stream and the per-sequence passes on hip_tail_stream behind an event, so that they run beside whatever
  * the caller queues on hip_stream next; the caller joins the two streams (an event on hip_tail_stream) before it reads
- * d_out.  hip_tail_stream NULL or equal to hip_stream: afg_celt_transform_hip. */
+ * d_out -- and before it frees or overwrites d_coeffs, d_recs or d_rec_base: in AFG_NUMERIC_TOLERANCE the whole walk,
+ * input reads included, runs on hip_tail_stream.  hip_tail_stream NULL or equal to hip_stream: afg_celt_transform_hip. */
 int afg_celt_transform_streams_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
                                    const float *d_coeffs, float *d_out, float *d_states, void *hip_stream,
                                    void *hip_tail_stream);
@@ -351,8 +355,8 @@ typedef enum afg_format {          /* AudioFileFormat, stream.d:36-47 */
 
 typedef struct afg_stream afg_stream;
 
-/* openFromMemory (stream.d:150-170): copies nothing it does not need after the call returns; never
- * throws; returns NULL only when out of memory.  On failure the stream is in error state with the
+/* openFromMemory (stream.d:150-170): copies the bytes, as the reference does (stream.d:2031-2041) -- `data` may be freed
+ * when the call returns; never throws; returns NULL only when out of memory.  On failure the stream is in error state with the
  * reference's message (internals.d:16-23). */
 afg_stream *afg_open_from_memory(const uint8_t *data, size_t length);
 int         afg_is_error(const afg_stream *s);                 /* stream.d:295-301 */

@@ -159,6 +159,21 @@ def test_walk_padded_output_stride(gpu):
     check(got[written], want[written])
 
 
+def test_walk_stereo_pair_two_mod_four_into_the_plane(gpu):
+    """A stereo stream whose frames start 2 mod 4 floats into the output plane (an odd number of stereo frames in front of
+    it): 8-byte aligned only, so the hot path's 16-byte stores do not apply."""
+    rec_base, recs, coeffs, total = synthetic.celt_batch(23, [5, 4], [2, 2], frame_sizes=(960,))
+    coeffs = (coeffs * 0.05).astype(np.float32)
+    recs = recs.copy()
+    recs["out_off"] += np.uint64(2)                                # every frame of both streams: offset = 2 (mod 4)
+    total += 2
+    assert (recs["out_off"][recs["out_stride"] == 2] % 4 >= 2).all()
+    want = oraclelib.celt_transform(rec_base, recs, coeffs, total)
+    got, _ = run_gpu(gpu, rec_base, recs, coeffs, total)
+    assert np.isnan(got[:2]).all()
+    check(got[2:], want[2:])
+
+
 def test_walk_at_full_scale_amplitude(gpu):
     """The generators' native level is 5 dB over full scale (rms 1.8): the absolute tolerance still holds there."""
     rec_base, recs, coeffs, total = synthetic.celt_batch(31, [60, 25], [2, 2], p_postfilter=0.5, p_transient=0.2)

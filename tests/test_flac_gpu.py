@@ -131,6 +131,28 @@ def test_flac_variant_mask_launches_the_same_samples(gpu):
     assert ((share < 0.01) | (share > 0.99)).all() and (share > 0.99).sum() >= 1           # whole groups or nothing
 
 
+def test_flac_transform_is_stream_ordered(gpu):
+    """afg_flac_transform_hip reads the records when the stream gets there, not at the call: records that earlier work on
+    the stream is still producing (here: copied into page-locked memory behind a long kernel) must decode like any other."""
+    import torch
+    frames, subs, res, total = synthetic.flac_batch(91, 96, block_size=576, orders=(12, 7))
+    want = oraclelib.flac_transform(frames, subs, res, total)
+    d_fr = torch.from_numpy(frames.view(np.uint8).copy()).to(gpu)
+    d_sf = torch.from_numpy(subs.view(np.uint8).copy()).to(gpu)
+    d_res = torch.from_numpy(res).to(gpu)
+    h_fr = torch.zeros(d_fr.numel(), dtype=torch.uint8).pin_memory()          # host-visible to the device, all zero for now
+    h_sf = torch.zeros(d_sf.numel(), dtype=torch.uint8).pin_memory()
+    out = torch.full((total,), -7, dtype=torch.int32, device=gpu)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(400_000_000)                                              # ~0.2 s of device time in front of the copies
+    h_fr.copy_(d_fr, non_blocking=True)
+    h_sf.copy_(d_sf, non_blocking=True)
+    assert not h_fr.any()                                                       # the host still sees the stale records
+    afgpu.flac_transform(len(frames), h_fr, h_sf, d_res, out, None, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
 def _encode_against(samples, coef, shift):
     """residuals that make the reference's 32-bit recurrence (drflac.d:1060-1099, :1235) reproduce `samples`"""
     order = len(coef)

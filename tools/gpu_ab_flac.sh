@@ -10,7 +10,6 @@ for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); k=d['roofline']['kernels'][0]; print('$1', round(k['avg_kernel_ms'],3), round(k['frac'],4), d['parity']['flac']['mismatches'])
 "; }
-AFG_FLAC_LANE=frame run lane=frame
 run lane=subframe
 AFG_FLAC_RES32=1 run lane=subframe,int32rows
 for v in "$@"; do AFG_LIB_PATH=$PWD/audio-formats_amd/lib/libafg_$v.so run $v; done
