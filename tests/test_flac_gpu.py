@@ -148,7 +148,9 @@ def test_flac_transform_is_stream_ordered(gpu):
     h_fr.copy_(d_fr, non_blocking=True)
     h_sf.copy_(d_sf, non_blocking=True)
     assert not h_fr.any()                                                       # the host still sees the stale records
-    afgpu.flac_transform(len(frames), h_fr, h_sf, d_res, out, None, None)
+    rc = afgpu.lib().afg_flac_transform_hip(len(frames), h_fr.data_ptr(), h_sf.data_ptr(), d_res.data_ptr(), out.data_ptr(), None,
+                                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, afgpu.lib().afg_last_error()
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
 
