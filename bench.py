@@ -224,9 +224,13 @@ def other_workloads(args):
       flac_int32_rows  C4 with int32 residual rows (8 B per sample moved) beside the headline's int16 rows
       celt_dense  8192 x Opus/CELT stereo, 200 frames of 960: the CELT kernel on a device-filling batch
       qoa         4096 x QOA stereo 4 s
+      device_inclusive  SURVEY 8d (b): parsed records in page-locked memory -> H2D + kernels + D2H, overlapped, per headline codec
       *_e2e       SURVEY 8d (c): file bytes in host memory -> afg_batch_decode (host parse, H2D, kernels, D2H) -> floats in
-                  host memory; PCIe-inclusive, never `value`
-    Every entry carries its own parity block against the oracle."""
+                  host memory; PCIe-inclusive, never `value`.  256 DISTINCT generated files per codec (every blob its own
+                  buffer), median of 5 windows of >= 1 s; beside each rate `cpu_baseline_e2e`: the same files from bytes to
+                  PCM through the oracle front-ends on the host cores (native thread pool, the cgroup quota's threads)
+    Every entry carries its own parity block against the oracle.  At N > 1 (default config) the same key holds
+    `c5` only: BASELINE configs[4] strong-scaled over the ranks that just ran the headline step."""
     out = {}
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -272,7 +276,7 @@ def other_workloads(args):
         out["flac_int32_rows"] = {"workload": d["config"]["workload"], "avg_kernel_ms": k["avg_kernel_ms"], "achieved": k["achieved"], "frac": k["frac"],
                                   "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "samples_per_s": k["samples_per_s"],
                                   "parity": d["parity"], "wall_s": time.perf_counter() - t0, "error": err}
-    d, err, wall = child([os.path.join(ROOT, "tools", "bench_codecs.py"), "--codec", "others", "--steps", "5"], 420)
+    d, err, wall = child([os.path.join(ROOT, "tools", "bench_codecs.py"), "--codec", "others", "--steps", "5"], 900)
     if d is None:
         out["codecs"] = {"error": err}
     else:
@@ -358,8 +362,6 @@ def run_rank(args, world, rank, local_rank):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
-    side = torch.cuda.Stream(device=dev) if args.config == "c5" else None
-
     def timed_steps(wl, steps, warmup):
         """W warm-up + K timed steps of one resident workload; returns (elapsed s, per-part ms lists)."""
         for _ in range(warmup):
@@ -374,21 +376,29 @@ def run_rank(args, world, rank, local_rank):
         per_part = [[ev[i][k][0].elapsed_time(ev[i][k][1]) for i in range(steps)] for k in range(len(wl.parts))]
         return elapsed, per_part
 
-    kern = {}                                         # name -> dict(ms list, samples, alg_bytes, units)
-    parity, cpu, extra = {}, None, {}
-    if args.config == "c5":
+    def reduce_min(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def measure_c5(steps, warmup, want_cpu):
+        """BASELINE configs[4] on this rank's shard: (elapsed s of this rank, samples of this rank, per-codec kernel records,
+        parity of rank 0's first wave, cpu baseline or None, extras, number of waves, the manifest)."""
+        kern5, parity5, cpu5, extra5 = {}, {}, None, {}
         man = corpus.c5_manifest(args.c5_files)
         waves = corpus.c5_shard_waves(man, rank, world, args.c5_wave_files or corpus.C5_WAVE_FILES)
-        elapsed, my_samples = 0.0, 0
+        elapsed5, my5 = 0.0, 0
         for wi, ids in enumerate(waves):
             wl = corpus.build_c5_wave(man, ids, dev)
             if args.only:
                 wl.parts = [p for p in wl.parts if p.name in args.only.split(",")]
-            e, per_part = timed_steps(wl, args.steps, args.warmup)
-            elapsed += e
-            my_samples += wl.samples
+            e, per_part = timed_steps(wl, steps, warmup)
+            elapsed5 += e
+            my5 += wl.samples
             for p, ms in zip(wl.parts, per_part):
-                k = kern.setdefault(p.name, {"kernel": p.kernel, "ms": [0.0] * args.steps, "samples": 0, "alg_bytes": 0, "units": 0})
+                k = kern5.setdefault(p.name, {"kernel": p.kernel, "ms": [0.0] * steps, "samples": 0, "alg_bytes": 0, "units": 0})
                 k["ms"] = [a + b for a, b in zip(k["ms"], ms)]
                 k["samples"] += p.samples; k["alg_bytes"] += p.alg_bytes; k["units"] += p.units
             # the Opus members on their own (in the step they run on a second stream beside the other codecs' kernels, so
@@ -402,16 +412,23 @@ def run_rank(args, world, rank, local_rank):
                         torch.cuda.synchronize()
                         if i:
                             ms.append(e0.elapsed_time(e1))
-                    extra["celt_alone_ms"] = extra.get("celt_alone_ms", 0.0) + sum(ms) / len(ms)
-                    extra["celt_alone_bytes"] = extra.get("celt_alone_bytes", 0) + p.alg_bytes
+                    extra5["celt_alone_ms"] = extra5.get("celt_alone_ms", 0.0) + sum(ms) / len(ms)
+                    extra5["celt_alone_bytes"] = extra5.get("celt_alone_bytes", 0) + p.alg_bytes
             if rank == 0 and wi == 0:
                 import oraclelib
-                parity = {p.name: p.check(oraclelib) for p in wl.parts}
-                if not args.no_cpu_baseline and world == 1:
-                    cpu = cpu_baseline(wl.parts, args.cpu_seconds)
+                parity5 = {p.name: p.check(oraclelib) for p in wl.parts}
+                if want_cpu:
+                    cpu5 = cpu_baseline(wl.parts, args.cpu_seconds)
             del wl
             torch.cuda.empty_cache()
         # ranks with fewer waves still meet the others' barriers: every rank has the same wave count by construction
+        return elapsed5, my5, kern5, parity5, cpu5, extra5, waves, man
+
+    side = torch.cuda.Stream(device=dev)             # the C5 waves put their Opus members on a second stream
+    kern = {}                                         # name -> dict(ms list, samples, alg_bytes, units)
+    parity, cpu, extra = {}, None, {}
+    if args.config == "c5":
+        elapsed, my_samples, kern, parity, cpu, extra, waves, man = measure_c5(args.steps, args.warmup, not args.no_cpu_baseline)
         total_samples = reduce_sum(float(my_samples))
         scaling = "strong"
         workload = (f"{args.c5_files}-file mixed corpus (40% MP3 / 25% Ogg Vorbis / 25% FLAC / 10% Opus-CELT, durations "
@@ -467,10 +484,33 @@ def run_rank(args, world, rank, local_rank):
                 del a, b
             except torch.cuda.OutOfMemoryError:
                 extra["measured_copy_GBs"] = None
-            if not args.no_cpu_baseline and world == 1:
-                cpu = cpu_baseline(wl.parts, args.cpu_seconds)
+            if not args.no_cpu_baseline:
+                cpu = cpu_baseline(wl.parts, args.cpu_seconds)       # rank 0's host cores, at every N
 
     elapsed = reduce_max(elapsed)
+    # ---- N > 1, default config: the scaling configuration itself (BASELINE configs[4], strong scaling) on the same ranks ----
+    c5_tail = None
+    if world > 1 and args.config == "c234" and not args.no_others:
+        wl = mp3 = p = None                              # release the headline batches: the C5 waves need the room
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        barrier()
+        e5, my5, kern5, parity5, _, extra5, waves5, man5 = measure_c5(3, 1, False)
+        e5_max, e5_min = reduce_max(e5), reduce_min(e5)
+        tot5 = reduce_sum(float(my5))
+        if rank == 0:
+            value5 = tot5 * 3 / e5_max
+            ref = (load_traffic("r04_c5.json") or load_traffic("r03_c5.json") or {})
+            ref_value = ref.get("value") if ref.get("n_gpus", 1) == 1 else None
+            c5_tail = {"workload": f"{args.c5_files}-file mixed corpus file-sharded over {world} GPU(s) by LPT on predicted device time (bench.py --config c5)",
+                       "value": value5, "unit": "samples/s", "scaling": "strong", "n_gpus": world, "steps": 3, "ms_per_step": e5_max / 3 * 1e3,
+                       "per_rank_ms_per_step": {"min": e5_min / 3 * 1e3, "max": e5_max / 3 * 1e3},
+                       "samples_per_step": int(tot5), "waves_per_gpu": len(waves5), "lpt_imbalance": corpus.c5_imbalance(man5, world),
+                       "n1_reference_value": ref_value, "n1_reference_source": "profiles/r04_c5.json (bench.py --config c5 on one GPU)" if ref_value else None,
+                       "efficiency_vs_n1": (value5 / (world * ref_value)) if ref_value else None,
+                       "kernels": [{"codec": n, "avg_kernel_ms": sum(k["ms"]) / len(k["ms"]), "samples_per_launch": int(k["samples"])} for n, k in kern5.items()],
+                       "parity": parity5}
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -542,6 +582,9 @@ def run_rank(args, world, rank, local_rank):
         gc.collect()
         torch.cuda.empty_cache()
         line["other_workloads"] = other_workloads(args)
+        failed += other_parity_failures(line["other_workloads"])
+    if c5_tail is not None:
+        line["other_workloads"] = {"c5": c5_tail}
         failed += other_parity_failures(line["other_workloads"])
     print(json.dumps(line), flush=True)
     if dist is not None:

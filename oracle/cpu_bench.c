@@ -7,6 +7,12 @@
  * (repeat, task) pairs from one atomic counter and write into a private output buffer, so nothing is allocated
  * or shared while the clock runs.  The caller gets the wall time and the CPU time the workers actually burned
  * (CLOCK_THREAD_CPUTIME_ID): cpu / wall is the parallelism achieved, whatever the cgroup quota allowed.
+ *
+ * Round 4: file tasks (codec 10..13) take a whole file from bytes to delivered PCM -- the oracle front-end (Huffman / code
+ * book / range decoding: mp3_frontend.c, vorbis_frontend.c, opus_frontend.c) and then the transform-stage oracle -- the CPU
+ * side of SURVEY 8d (c), bench.py's `cpu_baseline_e2e`.  FLAC has no oracle front-end (parity of the product's parser is
+ * pinned by an independent bitstream writer, tests/flac_bitstream.py): its task calls a parser the CALLER hands in as a
+ * function pointer (bench.py passes the product's host-only afg_flac_parse) and then the oracle's restore.
  */
 #define _GNU_SOURCE
 #include "afg_oracle.h"
@@ -18,7 +24,8 @@
 #include <time.h>
 
 typedef struct afgo_bench_task {
-    int32_t  codec;                  /* 0 MP3, 1 Vorbis, 2 FLAC, 3 CELT */
+    int32_t  codec;                  /* 0 MP3, 1 Vorbis, 2 FLAC, 3 CELT (transform stage); 10 MP3, 11 Ogg Vorbis, 12 Ogg Opus, 13 FLAC:
+                                        a file in memory, a = bytes, out_floats = byte count, b / c = parse / free functions (13) */
     uint32_t n;                      /* MP3: granules; Vorbis: packets; FLAC: frames; CELT: channel sequences */
     uint32_t channels;               /* MP3 / Vorbis */
     uint16_t bs0, bs1;               /* Vorbis block sizes */
@@ -49,6 +56,100 @@ static double now_s(clockid_t c)
     struct timespec ts;
     clock_gettime(c, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* the product's afg_flac_parsed (include/afg.h) as far as this file reads it */
+typedef struct flac_parsed {
+    uint32_t sample_rate, channels, bps, max_block;
+    uint64_t total_samples, n_frames, n_subframes, n_res, out_samples;
+    afgo_flac_frame *frames;
+    afgo_flac_subframe *subframes;
+    int32_t *res;
+    void *owner;
+} flac_parsed;
+typedef int (*flac_parse_fn)(const uint8_t *, size_t, flac_parsed *);
+typedef void (*flac_free_fn)(flac_parsed *);
+
+/* bytes -> delivered PCM of one file; returns the number of samples (channels included), 0 on failure */
+static uint64_t run_file(const afgo_bench_task *t)
+{
+    const uint8_t *data = (const uint8_t *)t->a;
+    const size_t size = (size_t)t->out_floats;
+    uint64_t samples = 0;
+    switch (t->codec) {
+    case 10: {
+        afgo_mp3_file f;
+        memset(&f, 0, sizeof(f));
+        if (afgo_mp3_decode_file(data, size, &f) == 0) {          /* front-end + transform + delivery (mp3_frontend.c) */
+            samples = f.pcm_samples;
+            afgo_mp3_file_free(&f);
+        }
+        break;
+    }
+    case 11: {
+        afgo_vorbis_file f;
+        memset(&f, 0, sizeof(f));
+        if (afgo_vorbis_decode_file(data, size, &f) != 0) break;
+        const uint32_t n = f.n_packets;
+        uint64_t *so = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (n ? n : 1)), *oo = so ? so + n : NULL, st = 0;
+        if (so && n) {
+            const uint64_t total = afgo_vorbis_layout(n, f.channels, f.blocksize0, f.blocksize1, f.pflags, 0, 0, so, oo, &st);
+            float *pcm = (float *)malloc(sizeof(float) * (size_t)(total ? total : 1));
+            if (pcm) {
+                const uint8_t nch = (uint8_t)f.channels;
+                const uint16_t b0 = (uint16_t)f.blocksize0, b1 = (uint16_t)f.blocksize1;
+                if (afgo_vorbis_transform(1, &n, &nch, &b0, &b1, f.pflags, so, oo, f.spec, pcm) == 0) samples = f.pcm_frames * (uint64_t)f.channels;
+                free(pcm);
+            }
+        }
+        free(so);
+        afgo_vorbis_file_free(&f);
+        break;
+    }
+    case 12: {
+        afgo_opus_file f;
+        memset(&f, 0, sizeof(f));
+        if (afgo_opus_decode_file(data, size, &f) != 0) break;
+        const uint64_t nf = f.n_frames, ch = (uint64_t)f.channels, total = f.pcm_frames * ch;
+        afgo_celt_frame *recs = (afgo_celt_frame *)malloc(sizeof(afgo_celt_frame) * (size_t)((nf && ch) ? nf * ch : 1));
+        float *pcm = (float *)malloc(sizeof(float) * (size_t)(total ? total : 1));
+        if (recs && pcm && nf) {
+            uint64_t base[3] = { 0, nf, 2 * nf };
+            for (uint64_t c = 0; c < ch; c++)
+                for (uint64_t i = 0; i < nf; i++) {                /* channel c of frame i: afg_oracle.h, afgo_opus_file */
+                    recs[c * nf + i] = f.frames[i];
+                    recs[c * nf + i].coef_off += c * f.frames[i].frame_size;
+                    recs[c * nf + i].out_off += c;
+                }
+            afgo_celt_transform((uint32_t)ch, base, recs, f.coeffs, pcm, NULL);
+            if (f.gain_i)
+                for (uint64_t i = 0; i < total; i++) pcm[i] *= f.gain;
+            afgo_opus_output(total, pcm, NULL, pcm);               /* int16 round trip / 32767 (dopus.d:8098-8105, stream.d:480) */
+            samples = total;
+        }
+        free(recs);
+        free(pcm);
+        afgo_opus_file_free(&f);
+        break;
+    }
+    case 13: {
+        flac_parsed fp;
+        memset(&fp, 0, sizeof(fp));
+        if (!t->b || ((flac_parse_fn)t->b)(data, size, &fp) != 0) break;
+        int32_t *pcm = (int32_t *)malloc(4 * (size_t)(fp.out_samples ? fp.out_samples : 1));
+        float *pcf = (float *)malloc(4 * (size_t)(fp.out_samples ? fp.out_samples : 1));
+        if (pcm && pcf) {
+            afgo_flac_transform(fp.n_frames, fp.frames, fp.subframes, fp.res, pcm, pcf);   /* + stream.d:505-511 float conversion */
+            samples = fp.out_samples;
+        }
+        free(pcm);
+        free(pcf);
+        if (t->c) ((flac_free_fn)t->c)(&fp);
+        break;
+    }
+    default: break;
+    }
+    return samples;
 }
 
 static void run_task(const afgo_bench_task *t, void *out)
@@ -91,8 +192,12 @@ static void *work(void *arg)
         const long i = atomic_fetch_add(&p->next, 1);
         if (i >= p->total) break;
         const afgo_bench_task *t = &p->tasks[i % p->n_tasks];
-        run_task(t, out);
-        done += t->out_floats;
+        if (t->codec >= 10) {
+            done += run_file(t);
+        } else {
+            run_task(t, out);
+            done += t->out_floats;
+        }
     }
     w->cpu_s = now_s(CLOCK_THREAD_CPUTIME_ID) - c0;
     atomic_fetch_add(&p->samples, done);
@@ -114,7 +219,7 @@ double afgo_bench_run(const afgo_bench_task *tasks, int n_tasks, int repeats, in
     atomic_init(&p.next, 0);
     atomic_init(&p.samples, 0);
     for (int i = 0; i < n_tasks; i++)
-        if (tasks[i].out_floats > p.max_out) p.max_out = tasks[i].out_floats;
+        if (tasks[i].codec < 10 && tasks[i].out_floats > p.max_out) p.max_out = tasks[i].out_floats;
     worker *w = (worker *)calloc((size_t)n_threads, sizeof(worker));
     if (!w) return -1.0;
     const double t0 = now_s(CLOCK_MONOTONIC);

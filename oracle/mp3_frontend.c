@@ -747,7 +747,7 @@ static int decode_frame(dec_t *dec, const uint8_t *mp3, int mp3_bytes, float *pc
     int i = 0, igr, frame_size = 0, success = 1;
     const uint8_t *hdr;
     bs_t bs_frame;
-    static scratch_t scratch;                    /* single-threaded test infrastructure */
+    static _Thread_local scratch_t scratch;      /* (a stack variable in the reference; one per thread: bench.py times files on a thread pool) */
     if (mp3_bytes > 4 && dec->header[0] == 0xff && hdr_compare(dec->header, mp3)) {
         frame_size = hdr_frame_bytes(mp3, dec->free_format_bytes) + hdr_padding(mp3);
         if (frame_size != mp3_bytes && (frame_size + HDR_SIZE > mp3_bytes || !hdr_compare(mp3, mp3 + frame_size))) frame_size = 0;

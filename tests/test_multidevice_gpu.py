@@ -270,6 +270,18 @@ def test_bench_launches_its_own_ranks(gpu):
     assert set(line["parity"]) == {"mp3", "vorbis", "flac", "celt"}
     assert all(p["mismatches"] == 0 for p in line["parity"].values())
     assert line["value"] > 0 and {k["codec"] for k in line["roofline"]["kernels"]} == {"mp3", "vorbis", "flac", "celt"}
+    # the default configuration at N > 1: the weak-scaling headline step, then BASELINE configs[4] (strong scaling) on the same ranks
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--files", "8", "--c5-files", "96",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-full-fetch"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["name"] == "c234"
+    c5 = line["other_workloads"]["c5"]
+    assert c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["value"] > 0
+    assert 0 < c5["per_rank_ms_per_step"]["min"] <= c5["per_rank_ms_per_step"]["max"] and c5["lpt_imbalance"] >= 1.0
+    assert set(c5["parity"]) == {"mp3", "vorbis", "flac", "celt"} and all(p["mismatches"] == 0 for p in c5["parity"].values())
+    assert "efficiency_vs_n1" in c5
     # a mislabelled run is refused: --gpus must agree with WORLD_SIZE
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
