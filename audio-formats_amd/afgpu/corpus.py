@@ -635,14 +635,21 @@ class Workload:
         stream the part is launched on.  side: optional second stream; parts marked `overlap` (the CELT part of the
         mixed corpus: ~1600 long serial chains that occupy a fraction of the device for their whole length) are
         launched there, forked from and joined back into `stream`, and run beside the other codecs' kernels."""
+        import os
         import torch
-        use_side = side is not None and any(getattr(p, "overlap", False) for p in self.parts)
+        # AFG_C5_ORDER (development, tools/gpu_c5_order.sh): "serial" keeps the Opus members on `stream`; a comma list of
+        # part names fixes the launch order (default: the overlapped part first, then the parts as built)
+        knob = os.environ.get("AFG_C5_ORDER", "")
+        use_side = side is not None and any(getattr(p, "overlap", False) for p in self.parts) and knob != "serial"
         order = list(range(len(self.parts)))
         if use_side:
             # the part with the serial tail goes first: its record-parallel kernel has the device to itself for its ~2 ms on
             # `stream`, its per-sequence passes then run on `side` as the oldest wavefronts beside the throughput kernels
             # of the other parts (afg_celt_transform_streams_hip)
             order.sort(key=lambda i: not getattr(self.parts[i], "overlap", False))
+        if "," in knob:
+            names = knob.split(",")
+            order.sort(key=lambda i: names.index(self.parts[i].name) if self.parts[i].name in names else len(names))
         for i in order:
             p = self.parts[i]
             tail = use_side and getattr(p, "overlap", False)
