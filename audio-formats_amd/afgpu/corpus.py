@@ -310,7 +310,8 @@ class Part:
 
 
 class Mp3Part(Part):
-    name, kernel = "mp3", "mp3_transform_kernel"
+    name = "mp3"
+    kernel = "mp3_tolerance_kernel (tolerance mode: csrc/mp3_kernel.h with fused multiply-adds; exact mode: mp3_transform_kernel)"
 
     def __init__(self, seed, granules_per_file, device, seg=0, file_ids=None, host=False):
         import torch
@@ -356,7 +357,7 @@ class Mp3Part(Part):
         want = checker.mp3_transform(self.granules[:n_files], self.channels[:n_files], self.coef[:nb * 576].cpu().numpy(),
                                        self.flags[:nb].cpu().numpy().view(np.uint32))
         got = self.pcm[:nb * 576].cpu().numpy()
-        return _float_parity(got, want)
+        return _float_parity(got, want, get_numeric_mode() == NUMERIC_TOLERANCE)
 
     def check_file(self, checker, f):
         """file f on its own (any position in the plane: the last files of a full-size batch sit beyond 2^32 bytes)"""
@@ -364,7 +365,7 @@ class Mp3Part(Part):
         nb = int(self.granules[f]) * 2
         want = checker.mp3_transform(self.granules[f:f + 1], self.channels[f:f + 1], self.coef[b0 * 576:(b0 + nb) * 576].cpu().numpy(),
                                      self.flags[b0:b0 + nb].cpu().numpy().view(np.uint32))
-        return _float_parity(self.pcm[b0 * 576:(b0 + nb) * 576].cpu().numpy(), want)
+        return _float_parity(self.pcm[b0 * 576:(b0 + nb) * 576].cpu().numpy(), want, get_numeric_mode() == NUMERIC_TOLERANCE)
 
 
 class VorbisPart(Part):

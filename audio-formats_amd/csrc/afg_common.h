@@ -48,6 +48,10 @@ struct PlanArena {
 int mp3_plan_create_at(afg_mp3_plan **plan, uint32_t n_streams, const uint32_t *granules, const uint8_t *channels,
                        const uint64_t *blk_base, uint32_t seg_granules, PlanArena *arena = nullptr);
 
+// the MP3 transform in AFG_NUMERIC_TOLERANCE (mp3_tolerance.hip); d_segs / d_streams are the plan's device tables
+void mp3_launch_tolerance(uint32_t n_segs, const void *d_segs, const void *d_streams, const float *d_coef,
+                          const uint32_t *d_flags, float *d_pcm, float *d_state, hipStream_t stream);
+
 // afg_vorbis_plan_create with an explicit input offset per stream (NULL: packed); see vorbis_transform.hip
 int vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const uint32_t *packets, const uint8_t *channels,
                           const uint16_t *blocksize0, const uint16_t *blocksize1, const uint8_t *pflags,

@@ -1,8 +1,8 @@
 """The outer surface in the DEFAULT numeric mode (AFG_NUMERIC_TOLERANCE): what a user of the library gets without setting
 anything.  The bit-exact suites (test_stream_gpu.py, test_multidevice_gpu.py, ...) pin AFG_NUMERIC=exact; here the same paths
 -- AudioStream pulls, seeks, afg_batch_decode over mixed batches, several device entries, a C5 wave -- run as shipped:
-MP3 / FLAC / QOA stay bit-identical to the oracle, Ogg Vorbis (csrc/vorbis_walk.hip) and Ogg Opus (csrc/celt_walk.hip)
-within north_star's 1e-5 RMS, and everything that must not depend on HOW a file was decoded (chunked pulls against the
+FLAC / QOA stay bit-identical to the oracle, MP3 (csrc/mp3_tolerance.hip), Ogg Vorbis (csrc/vorbis_walk.hip) and Ogg Opus
+(csrc/celt_walk.hip) within north_star's 1e-5 RMS, and everything that must not depend on HOW a file was decoded (chunked pulls against the
 batch decode, the device list, the sharding) is still compared bit for bit."""
 import numpy as np
 import pytest
@@ -54,7 +54,8 @@ def test_all_formats_in_one_batch_default_mode(gpu):
     for k in (0, 6):
         assert out[k]["frames"] == len(want_ogg) and rms(out[k]["pcm"], want_ogg) <= TOL
     assert np.array_equal(out[0]["pcm"].view(np.uint32), out[6]["pcm"].view(np.uint32))          # the same file twice: the same bits
-    assert np.array_equal(out[1]["pcm"].reshape(-1).view(np.uint32), oraclelib.mp3_decode_file(mp3)["pcm"].view(np.uint32))
+    want_mp3 = oraclelib.mp3_decode_file(mp3)["pcm"]
+    assert out[1]["pcm"].size == want_mp3.size and rms(out[1]["pcm"].reshape(-1), want_mp3) <= TOL
     assert np.array_equal(out[3]["pcm"].view(np.uint32), qoa_want.view(np.uint32))
     info, frames, subs, res = afgpu.flac_parse(flac)
     want_flac = oraclelib.flac_transform(frames, subs, res, info["out_samples"], want_float=True)[1]
@@ -113,7 +114,7 @@ def test_device_list_does_not_change_the_samples_default_mode(gpu):
 
 
 def test_c5_wave_default_mode(gpu):
-    """a wave of the mixed corpus with all four codecs resident together: MP3 / FLAC bit-exact, Vorbis / CELT within tolerance,
+    """a wave of the mixed corpus with all four codecs resident together: FLAC bit-exact, MP3 / Vorbis / CELT within tolerance,
     and the file results independent of which wave (shard) a file lands in"""
     import torch
     from afgpu import corpus
@@ -134,7 +135,7 @@ def test_c5_wave_default_mode(gpu):
     for part in wl.parts:
         for fid, want in zip(part.file_ids, oracle_file_outputs(part)):
             name, got = whole[int(fid)]
-            if name in ("mp3", "flac"):
+            if name == "flac":
                 assert np.array_equal(got.view(np.uint32), np.asarray(want).view(np.uint32)), (name, fid)
             else:
                 assert not np.isnan(got).any() and rms(got, want) <= TOL, (name, fid)

@@ -309,8 +309,11 @@ def bench_flac_e2e(files, distinct, threads):
 
 def bench_mp3_e2e(files, distinct, threads):
     """MP3: file bytes -> host parse (sync, Huffman, scalefactors) -> H2D -> requantisation + transform kernels -> D2H."""
+    import afgpu
     import oraclelib
-    return e2e_record("mp3", "MP3 128 kbit/s joint stereo", distinct, files, threads, lambda d: oraclelib.mp3_decode_file(d)["pcm"])
+    tol = afgpu.get_numeric_mode() == afgpu.NUMERIC_TOLERANCE
+    return e2e_record("mp3", "MP3 128 kbit/s joint stereo", distinct, files, threads, lambda d: oraclelib.mp3_decode_file(d)["pcm"],
+                      tolerance="rms" if tol else False)
 
 
 def bench_vorbis_e2e(files, distinct, threads):
@@ -436,7 +439,7 @@ def bench_mixed_e2e(files, gen, threads):
         return oraclelib.flac_transform(ff, fs, fr, info["out_samples"], want_float=True)[1]
     wants = {"mp3": lambda d: oraclelib.mp3_decode_file(d)["pcm"], "ogg": lambda d: oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(d)),
              "flac": flac_want, "opus": lambda d: oraclelib.opus_file_pcm(oraclelib.opus_decode_file(d))}
-    parity = {k: file_parity([items[i]], wants[k](gen[k][j]), (tol if k == "opus" else ("rms" if (tol and k == "ogg") else False)))
+    parity = {k: file_parity([items[i]], wants[k](gen[k][j]), (tol if k == "opus" else ("rms" if (tol and k in ("ogg", "mp3")) else False)))
               for k, (i, j) in first.items()}
     per = {}
     for (k, _), o in zip(kinds, items):

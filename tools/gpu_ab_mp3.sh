@@ -7,7 +7,7 @@ run() { python bench.py --config c2 --steps 5 --warmup 1 --no-cpu-baseline --no-
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); k=d['roofline']['kernels'][0]; print('$1', round(k['avg_kernel_ms'],3), round(k['frac'],4), d['parity']['mp3']['mismatches'])
+        d=json.loads(l); k=d['roofline']['kernels'][0]; print('$1', round(k['avg_kernel_ms'],3), round(k['frac'],4), d['parity']['mp3']['mismatches'], d['parity']['mp3']['rms_error'])
 "; }
 run product
 for v in "$@"; do AFG_LIB_PATH=$PWD/audio-formats_amd/lib/libafg_$v.so run $v; done
