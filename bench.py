@@ -523,8 +523,8 @@ def run_rank(args, world, rank, local_rank):
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
     # passes over the same full-size batch, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_collect.sh): only
     # for the kernels and batch sizes those passes were taken on
-    pmc_file = {"mp3": "r03_pmc_mp3_transform_kernel.json", "vorbis": "r03_pmc_vorbis_wave_kernel.json",
-                "flac": "r03_pmc_flac_restore1_kernel.json"}     # (FLAC: counters calibrated on its own access pattern, both instantiations)
+    pmc_file = {"mp3": "r04_pmc_mp3_tolerance_kernel.json", "vorbis": "r04_pmc_vorbis_walk_kernel.json",
+                "flac": "r04_pmc_flac_restore1_kernel.json"}     # (FLAC: counters calibrated on its own access pattern, both instantiations)
     kernels = []
     for name, k in kern.items():
         avg_ms = sum(k["ms"]) / len(k["ms"])

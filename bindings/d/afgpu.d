@@ -26,7 +26,8 @@ const(char)* afg_last_error();
 int afg_device_count();
 
 /// Numeric mode of the float transform stages (afg.h): exact = the reference's expression trees bit for bit; tolerance
-/// (default) = within 1e-5 RMS, which lets the Opus/CELT stage re-associate.  AFG_NUMERIC_FROM_ENV hands the choice back to
+/// (default) = within 1e-5 RMS, which lets the Opus/CELT stage re-associate, the Vorbis stage use one radix-8 FFT per block
+/// and the MP3 stage fuse its multiply-adds (round 4).  AFG_NUMERIC_FROM_ENV hands the choice back to
 /// the environment variable AFG_NUMERIC.  Returns the mode in effect before.
 enum AFG_NUMERIC_FROM_ENV = -1, AFG_NUMERIC_EXACT = 0, AFG_NUMERIC_TOLERANCE = 1;
 int afg_set_numeric_mode(int mode);
