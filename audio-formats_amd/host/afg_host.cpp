@@ -1712,28 +1712,15 @@ int afg_qoa_parse(const uint8_t *data, size_t length, uint32_t *channels, uint32
 
 namespace {
 
-// Host threads of a batch when the caller leaves the choice to the library: one per physical core of an SMT-2 host (with one
-// per logical CPU the parse stages ran up to 10x longer on a shared 256-CPU box: the stragglers wait for a CPU).
-unsigned default_threads()
+// The CPU time the process may actually use: a container's cgroup quota in CPUs (0: none / unknown).
+double cpu_quota()
 {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return hw >= 16 ? hw / 2 : hw;
-}
-
-// ... and for a stage that keeps the CPUs busy for longer than a scheduler period: no more than twice the CPU time the process
-// may actually use (a container's cgroup quota).  The GPU boxes of this project show 256 logical CPUs behind a 16-CPU quota:
-// stages of a few tens of milliseconds (FLAC / Vorbis / MP3 parse) finish inside the burst the quota allows and are fastest
-// with 128 threads; the Opus decode of a 2048-file batch takes half a second, is throttled, and runs at 1.7e9 samples/s with
-// 128 threads, 2.3e9 with 32.
-unsigned sustained_threads()
-{
-    static const unsigned n = [] {
-        unsigned t = default_threads();
-        double quota = 0;
+    static const double quota = [] {
+        double q = 0;
         if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                    // cgroup v2: "<quota|max> <period>"
-            char q[32] = { 0 };
+            char w[32] = { 0 };
             double period = 0;
-            if (std::fscanf(f, "%31s %lf", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) quota = std::atof(q) / period;
+            if (std::fscanf(f, "%31s %lf", w, &period) == 2 && period > 0 && std::strcmp(w, "max") != 0) q = std::atof(w) / period;
             std::fclose(f);
         } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // cgroup v1
             double us = -1, period = 100000;
@@ -1743,8 +1730,39 @@ unsigned sustained_threads()
                 if (std::fscanf(h, "%lf", &period) != 1) period = 100000;
                 std::fclose(h);
             }
-            if (us > 0 && period > 0) quota = us / period;
+            if (us > 0 && period > 0) q = us / period;
         }
+        return q;
+    }();
+    return quota;
+}
+
+// Host threads of a batch when the caller leaves the choice to the library: one per physical core of an SMT-2 host (with one
+// per logical CPU the parse stages ran up to 10x longer on a shared 256-CPU box: the stragglers wait for a CPU) -- and under a
+// cgroup quota no more than FOUR times the quota's CPUs.  The GPU boxes of this project show 256 logical CPUs behind a 16-CPU
+// quota.  Round 3 sized this on single calls, which finish inside the burst the quota allows (128 threads were fastest);
+// sustained -- back-to-back calls for seconds, what a service does and what bench.py times since round 4 -- the parse stages of
+// 2048-file batches run at 4.1 / 3.5 / 2.0e9 samples/s (MP3 / Vorbis / FLAC) with 128 threads, 4.2 / 4.1 / 2.5 with 32 and
+// 5.1 / 4.4 / 2.7 with 64 (tools/gpu_e2e_threads.sh): threads the quota cannot run only get descheduled in the middle of a file.
+unsigned default_threads()
+{
+    static const unsigned n = [] {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        unsigned t = hw >= 16 ? hw / 2 : hw;
+        const double quota = cpu_quota();
+        if (quota > 0) t = std::min(t, std::max(1u, (unsigned)(4 * quota + 0.5)));
+        return std::max(1u, t);
+    }();
+    return n;
+}
+
+// ... and for a stage that keeps every CPU busy for half a second by itself (the Opus range / PVQ decode of a 2048-file batch):
+// twice the quota (1.7e9 samples/s with 128 threads, 2.3e9 with 32).
+unsigned sustained_threads()
+{
+    static const unsigned n = [] {
+        unsigned t = default_threads();
+        const double quota = cpu_quota();
         if (quota > 0) t = std::min(t, std::max(1u, (unsigned)(2 * quota + 0.5)));
         return std::max(1u, t);
     }();
