@@ -18,6 +18,12 @@ LIB_PATH = os.environ.get("AFG_LIB_PATH", os.path.join(PKG_ROOT, "lib", "libafg_
 
 MP3_STATE_FLOATS = 1536
 VORBIS_LONG, VORBIS_PREV, VORBIS_NEXT = 1, 2, 4
+
+
+def VORBIS_NZ_EIGHTHS(e):
+    """afg.h AFG_VORBIS_NZ_EIGHTHS: a long packet's declaration that only its first e eighths may be nonzero."""
+    return (int(e) + 1) << 4
+
 FLAC_INDEPENDENT, FLAC_LEFT_SIDE, FLAC_RIGHT_SIDE, FLAC_MID_SIDE = 0, 8, 9, 10
 
 FLAC_SUBFRAME_DTYPE = np.dtype([("coef", np.int16, (32,)), ("order", np.uint8), ("shift", np.uint8),

@@ -12,7 +12,7 @@ walks its shard in waves of at most 8192 files so that a wave's planes fit one M
 import numpy as np
 
 from . import (CELT_FRAME_DTYPE, FLAC_FRAME_DTYPE, FLAC_INDEPENDENT, FLAC_LEFT_SIDE, FLAC_MID_SIDE,
-               FLAC_SUBFRAME_DTYPE, NUMERIC_TOLERANCE, VORBIS_LONG, Mp3Plan, VorbisPlan, celt_transform, flac_transform, flac_variants,
+               FLAC_SUBFRAME_DTYPE, NUMERIC_TOLERANCE, VORBIS_LONG, VORBIS_NZ_EIGHTHS, Mp3Plan, VorbisPlan, celt_transform, flac_transform, flac_variants,
                get_numeric_mode, sharding, synthetic)
 
 KIND_MP3, KIND_VORBIS, KIND_FLAC, KIND_CELT = 0, 1, 2, 3
@@ -373,10 +373,19 @@ class VorbisPart(Part):
     kernel = ("vorbis_walk_kernel (tolerance mode: IMDCT-2048 as one radix 8 x 8 x 8 FFT, csrc/vorbis_walk.hip; exact mode: vorbis_wave_kernel, "
               "the reference's 8-step algorithm)")
 
-    def __init__(self, seed, packets_per_file, device, seg=0, bs0=256, bs1=2048, file_ids=None, host=False):
+    def __init__(self, seed, packets_per_file, device, seg=0, bs0=256, bs1=2048, file_ids=None, host=False, declare_zero_tail=True):
         import torch
         n = np.asarray(packets_per_file, np.uint32)
         pflags = vorbis_flag_plane(seed, n, file_ids)
+        # what the host parser declares from the residue's end (host/afg_vorbis_front.cpp): the floor curve is zero from bin
+        # 743 of 1024 up, i.e. the last two eighths of a long block's spectrum
+        nz_bins = int(np.flatnonzero(synthetic.vorbis_floor_curve(bs1 // 2))[-1]) + 1
+        import os
+        if os.environ.get("AFG_VORBIS_DECLARE", "1") == "0":               # A/B only: the same spectra, nothing declared
+            declare_zero_tail = False
+        self.nz_eighths = -(-nz_bins * 8 // (bs1 // 2)) if declare_zero_tail else 8
+        if self.nz_eighths < 8:
+            pflags = np.where(pflags & VORBIS_LONG, pflags | np.uint8(VORBIS_NZ_EIGHTHS(self.nz_eighths)), pflags).astype(np.uint8)
         nf = len(n)
         self.plan = VorbisPlan(n, np.full(nf, 2, np.uint8), np.full(nf, bs0, np.uint16), np.full(nf, bs1, np.uint16), pflags, seg)
         if host:
@@ -389,14 +398,34 @@ class VorbisPart(Part):
             chunk = 1 << 28
             for o in range(0, self.plan.spec_floats, chunk):
                 self.spec[o:o + chunk].normal_(generator=gen)
-            if ((pflags & VORBIS_LONG) != 0).all():
-                self.spec.view(-1, bs1 // 2).mul_(torch.from_numpy(synthetic.vorbis_floor_curve(bs1 // 2)).to(device))
-            else:
-                self.spec.mul_(0.25)
+            # the same shaping as vorbis_spec_numpy: the floor curve (zeros above 16 kHz) on long blocks, 0.25 on short ones; a
+            # plane of 64-float rows, each row knowing which 64 bins of its channel it holds
+            rows_long, rows_short, row = bs1 // 128, bs0 // 128, 64
+            is_long = (pflags & VORBIS_LONG) != 0
+            per_packet = np.where(is_long, 2 * rows_long, 2 * rows_short).astype(np.int64)
+            first = np.concatenate([[0], np.cumsum(per_packet)])
+            kind = np.full(int(first[-1]), rows_long, np.int16)                       # rows_long = "a short block's row"
+            long_first = first[:-1][is_long]
+            if len(long_first):
+                idx = (long_first[:, None] + np.arange(2 * rows_long)[None, :]).reshape(-1)
+                kind[idx] = np.tile(np.arange(2 * rows_long) % rows_long, len(long_first))
+            table = np.concatenate([synthetic.vorbis_floor_curve(bs1 // 2).reshape(rows_long, row), np.full((1, row), 0.25, np.float32)])
+            d_table = torch.from_numpy(table).to(device)
+            d_kind = torch.from_numpy(kind).to(device)
+            view = self.spec.view(-1, row)
+            assert view.shape[0] == len(kind)
+            step = 1 << 22
+            for o in range(0, len(kind), step):
+                view[o:o + step].mul_(d_table[d_kind[o:o + step].long()])
+            del d_kind
         self.out = torch.empty(self.plan.out_floats, dtype=torch.float32, device=device)
         self.units = int(self.plan.total_packets) * 2
         self.samples = int(self.plan.out_floats)
-        self.alg_bytes = 4 * int(self.plan.spec_floats) + int(self.plan.total_packets) + 4 * int(self.plan.out_floats)
+        # declared-empty eighths of long blocks are not read: they are not algorithmic bytes of this launch (survey_bytes keeps
+        # SURVEY 8(d)'s per-packet figure, which counts the whole spectrum)
+        self.survey_bytes = 4 * int(self.plan.spec_floats) + int(self.plan.total_packets) + 4 * int(self.plan.out_floats)
+        n_long = int(((pflags & VORBIS_LONG) != 0).sum())
+        self.alg_bytes = self.survey_bytes - 4 * n_long * 2 * (bs1 // 2) * (8 - self.nz_eighths) // 8
 
     def launch(self, stream):
         self.plan.transform(self.spec, self.out, stream)

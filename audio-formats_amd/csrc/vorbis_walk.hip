@@ -256,12 +256,19 @@ __device__ __forceinline__ void walk_body(
     // share one in-order counter.
     f2 xin[2][8];
     auto issue = [&](int p) {
-        if (p < p_end && (flags_of(p) & AFG_VORBIS_LONG)) {
+        const unsigned flp = p < p_end ? flags_of(p) : 0u;
+        if (flp & AFG_VORBIS_LONG) {
             const f2 *src = (const f2 *)(spec + lane64(so_reg, p)) + group_of(fresh_lane());
+            // AFG_VORBIS_NZ_EIGHTHS: load r of a channel covers bins 128 r .. 128 r + 127, so a declared-empty eighth is a
+            // whole instruction that is not issued (a scalar test: no lane predicates)
+            const int nz = (int)(flp >> 4) ? (int)(flp >> 4) - 1 : 8;
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int r = 0; r < 8; r++) xin[c][r] = __builtin_nontemporal_load(src + c * (kN / 4) + 64 * r);
+                for (int r = 0; r < 8; r++) {
+                    xin[c][r] = f2{ 0.0f, 0.0f };
+                    if (r < nz) xin[c][r] = __builtin_nontemporal_load(src + c * (kN / 4) + 64 * r);
+                }
         } else {
             // nothing reads xin before the next issue(): say so, or the old values are copied around to survive the branch
 #pragma unroll

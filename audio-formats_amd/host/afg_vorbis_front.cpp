@@ -321,6 +321,7 @@ struct Floor1 {
 struct Residue {
     uint32_t begin = 0, end = 0, part_size = 1;
     int classifications = 1, classbook = 0, type = 0;
+    int max_dim = 1;                         // largest dimension among its value books
     int16_t books[64][8];
 };
 struct Mapping {
@@ -513,6 +514,7 @@ bool read_setup(Bits &br, Setup &st)
                 if (cascade[j] & (1 << k)) {
                     r.books[j][k] = (int16_t)br.get(8);
                     if (r.books[j][k] >= nbooks) return false;
+                    r.max_dim = std::max(r.max_dim, st.books[(size_t)r.books[j][k]].dim);
                 }
             }
     }
@@ -700,6 +702,9 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
     for (int i = 0; i < map.coupling; i++)
         if (!zero[map.mag[i]] || !zero[map.ang[i]]) zero[map.mag[i]] = zero[map.ang[i]] = false;
 
+    // how far into a channel's spectrum any residue of this packet can write: what AFG_VORBIS_NZ_EIGHTHS declares.  Nothing
+    // else puts a nonzero there: inverse coupling of (+0, +0) is (+0, +0) and the floor multiplies
+    uint32_t nz_bins = 0;
     // residues (:1586-1713)
     for (int sm = 0; sm < map.submaps; sm++) {
         float *buf[16];
@@ -718,6 +723,12 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
         const uint32_t rb = std::min(r.begin, actual), re = std::min(r.end, actual);
         const int part_read = (int)((re - rb) / r.part_size);
         if (classwords <= 0) continue;
+        if (ch) {
+            // type 2 interleaves its channels: position z belongs to bin z / ch
+            // (a type-2 vector is not cut at the end of its partition, :1405-1440: up to dim - 1 positions more)
+            const uint32_t last = rb + (uint32_t)part_read * r.part_size + (r.type == 2 ? (uint32_t)r.max_dim - 1 : 0u);
+            nz_bins = std::max(nz_bins, r.type == 2 ? (last + (uint32_t)ch - 1) / (uint32_t)ch : last);
+        }
         const size_t cls_pitch = (size_t)(part_read + classwords + 1);
         std::vector<int> &cls = sc.cls;                          // reused across packets: no allocation on the packet path
         cls.assign((size_t)std::max(ch, 1) * cls_pitch, 0);
@@ -812,6 +823,10 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
         }
     }
 
+    if (mode.blockflag) {
+        const uint32_t eighth = (uint32_t)n2 / 8;
+        flags |= AFG_VORBIS_NZ_EIGHTHS(std::min<uint32_t>(8, (nz_bins + eighth - 1) / eighth));
+    }
     if (sc.device_floor) {
         // the tail below as records: the floor points do_floor walks (:2262-2272), in its order, y scaled
         sc.mapping = mode.mapping;

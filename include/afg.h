@@ -161,6 +161,11 @@ int afg_mp3_requant_hip(uint64_t n_granules, const afg_mp3_qgranule *d_granules,
 #define AFG_VORBIS_LONG 1u   /* mode blockflag          (stb_vorbis2.d:2324) */
 #define AFG_VORBIS_PREV 2u   /* previous-window flag    (stb_vorbis2.d:2326) */
 #define AFG_VORBIS_NEXT 4u   /* next-window flag        (stb_vorbis2.d:2327) */
+/* Optional, bits 4..7 of a LONG packet's flag byte: only the first e eighths of every channel's n/2 spectral values may be
+ * different from +0.0 (e = 0 .. 8) -- what the host decoder knows from the residue's `end` (stb_vorbis2.d:1586-1600: bins past
+ * it are never written, inverse coupling and the floor multiply keep +0.0).  The device then need not fetch the rest (the
+ * tolerance-mode walk does not; the bit-exact kernels ignore the declaration).  0 in these bits: nothing declared. */
+#define AFG_VORBIS_NZ_EIGHTHS(e) ((((unsigned)(e)) + 1u) << 4)
 
 typedef struct afg_vorbis_plan afg_vorbis_plan;
 

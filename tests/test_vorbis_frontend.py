@@ -50,11 +50,30 @@ def same_records(data, upstream_seek=False):
     got = afgpu.vorbis_parse(data)
     for k in ("channels", "sample_rate", "blocksize0", "blocksize1", "total_samples", "pcm_frames"):
         assert got[k] == want[k], k
-    for k in ("pflags", "take_from", "take_count"):
+    np.testing.assert_array_equal(got["pflags"] & 7, want["pflags"], err_msg="pflags")
+    for k in ("take_from", "take_count"):
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
     assert got["spec"].shape == want["spec"].shape
     assert np.array_equal(got["spec"].view(np.uint32), want["spec"].view(np.uint32))      # bit-exact spectra
+    declared_tail_is_zero(got["pflags"], want)
     return got, want
+
+
+def declared_tail_is_zero(pflags, want):
+    """bits 4..7 of a long packet's flags (afg.h AFG_VORBIS_NZ_EIGHTHS) are the product's own: every long packet carries a
+    declaration, no short one does, and in the ORACLE's spectra the declared-empty eighths hold +0.0 and nothing else"""
+    ch, at = want["channels"], 0
+    for fl in pflags:
+        n2 = (want["blocksize1"] if fl & 1 else want["blocksize0"]) // 2
+        if fl & 1:
+            e = (int(fl) >> 4) - 1
+            assert 0 <= e <= 8
+            for c in range(ch):
+                tail = want["spec"][at + c * n2 + e * (n2 // 8):at + (c + 1) * n2]
+                assert not tail.view(np.uint32).any(), "a declared-empty eighth holds a nonzero (or -0.0)"
+        else:
+            assert fl >> 4 == 0
+        at += n2 * ch
 
 
 def test_real_file():
@@ -62,7 +81,7 @@ def test_real_file():
     assert (got["channels"], got["sample_rate"], got["blocksize0"], got["blocksize1"]) == (2, 44100, 256, 2048)
     assert got["total_samples"] == 22050 == got["pcm_frames"]          # the last page's granule position truncates the tail
     assert got["take_count"][0] == 0                                     # the first frame only primes the overlap (:2659)
-    assert set(got["pflags"]) >= {0, 7}                                  # short and long blocks
+    assert set(got["pflags"] & 7) >= {0, 7}                              # short and long blocks
     pcm = oraclelib.vorbis_file_pcm(got)
     assert pcm.shape == (22050, 2) and np.isfinite(pcm).all() and 0.3 < np.abs(pcm).max() < 1.0
 
@@ -144,7 +163,7 @@ def test_inconsistent_window_flags_end_the_stream():
         hit += 1
         n = len(got["pflags"])
         assert n == 6 and len(want["pflags"]) > n
-        np.testing.assert_array_equal(got["pflags"], want["pflags"][:n])
+        np.testing.assert_array_equal(got["pflags"] & 7, want["pflags"][:n])
         assert np.array_equal(got["spec"].view(np.uint32), want["spec"][:len(got["spec"])].view(np.uint32))
     assert hit >= 3
 

@@ -145,3 +145,34 @@ def test_walk_amplitude_range(gpu):
         diff = got.astype(np.float64) - want.astype(np.float64)
         rms, sig = np.sqrt(np.mean(diff ** 2)), np.sqrt(np.mean(want.astype(np.float64) ** 2))
         assert rms <= 1e-6 * sig, (amp, rms, sig)
+
+
+@pytest.mark.parametrize("eighths", [0, 1, 5, 6, 8])
+def test_walk_declared_zero_tail(gpu, eighths):
+    """AFG_VORBIS_NZ_EIGHTHS (afg.h): a long packet whose flags say "only the first e eighths of the spectrum can be nonzero"
+    decodes to the same bits as the same packet with nothing declared -- and what lies in the declared-empty part of the
+    plane is never looked at (NaN there leaves no trace)."""
+    from afgpu import VORBIS_NZ_EIGHTHS
+    packets, channels = [31, 14], [2, 2]
+    pflags, spec = synthetic.vorbis_batch(17 + eighths, packets, channels, [256] * 2, [2048] * 2, p_short_run=0.15)
+    plan = VorbisPlan(packets, channels, [256] * 2, [2048] * 2, pflags, 5)
+    so, _ = plan.offsets()
+    spec = spec.copy()
+    poisoned = spec.copy()
+    for p, f in enumerate(pflags):
+        if f & VORBIS_LONG:
+            for c in range(2):
+                o = int(so[p]) + 1024 * c
+                spec[o + 128 * eighths:o + 1024] = 0.0
+                poisoned[o + 128 * eighths:o + 1024] = np.nan
+    plain, want = run_both(gpu, packets, channels, [256] * 2, [2048] * 2, pflags, spec, 5)
+    check(plain, want)
+    declared = np.where(pflags & VORBIS_LONG, pflags | VORBIS_NZ_EIGHTHS(eighths), pflags).astype(np.uint8)
+    got, want2 = run_both(gpu, packets, channels, [256] * 2, [2048] * 2, declared, spec, 5)
+    assert (want2.view(np.uint32) == want.view(np.uint32)).all(), "the oracle must ignore the declaration"
+    assert (got.view(np.uint32) == plain.view(np.uint32)).all()
+    import torch
+    d_out = torch.full((plan.out_floats,), float("nan"), dtype=torch.float32, device=gpu)
+    VorbisPlan(packets, channels, [256] * 2, [2048] * 2, declared, 5).transform(torch.from_numpy(poisoned).to(gpu), d_out)
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy().view(np.uint32) == plain.view(np.uint32)).all()
