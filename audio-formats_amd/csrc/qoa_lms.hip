@@ -25,7 +25,7 @@ constexpr int kInRow = kStepSlices * 2 + 1;          // 64-bit words per tile ro
 constexpr int kFlushSlices = 4;                      // all-stereo path: slices staged per row before a flush (4 x 160 B = five full 128-byte lines)
 constexpr int kRowPairs = kFlushSlices * kSliceLen;  // (L,R) pairs per staged row
 constexpr int kRowPitch = kRowPairs + 2;             // dwords; 82: rows 8-byte aligned, 2-way bank conflicts at most
-constexpr int kFlushIters = kFramesPerWave * kRowPairs / 2 / 64;   // two pairs (8 staged bytes, 16 output bytes) per lane and iteration
+static_assert(kStepSlices % kFlushSlices == 0 && kRowPairs % 16 == 0, "a step is whole flushes, a row whole 128-byte lines");
 
 __device__ const short k_dequant[16 * 8] = {
     1, -1, 3, -3, 5, -5, 7, -7,  5, -5, 18, -18, 32, -32, 49, -49,
@@ -48,6 +48,149 @@ struct RowInfo {
     uint32_t samples;
     uint32_t channels;
 };
+
+// One slice (20 samples) of one channel: qoa_lms_predict (:231-239: wrapping int sum, arithmetic shift), dequantisation,
+// qoa_clamp_s16 (:278-286), qoa_lms_update (:241-254).  I24: every factor fits 24 signed bits -- histories are clamped int16,
+// a weight starts as an int16 and moves by at most 896 (= 14336 >> 4) per sample, i.e. stays below 2^23 for 9325 samples -- so
+// the products come from v_mad_i32_i24 (full rate; v_mul_lo_u32 is quarter rate), the low 32 bits of which are the wrapped
+// int product; the update  w += h < 0 ? -delta : delta  is one more such mad with the sign (+-1) kept beside each history value.
+template <bool I24>
+__device__ __forceinline__ void decode_slice(uint64_t slice, const short *dq, int (&h)[4], int (&w)[4], int (&sg)[4], int (&out)[kSliceLen])
+{
+    const short *dqs = dq + (int)(slice >> 60) * 8;
+#pragma unroll
+    for (int k = 0; k < kSliceLen; k++) {
+        const int deq = dqs[(int)(slice >> (57 - 3 * k)) & 7];
+        const int delta = deq >> 4;
+        int pred;
+        if (I24) {
+            pred = (int)((unsigned)__mul24(w[0], h[0]) + (unsigned)__mul24(w[1], h[1]) + (unsigned)__mul24(w[2], h[2]) +
+                         (unsigned)__mul24(w[3], h[3])) >> 13;
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = (int)((unsigned)__mul24(sg[i], delta) + (unsigned)w[i]);
+        } else {
+            pred = (int)((unsigned)w[0] * (unsigned)h[0] + (unsigned)w[1] * (unsigned)h[1] + (unsigned)w[2] * (unsigned)h[2] +
+                         (unsigned)w[3] * (unsigned)h[3]) >> 13;
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] += h[i] < 0 ? -delta : delta;
+        }
+        int rec = pred + deq;
+        rec = rec < -32768 ? -32768 : (rec > 32767 ? 32767 : rec);
+        h[0] = h[1]; h[1] = h[2]; h[2] = h[3]; h[3] = rec;
+        if (I24) { sg[0] = sg[1]; sg[1] = sg[2]; sg[2] = sg[3]; sg[3] = (rec >> 31) | 1; }
+        out[k] = rec;
+    }
+}
+
+constexpr int kI24MaxSamples = 9000;                 // see decode_slice
+
+// lgkmcnt(0) alone: a one-wavefront workgroup orders its LDS traffic without waiting for its global stores (which
+// __syncthreads' vmcnt(0) does: with HBM saturated by writes that wait is the kernel's time)
+__device__ __forceinline__ void lds_fence()
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// All-stereo wavefronts: (L,R) int16 pairs of four slices are staged per frame row and leave as five whole 128-byte lines per
+// row.  The next step's slices are fetched into registers at the top of a step and parked in the tile between the step's two
+// halves, just before the first half's stores: the one vmcnt wait of a step covers loads and stores issued half a step earlier.
+template <bool I24>
+__device__ __forceinline__ void stereo_walk(const RowInfo *rows, uint64_t *tile, uint32_t *stage16, const short *dq, const uint8_t *__restrict__ bytes,
+                                            int16_t *__restrict__ out_i16, float *__restrict__ out_f32, const RowInfo &me, int max_slices)
+{
+    const int lane = threadIdx.x;
+    const int fr = lane >> 1, slot = lane & 1;
+    constexpr int W = 2 * kStepSlices;                                  // 64-bit words per frame row and step
+    int h[4] = { 0, 0, 0, 0 }, w[4] = { 0, 0, 0, 0 }, sg[4] = { 1, 1, 1, 1 };
+    if (me.samples) {
+        // LMS state from the frame header (qoa.d:489-503): history then weights, 4 x int16 big-endian
+        const uint64_t *st = (const uint64_t *)(bytes + me.byte_off + 8 + 16 * slot);
+        const uint64_t hh = bswap64(st[0]), ww = bswap64(st[1]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            h[i] = (short)(hh >> (48 - 16 * i));
+            w[i] = (short)(ww >> (48 - 16 * i));
+            sg[i] = (h[i] >> 31) | 1;
+        }
+    }
+    uint64_t P[kStepSlices];
+    auto fetch = [&](int s0) {
+#pragma unroll
+        for (int i = 0; i < kStepSlices; i++) {
+            const int r = (64 / W) * i + lane / W, wd = lane % W;       // word = (slice, slot) = (wd >> 1, wd & 1)
+            const RowInfo m = rows[r];
+            const int sl = s0 + (wd >> 1);
+            // (always a load, never a write of P by anything else: a register move into P would have to wait for "pending" loads
+            // the compiler cannot see parked, i.e. for the stores just issued.  Past a row's last slice the frame header is
+            // read instead: in the plane, and decoded into samples that are never stored)
+            const uint64_t at = sl * kSliceLen < (int)m.samples ? 8 + 32 + ((uint64_t)sl * 2 + (wd & 1)) * 8 : 0;
+            P[i] = *(const uint64_t *)(bytes + m.byte_off + at);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < kStepSlices; i++) tile[((64 / W) * i + lane / W) * kInRow + lane % W] = P[i];
+    };
+    // four slices (S) -> staged rows -> global; `park_first`: the parked fetch goes between the compute and the stores
+    auto half_step = [&](const uint64_t *S, int base, bool park_first) {
+#pragma unroll
+        for (int j = 0; j < kFlushSlices; j++) {
+            if (base + j >= max_slices) break;
+            int rec[kSliceLen];
+            decode_slice<I24>(bswap64(S[j]), dq, h, w, sg, rec);
+            short *row16 = (short *)(stage16 + fr * kRowPitch + j * kSliceLen) + slot;
+#pragma unroll
+            for (int k = 0; k < kSliceLen; k++) row16[2 * k] = (short)rec[k];
+        }
+        if (park_first) park();
+        lds_fence();
+        // flush: lane = (row r of a group of 8, 16 output bytes u of a 128-byte line); five lines per row
+        const int first = base * kSliceLen;                                     // first sample of the staged rows
+        const int have = min(max_slices - base, kFlushSlices) * kSliceLen;      // samples staged per row
+#pragma unroll
+        for (int g = 0; g < kFramesPerWave / 8; g++) {
+            const int r = 8 * g + (lane >> 3);
+            const RowInfo m = rows[r];
+            const int lim = min((int)m.samples - first, have);                  // pairs of this row to write
+            const uint64_t o = m.out_off + (uint64_t)first * 2 + 4 * (lane & 7);
+#pragma unroll
+            for (int t = 0; t < kRowPairs / 16; t++) {
+                const int k = 2 * (lane & 7) + 16 * t;
+                const uint2 v = *(const uint2 *)(stage16 + r * kRowPitch + k);  // pairs k, k+1 of row r
+                const short l0 = (short)(v.x & 0xffff), r0 = (short)(v.x >> 16), l1 = (short)(v.y & 0xffff), r1 = (short)(v.y >> 16);
+                if (k + 2 <= lim) {
+                    if (out_i16) *(short4 *)(out_i16 + o + 32 * t) = make_short4(l0, r0, l1, r1);
+                    if (out_f32) {
+                        typedef float f32x4nt __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(f32x4nt{ (float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767),
+                                                             (float)l1 * (1.0f / 32767), (float)r1 * (1.0f / 32767) },
+                                                    (f32x4nt *)(out_f32 + o + 32 * t));
+                    }
+                } else if (k + 1 == lim) {
+                    if (out_i16) *(short2 *)(out_i16 + o + 32 * t) = make_short2(l0, r0);
+                    if (out_f32) *(float2 *)(out_f32 + o + 32 * t) = make_float2((float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767));
+                }
+            }
+        }
+        lds_fence();
+    };
+    static_assert(kStepSlices == 2 * kFlushSlices, "a step is two flushes");
+    fetch(0);
+    park();
+    for (int s0 = 0; s0 < max_slices; s0 += kStepSlices) {
+        lds_fence();
+        uint64_t S[kStepSlices];
+#pragma unroll
+        for (int j = 0; j < kStepSlices; j++) S[j] = tile[fr * kInRow + 2 * j + slot];
+        lds_fence();
+        // fetch and park on every path, also after the last step (header reads, see fetch): the compiler's wait-count
+        // bookkeeping is not path sensitive, and a "maybe pending" load at the loop head costs a vmcnt(0) behind the stores
+        fetch(s0 + kStepSlices);
+        half_step(S, s0, false);
+        half_step(S + kFlushSlices, s0 + kFlushSlices, true);
+    }
+}
 
 __global__ __launch_bounds__(64) void qoa_decode_kernel(
     const afg_qoa_frame *__restrict__ frames, const uint8_t *__restrict__ bytes,
@@ -84,20 +227,26 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
     }
     const int max_slices = (max_samples + kSliceLen - 1) / kSliceLen;
 
-    // all-stereo wavefronts (every frame two channels, rows 16-byte aligned) stage four slices per row as int16 and
-    // flush them as whole 128-byte lines
-    const bool all_stereo = __ballot((C != 2 || (me.out_off & 3)) && me.samples != 0) == 0;
+    // all-stereo wavefronts (every frame two channels, rows 16-byte aligned)
+    if (__ballot((C != 2 || (me.out_off & 3)) && me.samples != 0) == 0) {
+        if (max_samples <= kI24MaxSamples) stereo_walk<true>(rows, tile, stage16, dq, bytes, out_i16, out_f32, me, max_slices);
+        else stereo_walk<false>(rows, tile, stage16, dq, bytes, out_i16, out_f32, me, max_slices);
+        return;
+    }
 
+    // any other layout: one slice per step through a float staging tile, indexed stores
     for (int pair = 0; pair < max_pairs; pair++) {
         const int ch = 2 * pair + slot;
         const bool active = ch < C;
-        // LMS state from the frame header (qoa.d:489-503): history then weights, 4 x int16 big-endian
-        int h0 = 0, h1 = 0, h2 = 0, h3 = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        int h[4] = { 0, 0, 0, 0 }, w[4] = { 0, 0, 0, 0 }, sg[4] = { 1, 1, 1, 1 };
         if (active) {
             const uint64_t *st = (const uint64_t *)(bytes + me.byte_off + 8 + 16 * ch);
             const uint64_t hh = bswap64(st[0]), ww = bswap64(st[1]);
-            h0 = (short)(hh >> 48); h1 = (short)(hh >> 32); h2 = (short)(hh >> 16); h3 = (short)hh;
-            w0 = (short)(ww >> 48); w1 = (short)(ww >> 32); w2 = (short)(ww >> 16); w3 = (short)ww;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                h[i] = (short)(hh >> (48 - 16 * i));
+                w[i] = (short)(ww >> (48 - 16 * i));
+            }
         }
 
         for (int s0 = 0; s0 < max_slices; s0 += kStepSlices) {
@@ -119,66 +268,11 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
 
             for (int j = 0; j < kStepSlices && s0 + j < max_slices; j++) {
                 const int sidx = s0 + j;
-                uint64_t slice = bswap64(tile[fr * kInRow + 2 * j + slot]);
-                const int sf = (int)((slice >> 60) & 0xf);
-                const short *dqs = dq + sf * 8;
-                float outv[kSliceLen];
-#pragma unroll
-                for (int k = 0; k < kSliceLen; k++) {
-                    // qoa_lms_predict (:231-239): wrapping int sum, arithmetic shift
-                    const int pred = (int)((unsigned)w0 * (unsigned)h0 + (unsigned)w1 * (unsigned)h1 +
-                                           (unsigned)w2 * (unsigned)h2 + (unsigned)w3 * (unsigned)h3) >> 13;
-                    const int q = (int)((slice >> 57) & 0x7);
-                    const int deq = dqs[q];
-                    int rec = pred + deq;
-                    rec = rec < -32768 ? -32768 : (rec > 32767 ? 32767 : rec);       // qoa_clamp_s16 (:278-286)
-                    slice <<= 3;
-                    // qoa_lms_update (:241-254)
-                    const int delta = deq >> 4;
-                    w0 += h0 < 0 ? -delta : delta;
-                    w1 += h1 < 0 ? -delta : delta;
-                    w2 += h2 < 0 ? -delta : delta;
-                    w3 += h3 < 0 ? -delta : delta;
-                    h0 = h1; h1 = h2; h2 = h3; h3 = rec;
-                    outv[k] = (float)rec;
-                }
-                if (all_stereo) {
-                    // (one wavefront per workgroup: its LDS accesses complete in order, no barrier needed)
-                    const int jj = sidx % kFlushSlices;
-                    short *row16 = (short *)(stage16 + fr * kRowPitch + jj * kSliceLen) + slot;
-#pragma unroll
-                    for (int k = 0; k < kSliceLen; k++) row16[2 * k] = (short)outv[k];
-                    if (jj != kFlushSlices - 1 && sidx != max_slices - 1) continue;
-                    __builtin_amdgcn_wave_barrier();
-                    const int first = (sidx - jj) * kSliceLen;               // first sample of the staged rows
-                    const int have = (jj + 1) * kSliceLen;                   // samples staged per row
-#pragma unroll 4
-                    for (int it = 0; it < kFlushIters; it++) {
-                        const int idx = lane + 64 * it, r = idx / (kRowPairs / 2), k = 2 * (idx - r * (kRowPairs / 2));
-                        const RowInfo m = rows[r];
-                        const uint2 v = *(const uint2 *)(stage16 + r * kRowPitch + k);        // pairs k, k+1 of row r
-                        const short l0 = (short)(v.x & 0xffff), r0 = (short)(v.x >> 16), l1 = (short)(v.y & 0xffff), r1 = (short)(v.y >> 16);
-                        const int left = min((int)m.samples - first, have) - k;               // pairs of this row still to write from k
-                        const uint64_t o = m.out_off + (uint64_t)(first + k) * 2;
-                        if (left >= 2) {
-                            if (out_i16) *(short4 *)(out_i16 + o) = make_short4(l0, r0, l1, r1);
-                            if (out_f32) {
-                                typedef float f32x4nt __attribute__((ext_vector_type(4)));
-                                __builtin_nontemporal_store(f32x4nt{ (float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767),
-                                                                     (float)l1 * (1.0f / 32767), (float)r1 * (1.0f / 32767) },
-                                                            (f32x4nt *)(out_f32 + o));
-                            }
-                        } else if (left == 1) {
-                            if (out_i16) *(short2 *)(out_i16 + o) = make_short2(l0, r0);
-                            if (out_f32) *(float2 *)(out_f32 + o) = make_float2((float)l0 * (1.0f / 32767), (float)r0 * (1.0f / 32767));
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    continue;
-                }
+                int rec[kSliceLen];
+                decode_slice<false>(bswap64(tile[fr * kInRow + 2 * j + slot]), dq, h, w, sg, rec);
                 // stage [frame][sample][slot]
 #pragma unroll
-                for (int k = 0; k < kSliceLen; k++) stage[(fr * kSliceLen + k) * 2 + slot] = outv[k];
+                for (int k = 0; k < kSliceLen; k++) stage[(fr * kSliceLen + k) * 2 + slot] = (float)rec[k];
                 __syncthreads();
                 // store: frame rows of 20 samples x (1|2) slots
                 for (int idx = lane; idx < kFramesPerWave * kSliceLen * 2; idx += 64) {
