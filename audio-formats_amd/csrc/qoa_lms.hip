@@ -5,10 +5,11 @@
 // The sign-sign LMS adapts after every sample, so a frame-channel is strictly serial; frames carry
 // their full LMS state (:489-503) and are independent, so lane = (frame, channel):
 //   * a wavefront owns 32 frames x 2 channel slots and walks the 256 slices in steps of 8;
-//   * the big-endian 64-bit slices are fetched 8 steps at a time as coalesced 128-byte rows
-//     (8-byte loads: frame offsets are only 8-byte aligned) into an LDS tile with 17-word rows;
-//   * each lane decodes one slice (20 samples) per step in registers, the 32 x 20 x 2 samples of a
-//     step are staged in LDS and leave as 16-byte stores of 160-byte rows.
+//   * all-stereo wavefronts (the common case): a lane fetches its frame's big-endian 64-bit slices 16 bytes at a time (both
+//     channels of one slice index) and trades halves with the neighbouring lane; each lane decodes one slice (20 samples) at a
+//     time in registers, four slices of (L,R) int16 pairs are staged per frame row in LDS and leave as five whole 128-byte
+//     lines per row; the one wait for memory in a step sits where the loads are a step old and the last stores half a step;
+//   * any other layout goes slice by slice through an LDS tile of coalesced 128-byte rows and indexed stores.
 // Integer results are bit-exact (int arithmetic wraps exactly as in D).
 #include "afg_common.h"
 
@@ -54,6 +55,13 @@ struct RowInfo {
 // a weight starts as an int16 and moves by at most 896 (= 14336 >> 4) per sample, i.e. stays below 2^23 for 9325 samples -- so
 // the products come from v_mad_i32_i24 (full rate; v_mul_lo_u32 is quarter rate), the low 32 bits of which are the wrapped
 // int product; the update  w += h < 0 ? -delta : delta  is one more such mad with the sign (+-1) kept beside each history value.
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 template <bool I24>
 __device__ __forceinline__ void decode_slice(uint64_t slice, const short *dq, int (&h)[4], int (&w)[4], int (&sg)[4], int (&out)[kSliceLen])
 {
@@ -64,8 +72,12 @@ __device__ __forceinline__ void decode_slice(uint64_t slice, const short *dq, in
         const int delta = deq >> 4;
         int pred;
         if (I24) {
-            pred = (int)((unsigned)__mul24(w[0], h[0]) + (unsigned)__mul24(w[1], h[1]) + (unsigned)__mul24(w[2], h[2]) +
-                         (unsigned)__mul24(w[3], h[3])) >> 13;
+            // (a chain of mads ending on the newest sample, as written: the compiler's tree of three multiplies, one mad and
+            // an add3 is one instruction more, and two instead of one behind the sample just reconstructed)
+            int acc = __mul24(w[0], h[0]);
+            acc = mad24(w[1], h[1], acc);
+            acc = mad24(w[2], h[2], acc);
+            pred = mad24(w[3], h[3], acc) >> 13;
 #pragma unroll
             for (int i = 0; i < 4; i++) w[i] = (int)((unsigned)__mul24(sg[i], delta) + (unsigned)w[i]);
         } else {
@@ -93,15 +105,15 @@ __device__ __forceinline__ void lds_fence()
 }
 
 // All-stereo wavefronts: (L,R) int16 pairs of four slices are staged per frame row and leave as five whole 128-byte lines per
-// row.  The next step's slices are fetched into registers at the top of a step and parked in the tile between the step's two
-// halves, just before the first half's stores: the one vmcnt wait of a step covers loads and stores issued half a step earlier.
+// row.  The next step's slices are fetched into registers at the top of a step and unpacked between the second half's compute
+// and its stores: the one vmcnt wait of a step covers loads a step old and stores half a step old (loads and stores share
+// one in-order counter, so any wait for a load also waits for every older store).
 template <bool I24>
-__device__ __forceinline__ void stereo_walk(const RowInfo *rows, uint64_t *tile, uint32_t *stage16, const short *dq, const uint8_t *__restrict__ bytes,
+__device__ __forceinline__ void stereo_walk(const RowInfo *rows, uint32_t *stage16, const short *dq, const uint8_t *__restrict__ bytes,
                                             int16_t *__restrict__ out_i16, float *__restrict__ out_f32, const RowInfo &me, int max_slices)
 {
     const int lane = threadIdx.x;
     const int fr = lane >> 1, slot = lane & 1;
-    constexpr int W = 2 * kStepSlices;                                  // 64-bit words per frame row and step
     int h[4] = { 0, 0, 0, 0 }, w[4] = { 0, 0, 0, 0 }, sg[4] = { 1, 1, 1, 1 };
     if (me.samples) {
         // LMS state from the frame header (qoa.d:489-503): history then weights, 4 x int16 big-endian
@@ -114,26 +126,34 @@ __device__ __forceinline__ void stereo_walk(const RowInfo *rows, uint64_t *tile,
             sg[i] = (h[i] >> 31) | 1;
         }
     }
-    uint64_t P[kStepSlices];
-    auto fetch = [&](int s0) {
+    // no tile: a lane fetches 16 bytes = the two channels' slices sl = s0 + 2 m + slot and trades one of the two with its
+    // neighbour (the frame's other channel), which holds the slices of the other parity
+    struct __attribute__((aligned(8))) Two { uint64_t lo, hi; };
+    Two Q[kStepSlices / 2];
+    auto fetch2 = [&](int s0) {
 #pragma unroll
-        for (int i = 0; i < kStepSlices; i++) {
-            const int r = (64 / W) * i + lane / W, wd = lane % W;       // word = (slice, slot) = (wd >> 1, wd & 1)
-            const RowInfo m = rows[r];
-            const int sl = s0 + (wd >> 1);
-            // (always a load, never a write of P by anything else: a register move into P would have to wait for "pending" loads
-            // the compiler cannot see parked, i.e. for the stores just issued.  Past a row's last slice the frame header is
-            // read instead: in the plane, and decoded into samples that are never stored)
-            const uint64_t at = sl * kSliceLen < (int)m.samples ? 8 + 32 + ((uint64_t)sl * 2 + (wd & 1)) * 8 : 0;
-            P[i] = *(const uint64_t *)(bytes + m.byte_off + at);
+        for (int m = 0; m < kStepSlices / 2; m++) {
+            const int sl = s0 + 2 * m + slot;
+            // (always a load, on every path: the compiler's wait-count bookkeeping is not path sensitive, and a "maybe pending"
+            // load at the loop head costs a vmcnt(0) behind the stores just issued.  Past the frame's last slice the frame
+            // header is read instead: in the plane, and decoded into samples that are never stored)
+            const uint64_t at = sl * kSliceLen < (int)me.samples ? 8 + 32 + (uint64_t)sl * 16 : 0;
+            Q[m] = *(const Two *)(bytes + me.byte_off + at);
         }
     };
-    auto park = [&]() {
+    auto swap1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); };   // quad_perm [1,0,3,2]
+    auto unpack = [&](uint64_t *S) {
 #pragma unroll
-        for (int i = 0; i < kStepSlices; i++) tile[((64 / W) * i + lane / W) * kInRow + lane % W] = P[i];
+        for (int m = 0; m < kStepSlices / 2; m++) {
+            const uint64_t send = slot ? Q[m].lo : Q[m].hi;
+            const uint64_t recv = ((uint64_t)swap1((uint32_t)(send >> 32)) << 32) | swap1((uint32_t)send);
+            S[2 * m] = slot ? recv : Q[m].lo;
+            S[2 * m + 1] = slot ? Q[m].hi : recv;
+            asm volatile("" : "+v"(S[2 * m]), "+v"(S[2 * m + 1]) :: "memory");          // (here, not after the stores that follow)
+        }
     };
-    // four slices (S) -> staged rows -> global; `park_first`: the parked fetch goes between the compute and the stores
-    auto half_step = [&](const uint64_t *S, int base, bool park_first) {
+    // four slices (S) -> staged rows -> global; `Snext`: the fetched slices are unpacked between the compute and the stores
+    auto half_step = [&](const uint64_t *S, int base, uint64_t *Snext) {
 #pragma unroll
         for (int j = 0; j < kFlushSlices; j++) {
             if (base + j >= max_slices) break;
@@ -143,7 +163,7 @@ __device__ __forceinline__ void stereo_walk(const RowInfo *rows, uint64_t *tile,
 #pragma unroll
             for (int k = 0; k < kSliceLen; k++) row16[2 * k] = (short)rec[k];
         }
-        if (park_first) park();
+        if (Snext) unpack(Snext);               // the step's one vmcnt wait: loads a step old, stores half a step old
         lds_fence();
         // flush: lane = (row r of a group of 8, 16 output bytes u of a 128-byte line); five lines per row
         const int first = base * kSliceLen;                                     // first sample of the staged rows
@@ -176,19 +196,15 @@ __device__ __forceinline__ void stereo_walk(const RowInfo *rows, uint64_t *tile,
         lds_fence();
     };
     static_assert(kStepSlices == 2 * kFlushSlices, "a step is two flushes");
-    fetch(0);
-    park();
+    uint64_t S[kStepSlices], Sn[kStepSlices];
+    fetch2(0);
+    unpack(S);
     for (int s0 = 0; s0 < max_slices; s0 += kStepSlices) {
-        lds_fence();
-        uint64_t S[kStepSlices];
+        fetch2(s0 + kStepSlices);
+        half_step(S, s0, nullptr);
+        half_step(S + kFlushSlices, s0 + kFlushSlices, Sn);
 #pragma unroll
-        for (int j = 0; j < kStepSlices; j++) S[j] = tile[fr * kInRow + 2 * j + slot];
-        lds_fence();
-        // fetch and park on every path, also after the last step (header reads, see fetch): the compiler's wait-count
-        // bookkeeping is not path sensitive, and a "maybe pending" load at the loop head costs a vmcnt(0) behind the stores
-        fetch(s0 + kStepSlices);
-        half_step(S, s0, false);
-        half_step(S + kFlushSlices, s0 + kFlushSlices, true);
+        for (int j = 0; j < kStepSlices; j++) S[j] = Sn[j];
     }
 }
 
@@ -196,10 +212,10 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
     const afg_qoa_frame *__restrict__ frames, const uint8_t *__restrict__ bytes,
     int16_t *__restrict__ out_i16, float *__restrict__ out_f32, uint64_t n_frames)
 {
-    __shared__ uint64_t tile[kFramesPerWave * kInRow];
     __shared__ __attribute__((aligned(16))) uint32_t stage16[kFramesPerWave * kRowPitch];      // all-stereo path: (L,R) int16 pairs
-    static_assert(sizeof(uint32_t) * kFramesPerWave * kRowPitch >= sizeof(float) * kFramesPerWave * kSliceLen * 2, "staging overlay");
-    float *const stage = (float *)stage16;                                                     // general path: one slice of floats
+    float *const stage = (float *)stage16;                                                     // general path: one slice of floats ...
+    uint64_t *const tile = (uint64_t *)(stage16 + kFramesPerWave * kSliceLen * 2);             // ... and behind it the slice tile
+    static_assert(sizeof(uint32_t) * kFramesPerWave * kRowPitch >= sizeof(float) * kFramesPerWave * kSliceLen * 2 + 8 * kFramesPerWave * kInRow, "staging overlay");
     __shared__ RowInfo rows[kFramesPerWave];
     __shared__ short dq[16 * 8];
 
@@ -229,8 +245,8 @@ __global__ __launch_bounds__(64) void qoa_decode_kernel(
 
     // all-stereo wavefronts (every frame two channels, rows 16-byte aligned)
     if (__ballot((C != 2 || (me.out_off & 3)) && me.samples != 0) == 0) {
-        if (max_samples <= kI24MaxSamples) stereo_walk<true>(rows, tile, stage16, dq, bytes, out_i16, out_f32, me, max_slices);
-        else stereo_walk<false>(rows, tile, stage16, dq, bytes, out_i16, out_f32, me, max_slices);
+        if (max_samples <= kI24MaxSamples) stereo_walk<true>(rows, stage16, dq, bytes, out_i16, out_f32, me, max_slices);
+        else stereo_walk<false>(rows, stage16, dq, bytes, out_i16, out_f32, me, max_slices);
         return;
     }
 
