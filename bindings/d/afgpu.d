@@ -58,6 +58,8 @@ int afg_mp3_transform_hip(const(afg_mp3_plan)* plan, const(float)* d_coef, const
 // ---- Vorbis (replaces stb_vorbis2.d:2526-2527 + :2606-2657 + :3927-3952) ---------------------
 struct afg_vorbis_plan;
 enum AFG_VORBIS_LONG = 1u, AFG_VORBIS_PREV = 2u, AFG_VORBIS_NEXT = 4u;
+/// optional, long packets: only the first e eighths of the spectrum can be nonzero (residue end, stb_vorbis2.d:1586-1600)
+uint AFG_VORBIS_NZ_EIGHTHS(uint e) { return (e + 1u) << 4; }
 
 int afg_vorbis_plan_create(afg_vorbis_plan** plan, uint n_streams, const(uint)* packets,
                            const(ubyte)* channels, const(ushort)* blocksize0,
