@@ -13,15 +13,11 @@
 // Integer results are bit-exact (int arithmetic wraps exactly as in D).
 #include "afg_common.h"
 
-#ifndef AFG_QOA_STEP
-#define AFG_QOA_STEP 8
-#endif
-
 namespace {
 
 constexpr int kSliceLen = 20;
 constexpr int kFramesPerWave = 32;
-constexpr int kStepSlices = AFG_QOA_STEP;                       // slices fetched per channel per refill
+constexpr int kStepSlices = 8;                       // slices fetched per channel per step
 constexpr int kInRow = kStepSlices * 2 + 1;          // 64-bit words per tile row (+1 pad)
 constexpr int kFlushSlices = 4;                      // all-stereo path: slices staged per row before a flush (4 x 160 B = five full 128-byte lines)
 constexpr int kRowPairs = kFlushSlices * kSliceLen;  // (L,R) pairs per staged row
