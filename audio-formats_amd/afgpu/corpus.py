@@ -660,6 +660,33 @@ class Workload:
     def alg_bytes(self):
         return sum(p.alg_bytes for p in self.parts)
 
+    def step_side_by_side(self, stream, lanes, side=None, events=None, order=None):
+        """One launch of every part, part i on lanes[i % len(lanes)]: forked from `stream`, joined back into it.  The
+        throughput kernels have different bottlenecks (MP3 issue, Vorbis / FLAC their access patterns); side by side they
+        fill each other's gaps.  events as in step(): recorded on the stream each part runs on (overlapped spans)."""
+        import torch
+        fork = torch.cuda.Event()
+        fork.record(stream)
+        idx = list(range(len(self.parts))) if order is None else list(order)
+        for n, i in enumerate(idx):
+            p, s = self.parts[i], lanes[n % len(lanes)]
+            s.wait_event(fork)
+            if events is not None:
+                events[i][0].record(s)
+            tail = side is not None and getattr(p, "overlap", False)
+            if tail:
+                p.launch(s, side)
+                j = torch.cuda.Event()
+                j.record(side)
+                s.wait_event(j)
+            else:
+                p.launch(s)
+            if events is not None:
+                events[i][1].record(s)
+            done = torch.cuda.Event()
+            done.record(s)
+            stream.wait_event(done)
+
     def step(self, stream, events=None, side=None):
         """One launch of every part.  events: optional list of (start, end) torch events per part, recorded on the
         stream the part is launched on.  side: optional second stream; parts marked `overlap` (the CELT part of the
