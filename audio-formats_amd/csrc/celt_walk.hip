@@ -125,6 +125,50 @@ __device__ __forceinline__ void frame_fft_pfa(cpx *z, const float (&xa)[15], con
     __builtin_amdgcn_wave_barrier();
 }
 
+// The hot geometry (960 samples, one block): levels 4-5 of fft_calc (dopus.d:1596-1606) and the post-rotation of imdct15_half
+// (:1629-1636) in ONE pass over z.  Outputs n0 + 120 q (q = 0..3) of the radix-4 butterfly n0 are the post-rotation partners
+// of outputs (119 - n0) + 120 (3 - q) -- the partners' indices add up to 479 -- so a lane that runs the butterflies p and
+// 119 - p holds both ends of every pair: the rotation happens in registers, z is read once and written once (frame_rest: two
+// passes, 30 more LDS reads and 15 more writes per lane and channel).  60 butterfly pairs per channel on 32 lanes.
+__device__ __forceinline__ void last_pass_960(cpx *z, const float *ltab, float scale, int l)
+{
+    const cpx *ex4 = (const cpx *)(ltab + ex_off(4)), *ex5 = (const cpx *)(ltab + ex_off(5));
+    const cpx *tw = (const cpx *)(ltab + tw_off(6));
+    auto bfly = [&](cpx (&v)[4], int n0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = z[n0 + 120 * q];
+        const cpx e4 = ex4[n0], e5a = ex5[n0], e5b = ex5[n0 + 120];
+        cpx t, l0;
+        t = cmul(v[1], e4); l0 = v[0]; v[1] = cpx{ l0.re - t.re, l0.im - t.im }; v[0] = cpx{ l0.re + t.re, l0.im + t.im };
+        t = cmul(v[3], e4); l0 = v[2]; v[3] = cpx{ l0.re - t.re, l0.im - t.im }; v[2] = cpx{ l0.re + t.re, l0.im + t.im };
+        t = cmul(v[2], e5a); l0 = v[0]; v[2] = cpx{ l0.re - t.re, l0.im - t.im }; v[0] = cpx{ l0.re + t.re, l0.im + t.im };
+        t = cmul(v[3], e5b); l0 = v[1]; v[3] = cpx{ l0.re - t.re, l0.im - t.im }; v[1] = cpx{ l0.re + t.re, l0.im + t.im };
+    };
+    auto rot = [&](cpx za, cpx zb, int a, int b) {             // a < 240 <= b, a + b = 479
+        const cpx ta = tw[a], tc = tw[b];
+        const float r0 = za.im * ta.im - za.re * ta.re;
+        const float i1 = za.im * ta.re + za.re * ta.im;
+        const float r1 = zb.im * tc.im - zb.re * tc.re;
+        const float i0 = zb.im * tc.re + zb.re * tc.im;
+        z[a] = cpx{ scale * r0, scale * i0 };
+        z[b] = cpx{ scale * r1, scale * i1 };
+    };
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int p = l + 32 * u;
+        if (p < 60) {
+            cpx A[4], B[4];
+            bfly(A, p);
+            bfly(B, 119 - p);
+            rot(A[0], B[3], p, 479 - p);
+            rot(A[1], B[2], p + 120, 359 - p);
+            rot(B[1], A[2], 239 - p, p + 240);
+            rot(B[0], A[3], 119 - p, p + 360);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // load_inputs of celt_core.h for the hot geometry (960 samples, one block): two base pointers per lane and compile-time
 // element offsets, so that the 30 loads carry their offsets as immediates instead of a 64-bit address each
 __device__ __forceinline__ void load_inputs_960(float (&xa)[15], float (&xb)[15], const float *__restrict__ coeffs,
@@ -456,7 +500,12 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
                     load_inputs(xa, xb, coeffs, fr_next, gn, l);
                 }
             }
-            frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+            if (K960) {
+                radix_pass<3>(z, l, 32, 1, ltab, tb, true);
+                last_pass_960(z, ltab, fr.imdct_scale, l);
+            } else {
+                frame_rest(z, fr, g, ltab, lwin, tb, l, act);
+            }
             if (act) {                                       // vector_fmul_window of block 0
                 float *d = buf + 1024;
                 float va[2], vb[2];

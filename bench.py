@@ -55,8 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--c5-wave-files", type=int, default=0, help="files per resident wave of --config c5 (0 = the corpus default)")
     ap.add_argument("--only", default="", help="development: restrict --config c5 to these codecs (comma list)")
     ap.add_argument("--no-others", action="store_true",
-                    help="skip `other_workloads` (the C5 corpus, dense CELT, QOA and the end-to-end batches, each in a child process "
-                         "after the headline measurement; only at N = 1 with the default config)")
+                    help="skip `other_workloads` (the side-by-side step; the C5 corpus, dense CELT, QOA and the end-to-end batches, each in "
+                         "a child process after the headline measurement; only at N = 1 with the default config)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: ranks beyond the visible devices share them (rank % devices); the line says so")
     return ap.parse_args(argv)
@@ -470,7 +470,7 @@ def run_rank(args, world, rank, local_rank):
             # the same step with its kernels side by side on three streams, the persistent ones (MP3, Vorbis) launched first
             # and FLAC's grid filling in behind them: not the line's `value` -- there every kernel has the device to itself,
             # which is what a per-kernel roofline needs -- but what a caller gets who launches the three batches together
-            if len(wl.parts) == 3:
+            if len(wl.parts) == 3 and not args.no_others:
                 lanes = [torch.cuda.Stream(device=dev) for _ in wl.parts]
                 order = sorted(range(len(wl.parts)), key=lambda i: {"vorbis": 0, "mp3": 1}.get(wl.parts[i].name, 2))
                 n_sbs = max(3, min(args.steps, 10))

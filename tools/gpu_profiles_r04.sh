@@ -23,6 +23,7 @@ PY
 )
 bash tools/pmc_collect.sh r04_pmc_flac_restore1_kernel "flac_restore1_kernel" bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
 unset AFG_PMC_FETCH_FACTOR AFG_PMC_WRITE_FACTOR AFG_PMC_DISPATCHES_PER_LAUNCH
+bash tools/pmc_collect.sh r04_pmc_qoa_decode_kernel qoa_decode_kernel tools/bench_codecs.py --codec qoa --steps 3 > /dev/null
 cp gpurun_out/calib_flac/calib.json gpurun_out/r04_prof/r04_pmc_calib_flac.json 2>/dev/null
 head -12 gpurun_out/r04_prof/r04_kernel_stats.csv | cut -c1-160
-for k in mp3_tolerance_kernel vorbis_walk_kernel flac_restore1_kernel; do echo "== $k"; grep -E "hbm_bytes|valu_instructions|lds_instructions|wait_any|active_inst_valu_over|wait_inst_any" gpurun_out/r04_pmc_$k/derived.txt; done
+for k in mp3_tolerance_kernel vorbis_walk_kernel flac_restore1_kernel qoa_decode_kernel; do echo "== $k"; grep -E "hbm_bytes|valu_instructions|lds_instructions|wait_any|active_inst_valu_over|wait_inst_any" gpurun_out/r04_pmc_$k/derived.txt; done
