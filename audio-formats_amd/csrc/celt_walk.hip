@@ -130,7 +130,10 @@ __device__ __forceinline__ void frame_fft_pfa(cpx *z, const float (&xa)[15], con
 // of outputs (119 - n0) + 120 (3 - q) -- the partners' indices add up to 479 -- so a lane that runs the butterflies p and
 // 119 - p holds both ends of every pair: the rotation happens in registers, z is read once and written once (frame_rest: two
 // passes, 30 more LDS reads and 15 more writes per lane and channel).  60 butterfly pairs per channel on 32 lanes.
-__device__ __forceinline__ void last_pass_960(cpx *z, const float *ltab, float scale, int l)
+// The window of block 0 (vector_fmul_window, :230-243: d[k], d[119 - k] for k < 60, d = buf + 1024) rides along: d[60 + i] is
+// output i of this pass, so the lane that produces z[p], p < 30, holds s1 of k = 59 - 2p and 58 - 2p and only fetches the two
+// values of the previous frame's tail that go with them (w4 = win[k], win[119 - k] for those two k).
+__device__ __forceinline__ void last_pass_960(cpx *z, const float *ltab, float scale, int l, float *d, const float (&w4)[4])
 {
     const cpx *ex4 = (const cpx *)(ltab + ex_off(4)), *ex5 = (const cpx *)(ltab + ex_off(5));
     const cpx *tw = (const cpx *)(ltab + tw_off(6));
@@ -160,7 +163,21 @@ __device__ __forceinline__ void last_pass_960(cpx *z, const float *ltab, float s
             cpx A[4], B[4];
             bfly(A, p);
             bfly(B, 119 - p);
-            rot(A[0], B[3], p, 479 - p);
+            if (u == 0 && p < 30) {
+                const cpx ta = tw[p], tc = tw[479 - p];
+                const cpx za = A[0], zb = B[3];
+                const float r0 = za.im * ta.im - za.re * ta.re;
+                const float i1 = za.im * ta.re + za.re * ta.im;
+                const float r1 = zb.im * tc.im - zb.re * tc.re;
+                const float i0 = zb.im * tc.re + zb.re * tc.im;
+                z[479 - p] = cpx{ scale * r1, scale * i1 };
+                const float y0 = scale * r0, y1 = scale * i0;               // d[60 + 2p], d[61 + 2p]
+                const f32x2 t = *(const f32x2 *)(d + 58 - 2 * p);           // d[k2], d[k1]: the previous frame's tail
+                *(f32x2 *)(d + 58 - 2 * p) = f32x2{ t.x * w4[3] - y1 * w4[2], t.y * w4[1] - y0 * w4[0] };
+                z[p] = cpx{ t.y * w4[0] + y0 * w4[1], t.x * w4[2] + y1 * w4[3] };
+            } else {
+                rot(A[0], B[3], p, 479 - p);
+            }
             rot(A[1], B[2], p + 120, 359 - p);
             rot(B[1], A[2], 239 - p, p + 240);
             rot(B[0], A[3], 119 - p, p + 360);
@@ -466,6 +483,11 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             wi[u] = lwin[k];
             wj[u] = lwin[119 - k];
         }
+        float w960[4];                                       // ... and in last_pass_960's mapping (k = 59 - 2l, 58 - 2l)
+        {
+            const int k1 = 59 - 2 * min(l, 29), k2 = k1 - 1;
+            w960[0] = lwin[k1]; w960[1] = lwin[119 - k1]; w960[2] = lwin[k2]; w960[3] = lwin[119 - k2];
+        }
         __builtin_amdgcn_wave_barrier();
 
         afg_celt_frame fr = recs[my_base + a], fr_next = fr;
@@ -502,11 +524,11 @@ __global__ __launch_bounds__(64 * kWWaves) void celt_walk_kernel(
             }
             if (K960) {
                 radix_pass<3>(z, l, 32, 1, ltab, tb, true);
-                last_pass_960(z, ltab, fr.imdct_scale, l);
+                last_pass_960(z, ltab, fr.imdct_scale, l, buf + 1024, w960);
             } else {
                 frame_rest(z, fr, g, ltab, lwin, tb, l, act);
             }
-            if (act) {                                       // vector_fmul_window of block 0
+            if (!K960 && act) {                              // vector_fmul_window of block 0 (K960: inside last_pass_960)
                 float *d = buf + 1024;
                 float va[2], vb[2];
 #pragma unroll
