@@ -14,6 +14,9 @@
  *   - d_* pointers are device (HIP) pointers, everything else is host memory
  *   - hip_stream is a hipStream_t passed as void* (NULL = default stream);
  *     *_hip entries only enqueue work, they never synchronise
+ *   - the persistent kernels (Vorbis, CELT) draw their work from per-launch counters kept in rings: 32 launches of
+ *     one Vorbis plan, 64 CELT launches per device may be in flight at once on different streams (launches on ONE
+ *     stream run in order and cannot collide)
  *   - the library fails loudly (AFG_ERR_NO_DEVICE) when no gfx950 device or
  *     no device code is available: there is no CPU fallback in the product.
  */
