@@ -154,12 +154,48 @@ bool flac_residual(BitReader &br, uint32_t block_size, uint32_t order, int32_t *
         const bool escape = kSpecEscape && ((method == 0 && k == 15) || (method == 1 && k == 31));
         if (br.fail) return false;
         if (!escape) {
+            // The hot loop of the whole front-end.  Fast path: a 64-bit big-endian window `w` whose top `avail` bits are the
+            // stream at `pos` -- the unary part is a count of leading zeros, the k low bits a shift, and the window moves on
+            // by a shift (the dependent chain per symbol is clz + shift, not load + swap + clz); it is topped up from
+            // memory whenever eight whole bytes are left at the position.  Anything else -- a symbol that does not end
+            // inside the window (a run of 50 zeros), the last bytes of the buffer -- takes the bit reader.  Same values.
+            const size_t bytes = br.nbits >> 3;
+            size_t pos = br.pos;
+            uint64_t w = 0;
+            unsigned avail = 0;
             for (uint32_t j = 0; j < count; j++) {
-                uint32_t q;
-                if (!br.unary(q)) return false;
-                uint32_t v = (q << k) | (uint32_t)br.bits(k);
+                if (avail < 48) {
+                    const size_t bp = pos >> 3;
+                    const unsigned s = (unsigned)(pos & 7);
+                    w = 0;
+                    avail = 0;
+                    if (bp + 8 <= bytes) {
+                        uint64_t x;
+                        std::memcpy(&x, br.p + bp, 8);
+                        w = __builtin_bswap64(x) << s;
+                        avail = 64 - s;
+                    }
+                }
+                uint32_t q, low;
+                const unsigned lz = w ? (unsigned)__builtin_clzll(w) : 64u;
+                const unsigned need = lz + 1 + k;
+                if (need <= avail) {
+                    q = lz;
+                    low = k ? (uint32_t)((w << (lz + 1)) >> (64 - k)) : 0u;     // (lz + 1 <= 63 when k > 0)
+                    w = need < 64 ? w << need : 0;
+                    avail -= need;
+                    pos += need;
+                } else {
+                    br.pos = pos;
+                    if (!br.unary(q)) return false;
+                    low = (uint32_t)br.bits(k);
+                    pos = br.pos;
+                    avail = 0;
+                }
+                const uint32_t v = (q << k) | low;
                 dst[i++] = (int32_t)((v >> 1) ^ (~(v & 1) + 1));   // zig-zag, :1224
             }
+            br.pos = pos;
         } else {
             const unsigned raw = (unsigned)br.bits(5);
             for (uint32_t j = 0; j < count; j++) dst[i++] = (int32_t)br.sbits(raw);

@@ -177,3 +177,35 @@ def test_stream_without_device_fails_loudly():
     assert s.isError() and s.errorMessage() == "Decoder initialization failed"    # internals.d:18
     with pytest.raises(afgpu.AfgError):
         afgpu.batch_decode([data])
+
+
+@pytest.mark.parametrize("case", ["spikes", "silence", "noise24", "noise24_rice2", "short_tail"])
+def test_rice_decoder_extremes(case):
+    """the residual loop's windowed fast path (host/afg_flac_front.cpp) against the writer's records where it has to hand over
+    to the bit reader: unary runs far longer than a 64-bit window (rare spikes under a Rice parameter chosen for silence),
+    k = 0 throughout, 5-bit parameters with 20+ low bits, and symbols in the last eight bytes of the file"""
+    rng = np.random.default_rng(11)
+    kw = {}
+    if case == "spikes":
+        n, bps = 4096 * 2, 16
+        pcm = np.zeros((n, 2), np.int64)
+        at = rng.integers(20, n - 20, 24)
+        pcm[at, rng.integers(0, 2, 24)] = rng.integers(-30000, 30000, 24)
+    elif case == "silence":
+        n, bps = 4096 + 9, 16
+        pcm = np.zeros((n, 2), np.int64)
+        pcm[:, 1] = 1
+    elif case.startswith("noise24"):
+        n, bps = 1152 * 2 + 5, 24
+        pcm = rng.integers(-(1 << 23), 1 << 23, (n, 2))
+        kw["rice2"] = case.endswith("rice2")
+    else:
+        n, bps = 4096 + 3, 16
+        pcm = make_pcm(n, 2, 16, 5)
+    data, want = fb.encode_file(pcm, bps, 4096 if bps == 16 else 1152, orders=(8, 2), **kw)
+    parsed = afgpu.flac_parse(data)
+    check_records(parsed, want)
+    # ... and the same file with nothing behind its last frame byte but also with padding behind it: the fast path's
+    # "eight whole bytes left" test must not change a value
+    parsed2 = afgpu.flac_parse(data + bytes(16))
+    np.testing.assert_array_equal(parsed2[3][:len(parsed[3])], parsed[3])
