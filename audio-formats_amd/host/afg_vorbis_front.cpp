@@ -647,7 +647,18 @@ bool decode_packet(const uint8_t *d, const Demux &dm, const Packet &pk, const Se
     const Mapping &map = st.mappings[(size_t)mode.mapping];
     // a channel owns n floats although its spectrum is n/2: a type-2 residue on a single channel is bounded by 2 * n/2
     // (:1594) and may write into the upper half, as it does in the reference's blocksize-sized channel buffers
-    sc.spec.assign((size_t)C * (size_t)n, 0.0f);
+    // Only the n/2 values of a channel's spectrum are ever read; the upper half exists for that one residue shape, which
+    // needs it defined (it accumulates): the whole slot is cleared only when the mapping has such a submap.
+    if (sc.spec.size() < (size_t)C * (size_t)n) sc.spec.resize((size_t)C * (size_t)n);
+    {
+        bool upper = false;
+        int per_submap[16] = { 0 };
+        for (int j = 0; j < C; j++) per_submap[map.mux[j]]++;
+        for (int sm = 0; sm < map.submaps; sm++)
+            upper = upper || (per_submap[sm] == 1 && st.residues[map.residue_of[sm]].type == 2);
+        const size_t clear = upper ? (size_t)n : (size_t)n2;
+        for (int j = 0; j < C; j++) std::memset(sc.spec.data() + (size_t)j * (size_t)n, 0, clear * sizeof(float));
+    }
     sc.y.assign((size_t)C * 256, 0);
     bool zero[256], really_zero[256];
 
