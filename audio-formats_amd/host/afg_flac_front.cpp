@@ -130,6 +130,10 @@ bool read_utf8(BitReader &br, uint64_t &out)
 }
 
 // residual of one subframe into dst[order .. block_size), drflac.d:1279-1328 (+ Rice :1166-1224)
+// (two builds of this one function, chosen once at load: lzcnt / shlx / movbe shorten the loop by a quarter)
+#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("default", "arch=x86-64-v3")))
+#endif
 bool flac_residual(BitReader &br, uint32_t block_size, uint32_t order, int32_t *dst)
 {
     const unsigned method = (unsigned)br.bits(2);
