@@ -247,17 +247,25 @@ bool build_decoder(Book &b)
         if (!bu.place(root, l, s)) return false;             // over-subscribed
         used++;
     }
-    // table over the next 10 bits: a symbol (word <= 10 bits) or the tree node reached after 10 branches
-    for (uint32_t key = 0; key < (1u << kFast); key++) {
-        int32_t node = root, out = -1;
-        for (int bit = 0; bit < kFast; bit++) {
-            const int32_t c = b.tree[(size_t)node].child[(key >> bit) & 1];
-            if (c == kNone) { out = -1; node = -1; break; }
-            if (c < 0) { out = -(c + 1); node = -1; break; }
-            node = c;
+    // table over the next 10 bits: a symbol (word <= 10 bits) or the tree node reached after 10 branches.  One walk of the
+    // tree's top ten levels: whatever ends a path of d branches (a leaf, a missing child) owns every key whose low d bits are
+    // that path -- 2^(10-d) entries, 2^d apart -- and a node at depth 10 owns the one key that spells its path.
+    {
+        struct Item { int32_t node; uint32_t path; int depth; };
+        Item stack[2 * kFast + 2];
+        int top = 0;
+        stack[top++] = Item{ root, 0u, 0 };
+        while (top) {
+            const Item it = stack[--top];
+            if (it.depth == kFast) { b.fast[it.path] = -(it.node + 2); continue; }
+            for (int bit = 1; bit >= 0; bit--) {
+                const int32_t c = b.tree[(size_t)it.node].child[bit];
+                const uint32_t path = it.path | ((uint32_t)bit << it.depth);
+                if (c >= 0 && c != kNone) { stack[top++] = Item{ c, path, it.depth + 1 }; continue; }
+                const int32_t out = c == kNone ? -1 : -(c + 1);
+                for (uint32_t key = path; key < (1u << kFast); key += 2u << it.depth) b.fast[key] = out;
+            }
         }
-        if (node >= 0) out = -(node + 2);
-        b.fast[key] = out;
     }
     b.usable = used > 0;
     return true;
