@@ -71,7 +71,12 @@ for r in range(rounds):
             d = damage(base, 42)
             w = want_flac(d)
         else:
-            base = vb.make_file(int(rng.integers(0, 1 << 20)), n_packets=30, force_long_only=bool(rng.integers(0, 2)))
+            base = None
+            while base is None:                                  # (the writer's random set-up has dead ends for about one seed in 250)
+                try:
+                    base = vb.make_file(int(rng.integers(0, 1 << 20)), n_packets=30, force_long_only=bool(rng.integers(0, 2)))
+                except ValueError:
+                    pass
             d = damage(base, len(base) // 3)
             w = want_ogg(d)
         files.append(d); wants.append(w); kinds.append(kind)
