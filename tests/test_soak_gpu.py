@@ -1,0 +1,25 @@
+"""A short run of tools/soak_damaged.py: randomly damaged QOA / FLAC / Ogg Vorbis files through afg_batch_decode, against the
+oracle's decode of the same damaged bytes (QOA / FLAC bit for bit, Vorbis within tolerance), in both numeric modes."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+def soak(seed):
+    import soak_damaged
+    ok, rejected, bad = soak_damaged.run(4, seed)
+    assert bad == 0 and ok >= 20
+
+
+def test_damaged_files_exact_mode(gpu):
+    soak(7)
+
+
+@pytest.mark.numeric_tolerance
+def test_damaged_files_default_mode(gpu):
+    soak(8)

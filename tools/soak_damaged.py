@@ -14,7 +14,6 @@ import vorbis_bitstream as vb
 from test_flac_frontend import make_pcm
 from test_stream_gpu import qoa_file
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(2024)
 
 
@@ -56,49 +55,59 @@ def want_ogg(data):
     return None if rec is None else oraclelib.vorbis_file_pcm(rec)
 
 
-bad = 0
-n_ok = n_rejected = 0
-for r in range(rounds):
-    files, wants, kinds = [], [], []
-    for k in range(12):
-        kind = ("qoa", "flac", "ogg")[k % 3]
-        if kind == "qoa":
-            base, _ = qoa_file(int(rng.integers(3000, 30000)), int(rng.integers(1, 3)), 44100, int(rng.integers(0, 1 << 30)))
-            d = damage(base, 8)
-            w = want_qoa(d)
-        elif kind == "flac":
-            base, _ = fb.encode_file(make_pcm(int(rng.integers(2000, 20000)), 2, 16, int(rng.integers(0, 1 << 30))), 16, 4096, orders=(8, 12, 2))
-            d = damage(base, 42)
-            w = want_flac(d)
-        else:
-            base = None
-            while base is None:                                  # (the writer's random set-up has dead ends for about one seed in 250)
-                try:
-                    base = vb.make_file(int(rng.integers(0, 1 << 20)), n_packets=30, force_long_only=bool(rng.integers(0, 2)))
-                except ValueError:
-                    pass
-            d = damage(base, len(base) // 3)
-            w = want_ogg(d)
-        files.append(d); wants.append(w); kinds.append(kind)
-    res = afgpu.batch_decode(files, n_threads=4)
-    for kind, out, w, d in zip(kinds, res, wants, files):
-        if w is None or len(w) == 0:
-            n_rejected += 1
-            if out["status"] == 0 and out["frames"] > 0 and kind != "ogg":
-                print("product decoded what the oracle rejects", kind, out["frames"]); bad += 1
-            continue
-        if out["status"] != 0:
-            if kind == "ogg":                                    # (the product ends a stream at an inconsistent window)
+def run(rounds, seed=2024):
+    """-> (decoded, rejected, disagreements)"""
+    global rng
+    rng = np.random.default_rng(seed)
+    bad = 0
+    n_ok = n_rejected = 0
+    for r in range(rounds):
+        files, wants, kinds = [], [], []
+        for k in range(12):
+            kind = ("qoa", "flac", "ogg")[k % 3]
+            if kind == "qoa":
+                base, _ = qoa_file(int(rng.integers(3000, 30000)), int(rng.integers(1, 3)), 44100, int(rng.integers(0, 1 << 30)))
+                d = damage(base, 8)
+                w = want_qoa(d)
+            elif kind == "flac":
+                base, _ = fb.encode_file(make_pcm(int(rng.integers(2000, 20000)), 2, 16, int(rng.integers(0, 1 << 30))), 16, 4096, orders=(8, 12, 2))
+                d = damage(base, 42)
+                w = want_flac(d)
+            else:
+                base = None
+                while base is None:                                  # (the writer's random set-up has dead ends for about one seed in 250)
+                    try:
+                        base = vb.make_file(int(rng.integers(0, 1 << 20)), n_packets=30, force_long_only=bool(rng.integers(0, 2)))
+                    except ValueError:
+                        pass
+                d = damage(base, len(base) // 3)
+                w = want_ogg(d)
+            files.append(d); wants.append(w); kinds.append(kind)
+        res = afgpu.batch_decode(files, n_threads=4)
+        for kind, out, w, d in zip(kinds, res, wants, files):
+            if w is None or len(w) == 0:
+                n_rejected += 1
+                if out["status"] == 0 and out["frames"] > 0 and kind != "ogg":
+                    print("product decoded what the oracle rejects", kind, out["frames"]); bad += 1
                 continue
-            print("product rejected", kind, out["message"]); bad += 1; continue
-        n_ok += 1
-        got = out["pcm"]
-        n = min(len(got), len(w))
-        if kind == "ogg":
-            if n and float(np.sqrt(np.mean((got[:n].astype(np.float64) - w[:n]) ** 2))) > 1e-5 * max(1.0, float(np.abs(w[:n]).max())):
-                print("vorbis mismatch", len(got), len(w)); bad += 1
-        else:
-            if len(got) != len(w) or not np.array_equal(got.view(np.uint32), w.astype(np.float32).view(np.uint32)):
-                print(kind, "mismatch", len(got), len(w)); bad += 1
-print("rounds", rounds, "decoded", n_ok, "rejected", n_rejected, "bad", bad)
-sys.exit(1 if bad else 0)
+            if out["status"] != 0:
+                if kind == "ogg":                                    # (the product ends a stream at an inconsistent window, DESIGN 4)
+                    continue
+                print("product rejected", kind, out["message"]); bad += 1; continue
+            n_ok += 1
+            got = out["pcm"]
+            n = min(len(got), len(w))
+            if kind == "ogg":
+                if n and float(np.sqrt(np.mean((got[:n].astype(np.float64) - w[:n]) ** 2))) > 1e-5 * max(1.0, float(np.abs(w[:n]).max())):
+                    print("vorbis mismatch", len(got), len(w)); bad += 1
+            else:
+                if len(got) != len(w) or not np.array_equal(got.view(np.uint32), w.astype(np.float32).view(np.uint32)):
+                    print(kind, "mismatch", len(got), len(w)); bad += 1
+    return n_ok, n_rejected, bad
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    n_ok, n_rejected, bad = run(rounds)
+    print("rounds", rounds, "decoded", n_ok, "rejected", n_rejected, "bad", bad)
+    sys.exit(1 if bad else 0)
