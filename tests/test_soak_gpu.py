@@ -1,5 +1,6 @@
 """A short run of tools/soak_damaged.py: randomly damaged QOA / FLAC / Ogg Vorbis files through afg_batch_decode, against the
-oracle's decode of the same damaged bytes (QOA / FLAC bit for bit, Vorbis within tolerance), in both numeric modes."""
+oracle's decode of the same damaged bytes (QOA / FLAC bit for bit, MP3 / Vorbis within tolerance, Opus within one int16 step), in both
+numeric modes."""
 import os
 import sys
 

@@ -1,4 +1,4 @@
-"""development soak (GPU): randomly damaged QOA / FLAC / Ogg Vorbis files through afg_batch_decode against the oracle's
+"""development soak (GPU): randomly damaged QOA / FLAC / Ogg Vorbis / MP3 / Ogg Opus files through afg_batch_decode against the oracle's
 decode of the same damaged bytes -- statuses, lengths and samples (QOA / FLAC bit for bit, Vorbis within tolerance).
 usage: python tools/soak_damaged.py [rounds]"""
 import os
@@ -11,6 +11,8 @@ import afgpu
 import oraclelib
 import flac_bitstream as fb
 import vorbis_bitstream as vb
+import mp3_bitstream as mb
+import opus_bitstream as ob
 from test_flac_frontend import make_pcm
 from test_stream_gpu import qoa_file
 
@@ -55,6 +57,16 @@ def want_ogg(data):
     return None if rec is None else oraclelib.vorbis_file_pcm(rec)
 
 
+def want_mp3(data):
+    rec = oraclelib.mp3_decode_file(data)
+    return None if rec is None else rec["pcm"].reshape(-1, rec["channels"])
+
+
+def want_opus(data):
+    rec = oraclelib.opus_decode_file(data)
+    return None if isinstance(rec, int) or rec.get("error") else oraclelib.opus_file_pcm(rec)
+
+
 def run(rounds, seed=2024):
     """-> (decoded, rejected, disagreements)"""
     global rng
@@ -63,8 +75,8 @@ def run(rounds, seed=2024):
     n_ok = n_rejected = 0
     for r in range(rounds):
         files, wants, kinds = [], [], []
-        for k in range(12):
-            kind = ("qoa", "flac", "ogg")[k % 3]
+        for k in range(15):
+            kind = ("qoa", "flac", "ogg", "mp3", "opus")[k % 5]
             if kind == "qoa":
                 base, _ = qoa_file(int(rng.integers(3000, 30000)), int(rng.integers(1, 3)), 44100, int(rng.integers(0, 1 << 30)))
                 d = damage(base, 8)
@@ -73,6 +85,14 @@ def run(rounds, seed=2024):
                 base, _ = fb.encode_file(make_pcm(int(rng.integers(2000, 20000)), 2, 16, int(rng.integers(0, 1 << 30))), 16, 4096, orders=(8, 12, 2))
                 d = damage(base, 42)
                 w = want_flac(d)
+            elif kind == "mp3":
+                base = mb.make_file(int(rng.integers(0, 1 << 20)), n_frames=int(rng.integers(8, 40)), mode=("stereo", "ms", "mono")[int(rng.integers(0, 3))])[0]
+                d = damage(base, 4)
+                w = want_mp3(d)
+            elif kind == "opus":
+                base = ob.random_celt_file(rng, int(rng.integers(1, 3)), int(rng.integers(10, 40)), comments=(b"R128_TRACK_GAIN=-20000",))[0]
+                d = damage(base, len(base) // 2)
+                w = want_opus(d)
             else:
                 base = None
                 while base is None:                                  # (the writer's random set-up has dead ends for about one seed in 250)
@@ -87,19 +107,27 @@ def run(rounds, seed=2024):
         for kind, out, w, d in zip(kinds, res, wants, files):
             if w is None or len(w) == 0:
                 n_rejected += 1
-                if out["status"] == 0 and out["frames"] > 0 and kind != "ogg":
+                if out["status"] == 0 and out["frames"] > 0 and kind in ("qoa", "flac"):
                     print("product decoded what the oracle rejects", kind, out["frames"]); bad += 1
                 continue
             if out["status"] != 0:
-                if kind == "ogg":                                    # (the product ends a stream at an inconsistent window)
+                if kind in ("ogg", "opus"):                          # (the product ends a stream at an inconsistent window)
                     continue
                 print("product rejected", kind, out["message"]); bad += 1; continue
             n_ok += 1
             got = out["pcm"]
             n = min(len(got), len(w))
-            if kind == "ogg":
-                if n and float(np.sqrt(np.mean((got[:n].astype(np.float64) - w[:n]) ** 2))) > 1e-5 * max(1.0, float(np.abs(w[:n]).max())):
-                    print("vorbis mismatch", len(got), len(w)); bad += 1
+            diff = got[:n].astype(np.float64) - w[:n]
+            if kind == "opus":
+                # the decoder's int16 / 32767: the same values, or (default mode) a rare neighbour
+                if len(got) != len(w) or (n and np.abs(diff).max() > 1 / 32767 + 1.2e-7):
+                    print("opus mismatch", len(got), len(w), float(np.abs(diff).max()) if n else None); bad += 1
+            elif kind in ("ogg", "mp3"):
+                if kind == "mp3" and len(got) != len(w):
+                    print("mp3 length", len(got), len(w)); bad += 1
+                rms = float(np.sqrt(np.mean(diff ** 2))) if n else 0.0
+                if rms > 1e-5 * max(1.0, float(np.sqrt(np.mean(w[:n].astype(np.float64) ** 2))) if n else 1.0):
+                    print(kind, "mismatch", len(got), len(w), rms); bad += 1
             else:
                 if len(got) != len(w) or not np.array_equal(got.view(np.uint32), w.astype(np.float32).view(np.uint32)):
                     print(kind, "mismatch", len(got), len(w)); bad += 1
