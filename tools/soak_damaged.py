@@ -14,7 +14,7 @@ import vorbis_bitstream as vb
 import mp3_bitstream as mb
 import opus_bitstream as ob
 from test_flac_frontend import make_pcm
-from test_stream_gpu import qoa_file
+from test_stream_gpu import qoa_file, read_all
 
 rng = np.random.default_rng(2024)
 
@@ -67,7 +67,7 @@ def want_opus(data):
     return None if isinstance(rec, int) or rec.get("error") else oraclelib.opus_file_pcm(rec)
 
 
-def run(rounds, seed=2024):
+def run(rounds, seed=2024, streams=True):
     """-> (decoded, rejected, disagreements)"""
     global rng
     rng = np.random.default_rng(seed)
@@ -116,6 +116,20 @@ def run(rounds, seed=2024):
                 print("product rejected", kind, out["message"]); bad += 1; continue
             n_ok += 1
             got = out["pcm"]
+            if streams and out["frames"] > 0:
+                # the same bytes pulled through the AudioStream surface in odd-sized reads: chunked decoding must deliver the
+                # batch path's samples bit for bit
+                st = afgpu.AudioStream()
+                st.openFromMemory(d)
+                if st.isError():
+                    print("stream refuses what the batch decodes", kind, st.errorMessage()); bad += 1
+                else:
+                    pulled = read_all(st, out["channels"], int(rng.integers(300, 5000)))
+                    m = min(len(pulled), len(got))
+                    # (a stream that hits damage reports the error after delivering what came before it)
+                    if (len(pulled) != len(got) and not st.isError()) or not np.array_equal(pulled[:m].view(np.uint32), got[:m].view(np.uint32)):
+                        print("stream != batch", kind, len(pulled), len(got), st.isError()); bad += 1
+                st.cleanUp()
             n = min(len(got), len(w))
             diff = got[:n].astype(np.float64) - w[:n]
             if kind == "opus":
