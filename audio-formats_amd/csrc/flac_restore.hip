@@ -23,10 +23,7 @@
 
 namespace {
 
-#ifndef AFG_FLAC_TILE
-#define AFG_FLAC_TILE 32
-#endif
-constexpr int kT = AFG_FLAC_TILE;      // samples per tile step (16 or 32)
+constexpr int kT = 64;                 // samples per tile step (round 5; 32 until then: piece_off keeps that layout too)
 constexpr int kRowWords = 2 * kT;      // LDS row: [channel A | channel B], 2*kT/4 pieces of 4 words
 constexpr int kPieces = kT / 4;        // 16-byte pieces per channel chunk
 constexpr int kLoads = 2 * kPieces;    // 16-byte load instructions per tile step
@@ -51,10 +48,11 @@ __device__ __forceinline__ int wave_max(int v)
 // word offset of 16-byte piece `piece` (0..7) of tile row `row`
 __device__ __forceinline__ int piece_off(int row, int piece)
 {
-    // rotation making the one-row-per-lane 16-byte accesses conflict-free: row/2 for 8 pieces per
-    // row (two rows share a 256-byte bank row), row for 16 pieces per row
-    const int rot = (kT == 16) ? (row >> 1) : row;
-    return row * kRowWords + (((piece + rot) & (2 * kPieces - 1)) << 2);
+    // rotation by the row: the one-row-per-lane 16-byte accesses of the recurrence are conflict-free
+    if (kT == 32) return row * kRowWords + (((piece + row) & (2 * kPieces - 1)) << 2);
+    // 64-sample tiles: a channel chunk is a whole 256-byte bank row; rotate inside it, slot B half a row further
+    const int chunk = piece / kPieces;
+    return row * kRowWords + ((chunk * kPieces + ((piece + row + 8 * chunk) & (kPieces - 1))) << 2);
 }
 
 __device__ __forceinline__ int32_t shl32(int32_t v, unsigned sh) { return (int32_t)((uint32_t)v << (sh & 31u)); }
@@ -200,7 +198,7 @@ __device__ __forceinline__ void park_tile1(int32_t *tile, const RowMeta *meta, c
 }
 
 // decorrelate (drflac.d:2885-2941), shift, interleave, convert; 4 rows per instruction
-__device__ __forceinline__ void store_tile1(const int32_t *tile, const RowMeta *meta, const uint32_t *row_shift,
+__device__ __forceinline__ void store_tile1(const int32_t *tile, const RowMeta *meta, const uint8_t *row_shift,
                                             int32_t *__restrict__ out_i32, float *__restrict__ out_f32, int pair, int t0)
 {
     const int lane = threadIdx.x;
@@ -257,14 +255,131 @@ __device__ __forceinline__ void store_tile1(const int32_t *tile, const RowMeta *
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The common tile step (round 5).  A wavefront whose 32 frames are all stereo, hold their residual rows in one width and
+// lie within 1 GiB of each other takes every tile that is complete in all of its rows through a step without a branch:
+//   * rows and PCM go through buffer instructions -- a wave-uniform base in a descriptor, the lane's part fixed for the
+//     whole walk in one register per load, the tile's position in the scalar offset -- so neither side spends vector
+//     instructions on addresses;
+//   * the store phase is straight-line: the frame's decorrelation (drflac.d:2885-2941) is selected by masks from a
+//     32-byte row record in LDS, not by divergent branches (four rows with four assignments share a store instruction),
+//     and a store instruction takes rows i, i+8, i+16, i+24: the two rows a 32-lane LDS group reads sit in opposite
+//     halves of the bank row;
+//   * because the phase has no branch the compiler can count its eight stores, so the NEXT tile's rows -- issued before
+//     the recurrence -- are waited for after the stores (vmcnt(8)), not before them: the fetch has the recurrence and
+//     the store phase to land, where the general step (conditional stores: a counted wait is impossible, and an
+//     uncounted one would drain the stores just issued) must have it resident before its first store.
+// Everything else (other channel counts, mixed row widths, partial tiles, both outputs at once) takes the general step
+// below; the two leave the tile and the parked rows in the same state, so a walk switches between them tile by tile.
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kStoreNt = 2;            // cache policy of the PCM stores: nontemporal (the 512-byte pieces are written once)
+
+struct RowFast {                       // 32 bytes per tile row
+    uint32_t voff;                     // byte offset of the frame's PCM from the wavefront's base
+    uint32_t m_ls, m_rs, m_ms;         // 0 / ~0: the frame's channel assignment
+    uint32_t sh_a, sh_b;               // output shifts of the two channels (drflac.d:2883, :2894)
+    uint32_t in_a, in_b;               // byte offsets of the two residual rows from the wavefront's base
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    // the workgroup is one wavefront and its LDS instructions execute in order: only the compiler has to be held
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p)
+{
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, 0xffffffff, 0x00020000);
+}
+
+template <int MODE>
+__device__ __forceinline__ void load_fast(int4 (&nxt)[Loads1<MODE>::n], __amdgpu_buffer_rsrc_t rin, const RowFast *rf, int t)
+{
+    constexpr int L = MODE == 1 ? kPieces / 2 : kPieces;                     // lanes per row chunk of a fetch
+    const int lane = threadIdx.x;
+    // row chunk (64 / L) * i + lane / L: one lane-constant LDS address, the step an immediate
+    const uint32_t *mine = &rf[(lane / L) >> 1].in_a + ((lane / L) & 1);
+    const uint32_t piece = 16u * (uint32_t)(lane % L);
+#pragma unroll
+    for (int i = 0; i < Loads1<MODE>::n; i++) {
+        const uint32_t voff = mine[(32 / L) * i * (sizeof(RowFast) / 4)] + piece;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)voff, t * (MODE == 1 ? 2 : 4), 0);
+        nxt[i] = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+    }
+}
+
+template <bool F32>
+__device__ __forceinline__ void store_fast(const int32_t *tile, const RowFast *rf, __amdgpu_buffer_rsrc_t rout, int t0)
+{
+    constexpr int LPR = kT / 2, NI = kFpw / (64 / LPR);                      // lanes per row, store instructions per tile
+    const int lane = threadIdx.x, q = lane % LPR, g = lane / LPR;
+    // row NI * g + i, piece (q >> 1) + row (mod 16): one lane constant; kept opaque so that the addresses it gives are
+    // worked out again in every step (two instructions each) instead of being held in -- spilled -- registers
+    uint32_t c16 = 16u * (uint32_t)((q >> 1) + NI * g);
+    asm volatile("" : "+v"(c16));
+    const char *tb = (const char *)tile + NI * g * (kRowWords * 4) + 8 * (q & 1);
+    const RowFast *rfl = rf + NI * g;
+    // The tile's position goes into the vector offset, not the scalar one: a 16-byte store with a REGISTER scalar offset
+    // is taken by the compiler to have read its data when it issues, and the next instruction may overwrite the data
+    // registers; on this part it had not always (int32 rows at full size: the following step's address arithmetic showed
+    // up in lanes 12-15 of a row piece, a few thousand samples per launch, only under load).  Without the register the
+    // compiler spaces such a write from the store itself.
+    const uint32_t lane_off = 16u * (uint32_t)q + 8u * (uint32_t)t0;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const uint4 f = *(const uint4 *)&rfl[i];
+        const uint2 sh = *(const uint2 *)&rfl[i].sh_a;
+        const uint32_t s16 = (c16 + 16u * (uint32_t)i) & 0xf0u;
+        const char *pa = tb + i * (kRowWords * 4) + s16;
+        const int2 a = *(const int2 *)pa;
+        // slot B: eight pieces on within the (first) bank row; with 64-sample tiles in the row's second bank row
+        const int2 b = *(const int2 *)(tb + i * (kRowWords * 4) + (kT == 64 ? 256 : 0) + (s16 ^ 0x80u));
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const uint32_t av = (uint32_t)(e ? a.y : a.x), bv = (uint32_t)(e ? b.y : b.x);
+            const uint32_t x = av + bv, d = av - bv;                            // right/side :2899, left/side :2886
+            const uint32_t l0 = (f.z & x) | (~f.z & av);
+            const uint32_t r0 = (f.y & d) | (~f.y & bv);
+            const uint32_t m = (av << 1) | (bv & 1u);                           // mid/side :2911-2920
+            const uint32_t ml = (uint32_t)((int32_t)(m + bv) >> 1), mr = (uint32_t)((int32_t)(m - bv) >> 1);
+            o[2 * e] = ((f.w & ml) | (~f.w & l0)) << (sh.x & 31u);
+            o[2 * e + 1] = ((f.w & mr) | (~f.w & r0)) << (sh.y & 31u);
+        }
+        u32x4 v;
+        if (F32) {
+            const double factor = 1.0 / 2147483647.0;                           // stream.d:507
+            v.x = __float_as_uint((float)((double)(int32_t)o[0] * factor));
+            v.y = __float_as_uint((float)((double)(int32_t)o[1] * factor));
+            v.z = __float_as_uint((float)((double)(int32_t)o[2] * factor));
+            v.w = __float_as_uint((float)((double)(int32_t)o[3] * factor));
+        } else {
+            v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, rout, (int)(f.x + lane_off), 0, kStoreNt);
+    }
+}
+
 template <int MAXORD, bool WIDE, int MODE>
 __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, const RowMeta &me, bool valid,
                                             const afg_flac_subframe *__restrict__ subframes, uint32_t sf_index,
                                             const int32_t *__restrict__ res, int32_t *__restrict__ out_i32,
-                                            float *__restrict__ out_f32, int max_bs, int max_pairs, const uint32_t *row_shift)
+                                            float *__restrict__ out_f32, int max_bs, int max_pairs, const uint8_t *row_shift,
+                                            const RowFast *rf, bool fastw, int min_bs, uint64_t in_base, uint64_t out_base)
 {
     const int lane = threadIdx.x, row = lane >> 1, slot = lane & 1;
     const int my_ch = valid ? (int)(me.info & 0xff) : 0;
+    // the common step's descriptors and the lane's fixed part of every row fetch (MODE 2 -- mixed row widths -- has none)
+    constexpr bool kFastMode = MODE != 2;
+    // (bases made scalar word by word: a descriptor the compiler takes for divergent is applied in a loop over its values)
+    const __amdgpu_buffer_rsrc_t rin = uniform_rsrc((const char *)res + in_base * (MODE == 1 ? 2 : 4));
+    const __amdgpu_buffer_rsrc_t rout = uniform_rsrc(out_i32 ? (const void *)(out_i32 + out_base) : (const void *)(out_f32 + out_base));
     for (int pair = 0; pair < max_pairs; pair++) {
         int32_t c[MAXORD], h[MAXORD];
         int order = 0, shift = 0;
@@ -282,8 +397,26 @@ __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, 
         load_tile1<MODE>(nxt, meta, res, pair, 0);
         park_tile1<MODE>(tile, meta, nxt);
         __syncthreads();
-        for (int t0 = 0; t0 < max_bs; t0 += kT) {
-            if (t0 + kT < max_bs) load_tile1<MODE>(nxt, meta, res, pair, t0 + kT);   //  2 no row loads, 3 no recurrence, 4 no store phase at all)
+        int t0 = 0;
+        // the common step: tiles that are complete, with a complete successor, in every row (its own loop: what the general
+        // step keeps in registers for the whole walk does not crowd this one)
+        if (kFastMode && fastw) {
+            // (one loop per output type: with the choice inside, the compiler no longer counts the stores ahead of the wait)
+#define AFG_FLAC_FAST_WALK(F32)                                                                                        \
+            for (; t0 + 2 * kT <= min_bs; t0 += kT) {                                                                  \
+                load_fast<MODE>(nxt, rin, rf, t0 + kT);                                                                \
+                restore_tile1<MAXORD, WIDE>(tile, row, slot, t0, order, shift, u64, c, h);                             \
+                wave_sync();                                                                                           \
+                store_fast<F32>(tile, rf, rout, t0);                                                                   \
+                wave_sync();                                                                                           \
+                park_tile1<MODE>(tile, meta, nxt);                                                                     \
+                wave_sync();                                                                                           \
+            }
+            if (out_f32) { AFG_FLAC_FAST_WALK(true) } else { AFG_FLAC_FAST_WALK(false) }
+#undef AFG_FLAC_FAST_WALK
+        }
+        for (; t0 < max_bs; t0 += kT) {
+            if (t0 + kT < max_bs) load_tile1<MODE>(nxt, meta, res, pair, t0 + kT);
             if (t0 < (int)me.bs) restore_tile1<MAXORD, WIDE>(tile, row, slot, t0, order, shift, u64, c, h);
             __syncthreads();
             // make the prefetched residuals resident here: loads and stores share one in-order counter
@@ -300,18 +433,16 @@ __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, 
 
 // One kernel per (order bucket, accumulator width): a wavefront runs only in the instantiation that matches the largest
 // LPC order / widest accumulator among the subframes of its 32 frames and leaves the others at once.
-#ifndef AFG_FLAC_WAVES
-#define AFG_FLAC_WAVES 4               // wavefronts per SIMD the orders <= 12 instantiations are compiled for (register budget)
-#endif
 template <int LO, int MAXORD, bool WIDE>
-__global__ __launch_bounds__(64, (MAXORD <= 12 ? AFG_FLAC_WAVES : 2)) void flac_restore1_kernel(
+__global__ __launch_bounds__(64, 2) void flac_restore1_kernel(
     const afg_flac_frame *__restrict__ frames, const afg_flac_subframe *__restrict__ subframes,
     const int32_t *__restrict__ res, int32_t *__restrict__ out_i32, float *__restrict__ out_f32, uint64_t n_frames)
 {
-    static_assert(kT == 32, "the lane-per-subframe walk is written for 32-sample tile steps");
+    // 16 KB tile + 768 B + 1 KB + 256 B = 18 KB: eight wavefronts per CU, two per SIMD
     __shared__ __attribute__((aligned(16))) int32_t tile[kFpw * kRowWords];
     __shared__ RowMeta meta[kFpw];
-    __shared__ uint32_t row_shift[kFpw * 8];
+    __shared__ __attribute__((aligned(16))) RowFast rowfast[kFpw];
+    __shared__ uint8_t row_shift[kFpw * 8];
 
     const int lane = threadIdx.x;
     const uint64_t f = (uint64_t)blockIdx.x * kFpw + (lane >> 1);
@@ -341,25 +472,50 @@ __global__ __launch_bounds__(64, (MAXORD <= 12 ? AFG_FLAC_WAVES : 2)) void flac_
         me.bs = fr.block_size;
         me.info = (uint32_t)fr.channels | ((uint32_t)fr.assignment << 8) | ((uint32_t)fr.bps << 16) | ((uint32_t)(fr.res16 != 0) << 24);
     }
+    // the common step (above) needs every row stereo and one base per side within reach of a 32-bit byte offset
+    const uint64_t in_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(me.in_off >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)me.in_off);
+    const uint64_t out_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(me.out_off >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)me.out_off);
+    const bool near = valid && fr.channels == 2 && me.in_off >= in_base && me.in_off - in_base < (1ull << 27) &&
+                      me.out_off >= out_base && me.out_off - out_base < (1ull << 27);
+    const bool fastw = __all(near) && ((out_i32 != nullptr) != (out_f32 != nullptr));
     if ((lane & 1) == 0) {
+        uint32_t sh2[2] = { 0, 0 };
         for (int c = 0; c < 8; c++) {
             uint32_t sh = 0;
             if (valid && c < (int)fr.channels) sh = (32u - fr.bps) + subframes[sf_index + c].wasted;   // drflac.d:2883, :2894
-            row_shift[(lane >> 1) * 8 + c] = sh;
+            row_shift[(lane >> 1) * 8 + c] = (uint8_t)(sh & 31u);
+            if (c < 2) sh2[c] = sh & 31u;
         }
         meta[lane >> 1] = me;
+        RowFast rfv;
+        const int asg = valid ? (int)fr.assignment : 0;
+        rfv.voff = fastw ? (uint32_t)((me.out_off - out_base) * 4) : 0u;
+        rfv.m_ls = asg == AFG_FLAC_LEFT_SIDE ? ~0u : 0u;
+        rfv.m_rs = asg == AFG_FLAC_RIGHT_SIDE ? ~0u : 0u;
+        rfv.m_ms = asg == AFG_FLAC_MID_SIDE ? ~0u : 0u;
+        rfv.sh_a = sh2[0]; rfv.sh_b = sh2[1];
+        // residual rows: int16 rows padded to 8 samples (AFG_FLAC_ROW16), int32 rows back to back
+        const uint32_t esz = fr.res16 ? 2u : 4u;
+        const uint32_t chunk = fr.res16 ? ((me.bs + 7u) & ~7u) : me.bs;
+        rfv.in_a = fastw ? (uint32_t)(me.in_off - in_base) * esz : 0u;
+        rfv.in_b = rfv.in_a + chunk * esz;
+        rowfast[lane >> 1] = rfv;
     }
     __syncthreads();
 
-    const int max_bs = wave_max((int)me.bs);
-    const int max_pairs = wave_max(((int)(me.info & 0xff) + 1) >> 1);
+    // (scalar for the compiler too: a loop bound it takes for divergent makes the tile position a vector register)
+    const int max_bs = __builtin_amdgcn_readfirstlane(wave_max((int)me.bs));
+    const int min_bs = __builtin_amdgcn_readfirstlane(-wave_max(valid ? -(int)me.bs : -0x7fffffff));
+    const int max_pairs = __builtin_amdgcn_readfirstlane(wave_max(((int)(me.info & 0xff) + 1) >> 1));
     const bool any16 = __any(valid && (me.info >> 24) != 0), any32 = __any(valid && (me.info >> 24) == 0);
     if (!any16)
-        run_frames1<MAXORD, WIDE, 0>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
+        run_frames1<MAXORD, WIDE, 0>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, min_bs, in_base, out_base);
     else if (!any32)
-        run_frames1<MAXORD, WIDE, 1>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
+        run_frames1<MAXORD, WIDE, 1>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, min_bs, in_base, out_base);
     else
-        run_frames1<MAXORD, WIDE, 2>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift);
+        run_frames1<MAXORD, WIDE, 2>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, min_bs, in_base, out_base);
 }
 
 }  // namespace
