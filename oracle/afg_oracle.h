@@ -227,6 +227,35 @@ void afgo_flac_transform(uint64_t n_frames, const afgo_flac_frame *frames,
                          const afgo_flac_subframe *subframes, const int32_t *res,
                          int32_t *out_i32, float *out_f32);
 
+/* The FLAC front-end (oracle/flac_frontend.c): native FLAC bytes -> what drflac_read_s32 delivers, read to the end of the
+ * stream the way AudioStream reads it (stream.d:492-515), with the reference's 32-bit cache bit reader
+ * (drflac.d:680-1043), frame / subframe parse (:1444-1695) and fused Rice + prediction loop (:1143-1328). */
+#define AFGO_FLAC_F_IGNORED_FAILURE 1u   /* a subframe's sample decode failed and was delivered as the buffer stood (drflac.d:1591-1594) */
+#define AFGO_FLAC_F_UNINITIALISED   2u   /* ... and part of what was delivered had never been written: malloc'ed memory in the reference */
+#define AFGO_FLAC_F_UNDEFINED       4u   /* the next frame needs an operation D does not define (or overruns the decode buffer): stream ended there */
+typedef struct afgo_flac_file {
+    uint32_t channels, sample_rate, bps, max_block;    /* STREAMINFO */
+    uint64_t total_samples;                            /* STREAMINFO's count times channels (pFlac.totalSampleCount) */
+    uint64_t n_samples;                                /* interleaved int32 values delivered */
+    int32_t *pcm;
+    uint32_t n_frames;
+    uint32_t flags;                                    /* AFGO_FLAC_F_* */
+    uint64_t first_flag_sample;                        /* values delivered before the first flagged frame (UINT64_MAX: none) */
+} afgo_flac_file;
+int  afgo_flac_decode_file(const uint8_t *data, size_t size, afgo_flac_file *out);   /* 0 ok, -1 not native FLAC, -2 memory */
+void afgo_flac_file_free(afgo_flac_file *file);
+
+/* The QOA stream layer (oracle/qoa_lms.c): qoa_decode_header (qoa.d:413-453) + the frame loop of QOADecoder.readSamples
+ * (qoa.d:803-851) to the end of the stream: interleaved int16, and the float the reader delivers (* 1.0f / 32767). */
+typedef struct afgo_qoa_file {
+    uint32_t channels, samplerate, samples;            /* file header / first frame header */
+    uint64_t n_frames_pcm;                             /* sample frames delivered */
+    uint32_t n_qoa_frames;
+    int16_t *pcm;
+} afgo_qoa_file;
+int  afgo_qoa_decode_file(const uint8_t *data, size_t size, afgo_qoa_file *out);      /* 0 ok, -1 not QOA, -2 memory */
+void afgo_qoa_file_free(afgo_qoa_file *file);
+
 /* ------------------------------------------------------------------ QOA -- */
 
 /* Frame record (same layout as include/afg.h afg_qoa_frame). */

@@ -22,7 +22,9 @@
  *   AFGO_FLAC_F_IGNORED_FAILURE  drflac__decode_subframe drops the result of the sample decoders (:1591-1594): a
  *                                subframe whose decode fails half way is delivered with what the decode buffer held --
  *                                the samples decoded so far, then the previous frames' at those positions.  Restated
- *                                as the reference does it, on a buffer that starts zeroed.
+ *                                as the reference does it, on a buffer that starts zeroed.  The same flag marks a
+ *                                subframe whose partitions hold fewer samples than the block (a partition order the
+ *                                block size is not a multiple of, :1295-1327): its tail is stale in the same way.
  *   AFGO_FLAC_F_UNINITIALISED    ... and the buffer positions delivered had never been written: the reference reads
  *                                malloc'ed memory there (:2600-2607 clear only the struct), this restatement zeros.
  *   AFGO_FLAC_F_UNDEFINED        the frame needs an operation D leaves undefined or that writes outside the decode
@@ -511,7 +513,8 @@ static int decode_subframe(flac_t *f, int idx, int32_t *out)                    
         }
     }
     for (uint32_t i = 0; i < done; ++i) f->written[(size_t)(out - f->decoded) + i] = 1;
-    if (!ok) {                                                                   /* :1591-1594: the result is dropped */
+    if (!ok || done < block) {                                                   /* :1591-1594: the result is dropped; or 2^order partitions
+                                                                                    of block >> order samples that do not add up to the block */
         f->flags |= AFGO_FLAC_F_IGNORED_FAILURE;
         f->frame_flagged = 1;
         for (uint32_t i = done; i < block; ++i)
@@ -528,6 +531,7 @@ static uint32_t channel_count(uint8_t assignment)                               
 
 static int read_and_decode_next_frame(flac_t *f)                                 /* :1682-1688 + decode_frame :1658-1672 */
 {
+    const uint32_t flags_before = f->flags;                                      /* a frame that is dropped leaves no flag */
     f->frame_flagged = 0;
     if (!read_frame_header(&f->bs, f->bps, &f->header)) return 0;
     memset(f->sub, 0, sizeof(f->sub));
@@ -539,10 +543,10 @@ static int read_and_decode_next_frame(flac_t *f)                                
     }
     for (uint32_t i = 0; i < channels; ++i) {
         int r = decode_subframe(f, (int)i, f->decoded + (size_t)f->header.block * i);
-        if (r < 0) { f->flags |= AFGO_FLAC_F_UNDEFINED; return -1; }
-        if (!r) return 0;
+        if (r < 0) { f->flags = flags_before | AFGO_FLAC_F_UNDEFINED; return -1; }
+        if (!r) { f->flags = flags_before; return 0; }
     }
-    if (!seek_bits(&f->bs, (BITS_REMAINING(&f->bs) & 7) + 16)) return 0;       /* padding + CRC-16, not checked (:1667) */
+    if (!seek_bits(&f->bs, (BITS_REMAINING(&f->bs) & 7) + 16)) { f->flags = flags_before; return 0; }   /* padding + CRC-16, not checked (:1667) */
     f->remaining = f->header.block * channels;
     return 1;
 }

@@ -219,3 +219,117 @@ size_t afgo_qoa_encode(const int16_t *pcm, uint32_t samples, int channels, uint3
     }
     return (size_t)(p - out);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The stream layer: qoa_decode_header (qoa.d:413-453), QOADecoder.initialize (:770-791) and the frame loop of
+ * QOADecoder.readSamples (:803-851) over a memory stream, to the end of the stream.  qoa_decode_frame (:455-534) is
+ * restated again here AS A READER: it consumes the frame header, the LMS state and ceil(samples / 20) slices per
+ * channel from the cursor and leaves the cursor there -- the frame-size field is only checked against the bytes left
+ * (:477) and against the sample count (:481-486), it never positions the next frame.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { const uint8_t *d; size_t n, pos; } qoa_io;
+
+static int io_u64(qoa_io *io, uint64_t *v)                    /* read_ulong_BE, io.d:164-190: all eight bytes or an error */
+{
+    if (io->n - io->pos < 8) { io->pos = io->n; return 0; }
+    *v = rd64be(io->d + io->pos);
+    io->pos += 8;
+    return 1;
+}
+
+static uint32_t qoa_stream_frame(qoa_io *io, uint32_t want_channels, uint32_t want_rate, int16_t *sample_data, int *overrun)
+{
+    if ((long long)(io->n - io->pos) < 8 + QOA_LMS_LEN * 4 * (long long)want_channels) return 0;        /* :460 */
+    uint64_t fh;
+    if (!io_u64(io, &fh)) return 0;
+    int channels = (int)((fh >> 56) & 0xff);
+    int samplerate = (int)((fh >> 32) & 0xffffff);
+    int samples = (int)((fh >> 16) & 0xffff);
+    int frame_size = (int)(fh & 0xffff);
+    int data_size = frame_size - 8 - QOA_LMS_LEN * 4 * channels;
+    int num_slices = data_size / 8;
+    int max_total_samples = num_slices * QOA_SLICE_LEN;
+    if ((long long)(io->n - io->pos) < frame_size - 8) return 0;                                         /* :477 */
+    if (channels != (int)want_channels || samplerate != (int)want_rate || samples * channels > max_total_samples) return 0;
+    if (samples > QOA_FRAME_LEN) { *overrun = 1; return 0; }      /* the reference writes past its QOA_FRAME_LEN buffer (:786): undefined */
+    lms_t lms[8];
+    for (int c = 0; c < channels; c++) {
+        uint64_t history, weights;
+        if (!io_u64(io, &history)) return 0;
+        if (!io_u64(io, &weights)) return 0;
+        for (int i = 0; i < QOA_LMS_LEN; i++) {
+            lms[c].history[i] = (int16_t)(history >> 48);
+            history <<= 16;
+            lms[c].weights[i] = (int16_t)(weights >> 48);
+            weights <<= 16;
+        }
+    }
+    for (int sample_index = 0; sample_index < samples; sample_index += QOA_SLICE_LEN) {
+        for (int c = 0; c < channels; c++) {
+            uint64_t slice;
+            if (!io_u64(io, &slice)) return 0;
+            int scalefactor = (int)((slice >> 60) & 0xf);
+            int slice_start = sample_index * channels + c;
+            int end = sample_index + QOA_SLICE_LEN; if (end > samples) end = samples;
+            int slice_end = end * channels + c;
+            for (int si = slice_start; si < slice_end; si += channels) {
+                int predicted = lms_predict(&lms[c]);
+                int quantized = (int)((slice >> 57) & 0x7);
+                int dequantized = k_dequant_tab[scalefactor][quantized];
+                int reconstructed = clamp_s16(predicted + dequantized);
+                sample_data[si] = (int16_t)reconstructed;
+                slice <<= 3;
+                lms_update(&lms[c], reconstructed, dequantized);
+            }
+        }
+    }
+    return (uint32_t)samples;
+}
+
+#include <stdlib.h>
+
+int afgo_qoa_decode_file(const uint8_t *data, size_t size, afgo_qoa_file *out)
+{
+    memset(out, 0, sizeof(*out));
+    qoa_io io = { data, size, 0 };
+    if (size < 16) return -1;                                      /* QOA_MIN_FILESIZE, :416 */
+    uint64_t fh, first;
+    if (!io_u64(&io, &fh) || (fh >> 32) != QOA_MAGIC) return -1;
+    out->samples = (uint32_t)(fh & 0xffffffffu);
+    if (!out->samples) return -1;
+    if (!io_u64(&io, &first)) return -1;                           /* peek into the first frame header, :441-451 */
+    out->channels = (uint32_t)((first >> 56) & 0xff);
+    out->samplerate = (uint32_t)((first >> 32) & 0xffffff);
+    if (out->channels == 0 || out->samplerate == 0) return -1;
+    if (out->channels > 8) return -1;                              /* qoa_desc.lms has eight entries (:221): more is an overrun in the reference */
+    io.pos = 8;                                                    /* QOADecoder.initialize seeks back to the first frame, :781 */
+    size_t cap = (size_t)QOA_FRAME_LEN * out->channels * 4, n = 0;
+    int16_t *pcm = (int16_t *)malloc(cap * sizeof(int16_t));
+    int16_t *buffer = (int16_t *)calloc((size_t)QOA_FRAME_LEN * out->channels, sizeof(int16_t));
+    if (!pcm || !buffer) { free(pcm); free(buffer); return -2; }
+    for (;;) {
+        int overrun = 0;
+        uint32_t frame_len = qoa_stream_frame(&io, out->channels, out->samplerate, buffer, &overrun);
+        if (frame_len == 0) break;                                 /* readSamples returns what it has, :813-814 */
+        size_t cnt = (size_t)frame_len * out->channels;
+        if (n + cnt > cap) {
+            while (n + cnt > cap) cap *= 2;
+            int16_t *np = (int16_t *)realloc(pcm, cap * sizeof(int16_t));
+            if (!np) { free(pcm); free(buffer); return -2; }
+            pcm = np;
+        }
+        memcpy(pcm + n, buffer, cnt * sizeof(int16_t));
+        n += cnt;
+        out->n_qoa_frames++;
+    }
+    free(buffer);
+    out->pcm = pcm;
+    out->n_frames_pcm = n / out->channels;
+    return 0;
+}
+
+void afgo_qoa_file_free(afgo_qoa_file *file)
+{
+    free(file->pcm);
+    memset(file, 0, sizeof(*file));
+}

@@ -394,6 +394,67 @@ def opus_file_pcm(rec):
     return of.reshape(-1, ch)[:max(0, min(rec["pcm_frames"], rec["declared_frames"]))]
 
 
+class _FlacFile(C.Structure):
+    _fields_ = [("channels", C.c_uint32), ("sample_rate", C.c_uint32), ("bps", C.c_uint32), ("max_block", C.c_uint32),
+                ("total_samples", C.c_uint64), ("n_samples", C.c_uint64), ("pcm", C.POINTER(C.c_int32)),
+                ("n_frames", C.c_uint32), ("flags", C.c_uint32), ("first_flag_sample", C.c_uint64)]
+
+
+FLAC_F_IGNORED_FAILURE, FLAC_F_UNINITIALISED, FLAC_F_UNDEFINED = 1, 2, 4
+
+
+def flac_decode_file(data):
+    """Oracle FLAC front-end (oracle/flac_frontend.c) over a whole native FLAC file in memory: what drflac_read_s32
+    delivers to the end of the stream.  Returns the integer status (-1: not a file the reference opens) on failure."""
+    buf = bytes(data)
+    f = _FlacFile()
+    fn = lib().afgo_flac_decode_file
+    fn.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_FlacFile)]
+    fn.restype = C.c_int
+    rc = fn(buf, len(buf), C.byref(f))
+    if rc != 0:
+        return rc
+    try:
+        n = int(f.n_samples)
+        pcm = np.ctypeslib.as_array(f.pcm, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        first = int(f.first_flag_sample)
+        return {"channels": int(f.channels), "sample_rate": int(f.sample_rate), "bps": int(f.bps), "max_block": int(f.max_block),
+                "total_samples": int(f.total_samples), "pcm": pcm, "n_frames": int(f.n_frames), "flags": int(f.flags),
+                "first_flag_sample": None if first == 2 ** 64 - 1 else first}
+    finally:
+        free = lib().afgo_flac_file_free
+        free.argtypes = [C.POINTER(_FlacFile)]
+        free.restype = None
+        free(C.byref(f))
+
+
+class _QoaFile(C.Structure):
+    _fields_ = [("channels", C.c_uint32), ("samplerate", C.c_uint32), ("samples", C.c_uint32), ("n_frames_pcm", C.c_uint64),
+                ("n_qoa_frames", C.c_uint32), ("pcm", C.POINTER(C.c_int16))]
+
+
+def qoa_decode_file(data):
+    """Oracle QOA stream layer (oracle/qoa_lms.c): header + frame loop of QOADecoder.readSamples to the end of the stream."""
+    buf = bytes(data)
+    f = _QoaFile()
+    fn = lib().afgo_qoa_decode_file
+    fn.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_QoaFile)]
+    fn.restype = C.c_int
+    rc = fn(buf, len(buf), C.byref(f))
+    if rc != 0:
+        return rc
+    try:
+        n = int(f.n_frames_pcm) * int(f.channels)
+        pcm = np.ctypeslib.as_array(f.pcm, shape=(n,)).copy() if n else np.zeros(0, np.int16)
+        return {"channels": int(f.channels), "samplerate": int(f.samplerate), "samples": int(f.samples), "pcm": pcm,
+                "n_qoa_frames": int(f.n_qoa_frames)}
+    finally:
+        free = lib().afgo_qoa_file_free
+        free.argtypes = [C.POINTER(_QoaFile)]
+        free.restype = None
+        free(C.byref(f))
+
+
 # ------------------------------------------------------- CPU baseline pool ------
 class BenchTask(C.Structure):
     _fields_ = [("codec", C.c_int32), ("n", C.c_uint32), ("channels", C.c_uint32), ("bs0", C.c_uint16), ("bs1", C.c_uint16),
