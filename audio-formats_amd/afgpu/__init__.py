@@ -52,7 +52,7 @@ WAV_S8, WAV_S16LE, WAV_S24LE, WAV_FP32LE, WAV_FP64LE = range(5)
 # every symbol include/afg.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "afg_abi_version", "afg_status_string", "afg_last_error", "afg_device_count", "afg_device_name",
-    "afg_set_numeric_mode", "afg_get_numeric_mode",
+    "afg_set_numeric_mode", "afg_get_numeric_mode", "afg_dev_option",
     "afg_mp3_plan_create", "afg_mp3_plan_destroy", "afg_mp3_plan_blocks", "afg_mp3_plan_segments",
     "afg_mp3_transform_hip", "afg_mp3_requant_hip", "afg_mp3_parse_q", "afg_mp3_parsed_q_free", "afg_mp3_qtables",
     "afg_vorbis_plan_create", "afg_vorbis_plan_destroy", "afg_vorbis_plan_packets",
@@ -151,10 +151,39 @@ def mp3_flags(block_type=0, n_long_bands=0, aa_bands=31):
     return np.uint32(block_type | (n_long_bands << 8) | ((aa_bands + 1) << 16))
 
 
+# The library's test hooks (afg.h: afg_dev_option) under the environment-variable names the test-suite has always used:
+# THIS module reads the variables -- the C library reads none -- and hands changed values over before the next call.
+_DEV_ENV = {"AFG_CELT_PATH": ("celt_path", {"stream": 1, "split": 2, "walk": 3}), "AFG_CELT_DE_SEQ": ("celt_de_seq", None),
+            "AFG_CELT_DE_DUO": ("celt_de_duo", None), "AFG_CELT_SEG_RECS": ("celt_seg_recs", None),
+            "AFG_CELT_WHOLE_FRAMES": ("celt_whole_frames", None), "AFG_VORBIS_SINGLE": ("vorbis_single", None),
+            "AFG_MP3_CHUNKS": ("mp3_chunks", None), "AFG_MP3_FLOAT_UPLOAD": ("mp3_float_upload", None),
+            "AFG_VORBIS_HOST_FLOOR": ("vorbis_host_floor", None), "AFG_FLAC_HOST_RES32": ("flac_host_res32", None)}
+_dev_seen = {}
+
+
+def _sync_dev_options(L):
+    for env, (name, words) in _DEV_ENV.items():
+        raw = os.environ.get(env)
+        if _dev_seen.get(env, None) == raw and env in _dev_seen:
+            continue
+        _dev_seen[env] = raw
+        if raw is None:
+            value = -1
+        elif words is not None:
+            value = words.get(raw, -1)
+        else:
+            try:
+                value = int(raw)
+            except ValueError:
+                value = 1
+        L.afg_dev_option(name.encode(), value)
+
+
 def lib():
     """Load the C-ABI library (once).  torch is imported first so that both share one HIP runtime."""
     global _lib
     if _lib is not None:
+        _sync_dev_options(_lib)
         return _lib
     if not os.path.exists(LIB_PATH):
         raise AfgError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -258,7 +287,9 @@ def lib():
     L.afg_stream_synchronize.argtypes = [vp]
     L.afg_copy_probe_hip.argtypes = [vp, vp, C.c_size_t, vp]
     L.afg_lds_fill_probe_hip.argtypes = [C.c_uint32, vp]
+    L.afg_dev_option.argtypes = [C.c_char_p, C.c_int]
     _lib = L
+    _sync_dev_options(L)
     return L
 
 
@@ -387,18 +418,26 @@ def qoa_frames(file_bytes, out_base=0, byte_base=0):
         raise AfgError("not a QOA file")
     total = int.from_bytes(bytes(b[4:8]), "big")
     recs, pos, out = [], 8, out_base
-    channels = rate = 0
-    while pos + 8 <= b.size:
+    first = int.from_bytes(bytes(b[8:16]), "big")
+    channels, rate = (first >> 56) & 0xff, (first >> 32) & 0xffffff
+    if not total or not channels or not rate or channels > 8:
+        raise AfgError("not a QOA file")
+    # the reader of qoa.d:455-534: a frame is header + LMS state + ceil(samples / 20) slices per channel from the cursor;
+    # the frame-size field is checked (:477, :481-486), never used to find the next frame
+    while b.size - pos >= 8 + 16 * channels:
         hdr = int.from_bytes(bytes(b[pos:pos + 8]), "big")
         ch, sr, smp, fsz = (hdr >> 56) & 0xff, (hdr >> 32) & 0xffffff, (hdr >> 16) & 0xffff, hdr & 0xffff
-        if ch == 0 or fsz < 8 + 16 * ch or pos + fsz > b.size:
+        num_slices = int((fsz - 8 - 16 * ch) / 8)                    # truncating division, as D's
+        if b.size - pos - 8 < fsz - 8:
             break
-        channels, rate = channels or ch, rate or sr
-        if ch != channels or sr != rate or smp * ch > ((fsz - 8 - 16 * ch) // 8) * 20:
-            break                                                    # qoa.d:478-486: inconsistent frame ends decoding
+        if ch != channels or sr != rate or smp * ch > num_slices * 20 or smp == 0 or smp > 5120:
+            break
+        used = 8 + 16 * ch + 8 * ch * ((smp + 19) // 20)
+        if used > b.size - pos:
+            break
         recs.append((byte_base + pos, out, smp, ch, [0] * 5))
         out += smp * ch
-        pos += fsz
+        pos += used
     return np.array(recs, QOA_FRAME_DTYPE), channels, rate, total
 
 

@@ -60,6 +60,13 @@ int numeric_mode()
     return AFG_NUMERIC_TOLERANCE;
 }
 
+static std::atomic<long> g_dev_option[kDevCount] = { { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 } };
+static const char *const k_dev_option_name[kDevCount] = { "celt_path", "celt_de_seq", "celt_de_duo", "celt_seg_recs", "celt_whole_frames",
+                                                          "vorbis_single", "mp3_chunks", "mp3_float_upload", "vorbis_host_floor",
+                                                          "flac_host_res32" };
+
+long dev_option(DevOption which) { return g_dev_option[which].load(std::memory_order_relaxed); }
+
 int DeviceArray::upload(const void *host, size_t nbytes)
 {
     release();
@@ -105,6 +112,17 @@ const char *afg_status_string(int status)
 const char *afg_last_error(void) { return afg::g_err; }
 
 int afg_get_numeric_mode(void) { return afg::numeric_mode(); }
+
+int afg_dev_option(const char *name, int value)
+{
+    for (int i = 0; name && i < afg::kDevCount; i++)
+        if (!strcmp(name, afg::k_dev_option_name[i])) {
+            afg::g_dev_option[i].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+            return AFG_OK;
+        }
+    afg::set_error("afg_dev_option: no option named '%s'", name ? name : "(null)");
+    return AFG_ERR_INVALID;
+}
 
 int afg_set_numeric_mode(int mode)
 {

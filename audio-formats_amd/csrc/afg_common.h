@@ -25,6 +25,12 @@ int device_slot(int *dev, const char *who);
 // Numeric mode of the float transform stages (afg_set_numeric_mode; env AFG_NUMERIC=exact|tolerance until it is called).
 int numeric_mode();
 
+// Alternative code paths the test-suite runs side by side with the default ones (afg.h: afg_dev_option).  Set through
+// that call only -- the library reads no environment variable for them -- and -1 while unset.
+enum DevOption { kDevCeltPath, kDevCeltDeSeq, kDevCeltDeDuo, kDevCeltSegRecs, kDevCeltWholeFrames, kDevVorbisSingle,
+                 kDevMp3Chunks, kDevMp3FloatUpload, kDevVorbisHostFloor, kDevFlacHostRes32, kDevCount };
+long dev_option(DevOption which);
+
 #define AFG_HIP_CHECK(expr)                                                              \
     do {                                                                                 \
         hipError_t e__ = (expr);                                                         \

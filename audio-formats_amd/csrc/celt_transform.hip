@@ -1053,12 +1053,12 @@ __global__ __launch_bounds__(128) void celt_deemph_duo_kernel(
 
 // Sequences per wavefront from the number of sequences: the most chain lanes per wavefront that still leaves about a
 // wavefront per two SIMDs (512 wavefronts; measured: 16384 sequences run at the pass's memory rate with 32 per
-// wavefront).  AFG_CELT_DE_SEQ overrides (tests run every instantiation).
+// wavefront).  afg_dev_option("celt_de_seq") overrides (tests run every instantiation).
 int deemph_seq_for(uint32_t n_chan)
 {
-    if (const char *e = getenv("AFG_CELT_DE_SEQ")) {
-        const int v = atoi(e);
-        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) return v;
+    {
+        const long v = afg::dev_option(afg::kDevCeltDeSeq);
+        if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) return (int)v;
     }
     for (int seq = 32; seq > 2; seq >>= 1)
         if (n_chan / (uint32_t)seq >= 512u) return seq;
@@ -1071,11 +1071,11 @@ void launch_deemph(const uint64_t *d_rec_base, const afg_celt_frame *d_recs, flo
     int seq = deemph_seq_for(n_chan);
     // Few, long sequences (fewer than 16384: not enough for 512 wavefronts of 32 chains, the form that runs at memory rate): the
     // pass is as long as its longest chain, so the chain gets a wavefront of its own (celt_deemph_duo_kernel).
-    // AFG_CELT_DE_DUO=0 / 1 overrides (tests run both forms of every instantiation).
+    // afg_dev_option("celt_de_duo", 0 / 1) overrides (tests run both forms of every instantiation).
     bool duo = seq < 32;
-    if (const char *e = getenv("AFG_CELT_DE_DUO")) duo = atoi(e) != 0;
+    if (afg::dev_option(afg::kDevCeltDeDuo) >= 0) duo = afg::dev_option(afg::kDevCeltDeDuo) != 0;
     if (duo) {
-        if (!getenv("AFG_CELT_DE_SEQ")) seq = 8;             // 120-sample steps: every CELT frame size walks as rows
+        if (afg::dev_option(afg::kDevCeltDeSeq) < 0) seq = 8; // 120-sample steps: every CELT frame size walks as rows
         if (seq > 8) seq = 8;
         const dim3 grid((n_chan + (uint32_t)seq - 1) / (uint32_t)seq), block(128);
         switch (seq) {
@@ -1102,12 +1102,12 @@ CeltTables g_tb;
 uint32_t g_tab_floats = 0;
 bool g_tb_ready = false;
 
-// AFG_CELT_PATH=stream|split overrides the choice (tests exercise both paths on small batches)
+// afg_dev_option("celt_path", 1 stream | 2 split) overrides the choice (tests exercise both paths on small batches)
 bool use_stream_path(uint32_t pairs)
 {
-    const char *e = getenv("AFG_CELT_PATH");
-    if (e && !strcmp(e, "stream")) return true;
-    if (e && !strcmp(e, "split")) return false;
+    const long e = afg::dev_option(afg::kDevCeltPath);       // 1 stream, 2 split, 3 walk
+    if (e == 1) return true;
+    if (e == 2) return false;
     // The stream walk runs one wavefront per stereo stream for the stream's whole length (~30-80 us per frame of
     // wavefront latency: its throughput comes from thousands of resident wavefronts).  Below about two wavefronts per
     // SIMD the record-parallel transform + per-sequence filter passes finish sooner.
@@ -1292,10 +1292,10 @@ static int celt_transform_impl(uint32_t n_chan, const uint64_t *d_rec_base, cons
     const float *d_tables = nullptr;
     CeltTables tb;
     if (int rc = ensure_tables(&d_tables, &tb)) return rc;
-    // AFG_CELT_PATH=stream|split names one of the bit-exact paths, =walk the tolerance-mode walk; else the numeric mode decides
-    const char *path_env = getenv("AFG_CELT_PATH");
-    const bool forced_exact = path_env && (!strcmp(path_env, "stream") || !strcmp(path_env, "split"));
-    const bool forced_walk = path_env && !strcmp(path_env, "walk");
+    // afg_dev_option("celt_path"): 1 stream | 2 split name one of the bit-exact paths, 3 the tolerance-mode walk; else the numeric mode decides
+    const long path_opt = afg::dev_option(afg::kDevCeltPath);
+    const bool forced_exact = path_opt == 1 || path_opt == 2;
+    const bool forced_walk = path_opt == 3;
     if (forced_walk || (!forced_exact && afg::numeric_mode() == AFG_NUMERIC_TOLERANCE)) {
         if (tail_stream) {                                   // one kernel, all of it beside what the caller queues next
             hipEvent_t done = nullptr;

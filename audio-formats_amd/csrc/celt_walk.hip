@@ -748,11 +748,11 @@ int g_cus[AFG_MAX_DEVICES] = {};
 
 // Records per item from the number of channel sequences.  Long streams are cut into 64-frame pieces (the warm-up of a
 // piece costs two frames of transform: 3 %); with thousands of streams the pieces only have to even out the tail.
-// AFG_CELT_SEG_RECS overrides (0: whole channel pairs).
+// afg_dev_option("celt_seg_recs") overrides (0: whole channel pairs).
 static uint32_t seg_recs_for(uint32_t n_chan)
 {
-    if (const char *e = getenv("AFG_CELT_SEG_RECS")) {
-        const long v = atol(e);
+    {
+        const long v = afg::dev_option(afg::kDevCeltSegRecs);
         if (v >= 0 && v <= (1 << 24)) return (uint32_t)v;
     }
     return 128;
@@ -801,10 +801,10 @@ int afg::celt_walk_launch(uint32_t n_chan, const uint64_t *d_rec_base, const afg
     // With at least four channel pairs per wavefront slot (8 wavefronts x 256 CUs) sequences of up to 512 frames (10 s of 20 ms
     // frames: a walk of 4.6 ms) are walked whole -- a cut costs two frames of warm-up, and there are enough sequences to even
     // out the tail; with fewer every sequence is cut wherever it can be (the mixed corpus: 2 460 streams per wave, 22 ms against
-    // 29 ms with its short ones whole).  AFG_CELT_WHOLE_FRAMES overrides.
+    // 29 ms with its short ones whole).  afg_dev_option("celt_whole_frames") overrides.
     uint32_t whole_frames = (n_chan + 1) / 2 >= 4u * kWWaves * 256u ? 512 : 0;
-    if (const char *e = getenv("AFG_CELT_WHOLE_FRAMES")) {
-        const long v = atol(e);
+    {
+        const long v = afg::dev_option(afg::kDevCeltWholeFrames);
         if (v >= 0 && v <= (1 << 24)) whole_frames = (uint32_t)v;
     }
     const uint32_t pairs = (n_chan + 1) / 2;

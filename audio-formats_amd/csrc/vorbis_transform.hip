@@ -1181,6 +1181,7 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     }
     if (int rc = afg::require_device()) return rc;
     if (seg_packets == 0) seg_packets = 16;
+    const bool single_only = afg::dev_option(afg::kDevVorbisSingle) > 0;      // tests: the one-channel-per-wavefront walk
 
     std::vector<VorbisStream> streams(n_streams);
     std::vector<VorbisSeg> segs, wave_segs, walk_segs;
@@ -1253,9 +1254,9 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
         }
         for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
             uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
-            if (fast && channels[s] == 2 && bs[0] <= 512 && !getenv("AFG_VORBIS_SINGLE"))
+            if (fast && channels[s] == 2 && bs[0] <= 512 && !single_only)
                 walk_segs.push_back(VorbisSeg{ s, p0, cnt, kBothChannels });                                  // both channels; either kernel
-            else if (fast && channels[s] == 2 && !getenv("AFG_VORBIS_SINGLE"))
+            else if (fast && channels[s] == 2 && !single_only)
                 wave_segs.push_back(VorbisSeg{ s, p0, cnt, kBothChannels });                                  // both channels, interleaved
             else if (fast)
                 for (uint32_t c = 0; c < channels[s]; c++) wave_segs.push_back(VorbisSeg{ s, p0, cnt, c });   // one per channel

@@ -37,6 +37,8 @@
 #include "vorbis_core.h"
 #include "vorbis_walk.h"
 
+#include <mutex>
+
 #include <cmath>
 
 namespace afg_vorbis {
@@ -519,14 +521,15 @@ int walk_launch(const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *stre
                 const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
                 const float *spec, float *out, uint32_t *counter, uint32_t groups, hipStream_t stream)
 {
-    static bool attr_set[AFG_MAX_DEVICES] = {};
+    // once per device, whichever host thread gets here first (afg.h allows concurrent launches of one plan)
+    static std::once_flag attr_once[AFG_MAX_DEVICES];
     int dev = 0;
     if (int rc = afg::device_slot(&dev, "afg_vorbis_transform_hip")) return rc;
-    if (!attr_set[dev]) {
-        AFG_HIP_CHECK(hipFuncSetAttribute((const void *)vorbis_walk_kernel<kWalkWaves>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds));
-        attr_set[dev] = true;
-    }
+    hipError_t attr_rc = hipSuccess;
+    std::call_once(attr_once[dev], [&] {
+        attr_rc = hipFuncSetAttribute((const void *)vorbis_walk_kernel<kWalkWaves>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
+    });
+    AFG_HIP_CHECK(attr_rc);
     hipLaunchKernelGGL(vorbis_walk_kernel<kWalkWaves>, dim3(groups), dim3(64 * kWalkWaves), kWalkLds, stream, segs, n_segs,
                        streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter);
     return AFG_OK;

@@ -438,13 +438,19 @@ bool qoa_parse(const uint8_t *d, size_t n, QoaInfo &qi, std::vector<afg_qoa_fram
     if (qi.channels == 0 || qi.channels > 8 || qi.samplerate == 0) return false;
     size_t pos = 8;
     uint64_t out = 0;
-    while (pos + 8 + 16 * (size_t)qi.channels <= n) {
+    // qoa_decode_frame as the READER it is (qoa.d:455-534): header, LMS state and ceil(samples / 20) slices per channel are
+    // consumed from the cursor, and the next frame starts where that ends -- the frame-size field is only compared with
+    // the bytes left (:477) and with the sample count (:481-486), it positions nothing.
+    while (n - pos >= 8 + 16 * (size_t)qi.channels) {              // :460
         const uint64_t h = be64(d + pos);
-        const uint32_t ch = (uint32_t)((h >> 56) & 0xff), sr = (uint32_t)((h >> 32) & 0xffffff);
-        const uint32_t smp = (uint32_t)((h >> 16) & 0xffff), fsz = (uint32_t)(h & 0xffff);
-        if (fsz < 8 + 16 * ch || pos + fsz > n) break;
-        const uint32_t slices = (fsz - 8 - 16 * ch) / 8;
-        if (ch != qi.channels || sr != qi.samplerate || smp * ch > slices * 20 || smp == 0) break;   // qoa.d:478-486
+        const int ch = (int)((h >> 56) & 0xff), sr = (int)((h >> 32) & 0xffffff);
+        const int smp = (int)((h >> 16) & 0xffff), fsz = (int)(h & 0xffff);
+        const int num_slices = (fsz - 8 - 16 * ch) / 8;            // (may be negative: then no sample count passes :484)
+        if ((long long)(n - pos - 8) < (long long)fsz - 8) break;  // :477
+        if (ch != (int)qi.channels || sr != (int)qi.samplerate || smp * ch > num_slices * 20) break;   // :481-486
+        if (smp == 0 || smp > 5120) break;                         // an empty frame ends reading (:813); a longer one overruns the reference's buffer (:786)
+        const size_t used = 8 + 16 * (size_t)ch + 8 * (size_t)ch * (size_t)((smp + 19) / 20);
+        if (used > n - pos) break;                                 // a slice read fails (:512): the frame is not delivered
         afg_qoa_frame fr;
         std::memset(&fr, 0, sizeof(fr));
         fr.byte_off = pos;
@@ -453,7 +459,7 @@ bool qoa_parse(const uint8_t *d, size_t n, QoaInfo &qi, std::vector<afg_qoa_fram
         fr.channels = (uint8_t)ch;
         frames.push_back(fr);
         out += (uint64_t)smp * ch;
-        pos += fsz;
+        pos += used;
     }
     return !frames.empty();
 }

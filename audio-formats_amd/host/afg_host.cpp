@@ -71,10 +71,14 @@ struct Parsed {
 };
 
 // Vorbis: inverse coupling and floor curves on the device (default) or in the host parser (AFG_VORBIS_HOST_FLOOR=1)
-static bool vorbis_floor_on_device() { return std::getenv("AFG_VORBIS_HOST_FLOOR") == nullptr; }
+// debugging aids, read ONCE when the library is loaded (set them before that): poisoned allocations (the test-suite runs
+// with it: an output byte the library forgets to write shows up as NaN) and a trace of the staging pool
+static const bool g_poison_alloc = std::getenv("AFG_POISON_ALLOC") != nullptr;
+static const bool g_trace = std::getenv("AFG_TRACE") != nullptr;
+static bool vorbis_floor_on_device() { return afg::dev_option(afg::kDevVorbisHostFloor) <= 0; }
 
 // FLAC: residual rows that fit 16 bits are packed as int16 (default) or left as int32 (AFG_FLAC_HOST_RES32=1)
-static bool flac_rows_int16() { return std::getenv("AFG_FLAC_HOST_RES32") == nullptr; }
+static bool flac_rows_int16() { return afg::dev_option(afg::kDevFlacHostRes32) <= 0; }
 
 struct DeviceBuf {
     void *p = nullptr;
@@ -86,7 +90,7 @@ struct DeviceBuf {
         // AFG_POISON_ALLOC=1 (tests): fresh device buffers hold NaN patterns, so that a stage that reads what nobody wrote shows
         // (hipMemset runs on the null stream and returns early; the stages copy on non-blocking streams, which do not wait
         // for it: without the synchronisation the fill can land on top of an upload)
-        if (bytes && std::getenv("AFG_POISON_ALLOC")) {
+        if (bytes && g_poison_alloc) {
             (void)hipMemset(p, 0xff, bytes);
             (void)hipStreamSynchronize(nullptr);
         }
@@ -131,17 +135,17 @@ public:
                 out.pool = this; out.p = free_[best].first; out.cap = free_[best].second;
                 held_ -= out.cap;
                 free_.erase(free_.begin() + (long)best);
-                if (std::getenv("AFG_POISON_ALLOC")) std::memset(out.p, 0xff, out.cap);     // (tests: see DeviceBuf::alloc)
+                if (g_poison_alloc) std::memset(out.p, 0xff, out.cap);     // (tests: see DeviceBuf::alloc)
                 return AFG_OK;
             }
         }
         void *p = nullptr;
         const size_t cap = bytes ? bytes : 1;
-        if (getenv("AFG_TRACE")) fprintf(stderr, "[afg] staging pool miss: pinning %.1f MB\n", cap / 1e6);
+        if (g_trace) fprintf(stderr, "[afg] staging pool miss: pinning %.1f MB\n", cap / 1e6);
         hipError_t e = hipHostMalloc(&p, cap, hipHostMallocPortable);
         if (e != hipSuccess) { afg::set_error("hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); return AFG_ERR_OOM; }
         out.pool = this; out.p = p; out.cap = cap;
-        if (std::getenv("AFG_POISON_ALLOC")) std::memset(out.p, 0xff, out.cap);
+        if (g_poison_alloc) std::memset(out.p, 0xff, out.cap);
         return AFG_OK;
     }
     // Frees every buffer that is not on lease (afg_host_pool_trim): a long-lived process gives the pinned memory back.
@@ -176,7 +180,7 @@ StagingPool g_staging;
 
 // AFG_TRACE=1: wall-clock of the host stages on stderr (development aid)
 struct StageTimer {
-    bool on = std::getenv("AFG_TRACE") != nullptr;
+    bool on = g_trace;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void lap(const char *what)
     {
@@ -786,7 +790,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             std::vector<Chunk> chunks;
             {
                 size_t want = 8;
-                if (const char *ev = getenv("AFG_MP3_CHUNKS")) want = (size_t)std::max(1, atoi(ev));
+                if (afg::dev_option(afg::kDevMp3Chunks) > 0) want = (size_t)afg::dev_option(afg::kDevMp3Chunks);
                 const size_t target = std::max<size_t>((mp3_blocks + want - 1) / want, 8192);
                 Chunk c{ 0, 0, 0, 0, nullptr, nullptr, 0 };
                 for (size_t i = 0; i < nf; i++) {
@@ -2027,8 +2031,8 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
         bool fallback = false;
         if (total_bound) {
             // Quantised upload by default: int16 Huffman values + a record per granule, requantised on the device.
-            // AFG_MP3_FLOAT_UPLOAD=1 keeps the float spectra of round 1 (A/B of the bytes that cross the bus).
-            const bool qmode = !std::getenv("AFG_MP3_FLOAT_UPLOAD");
+            // afg_dev_option("mp3_float_upload", 1) keeps the float spectra of round 1 (A/B of the bytes that cross the bus).
+            const bool qmode = afg::dev_option(afg::kDevMp3FloatUpload) <= 0;
             const size_t per_block = qmode ? 576 * sizeof(int16_t) + sizeof(afg_mp3_qgranule) + sizeof(uint32_t)
                                            : 576 * sizeof(float) + sizeof(uint32_t);
             if (int rc = g_staging.take(total_bound * per_block + 64, mp3_stage)) return rc;
@@ -2054,7 +2058,7 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
             // pass 2, chunk by chunk: all host threads parse a chunk of files, its device work is queued, and they go on
             // with the next chunk while the copies and the kernel of this one run
             size_t want = 8;
-            if (const char *ev = getenv("AFG_MP3_CHUNKS")) want = (size_t)std::max(1, atoi(ev));
+            if (afg::dev_option(afg::kDevMp3Chunks) > 0) want = (size_t)afg::dev_option(afg::kDevMp3Chunks);
             const size_t target = std::max<size_t>((total_bound + want - 1) / want, 8192);
             for (size_t f0 = 0; f0 < (size_t)n_files;) {
                 size_t f1 = f0, acc = 0;

@@ -31,6 +31,7 @@ int afg_device_count();
 /// the environment variable AFG_NUMERIC.  Returns the mode in effect before.
 enum AFG_NUMERIC_FROM_ENV = -1, AFG_NUMERIC_EXACT = 0, AFG_NUMERIC_TOLERANCE = 1;
 int afg_set_numeric_mode(int mode);
+int afg_dev_option(const(char)* name, int value);
 int afg_get_numeric_mode();
 int afg_device_name(int device, char* buf, size_t buflen);
 

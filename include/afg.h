@@ -65,6 +65,15 @@ int         afg_device_count(void);        /* number of HIP devices visible, <0 
 #define AFG_NUMERIC_EXACT     0
 #define AFG_NUMERIC_TOLERANCE 1
 int         afg_set_numeric_mode(int mode);
+
+/* Test hooks, not part of the reference's surface: alternative code paths that deliver the same samples as the default
+ * ones, which the test-suite runs against each other.  The library reads no environment variable for them (rounds 1-4
+ * did, on every call); value < 0 returns an option to "not set".  Names: "celt_path" (1 stream walk, 2 split kernels --
+ * the two bit-exact paths --, 3 the tolerance-mode walk), "celt_de_seq" (2 .. 32 sequences per de-emphasis wavefront),
+ * "celt_de_duo" (0 / 1), "celt_seg_recs", "celt_whole_frames", "vorbis_single" (1: one channel per wavefront),
+ * "mp3_chunks", "mp3_float_upload" (1: float spectra instead of quantised values cross the bus), "vorbis_host_floor"
+ * (1: floor curves on the host), "flac_host_res32" (1: int32 residual rows only).  AFG_ERR_INVALID: no such name. */
+int         afg_dev_option(const char *name, int value);
 int         afg_get_numeric_mode(void);
 int         afg_device_name(int device, char *buf, size_t buflen);
 

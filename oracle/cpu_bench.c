@@ -10,9 +10,9 @@
  *
  * Round 4: file tasks (codec 10..13) take a whole file from bytes to delivered PCM -- the oracle front-end (Huffman / code
  * book / range decoding: mp3_frontend.c, vorbis_frontend.c, opus_frontend.c) and then the transform-stage oracle -- the CPU
- * side of SURVEY 8d (c), bench.py's `cpu_baseline_e2e`.  FLAC has no oracle front-end (parity of the product's parser is
- * pinned by an independent bitstream writer, tests/flac_bitstream.py): its task calls a parser the CALLER hands in as a
- * function pointer (bench.py passes the product's host-only afg_flac_parse) and then the oracle's restore.
+ * side of SURVEY 8d (c), bench.py's `cpu_baseline_e2e`.  Round 5: FLAC too (flac_frontend.c: the reference's scalar 32-bit
+ * cache reader with the prediction fused into the Rice loop, as drflac decodes); until then its task borrowed the
+ * product's parser.
  */
 #define _GNU_SOURCE
 #include "afg_oracle.h"
@@ -25,7 +25,7 @@
 
 typedef struct afgo_bench_task {
     int32_t  codec;                  /* 0 MP3, 1 Vorbis, 2 FLAC, 3 CELT (transform stage); 10 MP3, 11 Ogg Vorbis, 12 Ogg Opus, 13 FLAC:
-                                        a file in memory, a = bytes, out_floats = byte count, b / c = parse / free functions (13) */
+                                        a file in memory, a = bytes, out_floats = byte count */
     uint32_t n;                      /* MP3: granules; Vorbis: packets; FLAC: frames; CELT: channel sequences */
     uint32_t channels;               /* MP3 / Vorbis */
     uint16_t bs0, bs1;               /* Vorbis block sizes */
@@ -57,18 +57,6 @@ static double now_s(clockid_t c)
     clock_gettime(c, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
-
-/* the product's afg_flac_parsed (include/afg.h) as far as this file reads it */
-typedef struct flac_parsed {
-    uint32_t sample_rate, channels, bps, max_block;
-    uint64_t total_samples, n_frames, n_subframes, n_res, out_samples;
-    afgo_flac_frame *frames;
-    afgo_flac_subframe *subframes;
-    int32_t *res;
-    void *owner;
-} flac_parsed;
-typedef int (*flac_parse_fn)(const uint8_t *, size_t, flac_parsed *);
-typedef void (*flac_free_fn)(flac_parsed *);
 
 /* bytes -> delivered PCM of one file; returns the number of samples (channels included), 0 on failure */
 static uint64_t run_file(const afgo_bench_task *t)
@@ -132,19 +120,17 @@ static uint64_t run_file(const afgo_bench_task *t)
         afgo_opus_file_free(&f);
         break;
     }
-    case 13: {
-        flac_parsed fp;
-        memset(&fp, 0, sizeof(fp));
-        if (!t->b || ((flac_parse_fn)t->b)(data, size, &fp) != 0) break;
-        int32_t *pcm = (int32_t *)malloc(4 * (size_t)(fp.out_samples ? fp.out_samples : 1));
-        float *pcf = (float *)malloc(4 * (size_t)(fp.out_samples ? fp.out_samples : 1));
-        if (pcm && pcf) {
-            afgo_flac_transform(fp.n_frames, fp.frames, fp.subframes, fp.res, pcm, pcf);   /* + stream.d:505-511 float conversion */
-            samples = fp.out_samples;
+    case 13: {                                          /* FLAC: the oracle's own front-end (flac_frontend.c) + stream.d:505-511 */
+        afgo_flac_file f;
+        if (afgo_flac_decode_file(data, size, &f) != 0) break;
+        float *pcf = (float *)malloc(4 * (size_t)(f.n_samples ? f.n_samples : 1));
+        if (pcf) {
+            const double factor = 1.0 / 2147483647.0;
+            for (uint64_t i = 0; i < f.n_samples; i++) pcf[i] = (float)(f.pcm[i] * factor);
+            samples = f.n_samples;
         }
-        free(pcm);
         free(pcf);
-        if (t->c) ((flac_free_fn)t->c)(&fp);
+        afgo_flac_file_free(&f);
         break;
     }
     default: break;

@@ -52,6 +52,115 @@ window.Plotly = {
 """
 
 
+# A second stand-in: Chromium's MediaRecorder ENCODES a synthesised signal as Opus in WebM (WebRTC's libopus encoder, round 5).
+# Fullband music-like material at these rates makes it choose CELT-only 20 ms frames (TOC configuration 31, three frames to
+# a packet): valid streams from an encoder, which the random range-coder input of tests/opus_bitstream.py is not.
+FAKE_PLOTLY_ENCODE = r"""
+window.Plotly = {
+  version: '2.0.0',
+  toImage: function (fig, opts) {
+    const meta = fig.layout.meta;
+    return new Promise(function (resolve) {
+      try {
+        const ctx = new AudioContext({ sampleRate: 48000 });
+        const n = Math.floor(48000 * meta.secs), ch = meta.channels;
+        const buf = ctx.createBuffer(ch, n, 48000);
+        for (let c = 0; c < ch; c++) {
+          const d = buf.getChannelData(c);
+          let seed = meta.seed + 77 * c;
+          for (let i = 0; i < n; i++) {
+            seed = (seed * 1103515245 + 12345) & 0x7fffffff;
+            const noise = (seed / 0x7fffffff - 0.5);
+            const t = i / 48000;
+            if (meta.kind == 0)        // steady tones, a slow tremolo and a noise floor
+              d[i] = 0.25 * Math.sin(2 * Math.PI * (220 + 30 * c) * t) + 0.15 * Math.sin(2 * Math.PI * 1760 * t + c) * Math.sin(2 * Math.PI * 3 * t)
+                   + 0.1 * Math.sin(2 * Math.PI * 5200 * t) + 0.05 * noise;
+            else if (meta.kind == 1)   // a sweep with clicks every 125 ms: transients (short blocks, time-frequency switching)
+              d[i] = 0.3 * Math.sin(2 * Math.PI * (300 + 2500 * t) * t + c) + ((i % 6000) < 24 ? 0.6 * noise : 0.0) + 0.02 * noise;
+            else                       // decaying plucked notes over a quiet noise bed
+              d[i] = 0.4 * Math.exp(-6 * (t % 0.25)) * Math.sin(2 * Math.PI * (330 * (1 + Math.floor(t * 4) % 5 / 4)) * t + c) + 0.01 * noise;
+          }
+        }
+        const dest = ctx.createMediaStreamDestination();
+        dest.channelCount = ch;
+        const src = ctx.createBufferSource();
+        src.buffer = buf; src.connect(dest);
+        const rec = new MediaRecorder(dest.stream, { mimeType: 'audio/webm;codecs=opus', audioBitsPerSecond: meta.bps });
+        const chunks = [];
+        rec.ondataavailable = function (e) { chunks.push(e.data); };
+        rec.onstop = function () {
+          new Blob(chunks).arrayBuffer().then(function (ab) {
+            const u = new Uint8Array(ab); let s = '';
+            for (let i = 0; i < u.length; i += 0x8000) s += String.fromCharCode.apply(null, u.subarray(i, i + 0x8000));
+            resolve(JSON.stringify({ webm: btoa(s) }));
+          });
+        };
+        src.onended = function () { setTimeout(function () { rec.stop(); }, 200); };
+        ctx.resume().then(function () { rec.start(); src.start(); });
+        setTimeout(function () { resolve(JSON.stringify({ error: 'timeout', state: ctx.state })); }, (meta.secs + 10) * 1000);
+      } catch (e) { resolve(JSON.stringify({ error: String(e) })); }
+    });
+  }
+};
+"""
+
+
+def webm_opus_packets(data):
+    """(OpusHead from CodecPrivate, [packet bytes]) of a WebM file with one Opus track: the SimpleBlocks / Blocks, no lacing."""
+    def vint(b, p, keep=False):
+        first, n, mask = b[p], 1, 0x80
+        while n <= 8 and not (first & mask):
+            n += 1
+            mask >>= 1
+        v = first if keep else first & (mask - 1)
+        for i in range(1, n):
+            v = (v << 8) | b[p + i]
+        return v, p + n, n
+
+    out = {"head": None, "blocks": []}
+
+    def walk(p, end):
+        while p < end:
+            ident, p2, _ = vint(data, p, True)
+            size, p3, n = vint(data, p2)
+            e = end if size == (1 << (7 * n)) - 1 else p3 + size            # unknown size: to the end of the parent
+            if ident in (0x18538067, 0x1654AE6B, 0xAE, 0x1F43B675, 0xA0):   # Segment, Tracks, TrackEntry, Cluster, BlockGroup
+                walk(p3, min(e, end))
+            elif ident == 0x63A2:
+                out["head"] = bytes(data[p3:e])
+            elif ident in (0xA3, 0xA1):                                       # SimpleBlock / Block: track, int16 timecode, flags
+                _, q, _ = vint(data, p3)
+                assert data[q + 2] & 0x06 == 0, "laced block"
+                out["blocks"].append(bytes(data[q + 3:e]))
+            p = e
+    walk(0, len(data))
+    return out["head"], out["blocks"]
+
+
+class WebEncoder:
+    def __init__(self):
+        from kaleido.scopes.plotly import PlotlyScope
+        self.dir = tempfile.mkdtemp()
+        js = os.path.join(self.dir, "fake_plotly_encode.js")
+        with open(js, "w") as fh:
+            fh.write(FAKE_PLOTLY_ENCODE)
+        self.scope = PlotlyScope(plotlyjs=Path(js).as_uri())
+        self.scope.chromium_args += ("--autoplay-policy=no-user-gesture-required",)
+
+    def encode_ogg_opus(self, kind, channels, secs, bps, seed):
+        """-> an Ogg Opus file of CELT-only packets made by Chromium's encoder (remuxed from its WebM), or None"""
+        import opus_bitstream as ob
+        out = self.scope.transform({"data": [], "layout": {"meta": {"kind": kind, "channels": channels, "secs": secs, "bps": bps, "seed": seed}}},
+                                   format="json")
+        d = json.loads(out.decode() if isinstance(out, bytes) else out)
+        if "webm" not in d:
+            raise RuntimeError(str(d))
+        head, pkts = webm_opus_packets(base64.b64decode(d["webm"]))
+        if head is None or not pkts or any((p[0] >> 3) < 16 for p in pkts):   # a SILK or hybrid packet: not this path
+            return None
+        return ob.ogg_opus(pkts, head[9], preskip=head[10] | (head[11] << 8), gain=0, head=head, trim=0)
+
+
 class WebAudio:
     def __init__(self):
         from kaleido.scopes.plotly import PlotlyScope
@@ -99,6 +208,15 @@ def main():
         out[tag + "_file_gain0"] = np.frombuffer(a, np.uint8)
         out[tag + "_file_gain_m78dB"] = np.frombuffer(b, np.uint8)
         out[tag + "_pcm_m78dB"] = wa.decode(b, ch, 48000)
+    # encoder-made CELT: kept only if every packet is CELT-only (TOC configuration >= 16)
+    we = WebEncoder()
+    for k, (kind, ch, secs, bps) in enumerate(((0, 2, 1.5, 256000), (1, 2, 1.5, 160000), (2, 1, 1.5, 128000))):
+        ogg = we.encode_ogg_opus(kind, ch, secs, bps, 1000 + k)
+        if ogg is None:
+            print("encoder-made file", k, "holds SILK / hybrid packets: left out")
+            continue
+        out[f"opus_enc{k}_file"] = np.frombuffer(ogg, np.uint8)
+        out[f"opus_enc{k}_pcm"] = wa.decode(ogg, ch, 48000)
     np.savez_compressed(os.path.join(HERE, "independent_webaudio.npz"), **out)
     for k, v in out.items():
         print(k, v.shape, v.dtype)

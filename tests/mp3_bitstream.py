@@ -283,8 +283,16 @@ def expected_lines(version, g, q, iscf, bands, ms):
     return out
 
 
-def make_file(seed, n_frames=6, version="mpeg1", sr=0, mode="stereo", bitrate_index=9, id3=False):
-    """mode: mono | stereo | ms | intensity | ms+intensity.  Returns (bytes, list of per-frame dicts)."""
+# decoded PCM rms / rms of the requantised lines (records scale) of these streams, measured with the oracle: the IMDCT +
+# polyphase chain is energy-preserving up to this factor (x sqrt(2) with M/S, whose lines carry 1/sqrt(2))
+PCM_PER_LINE_RMS = 33.94
+
+
+def make_file(seed, n_frames=6, version="mpeg1", sr=0, mode="stereo", bitrate_index=9, id3=False, pcm_rms=0.05):
+    """mode: mono | stereo | ms | intensity | ms+intensity.  Returns (bytes, list of per-frame dicts).
+    pcm_rms: every granule's global_gain is chosen so that the decoded signal has about this rms (full scale = 1.0), as
+    an encoder's material does -- the code words are random, the level is not (None: global_gain random in [120, 200),
+    which decodes to tens to hundreds of times full scale)."""
     rng = np.random.default_rng(seed)
     nch = 1 if mode == "mono" else 2
     ms = "ms" in mode
@@ -317,6 +325,12 @@ def make_file(seed, n_frames=6, version="mpeg1", sr=0, mode="stereo", bitrate_in
                 g, bits, q, iscf, bands = gen_granule(rng, version, sr, nch, ch, gr, ms, intensity, share, prev_scf[ch],
                                                       prev_short=(gr == 1 and was_short[ch]))
                 was_short[ch] = g["block_type"] == 2
+                if pcm_rms is not None:
+                    unity = dict(g, global_gain=214 + (2 if ms else 0))                  # gain_exp == 0 in expected_lines
+                    r = float(np.sqrt(np.mean(expected_lines(version, unity, q, iscf, bands, ms) ** 2)))
+                    if r > 0.0:
+                        want = pcm_rms * float(rng.uniform(0.6, 1.4)) / (PCM_PER_LINE_RMS * (2.0 ** 0.5 if ms else 1.0))
+                        g["global_gain"] = int(np.clip(round(unity["global_gain"] + 4.0 * np.log2(want / r)), 0, 255))
                 row.append(g)
                 md.s += bits.s
                 if version == "mpeg1":

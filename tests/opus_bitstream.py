@@ -114,9 +114,27 @@ def ogg_opus(packets, channels, preskip=312, gain=0, comments=(), serial=0x4f505
     return b"".join(pages)
 
 
+def level_comment(packets, channels, preskip=312, pcm_rms=0.05):
+    """The R128_TRACK_GAIN comment (Q7.8 dB, dopus.d:8011-8059) that brings the decode of these packets to about pcm_rms of
+    full scale.  The payloads are random range-coder input, so their band energies -- and the level of the decode -- are
+    anything; an encoder's file sits inside full scale.  Measured with the oracle's decode of the same packets ahead of
+    the gain and the int16 conversion (this is test infrastructure); b"" if they do not decode."""
+    import oraclelib
+    rec = oraclelib.opus_decode_file(ogg_opus(packets, channels, preskip))
+    if isinstance(rec, int) or rec.get("error") or not rec["pcm_frames"]:
+        return b""
+    base, recs = oraclelib.opus_channel_records(rec)
+    pcm = oraclelib.celt_transform(base, recs, rec["coeffs"], rec["pcm_frames"] * rec["channels"]).astype(np.float64)
+    rms = float(np.sqrt(np.mean(pcm ** 2)))
+    if not np.isfinite(rms) or rms <= 0.0:
+        return b""
+    return b"R128_TRACK_GAIN=%d" % int(np.clip(round(5120.0 * np.log10(pcm_rms / rms)), -32768, 32767))
+
+
 def random_celt_file(rng, channels, n_packets, preskip=312, gain=0, comments=(), configs=None, codes=None, mixed_stereo=True,
-                     trim=None):
-    """A file of CELT-only packets (TOC configurations 16..31) with random framing codes and payloads."""
+                     trim=None, pcm_rms=None):
+    """A file of CELT-only packets (TOC configurations 16..31) with random framing codes and payloads.
+    pcm_rms: add the track gain that brings the decode to about this level (level_comment)."""
     pkts = []
     for _ in range(n_packets):
         config = int(rng.choice(configs)) if configs is not None else int(rng.integers(16, 32))
@@ -138,4 +156,7 @@ def random_celt_file(rng, channels, n_packets, preskip=312, gain=0, comments=(),
     if total - trim < preskip:
         trim = 0
         preskip = min(preskip, total)
+    if pcm_rms is not None:
+        c = level_comment(pkts, channels, preskip, pcm_rms)
+        comments = tuple(comments) + ((c,) if c else ())
     return ogg_opus(pkts, channels, preskip, gain, comments, rng=rng, trim=trim), pkts

@@ -30,6 +30,31 @@ def test_library_exports_every_declared_symbol():
     assert lib.afg_status_string(-2) == b"no usable gfx950 device"
 
 
+def test_d_binding_declares_the_headers_symbols():
+    """bindings/d/afgpu.d (what a maintainer of the reference imports; never compiled here: no D compiler) declares exactly the
+    functions include/afg.h declares."""
+    text = open(os.path.join(ROOT, "bindings", "d", "afgpu.d")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    in_d = sorted(set(re.findall(r"\b(afg_[a-z0-9_]+)\s*\(", text)))
+    names = declared_symbols()
+    assert [n for n in names if n not in in_d] == [], "declared in afg.h, missing from the D binding"
+    assert [n for n in in_d if n not in names] == [], "in the D binding, not in afg.h"
+
+
+def test_dev_options_are_set_by_call_not_by_environment():
+    """afg_dev_option (afg.h): the test hooks are named options of a call; the library holds no getenv for them (strings of
+    the binary), and an unknown name is refused."""
+    import afgpu
+    lib = afgpu.lib()
+    assert lib.afg_dev_option(b"celt_path", 3) == 0 and lib.afg_dev_option(b"celt_path", -1) == 0
+    assert lib.afg_dev_option(b"no_such_option", 1) != 0
+    so = open(os.path.join(ROOT, "audio-formats_amd", "lib", "libafg_hip.so"), "rb").read()
+    for name in (b"AFG_CELT_DE_SEQ", b"AFG_CELT_DE_DUO", b"AFG_CELT_PATH", b"AFG_CELT_SEG_RECS", b"AFG_CELT_WHOLE_FRAMES", b"AFG_VORBIS_SINGLE",
+                 b"AFG_MP3_CHUNKS", b"AFG_MP3_FLOAT_UPLOAD", b"AFG_VORBIS_HOST_FLOOR", b"AFG_FLAC_HOST_RES32"):
+        assert name not in so, name
+
+
 def test_record_layouts_match_the_header():
     import afgpu
     assert afgpu.FLAC_SUBFRAME_DTYPE.itemsize == 68 and afgpu.FLAC_FRAME_DTYPE.itemsize == 32

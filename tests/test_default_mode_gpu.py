@@ -84,7 +84,7 @@ def test_chunked_reads_equal_the_batch_decode_default_mode(gpu, kind):
         s.cleanUp()
     if kind == "ogg":
         ref = oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(data))
-        assert ref.shape == want["pcm"].shape and rms(want["pcm"], ref) <= TOL * max(1.0, float(np.abs(ref).max()))
+        assert ref.shape == want["pcm"].shape and rms(want["pcm"], ref) <= TOL          # absolute: the generated files sit inside full scale (round 5)
 
 
 def test_ogg_seeks_default_mode(gpu):

@@ -77,6 +77,36 @@ def test_full_size_vorbis_batch_default_mode(gpu):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.numeric_tolerance
+def test_full_size_mp3_batch_default_mode(gpu):
+    """C2 in the default numeric mode (mp3_tolerance_kernel: csrc/mp3_kernel.h with fused multiply-adds, the kernel the
+    headline is measured on): first, middle and last file within 1e-5 RMS of the oracle, every sample written, a second
+    launch bit-identical."""
+    import torch
+    if free_bytes() < 100e9:
+        pytest.skip("not enough free device memory for the full-size batch")
+    wl = corpus.build_c234(gpu, 0, ("mp3",), corpus.C2_FILES)
+    part = wl.parts[0]
+    out = part.out_plane()
+    out.fill_(float("nan"))
+    stream = torch.cuda.current_stream()
+    part.launch(stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert out.numel() * out.element_size() > 2 ** 32
+    n_files = len(part.file_bounds()) - 1
+    for f in (0, n_files // 2 + 1, n_files - 1):
+        r = part.check_file(oraclelib, f)
+        assert r["samples"] > 0 and r["mode"] == "tolerance" and r["mismatches"] == 0 and r["rms_error"] <= 1e-5, (f, r)
+        assert r["bitwise_mismatches"] > 0, "the exact kernel ran: this test would not be testing the tolerance build"
+    assert bool(torch.isfinite(out).all())
+    first = out.clone()
+    part.launch(stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(first, out)
+    del first, out, part, wl
+    torch.cuda.empty_cache()
+
+
 def test_full_size_celt_batch(gpu):
     """8192 stereo CELT streams of 200 frames (the stream-walk path, every wavefront slot taken four times over): first,
     middle and last stream against the oracle, everything written, deterministic."""

@@ -228,3 +228,39 @@ def test_default_numeric_mode_end_to_end(gpu):
         total += d.size
     print("int16 flip rate", flips / total)
     assert flips / total < 0.01
+
+
+def encoder_made_files():
+    import os
+    v = np.load(os.path.join(os.path.dirname(__file__), "golden", "independent_webaudio.npz"))
+    return [v[f"opus_enc{k}_file"].tobytes() for k in range(3)], [v[f"opus_enc{k}_pcm"] for k in range(3)]
+
+
+def test_encoder_made_files_exact_mode(gpu):
+    """Three clips from a real Opus encoder (Chromium's MediaRecorder: WebRTC's libopus, CELT-only fullband, code-3 packets of
+    three 20 ms frames; tests/golden/make_independent.py), transient and stationary, stereo and mono: the product's decode
+    is the oracle's bit for bit, batch and chunked stream reads alike -- and within 2e-3 of libopus' own decode of them."""
+    files, libopus = encoder_made_files()
+    res = afgpu.batch_decode(files)
+    for r, data, lo in zip(res, files, libopus):
+        rec, pcm = expected(data)
+        assert r["status"] == 0 and r["format"] == afgpu.FORMAT_OPUS and r["channels"] == rec["channels"], r["message"]
+        same_pcm(r["pcm"], pcm)
+        st = afgpu.AudioStream()
+        st.openFromMemory(data)
+        assert not st.isError(), st.errorMessage()
+        same_pcm(read_all(st, rec["channels"], 777), pcm)
+        st.cleanUp()
+        d = r["pcm"].astype(np.float64) - lo
+        assert np.sqrt(np.mean(d ** 2)) <= 2e-3 * np.sqrt(np.mean(lo.astype(np.float64) ** 2))
+
+
+@pytest.mark.numeric_tolerance
+def test_encoder_made_files_default_mode(gpu):
+    files, _ = encoder_made_files()
+    assert afgpu.get_numeric_mode() == afgpu.NUMERIC_TOLERANCE
+    for r, data in zip(afgpu.batch_decode(files), files):
+        rec, pcm = expected(data)
+        assert r["status"] == 0 and r["frames"] == len(pcm)
+        d = np.abs(r["pcm"].astype(np.float64) - pcm)
+        assert d.max() <= ONE_STEP and np.sqrt(np.mean(d ** 2)) <= 1e-5 and (d > 0).mean() < 0.01

@@ -17,10 +17,18 @@ unpinned"), but it is evidence from other hands:
     other random files (other seeds, mixed frame sizes or bandwidths) single frames differ by tens of percent between the
     two decoder lineages -- FFmpeg's CELT decoder is known not to track libopus on everything a random bitstream
     exercises -- and without the reference's own output those differences cannot be assigned to either side.  The Opus
-    front-end therefore stays "parity unpinned" in DESIGN.md."""
+    front-end therefore stays "parity unpinned" in DESIGN.md.
+  * Opus, ENCODER-MADE (round 5): three clips that Chromium's MediaRecorder encoded (WebRTC's libopus encoder; every
+    packet CELT-only fullband, three 20 ms frames each) and libopus decoded.  Valid streams, which the random payloads
+    above are not: the oracle's decode of the same bytes agrees to 2.2e-5 of the signal on the two stationary clips --
+    the level of the reference's int16 output conversion -- and to 1.0e-3 on the transient clip, where every bit of the
+    difference sits inside short-block frames (0.1-0.6 % of those frames) and their successors' overlap.  That bounds the
+    known distance between the FFmpeg CELT lineage (the reference's) and libopus on real material; it still does not say
+    which side the reference's own output would be on in those frames."""
 import os
 
 import numpy as np
+import pytest
 
 import oraclelib
 
@@ -92,3 +100,24 @@ def test_opus_mono_agrees_with_libopus():
     got, want = opus_case("opus_mono", 1)
     assert rms(got - want) <= 0.10 * rms(want), rms(got - want) / rms(want)
     assert rms(got[1:] - want[:-1]) > 5 * rms(got - want)
+
+
+@pytest.mark.parametrize("k,channels,bound", [(0, 2, 1e-4), (1, 2, 2e-3), (2, 1, 1e-4)])
+def test_encoder_made_opus_agrees_with_libopus(k, channels, bound):
+    v = vectors()
+    data = v[f"opus_enc{k}_file"].tobytes()
+    want = v[f"opus_enc{k}_pcm"].astype(np.float64)
+    rec = oraclelib.opus_decode_file(data)
+    assert not isinstance(rec, int) and not rec["error"] and rec["channels"] == channels and len(rec["frames"]) == 75
+    got = oraclelib.opus_file_pcm(rec).astype(np.float64)
+    assert got.shape == want.shape == (72000, channels) and 0.1 < rms(want) < 0.3          # an encoder's level
+    d = got - want
+    assert rms(d) <= bound * rms(want), rms(d) / rms(want)
+    assert rms(got[1:] - want[:-1]) > 100 * rms(d)                                          # aligned to the sample
+    # frame by frame: long-block frames that do not follow a transient agree to the int16 conversion's level
+    per = np.sqrt((d.reshape(75, 960, channels) ** 2).mean(axis=(1, 2))) / np.sqrt((want.reshape(75, 960, channels) ** 2).mean(axis=(1, 2)))
+    short = rec["frames"]["blocks"][:75] > 1
+    calm = ~short & ~np.roll(short, 1)
+    calm[0] = False
+    assert calm.sum() >= 40 and per[calm].max() <= 1e-4, per[calm].max()
+    assert per.max() <= 1e-2

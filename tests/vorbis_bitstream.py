@@ -72,8 +72,9 @@ def random_lengths(rng, used, max_len=16):
     return [int(v) for v in leaves]
 
 
-def write_codebook(b, rng, entries, dim, kind, lookup):
-    """kind: 'ordered' | 'dense' | 'sparse'.  lookup: 0 | 1 | 2 (for 1, entries must be values**dim)."""
+def write_codebook(b, rng, entries, dim, kind, lookup, level_exp=0):
+    """kind: 'ordered' | 'dense' | 'sparse'.  lookup: 0 | 1 | 2 (for 1, entries must be values**dim).
+    level_exp: added to the exponents of the book's minimum and delta values -- every vector of the book times 2^level_exp."""
     b.put(0x564342, 24)
     b.put(dim, 16)
     b.put(entries, 24)
@@ -108,8 +109,8 @@ def write_codebook(b, rng, entries, dim, kind, lookup):
     if lookup:
         def pack_float(mant, exp, neg):              # specification 9.2.2: 21-bit mantissa, 10-bit biased exponent
             return (0x80000000 if neg else 0) | ((exp + 788) << 21) | mant
-        b.put(pack_float(int(rng.integers(0, 1 << 12)), int(rng.integers(-16, -6)), int(rng.integers(0, 2))), 32)   # minimum
-        b.put(pack_float(int(rng.integers(1, 1 << 10)), int(rng.integers(-14, -8)), 0), 32)                          # delta
+        b.put(pack_float(int(rng.integers(0, 1 << 12)), int(rng.integers(-16, -6)) + level_exp, int(rng.integers(0, 2))), 32)   # minimum
+        b.put(pack_float(int(rng.integers(1, 1 << 10)), int(rng.integers(-14, -8)) + level_exp, 0), 32)                          # delta
         value_bits = int(rng.integers(1, 9))
         b.put(value_bits - 1, 4)
         b.put(int(rng.random() < 0.3), 1)            # sequence_p
@@ -124,7 +125,29 @@ def write_codebook(b, rng, entries, dim, kind, lookup):
 
 
 def make_file(seed, channels=2, bs=(256, 2048), n_packets=24, rate=44100, residue_types=(0, 1, 2), packet_bytes=(20, 400),
-              force_long_only=False, break_windows_at=None):
+              force_long_only=False, break_windows_at=None, pcm_rms=0.05):
+    """A random legal Ogg Vorbis file.  pcm_rms: the level of the decoded signal (full scale = 1.0): the packets are random
+    bits, so the file is written twice -- once as drawn, decoded (by the oracle: this is test infrastructure), and again
+    with every code book's value range moved by the power of two that brings the decode to about pcm_rms (the same draws:
+    the residue vectors scale exactly, floor and transform are linear in them).  A draw that decodes to silence stays as
+    it is (rms 0: callers that need signal check).  None: one pass, as drawn (rms anywhere from 0 to a thousand)."""
+    args = (seed, channels, bs, n_packets, rate, residue_types, packet_bytes, force_long_only, break_windows_at)
+    data = _make_file(*args, level_exp=0)
+    if pcm_rms is None:
+        return data
+    import oraclelib
+    rec = oraclelib.vorbis_decode_file(data)
+    if rec is None:
+        return data
+    pcm = oraclelib.vorbis_file_pcm(rec).astype(np.float64)
+    rms = float(np.sqrt(np.mean(pcm ** 2))) if pcm.size else 0.0
+    if not np.isfinite(rms) or rms <= 0.0:
+        return data
+    k = int(np.clip(round(float(np.log2(pcm_rms / rms))), -200, 60))
+    return _make_file(*args, level_exp=k) if k else data
+
+
+def _make_file(seed, channels, bs, n_packets, rate, residue_types, packet_bytes, force_long_only, break_windows_at, level_exp):
     rng = np.random.default_rng(seed)
     serial = int(rng.integers(1, 1 << 31))
     log0, log1 = bs[0].bit_length() - 1, bs[1].bit_length() - 1
@@ -170,7 +193,7 @@ def make_file(seed, channels=2, bs=(256, 2048), n_packets=24, rate=44100, residu
     for (entries, dim, lookup, kind) in all_books:
         if kind == "sparse" and entries < 8:
             kind = "dense"
-        write_codebook(b, rng, entries, dim, kind, lookup)
+        write_codebook(b, rng, entries, dim, kind, lookup, level_exp)
     b.put(0, 6)                                      # time-domain transforms: one, value 0
     b.put(0, 16)
     # floors

@@ -1,4 +1,4 @@
-"""Where do the FLAC kernel's samples differ from the oracle's?  (development aid)  usage: dbg_flac32.py [files] [res16: 0|1]"""
+"""Where do the FLAC kernel's samples differ from the oracle's?  (development aid)  usage: flac_mismatch_positions.py [files] [res16: 0|1]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
