@@ -388,6 +388,9 @@ class VorbisPart(Part):
             pflags = np.where(pflags & VORBIS_LONG, pflags | np.uint8(VORBIS_NZ_EIGHTHS(self.nz_eighths)), pflags).astype(np.uint8)
         nf = len(n)
         self.plan = VorbisPlan(n, np.full(nf, 2, np.uint8), np.full(nf, bs0, np.uint16), np.full(nf, bs1, np.uint16), pflags, seg)
+        # the same packets with nothing declared (every long block's whole spectrum fetched): built on first use (launch(full_fetch=True))
+        self._plan_full, self._plan_full_args = None, (n, np.full(nf, 2, np.uint8), np.full(nf, bs0, np.uint16), np.full(nf, bs1, np.uint16),
+                                                       (pflags & np.uint8(0x0f)).astype(np.uint8), seg)       # bits 4-7: AFG_VORBIS_NZ_EIGHTHS
         if host:
             self.spec = torch.from_numpy(vorbis_spec_numpy(seed, pflags, n, file_ids, bs0, bs1)).to(device)
             assert self.spec.numel() == self.plan.spec_floats
@@ -427,8 +430,13 @@ class VorbisPart(Part):
         n_long = int(((pflags & VORBIS_LONG) != 0).sum())
         self.alg_bytes = self.survey_bytes - 4 * n_long * 2 * (bs1 // 2) * (8 - self.nz_eighths) // 8
 
-    def launch(self, stream):
-        self.plan.transform(self.spec, self.out, stream)
+    def launch(self, stream, full_fetch=False):
+        if full_fetch:
+            if self._plan_full is None:
+                self._plan_full = VorbisPlan(*self._plan_full_args)
+            self._plan_full.transform(self.spec, self.out, stream)
+        else:
+            self.plan.transform(self.spec, self.out, stream)
 
     def out_plane(self):
         return self.out

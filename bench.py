@@ -467,6 +467,22 @@ def run_rank(args, world, rank, local_rank):
                         ms.append(e0.elapsed_time(e1))
                 extra["mp3_full_fetch"] = {"avg_kernel_ms": sum(ms) / len(ms), "frac": mp3.alg_bytes / (sum(ms) / len(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "note": "flag words without AFG_MP3_NZ_BANDS: all 32 subbands of every block fetched"}
+            # Vorbis likewise with nothing declared (no AFG_VORBIS_NZ_EIGHTHS: what a file whose residue runs to the top of the
+            # band gets): the headline's Vorbis figure owes its last 5 % to a property of the synthetic spectra
+            vb = next((p for p in wl.parts if p.name == "vorbis"), None)
+            if vb is not None and not args.no_full_fetch:
+                ms = []
+                for i in range(2 + min(args.steps, 10)):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream); vb.launch(stream, full_fetch=True); e1.record(stream)
+                    torch.cuda.synchronize()
+                    if i >= 2:
+                        ms.append(e0.elapsed_time(e1))
+                extra["vorbis_full_fetch"] = {"avg_kernel_ms": sum(ms) / len(ms), "samples_per_s": vb.samples / (sum(ms) / len(ms) * 1e-3),
+                                              "frac": vb.survey_bytes / (sum(ms) / len(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "note": "packet flags without AFG_VORBIS_NZ_EIGHTHS: every long block's whole spectrum fetched (40.1 GB, SURVEY 8d's figure)"}
+                vb.launch(stream)                          # leave the declared launch's output in the plane
+                torch.cuda.synchronize()
             # the same step with its kernels side by side on three streams, the persistent ones (MP3, Vorbis) launched first
             # and FLAC's grid filling in behind them: not the line's `value` -- there every kernel has the device to itself,
             # which is what a per-kernel roofline needs -- but what a caller gets who launches the three batches together
@@ -524,13 +540,13 @@ def run_rank(args, world, rank, local_rank):
         tot5 = reduce_sum(float(my5))
         if rank == 0:
             value5 = tot5 * 3 / e5_max
-            ref = (load_traffic("r04_c5.json") or load_traffic("r03_c5.json") or {})
+            ref = (load_traffic("r05_c5.json") or load_traffic("r04_c5.json") or {})
             ref_value = ref.get("value") if ref.get("n_gpus", 1) == 1 else None
             c5_tail = {"workload": f"{args.c5_files}-file mixed corpus file-sharded over {world} GPU(s) by LPT on predicted device time (bench.py --config c5)",
                        "value": value5, "unit": "samples/s", "scaling": "strong", "n_gpus": world, "steps": 3, "ms_per_step": e5_max / 3 * 1e3,
                        "per_rank_ms_per_step": {"min": e5_min / 3 * 1e3, "max": e5_max / 3 * 1e3},
                        "samples_per_step": int(tot5), "waves_per_gpu": len(waves5), "lpt_imbalance": corpus.c5_imbalance(man5, world),
-                       "n1_reference_value": ref_value, "n1_reference_source": "profiles/r04_c5.json (bench.py --config c5 on one GPU)" if ref_value else None,
+                       "n1_reference_value": ref_value, "n1_reference_source": "profiles/r05_c5.json (bench.py --config c5 on one GPU)" if ref_value else None,
                        "efficiency_vs_n1": (value5 / (world * ref_value)) if ref_value else None,
                        "kernels": [{"codec": n, "avg_kernel_ms": sum(k["ms"]) / len(k["ms"]), "samples_per_launch": int(k["samples"])} for n, k in kern5.items()],
                        "parity": parity5}
@@ -546,8 +562,8 @@ def run_rank(args, world, rank, local_rank):
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
     # passes over the same full-size batch, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_collect.sh): only
     # for the kernels and batch sizes those passes were taken on
-    pmc_file = {"mp3": "r04_pmc_mp3_tolerance_kernel.json", "vorbis": "r04_pmc_vorbis_walk_kernel.json",
-                "flac": "r04_pmc_flac_restore1_kernel.json"}     # (FLAC: counters calibrated on its own access pattern, both instantiations)
+    pmc_file = {"mp3": "r05_pmc_mp3_tolerance_kernel.json", "vorbis": "r05_pmc_vorbis_walk_kernel.json",
+                "flac": "r05_pmc_flac_restore1_kernel.json"}     # (FLAC: counters calibrated on its own access pattern, both instantiations)
     kernels = []
     for name, k in kern.items():
         avg_ms = sum(k["ms"]) / len(k["ms"])
@@ -582,7 +598,8 @@ def run_rank(args, world, rank, local_rank):
                 "overlapped_on_a_second_stream": ["celt"] if args.config == "c5" else [],
                 "whole_step": {"algorithmic_bytes": int(step_bytes), "kernel_ms": step_ms,
                                "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "measured_copy_GBs": extra.get("measured_copy_GBs"), "mp3_full_fetch": extra.get("mp3_full_fetch")}
+                "measured_copy_GBs": extra.get("measured_copy_GBs"), "mp3_full_fetch": extra.get("mp3_full_fetch"),
+                "vorbis_full_fetch": extra.get("vorbis_full_fetch")}
     if extra.get("celt_alone_ms"):
         roofline["celt_alone"] = {"avg_kernel_ms": extra["celt_alone_ms"], "frac": extra["celt_alone_bytes"] / (extra["celt_alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "note": "the Opus members of all waves launched on their own (no other kernel beside them), summed over the waves"}

@@ -48,7 +48,7 @@ def file_parity(items, want, tolerance=False):
             if tolerance is True:
                 step = np.abs(d) * 32767.0
                 rec["int16_flip_rate"] = float((step > 0).mean())
-                ok = ok and step.max() <= 1.0001 and (step > 0).mean() < 0.01
+                ok = ok and step.max() <= 1.004 and (step > 0).mean() < 0.01      # (int16 / 32767 near full scale: neighbours are 1 / 32767 +- 1.2e-7 apart)
             rec["mismatches"] += 0 if ok else max(bits, 1)
         else:
             rec["mismatches"] += bits
@@ -438,10 +438,13 @@ def bench_mixed_e2e(files, gen, threads):
         kinds.append((k, count[k] % len(gen[k])))
         count[k] += 1
     job, sec, windows = timed_batch(blobs, threads)
-    first = {}
+    picks = {}                                           # four DISTINCT files of every format: sixteen per batch
     for i, (k, j) in enumerate(kinds):
-        first.setdefault(k, (i, j))
-    items = [dict(o, pcm=o["pcm"].copy()) if any(i == v[0] for v in first.values()) else dict(o) for i, o in enumerate(job.items)]
+        lst = picks.setdefault(k, [])
+        if len(lst) < 4 and all(j != jj for _, jj in lst):
+            lst.append((i, j))
+    chosen = {i for lst in picks.values() for i, _ in lst}
+    items = [dict(o, pcm=o["pcm"].copy()) if i in chosen else dict(o) for i, o in enumerate(job.items)]
     job.close()
     samples = sum(o["frames"] * o["channels"] for o in items)
     ok = all(o["status"] == 0 and o["frames"] > 0 for o in items)
@@ -451,8 +454,17 @@ def bench_mixed_e2e(files, gen, threads):
         return (o["pcm"].astype(np.float64) * (1.0 / 2147483647.0)).astype(np.float32)
     wants = {"mp3": lambda d: oraclelib.mp3_decode_file(d)["pcm"], "ogg": lambda d: oraclelib.vorbis_file_pcm(oraclelib.vorbis_decode_file(d)),
              "flac": flac_want, "opus": lambda d: oraclelib.opus_file_pcm(oraclelib.opus_decode_file(d))}
-    parity = {k: file_parity([items[i]], wants[k](gen[k][j]), (tol if k == "opus" else ("rms" if (tol and k in ("ogg", "mp3")) else False)))
-              for k, (i, j) in first.items()}
+    parity = {}
+    for k, lst in picks.items():
+        mode = tol if k == "opus" else ("rms" if (tol and k in ("ogg", "mp3")) else False)
+        parts = [file_parity([items[i]], wants[k](gen[k][j]), mode) for i, j in lst]
+        n = sum(r["samples"] for r in parts)
+        parity[k] = {"files_checked": len(parts), "samples": n, "mismatches": sum(r["mismatches"] for r in parts),
+                     "rms_error": float(np.sqrt(sum(r["rms_error"] ** 2 * r["samples"] for r in parts) / max(n, 1))),
+                     "rms_signal_per_file": [round(r["rms_signal_per_file"][0], 5) for r in parts],
+                     "silent_files": sum(r.get("silent_files", 0) for r in parts)}
+        if "mode" in parts[0]:
+            parity[k]["mode"] = parts[0]["mode"]
     per = {}
     for (k, _), o in zip(kinds, items):
         per[k] = per.get(k, 0) + o["frames"] * o["channels"]

@@ -3,7 +3,7 @@
 # the calibration MI355X_MICROARCH.md asks for before trusting the counters on an access width it does not list.
 R="$GRAFT_REPO_ROOT"; [ -z "$R" ] && R=/root/repo
 export TMPDIR=/tmp
-[ -x "$R/tools/ubench_flacpattern.bin" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o "$R/tools/ubench_flacpattern.bin" "$R/tools/ubench_flacpattern.hip" 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o "$R/tools/ubench_flacpattern.bin" "$R/tools/ubench_flacpattern.hip" 2>/dev/null
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p "$R/gpurun_out/calib_flac/$c"
@@ -12,7 +12,7 @@ done
 cd "$R"
 python3 - <<'PY'
 import glob, sqlite3, json
-out = {"pattern": "k16<64,32>: 64 rows x 2 channels, 64-byte int16 row reads, 256-byte interleaved int32 row writes, C4 size",
+out = {"pattern": "k16<32,64,nt>: 32 frames x 2 channels, 128-byte int16 row reads, 512-byte nontemporal interleaved int32 row writes, C4 size",
        "known_read_bytes": 1323008 * 8192 * 2, "known_write_bytes": 1323008 * 8192 * 4}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     db = glob.glob(f"gpurun_out/calib_flac/{c}/**/*_results.db", recursive=True)[0]

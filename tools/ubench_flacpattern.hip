@@ -37,7 +37,7 @@ template <int ROWS, int T, int TILED = 0> __global__ __launch_bounds__(64) void 
 }
 // Variant: residuals as int16: per step ROWS*2 reads of 2T bytes (16-byte loads of 8 samples), widened into the
 // same LDS tile, writes unchanged (8T bytes per row).
-template <int ROWS, int T> __global__ __launch_bounds__(64) void k16(const short *__restrict__ in, int *__restrict__ out)
+template <int ROWS, int T, int NT = 0> __global__ __launch_bounds__(64) void k16(const short *__restrict__ in, int *__restrict__ out)
 {
     constexpr int PIECES = T / 8;                       // 16-byte pieces (8 samples) per row-channel chunk
     constexpr int LOADS = ROWS * 2 * PIECES / 64;
@@ -71,12 +71,12 @@ template <int ROWS, int T> __global__ __launch_bounds__(64) void k16(const short
         __builtin_amdgcn_wave_barrier();
     }
 }
-template <int ROWS, int T> void run16(const int *in, int *out, size_t frames, const char *name)
+template <int ROWS, int T, int NT = 0> void run16(const int *in, int *out, size_t frames, const char *name)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((k16<ROWS, T>), dim3(frames / ROWS), dim3(64), 0, 0, (const short *)in, out);
+        hipLaunchKernelGGL((k16<ROWS, T, NT>), dim3(frames / ROWS), dim3(64), 0, 0, (const short *)in, out);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("%-28s %.3f ms  (%.2f TB/s of 6 B per sample)\n", name, ms, 1.5 * frames * 8192 * 4 / ms / 1e9);
@@ -99,7 +99,8 @@ int main(int argc, char **argv)
     int *in, *out; hipMalloc(&in, frames * 8192 * 4); hipMalloc(&out, frames * 8192 * 4);
     hipMemset(in, 0, frames * 8192 * 4);
     if (argc > 1) {                                      // calibration of FETCH_SIZE / WRITE_SIZE on the restore kernel's pattern:
-        run16<64, 32>(in, out, frames, "int16 in: 64 x 64 B reads");   // known bytes: 2 B read + 4 B written per sample
+        // round 5's kernel: 32 frames x 2 channels per wavefront, 64-sample tiles, nontemporal 512-byte row pieces out
+        run16<32, 64, 1>(in, out, frames, "int16 in: 64 x 128 B reads, 32 x 512 B nontemporal writes");   // known bytes: 2 B read + 4 B written per sample
         printf("known bytes per launch: read %zu write %zu\n", frames * 8192 * 2, frames * 8192 * 4);
         return 0;
     }
@@ -115,5 +116,8 @@ int main(int argc, char **argv)
     run<64, 32, 2>(in, out, frames, "64 x 128 B, tiled both");
     run16<64, 32>(in, out, frames, "int16 in: 64 x 64 B reads");
     run16<64, 64>(in, out, frames, "int16 in: 64 x 128 B reads");
+    run16<32, 64, 0>(in, out, frames, "int16 in: 32 frames, 128 B reads, 512 B writes (round 5's tile)");
+    run16<32, 64, 1>(in, out, frames, "int16 in: 32 frames, 128 B reads, 512 B NONTEMPORAL writes (round 5's kernel)");
+    run16<16, 128, 1>(in, out, frames, "int16 in: 16 frames, 256 B reads, 1 KB nontemporal writes");
     return 0;
 }
