@@ -237,10 +237,13 @@ __device__ __forceinline__ void store_tile1(const int32_t *tile, const RowMeta *
         const double factor = 1.0 / 2147483647.0;                    // stream.d:507
         if (C == 2 && second) {
             const uint64_t o = m.out_off + (uint64_t)t * 2;
-            if (out_i32) *(int4 *)(out_i32 + o) = make_int4(l0, r0, l1, r1);
+            // (nontemporal, like the common step's: the row pieces are written once)
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            if (out_i32) __builtin_nontemporal_store(i32x4{ l0, r0, l1, r1 }, (i32x4 *)(out_i32 + o));
             if (out_f32)
-                *(float4 *)(out_f32 + o) = make_float4((float)((double)l0 * factor), (float)((double)r0 * factor),
-                                                       (float)((double)l1 * factor), (float)((double)r1 * factor));
+                __builtin_nontemporal_store(f32x4{ (float)((double)l0 * factor), (float)((double)r0 * factor), (float)((double)l1 * factor),
+                                                   (float)((double)r1 * factor) }, (f32x4 *)(out_f32 + o));
         } else {
             const int32_t vals[4] = { l0, r0, l1, r1 };
 #pragma unroll
@@ -257,7 +260,7 @@ __device__ __forceinline__ void store_tile1(const int32_t *tile, const RowMeta *
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// The common tile step (round 5).  A wavefront whose 32 frames are all stereo, hold their residual rows in one width and
+// The common tile step (round 5).  A wavefront whose 32 frames are all stereo (or all mono: slot B stays empty), hold their residual rows in one width and
 // lie within 1 GiB of each other takes every tile that is complete in all of its rows through a step without a branch:
 //   * rows and PCM go through buffer instructions -- a wave-uniform base in a descriptor, the lane's part fixed for the
 //     whole walk in one register per load, the tile's position in the scalar offset -- so neither side spends vector
@@ -290,12 +293,14 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+constexpr uint32_t kFastReach = 0x80000000u;          // bytes a wavefront's descriptors cover; an offset past it is "no row" (reads 0)
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p)
 {
     const uint64_t a = (uint64_t)(uintptr_t)p;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, 0xffffffff, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, (int)kFastReach, 0x00020000);
 }
 
 template <int MODE>
@@ -311,6 +316,33 @@ __device__ __forceinline__ void load_fast(int4 (&nxt)[Loads1<MODE>::n], __amdgpu
         const uint32_t voff = mine[(32 / L) * i * (sizeof(RowFast) / 4)] + piece;
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)voff, t * (MODE == 1 ? 2 : 4), 0);
         nxt[i] = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+    }
+}
+
+// mono frames: slot A only, 64 samples = 256 bytes per row, four rows to a store instruction
+template <bool F32>
+__device__ __forceinline__ void store_fast_mono(const int32_t *tile, const RowFast *rf, __amdgpu_buffer_rsrc_t rout, int t0)
+{
+    static_assert(kT == 64, "the mono store is written for 64-sample tiles");
+    const int lane = threadIdx.x, q = lane & 15, g = lane >> 4;
+    uint32_t c16 = 16u * (uint32_t)(q + (kFpw / 4) * g);          // piece q of row 8g + i sits at slot (q + row) mod 16
+    asm volatile("" : "+v"(c16));
+    const char *tb = (const char *)tile + (kFpw / 4) * g * (kRowWords * 4);
+    const RowFast *rfl = rf + (kFpw / 4) * g;
+    const uint32_t lane_off = 16u * (uint32_t)q + 4u * (uint32_t)t0;
+#pragma unroll
+    for (int i = 0; i < kFpw / 4; i++) {
+        const uint32_t voff = rfl[i].voff, sh = rfl[i].sh_a;
+        const int4 a = *(const int4 *)(tb + i * (kRowWords * 4) + ((c16 + 16u * (uint32_t)i) & 0xf0u));
+        u32x4 v = { (uint32_t)a.x << (sh & 31u), (uint32_t)a.y << (sh & 31u), (uint32_t)a.z << (sh & 31u), (uint32_t)a.w << (sh & 31u) };
+        if (F32) {
+            const double factor = 1.0 / 2147483647.0;                           // stream.d:507
+            v.x = __float_as_uint((float)((double)(int32_t)v.x * factor));
+            v.y = __float_as_uint((float)((double)(int32_t)v.y * factor));
+            v.z = __float_as_uint((float)((double)(int32_t)v.z * factor));
+            v.w = __float_as_uint((float)((double)(int32_t)v.w * factor));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, rout, (int)(voff + lane_off), 0, kStoreNt);
     }
 }
 
@@ -371,12 +403,13 @@ __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, 
                                             const afg_flac_subframe *__restrict__ subframes, uint32_t sf_index,
                                             const int32_t *__restrict__ res, int32_t *__restrict__ out_i32,
                                             float *__restrict__ out_f32, int max_bs, int max_pairs, const uint8_t *row_shift,
-                                            const RowFast *rf, bool fastw, int min_bs, uint64_t in_base, uint64_t out_base)
+                                            const RowFast *rf, bool fastw, bool mono, int min_bs, uint64_t in_base, uint64_t out_base)
 {
     const int lane = threadIdx.x, row = lane >> 1, slot = lane & 1;
     const int my_ch = valid ? (int)(me.info & 0xff) : 0;
     // the common step's descriptors and the lane's fixed part of every row fetch (MODE 2 -- mixed row widths -- has none)
-    constexpr bool kFastMode = MODE != 2;
+    // (int32 rows under orders above 12 keep the general step: 64 row registers beside 64 of taps and history spill inside the loop)
+    constexpr bool kFastMode = MODE != 2 && !(MODE == 0 && MAXORD > 12);
     // (bases made scalar word by word: a descriptor the compiler takes for divergent is applied in a loop over its values)
     const __amdgpu_buffer_rsrc_t rin = uniform_rsrc((const char *)res + in_base * (MODE == 1 ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rout = uniform_rsrc(out_i32 ? (const void *)(out_i32 + out_base) : (const void *)(out_f32 + out_base));
@@ -402,17 +435,21 @@ __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, 
         // step keeps in registers for the whole walk does not crowd this one)
         if (kFastMode && fastw) {
             // (one loop per output type: with the choice inside, the compiler no longer counts the stores ahead of the wait)
-#define AFG_FLAC_FAST_WALK(F32)                                                                                        \
+#define AFG_FLAC_FAST_WALK(F32, STORE)                                                                                        \
             for (; t0 + 2 * kT <= min_bs; t0 += kT) {                                                                  \
                 load_fast<MODE>(nxt, rin, rf, t0 + kT);                                                                \
                 restore_tile1<MAXORD, WIDE>(tile, row, slot, t0, order, shift, u64, c, h);                             \
                 wave_sync();                                                                                           \
-                store_fast<F32>(tile, rf, rout, t0);                                                                   \
+                STORE<F32>(tile, rf, rout, t0);                                                                        \
                 wave_sync();                                                                                           \
                 park_tile1<MODE>(tile, meta, nxt);                                                                     \
                 wave_sync();                                                                                           \
             }
-            if (out_f32) { AFG_FLAC_FAST_WALK(true) } else { AFG_FLAC_FAST_WALK(false) }
+            if (mono) {
+                if (out_f32) { AFG_FLAC_FAST_WALK(true, store_fast_mono) } else { AFG_FLAC_FAST_WALK(false, store_fast_mono) }
+            } else {
+                if (out_f32) { AFG_FLAC_FAST_WALK(true, store_fast) } else { AFG_FLAC_FAST_WALK(false, store_fast) }
+            }
 #undef AFG_FLAC_FAST_WALK
         }
         for (; t0 < max_bs; t0 += kT) {
@@ -477,9 +514,15 @@ __global__ __launch_bounds__(64, 2) void flac_restore1_kernel(
                              (uint32_t)__builtin_amdgcn_readfirstlane((int)me.in_off);
     const uint64_t out_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(me.out_off >> 32)) << 32) |
                               (uint32_t)__builtin_amdgcn_readfirstlane((int)me.out_off);
-    const bool near = valid && fr.channels == 2 && me.in_off >= in_base && me.in_off - in_base < (1ull << 27) &&
-                      me.out_off >= out_base && me.out_off - out_base < (1ull << 27);
+    const int wave_ch = __builtin_amdgcn_readfirstlane(valid ? (int)fr.channels : 0);       // mono or stereo throughout
+    const bool mono = wave_ch == 1;
+    const bool near = valid && (int)fr.channels == wave_ch && (wave_ch == 1 || wave_ch == 2) && me.in_off >= in_base &&
+                      me.in_off - in_base < (1ull << 27) && me.out_off >= out_base && me.out_off - out_base < (1ull << 27);
+#ifdef AFG_FLAC_ABL_NOFAST
+    const bool fastw = false;
+#else
     const bool fastw = __all(near) && ((out_i32 != nullptr) != (out_f32 != nullptr));
+#endif
     if ((lane & 1) == 0) {
         uint32_t sh2[2] = { 0, 0 };
         for (int c = 0; c < 8; c++) {
@@ -500,7 +543,7 @@ __global__ __launch_bounds__(64, 2) void flac_restore1_kernel(
         const uint32_t esz = fr.res16 ? 2u : 4u;
         const uint32_t chunk = fr.res16 ? ((me.bs + 7u) & ~7u) : me.bs;
         rfv.in_a = fastw ? (uint32_t)(me.in_off - in_base) * esz : 0u;
-        rfv.in_b = rfv.in_a + chunk * esz;
+        rfv.in_b = mono ? kFastReach : rfv.in_a + chunk * esz;         // a mono frame has no second row: past the descriptor's reach, reads 0
         rowfast[lane >> 1] = rfv;
     }
     __syncthreads();
@@ -511,11 +554,11 @@ __global__ __launch_bounds__(64, 2) void flac_restore1_kernel(
     const int max_pairs = __builtin_amdgcn_readfirstlane(wave_max(((int)(me.info & 0xff) + 1) >> 1));
     const bool any16 = __any(valid && (me.info >> 24) != 0), any32 = __any(valid && (me.info >> 24) == 0);
     if (!any16)
-        run_frames1<MAXORD, WIDE, 0>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, min_bs, in_base, out_base);
+        run_frames1<MAXORD, WIDE, 0>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, mono, min_bs, in_base, out_base);
     else if (!any32)
-        run_frames1<MAXORD, WIDE, 1>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, min_bs, in_base, out_base);
+        run_frames1<MAXORD, WIDE, 1>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, mono, min_bs, in_base, out_base);
     else
-        run_frames1<MAXORD, WIDE, 2>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, min_bs, in_base, out_base);
+        run_frames1<MAXORD, WIDE, 2>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, mono, min_bs, in_base, out_base);
 }
 
 }  // namespace

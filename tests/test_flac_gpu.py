@@ -92,6 +92,43 @@ def test_flac_int16_residual_rows(gpu, kw, every):
     assert (got_f.view(np.uint32) == want_f.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n_frames=130, block_size=4096, orders=(8, 12)),
+    dict(n_frames=96, block_size=4096, channels=1, orders=(8, 12)),            # mono: slot B of every tile row stays empty
+    dict(n_frames=70, block_size=1152, orders=(0, 1, 2, 3, 4)),
+    dict(n_frames=65, block_size=4096, orders=(13, 16, 24, 32)),
+    dict(n_frames=200, vary_block=True, orders=(2, 8, 12, 31)),                # ragged blocks: common and general steps alternate
+    dict(n_frames=64, block_size=4096, bps=24, orders=(8, 12), residual_scale=3000.0),
+    dict(n_frames=40, block_size=500, channels=6, orders=(4, 8)),              # (never the common step: stays on the general one)
+])
+@pytest.mark.parametrize("rows16", [False, True])
+@pytest.mark.parametrize("out", ["int32", "float"])
+def test_flac_common_step_one_output(gpu, kw, rows16, out):
+    """The branch-free common step of the restore kernel (csrc/flac_restore.hip, round 5) runs when exactly ONE output is
+    asked for -- what afg_batch_decode, the stream surface and bench.py do -- and every frame of a wavefront is stereo (or
+    mono) with one row width; the tests above ask for both outputs and so take the general step.  Same samples either way."""
+    import torch
+    frames, subframes, res, total = synthetic.flac_batch(31, **kw)
+    want_i, want_f = oraclelib.flac_transform(frames, subframes, res, total, want_float=True)
+    if rows16:
+        frames, res = synthetic.flac_pack16(frames, res, 1)
+    d_frames = torch.from_numpy(frames.view(np.uint8).copy()).to(gpu)
+    d_sub = torch.from_numpy(subframes.view(np.uint8).copy()).to(gpu)
+    d_res = torch.from_numpy(res).to(gpu)
+    if out == "int32":
+        d_out = torch.full((total,), -12345, dtype=torch.int32, device=gpu)
+        afgpu.flac_transform(len(frames), d_frames, d_sub, d_res, d_out, None)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert (got == want_i).all(), f"{int((got != want_i).sum())} int32 mismatches, first at {int(np.nonzero(got != want_i)[0][0])}"
+    else:
+        d_out = torch.full((total,), float("nan"), dtype=torch.float32, device=gpu)
+        afgpu.flac_transform(len(frames), d_frames, d_sub, d_res, None, d_out)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert (got.view(np.uint32) == want_f.view(np.uint32)).all()
+
+
 def test_flac_variant_mask_launches_the_same_samples(gpu):
     """afg_flac_variants on the host records + afg_flac_transform_variants_hip (only the populated instantiations, two
     streams) against the plain entry and the oracle: mixed orders and accumulator widths so that several instantiations
