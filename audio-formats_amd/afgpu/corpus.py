@@ -268,7 +268,7 @@ def vorbis_flag_plane(seed, packets_per_file, file_ids=None, p_short_run=0.02):
 
 def vorbis_spec_numpy(seed, pflags, packets_per_file, file_ids=None, bs0=256, bs1=2048):
     ids = _ids(len(packets_per_file), file_ids)
-    curve = {bs1 // 2: synthetic.vorbis_floor_curve(bs1 // 2), bs0 // 2: np.float32(0.25) * np.ones(bs0 // 2, np.float32)}
+    curve = {bs1 // 2: synthetic.vorbis_floor_curve(bs1 // 2), bs0 // 2: np.float32(0.25 * synthetic.VORBIS_LEVEL) * np.ones(bs0 // 2, np.float32)}
     out, pk = [], 0
     for k, n in enumerate(packets_per_file):
         rng = np.random.default_rng([seed, int(ids[k]), 7])
@@ -412,7 +412,7 @@ class VorbisPart(Part):
             if len(long_first):
                 idx = (long_first[:, None] + np.arange(2 * rows_long)[None, :]).reshape(-1)
                 kind[idx] = np.tile(np.arange(2 * rows_long) % rows_long, len(long_first))
-            table = np.concatenate([synthetic.vorbis_floor_curve(bs1 // 2).reshape(rows_long, row), np.full((1, row), 0.25, np.float32)])
+            table = np.concatenate([synthetic.vorbis_floor_curve(bs1 // 2).reshape(rows_long, row), np.full((1, row), 0.25 * synthetic.VORBIS_LEVEL, np.float32)])
             d_table = torch.from_numpy(table).to(device)
             d_kind = torch.from_numpy(kind).to(device)
             view = self.spec.view(-1, row)

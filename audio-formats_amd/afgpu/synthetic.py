@@ -16,9 +16,16 @@ from . import (CELT_FRAME_DTYPE, FLAC_FRAME_DTYPE, FLAC_INDEPENDENT, FLAC_LEFT_S
 MP3_CUTOFF_LINE = 418            # ~16 kHz at 44.1 kHz: lines above are zero at 128 kbps
 
 
+# Level of the synthetic spectra (round 5): N(0, 1) lines under these shapes decoded to 8.2 (MP3) and 6.6 (Vorbis) times full
+# scale; scaled so that the PCM has an encoder's level, rms about 0.05 -- the 1e-5 tolerance is then an absolute one on a
+# signal inside full scale (timing does not depend on the values)
+MP3_LEVEL = 0.05 / 8.18
+VORBIS_LEVEL = 0.05 / 6.65
+
+
 def mp3_tilt():
     k = np.arange(576, dtype=np.float64)
-    t = 2.0 ** (-k / 48.0)
+    t = MP3_LEVEL * 2.0 ** (-k / 48.0)
     t[MP3_CUTOFF_LINE:] = 0.0
     return t.astype(np.float32)
 
@@ -109,7 +116,7 @@ def mp3_batch_device(seed, n_files, granules_per_file, device, p_event=0.04, fil
 
 def vorbis_floor_curve(n2):
     k = np.arange(n2, dtype=np.float64)
-    curve = 10.0 ** (-(k / n2) * 2.5)                # ~50 dB down at Nyquist
+    curve = VORBIS_LEVEL * 10.0 ** (-(k / n2) * 2.5) # ~50 dB down at Nyquist
     curve[int(n2 * 16000 / 22050):] = 0.0            # zeros above 16 kHz
     return curve.astype(np.float32)
 
@@ -303,7 +310,7 @@ def vorbis_batch_device(seed, n_files, packets_per_file, device, bs0=256, bs1=20
     if is_long.all():
         spec.view(-1, bs1 // 2).mul_(curve)
     else:
-        spec.mul_(0.25)
+        spec.mul_(0.25 * VORBIS_LEVEL)
     return plan, spec
 
 
