@@ -277,7 +277,11 @@ __device__ __forceinline__ void store_tile1(const int32_t *tile, const RowMeta *
 // below; the two leave the tile and the parked rows in the same state, so a walk switches between them tile by tile.
 // ---------------------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kStoreNt = 2;            // cache policy of the PCM stores: nontemporal (the 512-byte pieces are written once)
+// cache policy bits of the buffer instructions (gfx940+: sc0 = 1, nt = 2, sc1 = 16).  PCM pieces are written once and never
+// read, residual rows are read once: nontemporal both ways, the stores also sc1 (A/B on one box, C4: plain 13.5 ms, nt stores
+// 12.06, + sc1 11.96-12.17, + nt loads 11.69-11.95)
+constexpr int kStoreNt = 2 | 16;
+constexpr int kLoadNt = 2;
 
 struct RowFast {                       // 32 bytes per tile row
     uint32_t voff;                     // byte offset of the frame's PCM from the wavefront's base
@@ -314,7 +318,7 @@ __device__ __forceinline__ void load_fast(int4 (&nxt)[Loads1<MODE>::n], __amdgpu
 #pragma unroll
     for (int i = 0; i < Loads1<MODE>::n; i++) {
         const uint32_t voff = mine[(32 / L) * i * (sizeof(RowFast) / 4)] + piece;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)voff, t * (MODE == 1 ? 2 : 4), 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)voff, t * (MODE == 1 ? 2 : 4), kLoadNt);
         nxt[i] = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
     }
 }
