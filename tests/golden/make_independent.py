@@ -190,6 +190,58 @@ def opus_pair(seed, channels, n_packets):
     return (ob.ogg_opus(pkts, channels, 312, 0, (), trim=0), ob.ogg_opus(pkts, channels, 312, (-20000) & 0xffff, (), trim=0))
 
 
+def generated_streams(wa, out):
+    """Round 5: FFmpeg's mp3float and vorbis decoders on files from this repository's own bitstream writers -- random code
+    words, but legal streams: every Huffman table, linbits escapes, scfsi, all block types in encoder order, MPEG-1/2/2.5;
+    every code-book kind, residue types 1 and 2, multi-stage cascades, channel coupling.  Left out on purpose, each because the
+    two decoder families are KNOWN to read it differently (tests/test_oracle_independent.py has the details): MP3 mixed
+    blocks and intensity stereo (the writer's right channel is not empty above the intensity bound, as an encoder's is); Vorbis
+    residue type 0, sequence_p books, lookup type 2 (FFmpeg refuses it), packets that end early."""
+    import mp3_bitstream as mb
+    import vorbis_bitstream as vb
+    import oraclelib
+    mb.MIXED_P = 0.0
+    k = 0
+    for seed, (ver, sr, mode) in enumerate([("mpeg1", 0, "stereo"), ("mpeg1", 1, "ms"), ("mpeg1", 2, "mono"), ("mpeg2", 0, "ms"),
+                                            ("mpeg2", 2, "stereo"), ("mpeg25", 1, "ms")]):
+        data, _, cfg = mb.make_file(600 + seed, n_frames=10, version=ver, sr=sr, mode=mode, strict=True)
+        out[f"gen_mp3_{k}_file"] = np.frombuffer(data, np.uint8)
+        out[f"gen_mp3_{k}_pcm"] = wa.decode(data, 1 if mode == "mono" else 2, cfg["hz"])
+        out[f"gen_mp3_{k}_rate"] = np.array([cfg["hz"]])
+        k += 1
+    mb.MIXED_P = 0.4
+    vb.LOOKUP1_ONLY = True
+    vb.SIMPLE = {"no_seq", "one_submap", "plain_coupling", "no_short_packets"}
+    kept = tried = decoded = 0
+    seed = 820
+    while kept < 6 and tried < 40:
+        tried += 1
+        seed += 1
+        try:
+            data = vb.make_file(seed, n_packets=6, packet_bytes=(9000, 10000), residue_types=(1, 2))
+        except ValueError:
+            continue
+        rec = oraclelib.vorbis_decode_file(data)
+        got = oraclelib.vorbis_file_pcm(rec)
+        if got.size == 0 or not np.abs(got).max() > 0:
+            continue
+        try:
+            ref = wa.decode(data, got.shape[1], 44100)
+        except RuntimeError:
+            continue
+        decoded += 1
+        n = min(len(got), len(ref))
+        d = got[:n].astype(np.float64) - ref[:n]
+        if len(ref) < len(got) or np.sqrt(np.mean(d ** 2)) > 1e-4 * np.sqrt(np.mean(ref[:n].astype(np.float64) ** 2)):
+            continue                                    # FFmpeg took one of its error paths on this random content: not comparable
+        out[f"gen_ogg_{kept}_file"] = np.frombuffer(data, np.uint8)
+        out[f"gen_ogg_{kept}_pcm"] = ref
+        kept += 1
+    out["gen_ogg_selection"] = np.array([tried, decoded, kept])
+    vb.LOOKUP1_ONLY = False
+    vb.SIMPLE = set()
+
+
 def main():
     import flac_bitstream as fb
     from test_flac_frontend import make_pcm
@@ -217,6 +269,7 @@ def main():
             continue
         out[f"opus_enc{k}_file"] = np.frombuffer(ogg, np.uint8)
         out[f"opus_enc{k}_pcm"] = wa.decode(ogg, ch, 48000)
+    generated_streams(wa, out)
     np.savez_compressed(os.path.join(HERE, "independent_webaudio.npz"), **out)
     for k, v in out.items():
         print(k, v.shape, v.dtype)

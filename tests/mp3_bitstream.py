@@ -102,13 +102,19 @@ def scf_layout(version, g, ch, intensity):
     return widths, [int(v) for v in row[k:k + 4]], n_long, n_short
 
 
-def gen_granule(rng, version, sr, nch, ch, gr, mode_ms, intensity, budget_bits, prev_scf, prev_short=False):
+MIXED_P = 0.4                        # share of short blocks written as mixed blocks (an encoder hardly ever writes one)
+
+
+def gen_granule(rng, version, sr, nch, ch, gr, mode_ms, intensity, budget_bits, prev_scf, prev_short=False, strict_after=None):
     """Random granule-channel.  Returns (side dict, main-data Bits, q[576] ints in coded order, iscf list)."""
     for attempt in range(20):
         g = {}
         bt = int(rng.choice([0, 0, 0, 1, 2, 2, 3]))
+        if strict_after is not None:
+            # what an encoder may write: long -> long | start, start -> short, short -> short | stop, stop -> long | start
+            bt = int(rng.choice({0: [0, 0, 0, 1], 1: [2], 2: [2, 3], 3: [0, 0, 1]}[strict_after]))
         g["block_type"] = bt
-        g["mixed"] = int(bt == 2 and rng.random() < 0.4)
+        g["mixed"] = int(bt == 2 and rng.random() < MIXED_P)
         g["global_gain"] = int(rng.integers(120, 200))
         g["scalefac_scale"] = int(rng.integers(0, 2))
         g["count1_table"] = int(rng.integers(0, 2))
@@ -129,6 +135,9 @@ def gen_granule(rng, version, sr, nch, ch, gr, mode_ms, intensity, budget_bits, 
         ends = np.cumsum(bands)
         if bt == 0:
             g["region"] = [int(rng.integers(0, 16)), int(rng.integers(0, 8))]
+            if strict_after is not None:
+                while g["region"][0] + g["region"][1] + 2 > 22:          # region boundaries inside the 22 long bands
+                    g["region"] = [int(rng.integers(0, 16)), int(rng.integers(0, 8))]
             g["tables"] = [int(rng.choice([t for t in range(32) if t not in (4, 14)])) for _ in range(3)]
         else:
             g["region"] = [8 if (bt == 2 and not g["mixed"]) else 7, 255]
@@ -288,7 +297,7 @@ def expected_lines(version, g, q, iscf, bands, ms):
 PCM_PER_LINE_RMS = 33.94
 
 
-def make_file(seed, n_frames=6, version="mpeg1", sr=0, mode="stereo", bitrate_index=9, id3=False, pcm_rms=0.05):
+def make_file(seed, n_frames=6, version="mpeg1", sr=0, mode="stereo", bitrate_index=9, id3=False, pcm_rms=0.05, strict=False):
     """mode: mono | stereo | ms | intensity | ms+intensity.  Returns (bytes, list of per-frame dicts).
     pcm_rms: every granule's global_gain is chosen so that the decoded signal has about this rms (full scale = 1.0), as
     an encoder's material does -- the code words are random, the level is not (None: global_gain random in [120, 200),
@@ -310,6 +319,7 @@ def make_file(seed, n_frames=6, version="mpeg1", sr=0, mode="stereo", bitrate_in
     main_pos = 0
     prev_scf = [[0] * 64, [0] * 64]
     was_short = [False, False]
+    last_bt = [0, 0]                 # strict=True: block types follow the window-switching state machine, regions stay inside the band table
     for f in range(n_frames):
         pad = int(rng.integers(0, 2))
         frame_bytes = samples * kbps * 125 // hz + pad
@@ -323,8 +333,9 @@ def make_file(seed, n_frames=6, version="mpeg1", sr=0, mode="stereo", bitrate_in
             for ch in range(nch):
                 share = max(0, (budget - md.n()) // ((ngr - gr) * nch - ch) - 8)
                 g, bits, q, iscf, bands = gen_granule(rng, version, sr, nch, ch, gr, ms, intensity, share, prev_scf[ch],
-                                                      prev_short=(gr == 1 and was_short[ch]))
+                                                      prev_short=(gr == 1 and was_short[ch]), strict_after=(last_bt[ch] if strict else None))
                 was_short[ch] = g["block_type"] == 2
+                last_bt[ch] = g["block_type"]
                 if pcm_rms is not None:
                     unity = dict(g, global_gain=214 + (2 if ms else 0))                  # gain_exp == 0 in expected_lines
                     r = float(np.sqrt(np.mean(expected_lines(version, unity, q, iscf, bands, ms) ** 2)))

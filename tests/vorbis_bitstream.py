@@ -72,12 +72,19 @@ def random_lengths(rng, used, max_len=16):
     return [int(v) for v in leaves]
 
 
+# development switches of the independent-decoder comparison (tests/golden/make_independent.py): names of generator features to leave out
+SIMPLE = set()
+LOOKUP1_ONLY = False                 # vector books of lookup type 1 only (FFmpeg's Vorbis decoder refuses type 2: tests/golden/make_independent.py)
+
+
 def write_codebook(b, rng, entries, dim, kind, lookup, level_exp=0):
     """kind: 'ordered' | 'dense' | 'sparse'.  lookup: 0 | 1 | 2 (for 1, entries must be values**dim).
     level_exp: added to the exponents of the book's minimum and delta values -- every vector of the book times 2^level_exp."""
     b.put(0x564342, 24)
     b.put(dim, 16)
     b.put(entries, 24)
+    if "dense_only" in SIMPLE:
+        kind = "dense"
     if kind == "ordered":
         lens = sorted(random_lengths(rng, entries))
         b.put(1, 1)
@@ -113,7 +120,7 @@ def write_codebook(b, rng, entries, dim, kind, lookup, level_exp=0):
         b.put(pack_float(int(rng.integers(1, 1 << 10)), int(rng.integers(-14, -8)) + level_exp, 0), 32)                          # delta
         value_bits = int(rng.integers(1, 9))
         b.put(value_bits - 1, 4)
-        b.put(int(rng.random() < 0.3), 1)            # sequence_p
+        b.put(int(rng.random() < 0.3 and "no_seq" not in SIMPLE), 1)            # sequence_p
         if lookup == 1:
             vals = round(entries ** (1.0 / dim))
             assert vals ** dim == entries
@@ -173,7 +180,7 @@ def _make_file(seed, channels, bs, n_packets, rate, residue_types, packet_bytes,
     # vector books for residues
     vq = []
     for _ in range(5):
-        if rng.random() < 0.5:
+        if rng.random() < 0.5 or LOOKUP1_ONLY:
             dim = int(rng.choice([1, 2, 4]))
             vals = int(rng.integers(2, 5))
             vq.append(add_book(vals ** dim, dim, rng.choice(["ordered", "dense"]), 1))
@@ -203,6 +210,8 @@ def _make_file(seed, channels, bs, n_packets, rate, residue_types, packet_bytes,
         b.put(1, 16)
         partitions = int(rng.integers(1, 6))
         classes = int(rng.integers(1, 4))
+        if "simple_floor" in SIMPLE:
+            classes = 1
         b.put(partitions, 5)
         plist = [int(rng.integers(0, classes)) for _ in range(partitions)]
         for c in plist:
@@ -211,14 +220,19 @@ def _make_file(seed, channels, bs, n_packets, rate, residue_types, packet_bytes,
         for c in range(max(plist) + 1):
             cdim = int(rng.integers(1, 5))
             sub = int(rng.integers(0, 3))
+            if "simple_floor" in SIMPLE:
+                sub = 0
             cdims.append(cdim)
             b.put(cdim - 1, 3)
             b.put(sub, 2)
             if sub:
                 b.put(int(rng.choice(scalar)), 8)
             for _k in range(1 << sub):
-                b.put(0 if rng.random() < 0.2 else int(rng.choice(scalar)) + 1, 8)     # 0 = no book (value 0)
-        b.put(int(rng.integers(0, 4)), 2)            # multiplier - 1
+                b.put(0 if (rng.random() < 0.2 and "simple_floor" not in SIMPLE) else int(rng.choice(scalar)) + 1, 8)     # 0 = no book (value 0)
+        mult1 = int(rng.integers(0, 4))
+        if "no_mult3" in SIMPLE and mult1 == 2:      # multiplier 3: range 86 in 7-bit words, i.e. ordinates past the range are writable
+            mult1 = 1
+        b.put(mult1, 2)                              # multiplier - 1
         rangebits = int(rng.integers(6, 10))
         b.put(rangebits, 4)
         count = sum(cdims[c] for c in plist)
@@ -239,7 +253,8 @@ def _make_file(seed, channels, bs, n_packets, rate, residue_types, packet_bytes,
         b.put(part - 1, 24)
         b.put(classifications - 1, 6)
         b.put(len(books) + r, 8)                     # classbook
-        cascades = [int(rng.integers(0, 8)) | (int(rng.integers(0, 4)) << 3 if rng.random() < 0.3 else 0) for _ in range(classifications)]
+        cascades = [int(rng.integers(0, 8)) | (int(rng.integers(0, 4)) << 3 if (rng.random() < 0.3 and "low_cascade" not in SIMPLE) else 0)
+                    for _ in range(classifications)]
         for c in cascades:
             b.put(c & 7, 3)
             hi = c >> 3
@@ -257,16 +272,20 @@ def _make_file(seed, channels, bs, n_packets, rate, residue_types, packet_bytes,
     b.put(n_maps - 1, 6)
     for m in range(n_maps):
         b.put(0, 16)
-        submaps = int(rng.integers(1, 3)) if channels > 1 else 1
+        submaps = int(rng.integers(1, 3)) if (channels > 1 and "one_submap" not in SIMPLE) else 1
         b.put(1 if submaps > 1 else 0, 1)
         if submaps > 1:
             b.put(submaps - 1, 4)
-        steps = int(rng.integers(0, min(channels, 3))) if channels > 1 else 0
+        steps = int(rng.integers(0, min(channels, 3))) if (channels > 1 and "no_coupling" not in SIMPLE) else 0
+        if "plain_coupling" in SIMPLE:
+            steps = min(steps, 1)
         b.put(1 if steps else 0, 1)
         if steps:
             b.put(steps - 1, 8)
             for _ in range(steps):
                 mag, ang = rng.choice(channels, 2, replace=False)
+                if "plain_coupling" in SIMPLE:               # what an encoder writes for a stereo pair: one step, magnitude 0, angle 1
+                    mag, ang = 0, 1
                 b.put(int(mag), ilog(channels - 1))
                 b.put(int(ang), ilog(channels - 1))
         b.put(0, 2)
@@ -316,7 +335,7 @@ def _make_file(seed, channels, bs, n_packets, rate, residue_types, packet_bytes,
         nbytes = int(rng.integers(packet_bytes[0], packet_bytes[1]))
         for _ in range(nbytes):
             pb.put(int(rng.integers(0, 256)), 8)
-        if rng.random() < 0.15:
+        if rng.random() < 0.15 and "no_short_packets" not in SIMPLE:
             pkts.append(pb.bytes()[:int(rng.integers(1, 4))])             # a very short packet: end-of-packet paths
         else:
             pkts.append(pb.bytes())
