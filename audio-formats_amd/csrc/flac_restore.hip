@@ -13,10 +13,12 @@
 //     sum is kept in int64 instead; its low 32 bits are exactly the wrapping sum, so the flag only selects which bits
 //     are shifted (drflac.d:1098 vs :1139);
 //   * residual planes are subframe-major in HBM (what the Rice decoder writes, as int32 or -- 16-bit material -- int16
-//     rows), so a wavefront moves 32 frames x 2 channels x 32 samples per step through an 8 KB LDS tile.  The next step's
-//     rows are already in flight (16-byte loads parked in registers) while the current step runs its recurrence; the
-//     tile is stored as 16-byte pieces rotated by the row, which makes the one-row-per-lane 16-byte accesses of the
-//     recurrence conflict-free; outputs leave as interleaved 16-byte stores with the decorrelation done on the way.
+//     rows), so a wavefront moves 32 frames x 2 channels x 64 samples per step through a 16 KB LDS tile (round 5; 32
+//     samples and 8 KB until then).  The next step's rows are already in flight (16-byte loads parked in registers)
+//     while the current step runs its recurrence; the tile is stored as 16-byte pieces rotated by the row, which makes
+//     the one-row-per-lane 16-byte accesses of the recurrence conflict-free; outputs leave as interleaved 16-byte
+//     stores -- 512 bytes per row and step, nontemporal -- with the decorrelation done on the way.  Two tile steps: the
+//     branch-free COMMON step (stereo or mono wavefronts, complete tiles, one output; below) and the GENERAL one.
 #include "afg_common.h"
 
 #include <mutex>
@@ -522,11 +524,7 @@ __global__ __launch_bounds__(64, 2) void flac_restore1_kernel(
     const bool mono = wave_ch == 1;
     const bool near = valid && (int)fr.channels == wave_ch && (wave_ch == 1 || wave_ch == 2) && me.in_off >= in_base &&
                       me.in_off - in_base < (1ull << 27) && me.out_off >= out_base && me.out_off - out_base < (1ull << 27);
-#ifdef AFG_FLAC_ABL_NOFAST
-    const bool fastw = false;
-#else
     const bool fastw = __all(near) && ((out_i32 != nullptr) != (out_f32 != nullptr));
-#endif
     if ((lane & 1) == 0) {
         uint32_t sh2[2] = { 0, 0 };
         for (int c = 0; c < 8; c++) {
