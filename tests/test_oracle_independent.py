@@ -159,8 +159,8 @@ def test_generated_vorbis_agrees_with_ffmpeg():
     long enough never to end early): the oracle (stb_vorbis restated) equals FFmpeg's decoder to 4e-7 of the signal.
     What the selection means: of the files FFmpeg decodes at all, a quarter to a third agree like this (`gen_ogg_selection`
     = tried, decoded by FFmpeg, agreeing); the others differ in LEVEL from their first packets on -- the packets are random
-    words, which an encoder's are not, and the candidates that could be switched off one at a time (code-book kinds,
-    cascades, coupling, block sizes, floor multiplier 3) are not the cause; not isolated further.  Known and left out:
+    words, which an encoder's are not.  Switching generator features off moves the share without explaining it (residue ends
+    inside the shortest block: 8-11 of 20 agree; everything optional off, long blocks only: 14 of 20); not isolated further.  Known and left out:
     residue type 0 (the reference inherits stb_vorbis' `n - offset - k` length, which goes negative after the first
     partition: stb_vorbis2.d:1571), sequence_p books (the running sum is not reset per entry when a lookup-1 book is
     expanded, and applied again on decode: :2960-2975, :1351-1358), lookup type 2 (FFmpeg refuses it), packets that end

@@ -247,6 +247,9 @@ def _make_file(seed, channels, bs, n_packets, rate, residue_types, packet_bytes,
         part = int(rng.choice([2, 4, 8, 16, 32]))
         begin = int(rng.integers(0, 3)) * part
         end = begin + part * int(rng.integers(2, 40))
+        if "res_end_small" in SIMPLE:                # inside the shortest spectrum (blocksize_0 / 2 values per channel)
+            end = min(end, (bs[0] // 2 // part) * part)
+            begin = min(begin, max(0, end - part))
         b.put(rtype, 16)
         b.put(begin, 24)
         b.put(end, 24)
