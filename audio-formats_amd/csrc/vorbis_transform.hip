@@ -614,7 +614,7 @@ __device__ __forceinline__ void vorbis_wave_body(
                 } else {
                     const float *wt = tables + ((pn * 2 == bs1) ? tab1 : tab0) + (pn * 2) + (pn * 2 / 4);
 #pragma unroll
-                    for (int i = 0; i < 2; i++) {                  // pn is 64 or 128 here
+                    for (int i = 0; i < 8; i++) {                  // pn is 64 .. 512 here (blocksize_0 <= 1024)
                         const int jj = lane + 64 * i;
                         if (jj < nwin) o[jj * C + c] = smem[left + jj] * wt[jj] + pv[i] * wt[pn - 1 - jj];
                     }
@@ -624,9 +624,10 @@ __device__ __forceinline__ void vorbis_wave_body(
             if (plen == kNL / 2) {                                                     // :2641-2643; the long-long case:
 #pragma unroll
                 for (int i = 0; i < 16; i++) pv[i] = smem[right + lane + 64 * i];      // sixteen reads, no conditions
-            } else {                                                                   // 64 or 128 samples
-                pv[0] = smem[right + lane];
-                if (plen > 64) pv[1] = smem[right + lane + 64];
+            } else {                                                                   // 64 .. 512 samples
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (64 * i < plen) pv[i] = smem[right + lane + 64 * i];
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1014,7 +1015,7 @@ __device__ __forceinline__ void vorbis_wave2_body(
             } else {
                 const float *wt = tables + ((pn * 2 == bs1) ? tab1 : tab0) + (pn * 2) + (pn * 2 / 4);
 #pragma unroll
-                for (int i = 0; i < 2; i++) {                  // pn is 64 or 128 here
+                for (int i = 0; i < 8; i++) {                  // pn is 64 .. 512 here (blocksize_0 <= 1024)
                     const int jj = lane + 64 * i;
                     if (jj < nwin) {
                         const float w0 = wt[jj], w1 = wt[pn - 1 - jj];
@@ -1030,13 +1031,13 @@ __device__ __forceinline__ void vorbis_wave2_body(
                 pv[0][i] = sm0[right + lane + 64 * i];
                 pv[1][i] = sm1[right + lane + 64 * i];
             }
-        } else {
-            pv[0][0] = sm0[right + lane];
-            pv[1][0] = sm1[right + lane];
-            if (plen > 64) {
-                pv[0][1] = sm0[right + lane + 64];
-                pv[1][1] = sm1[right + lane + 64];
-            }
+        } else {                                               // 64 .. 512 samples
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (64 * i < plen) {
+                    pv[0][i] = sm0[right + lane + 64 * i];
+                    pv[1][i] = sm1[right + lane + 64 * i];
+                }
         }
         __builtin_amdgcn_wave_barrier();
         previous_length = plen;
@@ -1048,6 +1049,7 @@ __device__ __forceinline__ void vorbis_wave2_body(
 #endif
 constexpr int kWavesPerGroup = AFG_VORBIS_GROUP_WAVES;
 constexpr int kWaveStride = 2 * kWaveLds;             // transform areas of two channels: previous_window is in registers
+constexpr uint32_t kCounterSets = 32, kCountersPerLaunch = 1 + kWalkShapes + 1;   // (padded to 8)
 constexpr uint32_t kBothChannels = 0xffffffffu;       // VorbisSeg.pad of a wavefront that walks both channels of a stereo stream
 
 #ifndef AFG_VORBIS_WAVES_PER_EU
@@ -1148,13 +1150,17 @@ struct afg_vorbis_plan {
     size_t lds_bytes = 0;
     std::vector<uint64_t> h_spec_off, h_out_off;
     uint32_t n_wave_segs = 0;      // segments of streams on the wave-level fast path
-    uint32_t n_walk_segs = 0;      // the first n_walk_segs of them: stereo streams the tolerance-mode walk takes (vorbis_walk.hip)
-    uint32_t walk_groups = 0;
-    afg::DeviceArray d_walk_tables;
+    // AFG_NUMERIC_TOLERANCE (vorbis_walk.hip): the segments of the streams the walk takes, one run per shape in
+    // d_walk_segs.  The same streams' segments for the bit-exact kernels are the first n_wave_walk of d_wave_segs and the
+    // last n_segs_walk of d_segs: a launch in tolerance mode with aligned planes skips those.
+    uint32_t walk_first[kWalkShapes + 1] = {};
+    uint32_t n_wave_walk = 0, n_segs_walk = 0;
+    afg::DeviceArray d_walk_segs, d_walk_tables[kWalkShapes];
     uint32_t tab2048 = 0;          // float offset of the n = 2048 table set
     afg::DeviceArray d_segs, d_wave_segs, d_streams, d_pflags, d_spec_off, d_out_off, d_tables;
-    // work counters of the persistent wave kernel: launch k uses (and first clears, on its stream) counter k % 64, so
-    // launches of one plan that overlap on different streams do not share one
+    // work counters of the persistent kernels: launch k uses (and first clears, on its stream) set k % kCounterSets -- one
+    // counter for the wave kernel, one per walk shape -- so launches of one plan that overlap on different streams do not
+    // share one
     afg::DeviceArray d_counters;
     mutable std::atomic<uint32_t> launches{ 0 };
     uint32_t wave_groups = 0;      // workgroups the persistent kernel is launched with
@@ -1184,7 +1190,7 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     const bool single_only = afg::dev_option(afg::kDevVorbisSingle) > 0;      // tests: the one-channel-per-wavefront walk
 
     std::vector<VorbisStream> streams(n_streams);
-    std::vector<VorbisSeg> segs, wave_segs, walk_segs;
+    std::vector<VorbisSeg> segs, segs_walk, wave_segs, wave_walk, walk_segs[kWalkShapes];
     std::vector<float> tables;
     std::map<int, uint32_t> tab_of;
     auto p = new (std::nothrow) afg_vorbis_plan;
@@ -1252,16 +1258,17 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
             if (prev_len) oo += (uint64_t)(right - left) * channels[s];                // :2645-2656
             prev_len = right_end - right;
         }
+        const int shape = single_only ? -1 : walk_shape((int)channels[s], bs[0], bs[1]);
         for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
             uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
-            if (fast && channels[s] == 2 && bs[0] <= 512 && !single_only)
-                walk_segs.push_back(VorbisSeg{ s, p0, cnt, kBothChannels });                                  // both channels; either kernel
-            else if (fast && channels[s] == 2 && !single_only)
-                wave_segs.push_back(VorbisSeg{ s, p0, cnt, kBothChannels });                                  // both channels, interleaved
+            if (shape >= 0) walk_segs[shape].push_back(VorbisSeg{ s, p0, cnt, 0 });
+            auto &wave_list = shape >= 0 ? wave_walk : wave_segs;
+            if (fast && channels[s] == 2 && !single_only)
+                wave_list.push_back(VorbisSeg{ s, p0, cnt, kBothChannels });                                  // both channels, interleaved
             else if (fast)
-                for (uint32_t c = 0; c < channels[s]; c++) wave_segs.push_back(VorbisSeg{ s, p0, cnt, c });   // one per channel
+                for (uint32_t c = 0; c < channels[s]; c++) wave_list.push_back(VorbisSeg{ s, p0, cnt, c });   // one per channel
             else
-                segs.push_back(VorbisSeg{ s, p0, cnt, 0 });
+                (shape >= 0 ? segs_walk : segs).push_back(VorbisSeg{ s, p0, cnt, 0 });
         }
     }
     if (lds > 160 * 1024) {
@@ -1269,8 +1276,16 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
         delete p;
         return AFG_ERR_UNSUPPORTED;
     }
-    p->n_walk_segs = (uint32_t)walk_segs.size();
-    wave_segs.insert(wave_segs.begin(), walk_segs.begin(), walk_segs.end());
+    p->n_wave_walk = (uint32_t)wave_walk.size();
+    wave_segs.insert(wave_segs.begin(), wave_walk.begin(), wave_walk.end());
+    p->n_segs_walk = (uint32_t)segs_walk.size();
+    segs.insert(segs.end(), segs_walk.begin(), segs_walk.end());
+    std::vector<VorbisSeg> all_walk;
+    for (int k = 0; k < kWalkShapes; k++) {
+        p->walk_first[k] = (uint32_t)all_walk.size();
+        all_walk.insert(all_walk.end(), walk_segs[k].begin(), walk_segs[k].end());
+    }
+    p->walk_first[kWalkShapes] = (uint32_t)all_walk.size();
     p->n_streams = n_streams;
     p->n_segs = (uint32_t)segs.size();
     p->n_wave_segs = (uint32_t)wave_segs.size();
@@ -1286,22 +1301,23 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     if (!rc) rc = p->d_spec_off.upload(p->h_spec_off.data(), p->h_spec_off.size() * sizeof(uint64_t));
     if (!rc) rc = p->d_out_off.upload(p->h_out_off.data(), p->h_out_off.size() * sizeof(uint64_t));
     if (!rc) rc = p->d_tables.upload(tables.data(), tables.size() * sizeof(float));
+    if (!rc && (p->n_wave_segs || !all_walk.empty())) {
+        const std::vector<uint32_t> zeros(kCounterSets * kCountersPerLaunch, 0u);
+        rc = p->d_counters.upload(zeros.data(), zeros.size() * sizeof(uint32_t));
+    }
     if (!rc && p->n_wave_segs) {
-        const uint32_t zeros[64] = {};
-        rc = p->d_counters.upload(zeros, sizeof(zeros));
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const uint32_t need = (p->n_wave_segs + kWavesPerGroup - 1) / kWavesPerGroup;
         p->wave_groups = need < (uint32_t)cus ? need : (uint32_t)cus;
     }
-    if (!rc && p->n_walk_segs) {
-        std::vector<float> wt(walk_table_floats());
-        walk_build_tables(wt.data(), tables.data() + tab_of[kNL] + kNL + kNL / 4);
-        rc = p->d_walk_tables.upload(wt.data(), wt.size() * sizeof(float));
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const uint32_t need = (p->n_walk_segs + walk_waves_per_group() - 1) / walk_waves_per_group();
-        p->walk_groups = need < (uint32_t)cus ? need : (uint32_t)cus;
+    if (!rc) rc = p->d_walk_segs.upload(all_walk.data(), all_walk.size() * sizeof(VorbisSeg));
+    for (int k = 0; k < kWalkShapes && !rc; k++) {
+        if (p->walk_first[k + 1] == p->walk_first[k]) continue;
+        const int n = 1024 << (k >> 1);
+        std::vector<float> wt(walk_table_floats(k));
+        walk_build_tables(k, wt.data(), tables.data() + tab_of[n] + n + n / 4);
+        rc = p->d_walk_tables[k].upload(wt.data(), wt.size() * sizeof(float));
     }
     if (!rc && p->n_wave_segs) {
         hipError_t e = hipFuncSetAttribute((const void *)vorbis_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1340,7 +1356,8 @@ void afg_vorbis_plan_destroy(afg_vorbis_plan *plan)
     plan->d_out_off.release();
     plan->d_tables.release();
     plan->d_counters.release();
-    plan->d_walk_tables.release();
+    plan->d_walk_segs.release();
+    for (auto &t : plan->d_walk_tables) t.release();
     delete plan;
 }
 
@@ -1364,33 +1381,35 @@ int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, f
         afg::set_error("afg_vorbis_transform_hip: NULL device pointer");
         return AFG_ERR_INVALID;
     }
-    // AFG_NUMERIC_TOLERANCE: the stereo 2048-sample streams take the re-factored walk (vorbis_walk.hip: 16-byte PCM stores,
+    // AFG_NUMERIC_TOLERANCE: the streams vorbis_walk.hip has a shape for take the re-factored walk (16-byte PCM stores,
     // 8-byte spectrum loads -- hence the alignment test); everything else, and everything in AFG_NUMERIC_EXACT, the bit-exact kernels
-    uint32_t walk = 0;
-    if (plan->n_walk_segs && afg::numeric_mode() == AFG_NUMERIC_TOLERANCE && ((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_spec & 7) == 0)
-        walk = plan->n_walk_segs;
-    if (plan->n_wave_segs) {
-        uint32_t *counter = (uint32_t *)plan->d_counters.ptr + 2 * (plan->launches.fetch_add(1) & 31u);
-        AFG_HIP_CHECK(hipMemsetAsync(counter, 0, 2 * sizeof(uint32_t), (hipStream_t)hip_stream));
-        if (walk)
-            if (int rc = walk_launch((const VorbisSeg *)plan->d_wave_segs.ptr, walk, (const VorbisStream *)plan->d_streams.ptr,
+    const uint32_t n_walk = plan->walk_first[kWalkShapes];
+    const bool walk = n_walk && afg::numeric_mode() == AFG_NUMERIC_TOLERANCE && ((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_spec & 7) == 0;
+    const uint32_t wave_skip = walk ? plan->n_wave_walk : 0, n_segs = plan->n_segs - (walk ? plan->n_segs_walk : 0);
+    if (walk || plan->n_wave_segs > wave_skip) {
+        uint32_t *counter = (uint32_t *)plan->d_counters.ptr + kCountersPerLaunch * (plan->launches.fetch_add(1) % kCounterSets);
+        AFG_HIP_CHECK(hipMemsetAsync(counter, 0, kCountersPerLaunch * sizeof(uint32_t), (hipStream_t)hip_stream));
+        for (int k = 0; walk && k < kWalkShapes; k++) {
+            const uint32_t first = plan->walk_first[k], count = plan->walk_first[k + 1] - first;
+            if (!count) continue;
+            if (int rc = walk_launch(k, (const VorbisSeg *)plan->d_walk_segs.ptr + first, count, (const VorbisStream *)plan->d_streams.ptr,
                                      (const uint8_t *)plan->d_pflags.ptr, (const uint64_t *)plan->d_spec_off.ptr,
                                      (const uint64_t *)plan->d_out_off.ptr, (const float *)plan->d_tables.ptr,
-                                     (const float *)plan->d_walk_tables.ptr, d_spec, d_out, counter + 1, plan->walk_groups,
-                                     (hipStream_t)hip_stream))
+                                     (const float *)plan->d_walk_tables[k].ptr, d_spec, d_out, counter + 1 + k, (hipStream_t)hip_stream))
                 return rc;
-        if (plan->n_wave_segs > walk) {
-            const uint32_t rest = plan->n_wave_segs - walk, need = (rest + kWavesPerGroup - 1) / kWavesPerGroup;
+        }
+        if (plan->n_wave_segs > wave_skip) {
+            const uint32_t rest = plan->n_wave_segs - wave_skip, need = (rest + kWavesPerGroup - 1) / kWavesPerGroup;
             hipLaunchKernelGGL(vorbis_wave_kernel, dim3(need < plan->wave_groups ? need : plan->wave_groups),
                                dim3(64 * kWavesPerGroup), sizeof(float) * (kTabFloats + kWavesPerGroup * kWaveStride),
-                               (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_wave_segs.ptr + walk, rest,
+                               (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_wave_segs.ptr + wave_skip, rest,
                                (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
                                (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
                                (const float *)plan->d_tables.ptr, plan->tab2048, d_spec, d_out, counter);
         }
     }
-    if (plan->n_segs)
-        hipLaunchKernelGGL(vorbis_transform_kernel, dim3(plan->n_segs), dim3(kThreads), plan->lds_bytes,
+    if (n_segs)
+        hipLaunchKernelGGL(vorbis_transform_kernel, dim3(n_segs), dim3(kThreads), plan->lds_bytes,
                            (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_segs.ptr,
                            (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
                            (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,

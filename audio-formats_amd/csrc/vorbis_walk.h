@@ -5,13 +5,17 @@
 
 namespace afg_vorbis {
 
-size_t walk_table_floats();
-// dst: walk_table_floats() floats; window2048: the n = 2048 window as stb_vorbis2.d:866-873 builds it (1024 floats)
-void walk_build_tables(float *dst, const float *window2048);
-uint32_t walk_waves_per_group();
-// Stereo segments of streams with blocksize_1 = 2048 and blocksize_0 <= 512; `out` 16-byte aligned; *counter zeroed on `stream`.
-int walk_launch(const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *streams, const uint8_t *pflags,
+constexpr int kWalkShapes = 6;
+// The walk's kernel for a stream: 2 * (log2(blocksize_1) - 10) + (channels - 1) for mono / stereo streams with
+// blocksize_1 in {1024, 2048, 4096} and blocksize_0 <= 512, < blocksize_1; -1 for every other stream.
+int walk_shape(int channels, int blocksize0, int blocksize1);
+size_t walk_table_floats(int shape);
+// dst: walk_table_floats(shape) floats; window: the window of the shape's blocksize_1 as stb_vorbis2.d:866-873 builds it
+void walk_build_tables(int shape, float *dst, const float *window);
+// Segments (VorbisSeg.pad unused: one wavefront walks every channel) of streams of one shape; `out` 16-byte aligned;
+// *counter zeroed on `stream`.
+int walk_launch(int shape, const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *streams, const uint8_t *pflags,
                 const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
-                const float *spec, float *out, uint32_t *counter, uint32_t groups, hipStream_t stream);
+                const float *spec, float *out, uint32_t *counter, hipStream_t stream);
 
 }  // namespace afg_vorbis

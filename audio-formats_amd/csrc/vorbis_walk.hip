@@ -1,4 +1,4 @@
-// vorbis_walk.hip -- Vorbis inverse MDCT + window / overlap-add in AFG_NUMERIC_TOLERANCE (round 4).
+// vorbis_walk.hip -- Vorbis inverse MDCT + window / overlap-add in AFG_NUMERIC_TOLERANCE (round 4; other sizes round 5).
 //
 // Same seam as vorbis_transform.hip (reference stb_vorbis2.d:2526-2527 inverse_mdct, :2606-2657 vorbis_finish_frame,
 // :3927-3952 interleave), same records, same walk over 16-packet segments -- but NOT the reference's factorisation.
@@ -6,30 +6,36 @@
 // six different orders; scheduling it bit for bit costs six pass -> LDS -> pass boundaries per transform
 // (vorbis_transform.hip).  north_star asks for 1e-5 RMS, so this file computes the same transform,
 //
-//     y[m] = sum_{k < n/2} X[k] cos(pi/(2n) (2m + 1 + n/2)(2k + 1)),   n = 2048                      
+//     y[m] = sum_{k < n/2} X[k] cos(pi/(2n) (2m + 1 + n/2)(2k + 1)),   n = blocksize_1 in {1024, 2048, 4096}   
 //
-// the textbook way: y is the odd/even extension of the DCT-IV u of X, and u comes from ONE 512-point complex FFT,
+// the textbook way: y is the odd/even extension of the DCT-IV u of X, and u comes from ONE complex FFT of N = n/4 points,
 //
-//     t[q] = (X[2q] + i X[1023-2q]) w[q],   Z = FFT512(t),   c[k] = Z[k] w[k],   w[k] = exp(-2 pi i (k + 1/8) / 2048)
-//     u[2k] = Re c[k],   u[1023-2k] = -Im c[k]
+//     t[q] = (X[2q] + i X[n/2-1-2q]) w[q],   Z = FFT_N(t),   c[k] = Z[k] w[k],   w[k] = exp(-2 pi i (k + 1/8) / n)
+//     u[2k] = Re c[k],   u[n/2-1-2k] = -Im c[k]
 //
-// run as radix 8 x 8 x 8 with eight points per lane: three register passes, two transposes through LDS.
-// Window and overlap never see y: output frames j and 1023-j of a long block that follows a long block are
+// held R = N/64 points per lane: register passes with transposes through LDS between them,
 //
-//     out[j]      =  a w[j]      - b w[1023-j]          a = u_cur[512+j],  b = u_prev[511-j]
-//     out[1023-j] = -a w[1023-j] - b w[j]
+//     R = 4  (n = 1024):  4 x 4 x 4 x 4        R = 8  (n = 2048):  8 x 8 x 8        R = 16 (n = 4096): 16 x 4 x 16
 //
-// (time-domain alias cancellation written on u), and both a and b of frames j, j+1 come from the pair c[k], c[511-k] with
-// k = 256 + j/2.  The lane that ends the FFT with c[k] therefore keeps the carried state of exactly its own frames: 8
-// floats per channel instead of the 16 of previous_window (:2641-2643), and the PCM leaves as 16-byte stores of two
-// interleaved stereo frames.  The mirror k <-> 511-k -- needed once on the way in (X[2q] and X[1023-2q] arrive in different
-// lanes) and once on the way out -- is an exchange between lanes l and l ^ 32 (v_permlane32_swap), because lanes 32..63 walk
-// their point groups in descending order.
+// (tests/vorbis_walk_model.py restates the index algebra of every pass on [64 lanes][R] arrays and checks it against a
+// library FFT, and every LDS access for bank conflicts, on the CPU.)
+// Window and overlap never see y: output frames j and n/2-1-j of a long block that follows a long block are
+//
+//     out[j]        =  a w[j]        - b w[n/2-1-j]          a = u_cur[n/4+j],  b = u_prev[n/4-1-j]
+//     out[n/2-1-j]  = -a w[n/2-1-j]  - b w[j]
+//
+// (time-domain alias cancellation written on u), and both a and b of frames j, j+1 come from the pair c[k], c[N-1-k] with
+// k = N/2 + j/2.  The lane that ends the FFT with c[k] therefore keeps the carried state of exactly its own frames: R
+// floats per channel instead of the n/128 of previous_window (:2641-2643), and the PCM leaves as 16-byte stores of two
+// interleaved stereo frames (8-byte stores of two frames for a mono stream).  The mirror k <-> N-1-k -- needed once on the
+// way in (X[2q] and X[n/2-1-2q] arrive in different lanes) and once on the way out -- is an exchange between lanes l and
+// l ^ 32 (v_permlane32_swap), because lanes 32..63 walk their point groups in descending order.
 //
 // Packets that are not "long between two long blocks" (short blocks, the long blocks beside them) take the reference's
 // own arithmetic for the parts that differ: short blocks run vorbis_core.h's inverse_mdct_lds, long blocks with a short
-// neighbour scatter u to LDS and window through a y(m) accessor.  Streams this walk does not take (mono, more than two
-// channels, blocksize_1 != 2048, blocksize_0 > 512) stay on the bit-exact kernels, which are within any tolerance.
+// neighbour scatter u to LDS and window through a y(m) accessor.  One wavefront walks all channels (1 or 2) of a segment.
+// Streams this walk does not take (more than two channels, other long block sizes, blocksize_0 > 512 or = blocksize_1)
+// stay on the bit-exact kernels, which are within any tolerance.
 //
 // Compiled with -ffp-contract=fast (Makefile): multiply-adds fuse.  Error against the oracle on the C3 workload (N(0,1)
 // spectra, output RMS 6.8): 1e-6 RMS, i.e. 1.5e-7 of the signal (tests/test_vorbis_walk_gpu.py).
@@ -48,14 +54,34 @@ namespace {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int kN = 2048;
-constexpr int kChanF2 = 576;                       // complex slots of one channel's transform area (4608 bytes)
-constexpr int kWaveF2 = 2 * kChanF2;
-// table block (walk_build_tables): W[512] | W1[7][64] | W2[7][8] as float2, then the n = 2048 window (1024 floats)
-constexpr int kTwW = 0, kTwW1 = 512, kTwW2 = 512 + 7 * 64, kTwEnd = kTwW2 + 7 * 8;
-constexpr int kTabFloats = 2 * kTwEnd + kN / 2;    // 3056
+// Geometry of one long block size: R points per lane.  Table block (walk_build_tables): W[N] | pass twiddles as float2,
+// then the window of the long block (n/2 floats).
+template <int R>
+struct Geo {
+    static constexpr int kN = 256 * R;                              // blocksize_1
+    static constexpr int kPts = 64 * R;                             // N: complex points of the FFT
+    // complex slots of one channel's transform area: the padded transposes (tests/vorbis_walk_model.py: highest slot 303 /
+    // 567 / 1143), u in natural order (n/2 floats) and a short block with its scratch (1.5 blocksize_0 <= 768 floats)
+    static constexpr int kChanF2 = R == 4 ? 384 : R == 8 ? 576 : 1152;
+    static constexpr int kTw1 = kPts;                               // W_N^(j k), k = 1..R-1: [R-1][64]
+    static constexpr int kTw2 = kTw1 + (R - 1) * 64;                // R = 8: W_64^(n0 k) [7][8]; else W_64^(m k) [3][16]
+    static constexpr int kTw3 = kTw2 + (R == 8 ? 56 : 48);          // R = 4: W_16^(n4 k) [3][4]
+    static constexpr int kTwEnd = kTw3 + (R == 4 ? 12 : 0);
+    static constexpr int kTabFloats = 2 * kTwEnd + kN / 2;          // 1528 / 3056 / 6112
+    static_assert(kTabFloats % 4 == 0, "staged in 16-byte pieces");
+};
 
 __device__ __forceinline__ f2 cmul(f2 a, f2 w) { return f2{ a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x }; }
+
+// 4-point DFT, forward, natural order in and out
+__device__ __forceinline__ void dft4(f2 &a0, f2 &a1, f2 &a2, f2 &a3)
+{
+    const f2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    a1 = f2{ d02.x + d13.y, d02.y - d13.x };
+    a3 = f2{ d02.x - d13.y, d02.y + d13.x };
+}
 
 // 8-point DFT, forward (exp(-2 pi i a b / 8)), natural order in and out
 __device__ __forceinline__ void dft8(f2 (&a)[8])
@@ -77,6 +103,52 @@ __device__ __forceinline__ void dft8(f2 (&a)[8])
     a[7] = f2{ d2.x - s * D3.y, d2.y + s * D3.x };
 }
 
+// a * exp(-2 pi i M / 16) for the exponents a 4 x 4 split of 16 points meets (0, 1, 2, 3, 4, 6, 9)
+template <int M>
+__device__ __forceinline__ f2 mul_w16(f2 a)
+{
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    if constexpr (M == 0) return a;
+    else if constexpr (M == 1) return f2{ a.x * c1 + a.y * s1, a.y * c1 - a.x * s1 };
+    else if constexpr (M == 2) return f2{ (a.x + a.y) * h, (a.y - a.x) * h };
+    else if constexpr (M == 3) return f2{ a.x * s1 + a.y * c1, a.y * s1 - a.x * c1 };
+    else if constexpr (M == 4) return f2{ a.y, -a.x };
+    else if constexpr (M == 6) return f2{ (a.y - a.x) * h, -(a.x + a.y) * h };
+    else {
+        static_assert(M == 9, "exponent");
+        return f2{ -(a.x * c1 + a.y * s1), a.x * s1 - a.y * c1 };
+    }
+}
+
+// 16-point DFT, forward, natural order in and out: index n = nl + 4 nh, four 4-point DFTs over nh, W_16^(nl ka), four over nl
+__device__ __forceinline__ void dft16(f2 (&a)[16])
+{
+#pragma unroll
+    for (int nl = 0; nl < 4; nl++) dft4(a[nl], a[nl + 4], a[nl + 8], a[nl + 12]);       // a[nl + 4 ka]
+    a[5] = mul_w16<1>(a[5]);
+    a[9] = mul_w16<2>(a[9]);
+    a[13] = mul_w16<3>(a[13]);
+    a[6] = mul_w16<2>(a[6]);
+    a[10] = mul_w16<4>(a[10]);
+    a[14] = mul_w16<6>(a[14]);
+    a[7] = mul_w16<3>(a[7]);
+    a[11] = mul_w16<6>(a[11]);
+    a[15] = mul_w16<9>(a[15]);
+    // over nl for each ka: inputs a[nl + 4 ka], outputs k = ka + 4 kb
+    f2 o[16];
+#pragma unroll
+    for (int ka = 0; ka < 4; ka++) {
+        f2 x0 = a[4 * ka], x1 = a[4 * ka + 1], x2 = a[4 * ka + 2], x3 = a[4 * ka + 3];
+        dft4(x0, x1, x2, x3);
+        o[ka] = x0;
+        o[ka + 4] = x1;
+        o[ka + 8] = x2;
+        o[ka + 12] = x3;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = o[k];
+}
+
 __device__ __forceinline__ void lane_swap32(float &x, float &y)      // x of lanes 32..63 <-> y of lanes 0..31
 {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -90,12 +162,14 @@ __device__ __forceinline__ void cross32(float &a, float &b)
     lane_swap32(b, a);
 }
 
-__device__ __forceinline__ void settle(f2 (&x)[2][8])
+template <int CH, int R>
+__device__ __forceinline__ void settle(f2 (&x)[CH][R])
 {
 #pragma unroll
-    for (int c = 0; c < 2; c++)
-        asm volatile("" : "+v"(x[c][0]), "+v"(x[c][1]), "+v"(x[c][2]), "+v"(x[c][3]), "+v"(x[c][4]), "+v"(x[c][5]),
-                     "+v"(x[c][6]), "+v"(x[c][7]) : : "memory");
+    for (int c = 0; c < CH; c++)
+#pragma unroll
+        for (int r = 0; r < R; r += 4)
+            asm volatile("" : "+v"(x[c][r]), "+v"(x[c][r + 1]), "+v"(x[c][r + 2]), "+v"(x[c][r + 3]) : : "memory");
 }
 
 // Lane geometry (constant for the life of a wavefront).  Group index j: lanes 0..31 take j = lane, lanes 32..63 take
@@ -110,125 +184,295 @@ __device__ __forceinline__ int fresh_lane()
 }
 __device__ __forceinline__ int group_of(int lane) { return lane < 32 ? lane : 95 - lane; }
 
-// The 512-point FFT of both channels with the pre- and post-twiddle: xin[c][r] = (X[2q], X[2q+1]) at q = j + 64 r in,
-// P[c][k2] = c[j + 64 k2] out.  U: the wavefront's transform area (channel c at U + c kChanF2).
-template <typename Next>
-__device__ __forceinline__ void fft512_pair(f2 (&xin)[2][8], f2 (&P)[2][8], f2 *U, const f2 *T, Next next)
+// The passes between the pre- and the post-twiddle: e[c][r] = point j + 64 r in, e[c][s] = bin j + 64 s out (not yet
+// multiplied by w).  U: the wavefront's transform area (channel c at U + c kChanF2); T: the table block.
+template <int R, int CH>
+__device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T)
 {
-    int j = group_of(fresh_lane());      // pass 1: points j + 64 r
-    // X[2q+1] is the imaginary part of point 511 - q = (63 - j) + 64 (7 - r): the other half-wave's slot 7 - r
+    using G = Geo<R>;
+    constexpr int F = G::kChanF2;
+    int j = group_of(fresh_lane());
+    if constexpr (R == 8) {
+        // pass 1: over r = q >> 6 -> k0; twiddle W512^(j k0)
 #pragma unroll
-    for (int c = 0; c < 2; c++)
+        for (int c = 0; c < CH; c++) dft8(e[c]);
+        {
+            const f2 *W1 = T + G::kTw1 + j;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float a = xin[c][r].y, b = xin[c][7 - r].y;
+            for (int k = 1; k < 8; k++) {
+                const f2 w = W1[64 * (k - 1)];
+#pragma unroll
+                for (int c = 0; c < CH; c++) e[c][k] = cmul(e[c][k], w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) U[c * F + j + 68 * k] = e[c][k];
+        __builtin_amdgcn_wave_barrier();
+        // pass 2: lane (n0, k0) = (lane >> 3, lane & 7) over n1 -> k1; reads U[n0 + 8 n1 + 68 k0], twiddle W64^(n0 k1),
+        // writes V[k0 + 8 k1 + 72 n0] (the same area: all reads are issued before the first write)
+        const int l2 = fresh_lane();
+        const int n0 = l2 >> 3, r2 = n0 + 68 * (l2 & 7), w2 = (l2 & 7) + 72 * n0;
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[c][k] = U[c * F + r2 + 8 * k];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; c++) dft8(e[c]);
+        {
+            const f2 *W2 = T + G::kTw2 + n0;
+#pragma unroll
+            for (int k = 1; k < 8; k++) {
+                const f2 w = W2[8 * (k - 1)];
+#pragma unroll
+                for (int c = 0; c < CH; c++) e[c][k] = cmul(e[c][k], w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) U[c * F + w2 + 8 * k] = e[c][k];
+        __builtin_amdgcn_wave_barrier();
+        // pass 3: lane (k0 + 8 k1 = j) over n0 -> k2
+        j = group_of(fresh_lane());
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[c][k] = U[c * F + j + 72 * k];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; c++) dft8(e[c]);
+    } else if constexpr (R == 16) {
+        // 16 x 4 x 16: q = n3 + 16 n2 + 64 n1 -> k = k1 + 16 k2 + 64 k3.  pass 1: over r = n1 -> k1; twiddle W1024^(j k1)
+#pragma unroll
+        for (int c = 0; c < CH; c++) dft16(e[c]);
+        {
+            const f2 *W1 = T + G::kTw1 + j;
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                const f2 w = W1[64 * (k - 1)];
+#pragma unroll
+                for (int c = 0; c < CH; c++) e[c][k] = cmul(e[c][k], w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) U[c * F + j + 72 * k] = e[c][k];
+        __builtin_amdgcn_wave_barrier();
+        // pass 2: lane (n3, g) = (lane >> 2, lane & 3) takes the items k1 = g + 4 i, each a 4-point DFT over n2 -> k2:
+        // reads U[n3 + 16 n2 + 72 k1], twiddle W64^(n3 k2), writes V[k1 + 16 k2 + 68 n3]
+        const int l2 = fresh_lane();
+        const int n3 = l2 >> 2, r2 = n3 + 72 * (l2 & 3), w2 = (l2 & 3) + 68 * n3;
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int n2 = 0; n2 < 4; n2++) e[c][4 * i + n2] = U[c * F + r2 + 16 * n2 + 288 * i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) dft4(e[c][4 * i], e[c][4 * i + 1], e[c][4 * i + 2], e[c][4 * i + 3]);
+        {
+            const f2 *W2 = T + G::kTw2 + n3;
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                const f2 w = W2[16 * (k - 1)];
+#pragma unroll
+                for (int c = 0; c < CH; c++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) e[c][4 * i + k] = cmul(e[c][4 * i + k], w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) U[c * F + w2 + 4 * i + 16 * k] = e[c][4 * i + k];
+        __builtin_amdgcn_wave_barrier();
+        // pass 3: lane j = k1 + 16 k2 over n3 -> k3
+        j = group_of(fresh_lane());
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) e[c][k] = U[c * F + j + 68 * k];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; c++) dft16(e[c]);
+    } else {
+        static_assert(R == 4, "points per lane");
+        // 4 x 4 x 4 x 4: q = n4 + 4 n3 + 16 n2 + 64 n1 -> k = k1 + 4 k2 + 16 k3 + 64 k4.  pass 1: over r = n1 -> k1
+#pragma unroll
+        for (int c = 0; c < CH; c++) dft4(e[c][0], e[c][1], e[c][2], e[c][3]);
+        {
+            const f2 *W1 = T + G::kTw1 + j;
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                const f2 w = W1[64 * (k - 1)];
+#pragma unroll
+                for (int c = 0; c < CH; c++) e[c][k] = cmul(e[c][k], w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) U[c * F + j + 80 * k] = e[c][k];
+        __builtin_amdgcn_wave_barrier();
+        // pass 2: lane (m, k1) = (lane & 15, lane >> 4), m = n4 + 4 n3, over n2 -> k2: reads U[m + 16 n2 + 80 k1], twiddle
+        // W64^(m k2), writes slot m + 16 kk + 4 (kk >> 1) of kk = k1 + 4 k2
+        {
+            const int l2 = fresh_lane();
+            const int m = l2 & 15, k1 = l2 >> 4, r2 = m + 80 * k1, w2 = m + 16 * k1 + 4 * (k1 >> 1);
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) e[c][k] = U[c * F + r2 + 16 * k];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < CH; c++) dft4(e[c][0], e[c][1], e[c][2], e[c][3]);
+            const f2 *W2 = T + G::kTw2 + m;
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                const f2 w = W2[16 * (k - 1)];
+#pragma unroll
+                for (int c = 0; c < CH; c++) e[c][k] = cmul(e[c][k], w);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) U[c * F + w2 + 72 * k] = e[c][k];
+            __builtin_amdgcn_wave_barrier();
+        }
+        // pass 3: lane (n4, kk) = (lane & 3, lane >> 2) over n3 -> k3: twiddle W16^(n4 k3), writes V[kk + 16 k3 + 72 n4]
+        {
+            const int l3 = fresh_lane();
+            const int n4 = l3 & 3, kk = l3 >> 2, r3 = n4 + 16 * kk + 4 * (kk >> 1), w3 = kk + 72 * n4;
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) e[c][k] = U[c * F + r3 + 4 * k];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < CH; c++) dft4(e[c][0], e[c][1], e[c][2], e[c][3]);
+            const f2 *W3 = T + G::kTw3 + n4;
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                const f2 w = W3[4 * (k - 1)];
+#pragma unroll
+                for (int c = 0; c < CH; c++) e[c][k] = cmul(e[c][k], w);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) U[c * F + w3 + 16 * k] = e[c][k];
+            __builtin_amdgcn_wave_barrier();
+        }
+        // pass 4: lane j = kk + 16 k3 over n4 -> k4
+        j = group_of(fresh_lane());
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[c][k] = U[c * F + j + 72 * k];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < CH; c++) dft4(e[c][0], e[c][1], e[c][2], e[c][3]);
+    }
+}
+
+// The N-point FFT of all channels with the pre- and post-twiddle: xin[c][r] = (X[2q], X[2q+1]) at q = j + 64 r in,
+// P[c][s] = c[j + 64 s] out.
+template <int R, int CH, typename Next>
+__device__ __forceinline__ void fft_lanes(f2 (&xin)[CH][R], f2 (&P)[CH][R], f2 *U, const f2 *T, Next next)
+{
+    int j = group_of(fresh_lane());      // points j + 64 r
+    // X[2q+1] is the imaginary part of point N-1 - q = (63 - j) + 64 (R-1 - r): the other half-wave's slot R-1 - r
+#pragma unroll
+    for (int c = 0; c < CH; c++)
+#pragma unroll
+        for (int r = 0; r < R / 2; r++) {
+            float a = xin[c][r].y, b = xin[c][R - 1 - r].y;
             cross32(a, b);
             xin[c][r].y = a;
-            xin[c][7 - r].y = b;
+            xin[c][R - 1 - r].y = b;
         }
-    f2 e[2][8];
+    f2 e[CH][R];
     {
-        const f2 *W = T + kTwW + j;
+        const f2 *W = T + j;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < R; r++) {
             const f2 w = W[64 * r];
 #pragma unroll
-            for (int c = 0; c < 2; c++) e[c][r] = cmul(xin[c][r], w);
+            for (int c = 0; c < CH; c++) e[c][r] = cmul(xin[c][r], w);
         }
     }
     next();                                          // the spectrum registers are free: fetch the next packet's
-    // pass 1: over r = q >> 6 -> k0; twiddle W512^(j k0)
-#pragma unroll
-    for (int c = 0; c < 2; c++) dft8(e[c]);
-    {
-        const f2 *W1 = T + kTwW1 + j;
-#pragma unroll
-        for (int k = 1; k < 8; k++) {
-            const f2 w = W1[64 * (k - 1)];
-#pragma unroll
-            for (int c = 0; c < 2; c++) e[c][k] = cmul(e[c][k], w);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) U[c * kChanF2 + j + 68 * k] = e[c][k];
-    __builtin_amdgcn_wave_barrier();
-    // pass 2: lane (n0, k0) = (lane >> 3, lane & 7) over n1 -> k1; reads U[n0 + 8 n1 + 68 k0], twiddle W64^(n0 k1), writes
-    // V[k0 + 8 k1 + 72 n0] (the same area: all reads are issued before the first write)
-    const int l2 = fresh_lane();
-    const int n0 = l2 >> 3, r2 = n0 + 68 * (l2 & 7), w2 = (l2 & 7) + 72 * n0;
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) e[c][k] = U[c * kChanF2 + r2 + 8 * k];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < 2; c++) dft8(e[c]);
-    {
-        const f2 *W2 = T + kTwW2 + n0;
-#pragma unroll
-        for (int k = 1; k < 8; k++) {
-            const f2 w = W2[8 * (k - 1)];
-#pragma unroll
-            for (int c = 0; c < 2; c++) e[c][k] = cmul(e[c][k], w);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) U[c * kChanF2 + w2 + 8 * k] = e[c][k];
-    __builtin_amdgcn_wave_barrier();
-    // pass 3: lane (k0 + 8 k1 = j) over n0 -> k2; post-twiddle
+    fft_passes<R, CH>(e, U, T);
     j = group_of(fresh_lane());
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) e[c][k] = U[c * kChanF2 + j + 72 * k];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < 2; c++) dft8(e[c]);
     {
-        const f2 *W = T + kTwW + j;
+        const f2 *W = T + j;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < R; k++) {
             const f2 w = W[64 * k];
 #pragma unroll
-            for (int c = 0; c < 2; c++) P[c][k] = cmul(e[c][k], w);
+            for (int c = 0; c < CH; c++) P[c][k] = cmul(e[c][k], w);
         }
     }
 }
 
-// y[m] of a long block from its u (floats at uf[0..1024)): the odd / even extension of the DCT-IV
+// y[m] of a long block of n samples from its u (floats at uf[0..n/2)): the odd / even extension of the DCT-IV
+template <int N>
 __device__ __forceinline__ float y_of_u(const float *uf, int m)
 {
-    if (m < 512) return uf[512 + m];
-    if (m < 1536) return -uf[1535 - m];
-    return -uf[m - 1536];
+    if (m < N / 4) return uf[N / 4 + m];
+    if (m < 3 * N / 4) return -uf[3 * N / 4 - 1 - m];
+    return -uf[m - 3 * N / 4];
 }
 
-// One wavefront walks both channels of a stereo segment.
+// two frames of all channels: 16 bytes of a stereo stream, 8 of a mono one
+template <int CH>
+__device__ __forceinline__ void store_pair(float *o, int pair, const float (&f0)[CH], const float (&f1)[CH])
+{
+    if constexpr (CH == 2) __builtin_nontemporal_store((f4{ f0[0], f0[1], f1[0], f1[1] }), (f4 *)o + pair);
+    else __builtin_nontemporal_store((f2{ f0[0], f1[0] }), (f2 *)o + pair);
+}
+template <int CH>
+__device__ __forceinline__ void store_frame(float *o, int frame, const float (&v)[CH])
+{
+    if constexpr (CH == 2) __builtin_nontemporal_store((f2{ v[0], v[1] }), (f2 *)o + frame);
+    else __builtin_nontemporal_store(v[0], o + frame);
+}
+
+// One wavefront walks the CH channels of a segment whose long blocks have 256 R samples.
+template <int R, int CH>
 __device__ __forceinline__ void walk_body(
     f2 *U, const f2 *T, const VorbisSeg &seg, const VorbisStream &st, const uint8_t *__restrict__ pflags,
     const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off, const float *tables,
     const float *__restrict__ spec, float *__restrict__ out)
 {
+    using G = Geo<R>;
+    constexpr int kN = G::kN, kPts = G::kPts, kChanF2 = G::kChanF2, H = R / 2;
     const int lane = threadIdx.x & 63;
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
     const uint32_t tab0 = st.tab[0];
-    const float *const lwin = (const float *)(T + kTwEnd);       // window of n = 2048 (LDS)
+    const float *const lwin = (const float *)(T + G::kTwEnd);    // window of the long block (LDS)
 
     int previous_length = 0;
-    bool carry_u = false;                            // carried state is in u form (8 floats per channel: a long block's right half)
     const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
     const int p_end = (int)(seg.p0 + seg.count);
 
     // Carried state, per channel.  After a long block whose right window is long: cb[c][2 i], cb[c][2 i + 1] =
-    // u[1023 - 2k], u[1022 - 2k] for k = j + 64 (4 + i) -- the b of frames 2k - 512 and 2k - 511 of the next block.
+    // u[n/2-1 - 2k], u[n/2-2 - 2k] for k = j + 64 (R/2 + i) -- the b of frames 2k - n/4 and 2k - n/4 + 1 of the next block.
     // Otherwise previous_window itself (:2641-2643): sample lane + 64 i in cb[c][i] (64 .. 256 samples).
-    float cb[2][8];
+    float cb[CH][R];
 #pragma unroll
-    for (int i = 0; i < 8; i++) cb[0][i] = cb[1][i] = 0.0f;
+    for (int c = 0; c < CH; c++)
+#pragma unroll
+        for (int i = 0; i < R; i++) cb[c][i] = 0.0f;
 
     int fbase = 0;
     unsigned fl_reg = 0;
@@ -256,27 +500,27 @@ __device__ __forceinline__ void walk_body(
     // One packet's spectra are in flight: the pre-twiddle of transform k empties xin, the loads of transform k+1 follow
     // at once and are waited for (settle) just before the PCM stores of transform k enter the queue -- loads and stores
     // share one in-order counter.
-    f2 xin[2][8];
+    f2 xin[CH][R];
     auto issue = [&](int p) {
         const unsigned flp = p < p_end ? flags_of(p) : 0u;
         if (flp & AFG_VORBIS_LONG) {
             const f2 *src = (const f2 *)(spec + lane64(so_reg, p)) + group_of(fresh_lane());
-            // AFG_VORBIS_NZ_EIGHTHS: load r of a channel covers bins 128 r .. 128 r + 127, so a declared-empty eighth is a
-            // whole instruction that is not issued (a scalar test: no lane predicates)
+            // AFG_VORBIS_NZ_EIGHTHS: load r of a channel covers bins 128 r .. 128 r + 127 of n/2 = 128 R, so a load whose
+            // bins all lie in the declared-empty eighths is a whole instruction that is not issued (a scalar test)
             const int nz = (int)(flp >> 4) ? (int)(flp >> 4) - 1 : 8;
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < CH; c++)
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
+                for (int r = 0; r < R; r++) {
                     xin[c][r] = f2{ 0.0f, 0.0f };
-                    if (r < nz) xin[c][r] = __builtin_nontemporal_load(src + c * (kN / 4) + 64 * r);
+                    if (8 * r < nz * R) xin[c][r] = __builtin_nontemporal_load(src + c * kPts + 64 * r);
                 }
         } else {
             // nothing reads xin before the next issue(): say so, or the old values are copied around to survive the branch
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < CH; c++)
 #pragma unroll
-                for (int r = 0; r < 8; r++) asm volatile("" : "=v"(xin[c][r]));
+                for (int r = 0; r < R; r++) asm volatile("" : "=v"(xin[c][r]));
         }
     };
     issue(p_first);
@@ -293,29 +537,47 @@ __device__ __forceinline__ void walk_body(
         const int nout = right - left, plen = right_end - right;
         float *const o = out + lane64(oo_reg, p);        // interleaved frames; 16-byte aligned (checked at launch)
         auto next = [&]() { issue(p + 1); };
+        // previous_window sample jj of channel c (jj < 256): cb[c][jj >> 6], a register: spelled out
+        auto carried = [&](int c, int jj) -> float {
+            const int i = jj >> 6;
+            return i == 0 ? cb[c][0] : i == 1 ? cb[c][1] : i == 2 ? cb[c][2] : cb[c][3];
+        };
 
         if (lng) {
             const bool wprev = (fl & AFG_VORBIS_PREV) != 0, wnext = (fl & AFG_VORBIS_NEXT) != 0;
-            f2 P[2][8];
-            fft512_pair(xin, P, U, T, next);
+            f2 P[CH][R];
+            if constexpr (R == 4) {
+                // a load covers two eighths of this size's spectrum (lanes 0..31 the first): an odd declaration leaves the
+                // upper lanes of its last load holding bins that must not be looked at
+                const int nz = (int)(fl >> 4) ? (int)(fl >> 4) - 1 : 8;
+                if (nz & 1) {
+                    const bool low = fresh_lane() < 32;
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+                            if (r == (nz >> 1)) xin[c][r] = low ? xin[c][r] : f2{ 0.0f, 0.0f };
+                }
+            }
+            fft_lanes<R, CH>(xin, P, U, T, next);
             if (!(wprev && wnext)) {
-                // a short neighbour: u of both channels to LDS in natural order for the y(m) accessor below
+                // a short neighbour: u of every channel to LDS in natural order for the y(m) accessor below
                 float *const uf = (float *)U;
 #pragma unroll
-                for (int c = 0; c < 2; c++)
+                for (int c = 0; c < CH; c++)
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
+                    for (int k = 0; k < R; k++) {
                         const int kk = group_of(lane) + 64 * k;
                         uf[c * (2 * kChanF2) + 2 * kk] = P[c][k].x;
-                        uf[c * (2 * kChanF2) + 1023 - 2 * kk] = -P[c][k].y;
+                        uf[c * (2 * kChanF2) + kN / 2 - 1 - 2 * kk] = -P[c][k].y;
                     }
                 __builtin_amdgcn_wave_barrier();
             }
-            // c[511 - k] for k = j + 64 s, s = 4..7: slot 7 - s of lane ^ 32
+            // c[N-1 - k] for k = j + 64 s, s = R/2 .. R-1: slot R-1 - s of lane ^ 32
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < CH; c++) {
 #pragma unroll
-                for (int k = 0; k < 4; k += 2) {
+                for (int k = 0; k < H; k += 2) {
                     float ax = P[c][k].x, bx = P[c][k + 1].x, ay = P[c][k].y, by = P[c][k + 1].y;
                     cross32(ax, bx);
                     cross32(ay, by);
@@ -323,37 +585,29 @@ __device__ __forceinline__ void walk_body(
                     P[c][k + 1] = f2{ bx, by };
                 }
             }
-            // slot of the mirror of s = 4 + i after the crossing: P[c][0] holds lane^32's slot 1, P[c][1] its slot 0, ...
-            constexpr int mir[4] = { 2, 3, 0, 1 };        // s = 4: slot 3 -> P[2]; 5: slot 2 -> P[3]; 6: slot 1 -> P[0]; 7: slot 0 -> P[1]
+            // after the crossing P[c][k] holds lane ^ 32's slot k ^ 1: the mirror of s = R/2 + i, slot R/2-1 - i, is P[c][mir(i)]
+            auto mir = [](int i) constexpr { return (H - 1 - i) ^ 1; };
             settle(xin);
             if (emit && wprev) {
-                // frames j0, j0+1 (j0 = 2 (j + 64 i)) and 1022-j0, 1023-j0 of the block, both channels: two 16-byte stores
+                // frames j0, j0+1 (j0 = 2 (j + 64 i)) and n/2-2-j0, n/2-1-j0 of the block, all channels: two stores
                 const int j = group_of(fresh_lane());
                 const f2 *const wlo = (const f2 *)lwin + j;
-                const f2 *const whi = (const f2 *)lwin + 511 - j;
-                f4 *const olo = (f4 *)o + j;
-                f4 *const ohi = (f4 *)o + 511 - j;
+                const f2 *const whi = (const f2 *)lwin + (kPts - 1) - j;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < H; i++) {
                     const f2 w0 = wlo[64 * i];                     // w[j0], w[j0+1]
-                    const f2 w1 = whi[-64 * i];                    // w[1022-j0], w[1023-j0]
-                    f4 lo, hi;
-                    {
-                        const float a0 = P[0][4 + i].x, a1 = -P[0][mir[i]].y, b0 = cb[0][2 * i], b1 = cb[0][2 * i + 1];
-                        lo.x = a0 * w0.x - b0 * w1.y;
-                        lo.z = a1 * w0.y - b1 * w1.x;
-                        hi.z = -a0 * w1.y - b0 * w0.x;
-                        hi.x = -a1 * w1.x - b1 * w0.y;
+                    const f2 w1 = whi[-64 * i];                    // w[n/2-2-j0], w[n/2-1-j0]
+                    float lo0[CH], lo1[CH], hi0[CH], hi1[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; c++) {
+                        const float a0 = P[c][H + i].x, a1 = -P[c][mir(i)].y, b0 = cb[c][2 * i], b1 = cb[c][2 * i + 1];
+                        lo0[c] = a0 * w0.x - b0 * w1.y;
+                        lo1[c] = a1 * w0.y - b1 * w1.x;
+                        hi1[c] = -a0 * w1.y - b0 * w0.x;
+                        hi0[c] = -a1 * w1.x - b1 * w0.y;
                     }
-                    {
-                        const float a0 = P[1][4 + i].x, a1 = -P[1][mir[i]].y, b0 = cb[1][2 * i], b1 = cb[1][2 * i + 1];
-                        lo.y = a0 * w0.x - b0 * w1.y;
-                        lo.w = a1 * w0.y - b1 * w1.x;
-                        hi.w = -a0 * w1.y - b0 * w0.x;
-                        hi.y = -a1 * w1.x - b1 * w0.y;
-                    }
-                    __builtin_nontemporal_store(lo, olo + 64 * i);
-                    __builtin_nontemporal_store(hi, ohi - 64 * i);
+                    store_pair<CH>(o, j + 64 * i, lo0, lo1);
+                    store_pair<CH>(o, (kPts - 1) - j - 64 * i, hi0, hi1);
                 }
             }
             if (!(wprev && wnext)) {
@@ -362,16 +616,15 @@ __device__ __forceinline__ void walk_body(
                     // :2606-2657 on y(m): frames the u-form path above did not write
                     const float *wt = tables + tab0 + bs0 + bs0 / 4;      // window of blocksize_0 (:2245-2251)
                     for (int jj = (wprev ? kN / 2 : 0) + lane; jj < nout; jj += 64) {
-                        float v0 = y_of_u(uf, left + jj), v1 = y_of_u(uf + 2 * kChanF2, left + jj);
+                        float v[CH];
+#pragma unroll
+                        for (int c = 0; c < CH; c++) v[c] = y_of_u<kN>(uf + c * (2 * kChanF2), left + jj);
                         if (!wprev && jj < pn) {                           // pn = blocksize_0 / 2 here
                             const float wa = wt[jj], wb = wt[pn - 1 - jj];
-                            const int i = jj >> 6;                         // cb[.][jj >> 6], a register: spelled out
-                            const float c0 = i == 0 ? cb[0][0] : i == 1 ? cb[0][1] : i == 2 ? cb[0][2] : cb[0][3];
-                            const float c1 = i == 0 ? cb[1][0] : i == 1 ? cb[1][1] : i == 2 ? cb[1][2] : cb[1][3];
-                            v0 = v0 * wa + c0 * wb;
-                            v1 = v1 * wa + c1 * wb;
+#pragma unroll
+                            for (int c = 0; c < CH; c++) v[c] = v[c] * wa + carried(c, jj) * wb;
                         }
-                        __builtin_nontemporal_store((f2{ v0, v1 }), (f2 *)o + jj);
+                        store_frame<CH>(o, jj, v);
                     }
                 }
                 if (!wnext) {
@@ -379,82 +632,78 @@ __device__ __forceinline__ void walk_body(
                     for (int i = 0; i < 4; i++) {
                         const int m = right + lane + 64 * i;
                         const bool in = lane + 64 * i < plen;
-                        cb[0][i] = in ? y_of_u(uf, m < kN ? m : 0) : 0.0f;
-                        cb[1][i] = in ? y_of_u(uf + 2 * kChanF2, m < kN ? m : 0) : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < CH; c++) cb[c][i] = in ? y_of_u<kN>(uf + c * (2 * kChanF2), m < kN ? m : 0) : 0.0f;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
             if (wnext) {
 #pragma unroll
-                for (int c = 0; c < 2; c++)
+                for (int c = 0; c < CH; c++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        cb[c][2 * i] = -P[c][4 + i].y;               // u[1023 - 2k]
-                        cb[c][2 * i + 1] = P[c][mir[i]].x;           // u[2 (511 - k)] = u[1022 - 2k]
+                    for (int i = 0; i < H; i++) {
+                        cb[c][2 * i] = -P[c][H + i].y;               // u[n/2-1 - 2k]
+                        cb[c][2 * i + 1] = P[c][mir(i)].x;           // u[2 (N-1 - k)] = u[n/2-2 - 2k]
                     }
             }
-            carry_u = wnext;
         } else {
             // short block: the reference's own transform (vorbis_core.h) over LDS, previous_window in cb
             const float *Tn = tables + tab0;
             const float *A = Tn, *B = Tn + n / 2, *Ct = Tn + n;
             const float *src = spec + lane64(so_reg, p);
-            float *const sm0 = (float *)U, *const sm1 = (float *)U + 2 * kChanF2;
+            float *const sm = (float *)U;
             const int n2 = n >> 1;
             for (int k = lane; k < n2; k += 64) {
-                sm0[k] = src[k];
-                sm1[k] = src[n2 + k];
+#pragma unroll
+                for (int c = 0; c < CH; c++) sm[c * (2 * kChanF2) + k] = src[c * n2 + k];
             }
             __builtin_amdgcn_wave_barrier();
 #pragma nounroll
-            for (int c = 0; c < 2; c++) {
-                float *const sm = (float *)U + c * (2 * kChanF2);
-                inverse_mdct_lds<64>(sm, sm + n, n, 31 - __clz(n), A, B, Ct);
+            for (int c = 0; c < CH; c++) {
+                float *const s = sm + c * (2 * kChanF2);
+                inverse_mdct_lds<64>(s, s + n, n, 31 - __clz(n), A, B, Ct);
             }
             next();
             settle(xin);
             if (emit) {
                 const float *wt = Tn + n + n / 4;
                 for (int jj = lane; jj < nout; jj += 64) {
-                    float v0 = sm0[left + jj], v1 = sm1[left + jj];
+                    float v[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; c++) v[c] = sm[c * (2 * kChanF2) + left + jj];
                     if (jj < pn) {
                         const float wa = wt[jj], wb = wt[pn - 1 - jj];
-                        const int i = jj >> 6;
-                        const float c0 = i == 0 ? cb[0][0] : i == 1 ? cb[0][1] : i == 2 ? cb[0][2] : cb[0][3];
-                        const float c1 = i == 0 ? cb[1][0] : i == 1 ? cb[1][1] : i == 2 ? cb[1][2] : cb[1][3];
-                        v0 = v0 * wa + c0 * wb;
-                        v1 = v1 * wa + c1 * wb;
+#pragma unroll
+                        for (int c = 0; c < CH; c++) v[c] = v[c] * wa + carried(c, jj) * wb;
                     }
-                    __builtin_nontemporal_store((f2{ v0, v1 }), (f2 *)o + jj);
+                    store_frame<CH>(o, jj, v);
                 }
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const bool in = lane + 64 * i < plen;
-                cb[0][i] = in ? sm0[right + lane + 64 * i] : 0.0f;
-                cb[1][i] = in ? sm1[right + lane + 64 * i] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < CH; c++) cb[c][i] = in ? sm[c * (2 * kChanF2) + right + lane + 64 * i] : 0.0f;
             }
             __builtin_amdgcn_wave_barrier();
-            carry_u = false;
         }
         previous_length = plen;
     }
-    (void)carry_u;
 }
 
 
-template <int WAVES>
+template <int R, int CH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void vorbis_walk_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off,
     const float *tables, const float *__restrict__ walk_tables, const float *__restrict__ spec, float *__restrict__ out,
     uint32_t *__restrict__ next_seg)
 {
+    using G = Geo<R>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
-        constexpr int kQuads = kTabFloats / 4, kPer = (kQuads + 64 * WAVES - 1) / (64 * WAVES);
-        static_assert(kTabFloats % 4 == 0, "16-byte pieces");
+        constexpr int kQuads = G::kTabFloats / 4, kPer = (kQuads + 64 * WAVES - 1) / (64 * WAVES);
         f4 t[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; k++) {
@@ -469,7 +718,7 @@ __global__ __launch_bounds__(64 * WAVES) void vorbis_walk_kernel(
     }
     __syncthreads();
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    f2 *const U = (f2 *)(lds + kTabFloats) + wave * kWaveF2;
+    f2 *const U = (f2 *)(lds + G::kTabFloats) + wave * (CH * G::kChanF2);
     const f2 *const T = (const f2 *)lds;
     for (;;) {
         uint32_t sidx = 0;
@@ -478,61 +727,112 @@ __global__ __launch_bounds__(64 * WAVES) void vorbis_walk_kernel(
         if (sidx >= n_segs) return;
         const VorbisSeg seg = segs[sidx];
         const VorbisStream st = streams[seg.stream];
-        walk_body(U, T, seg, st, pflags, spec_off, out_off, tables, spec, out);
+        walk_body<R, CH>(U, T, seg, st, pflags, spec_off, out_off, tables, spec, out);
     }
 }
 
-#ifndef AFG_VORBIS_WALK_WAVES
-#define AFG_VORBIS_WALK_WAVES 8
-#endif
-constexpr int kWalkWaves = AFG_VORBIS_WALK_WAVES;
-constexpr size_t kWalkLds = sizeof(float) * (kTabFloats + (size_t)kWalkWaves * 2 * kWaveF2);
+// Wavefronts per workgroup of each shape: what the LDS of a CU holds (tables once per workgroup + one transform area per
+// wavefront) at the register budget the shape compiles to.
+template <int R, int CH> struct Shape { static constexpr int kWaves = 8; };
+template <> struct Shape<16, 2> { static constexpr int kWaves = 7; };      // 7 x 18432 + 24448 bytes of 160 KB
 
-}  // namespace
+template <int R, int CH>
+constexpr size_t shape_lds() { return sizeof(float) * (Geo<R>::kTabFloats + (size_t)Shape<R, CH>::kWaves * CH * 2 * Geo<R>::kChanF2); }
 
-size_t walk_table_floats() { return kTabFloats; }
-
-void walk_build_tables(float *dst, const float *window2048)
+template <int R, int CH>
+int launch_shape(const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *streams, const uint8_t *pflags,
+                 const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
+                 const float *spec, float *out, uint32_t *counter, hipStream_t stream)
 {
-    const double two_pi = 6.283185307179586476925286766559;
-    for (int k = 0; k < 512; k++) {
-        const double a = two_pi * (k + 0.125) / 2048.0;
-        dst[2 * (kTwW + k)] = (float)std::cos(a);
-        dst[2 * (kTwW + k) + 1] = (float)-std::sin(a);
-    }
-    for (int k0 = 1; k0 < 8; k0++)
-        for (int j = 0; j < 64; j++) {
-            const double a = two_pi * (double)(j * k0) / 512.0;
-            dst[2 * (kTwW1 + (k0 - 1) * 64 + j)] = (float)std::cos(a);
-            dst[2 * (kTwW1 + (k0 - 1) * 64 + j) + 1] = (float)-std::sin(a);
-        }
-    for (int k1 = 1; k1 < 8; k1++)
-        for (int n0 = 0; n0 < 8; n0++) {
-            const double a = two_pi * (double)(n0 * k1) / 64.0;
-            dst[2 * (kTwW2 + (k1 - 1) * 8 + n0)] = (float)std::cos(a);
-            dst[2 * (kTwW2 + (k1 - 1) * 8 + n0) + 1] = (float)-std::sin(a);
-        }
-    std::memcpy(dst + 2 * kTwEnd, window2048, sizeof(float) * (kN / 2));
-}
-
-uint32_t walk_waves_per_group() { return kWalkWaves; }
-
-int walk_launch(const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *streams, const uint8_t *pflags,
-                const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
-                const float *spec, float *out, uint32_t *counter, uint32_t groups, hipStream_t stream)
-{
+    constexpr int kWaves = Shape<R, CH>::kWaves;
+    constexpr size_t kLds = shape_lds<R, CH>();
     // once per device, whichever host thread gets here first (afg.h allows concurrent launches of one plan)
     static std::once_flag attr_once[AFG_MAX_DEVICES];
+    static int per_cu[AFG_MAX_DEVICES];
+    static int cus[AFG_MAX_DEVICES];
     int dev = 0;
     if (int rc = afg::device_slot(&dev, "afg_vorbis_transform_hip")) return rc;
     hipError_t attr_rc = hipSuccess;
     std::call_once(attr_once[dev], [&] {
-        attr_rc = hipFuncSetAttribute((const void *)vorbis_walk_kernel<kWalkWaves>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWalkLds);
+        const void *fn = (const void *)vorbis_walk_kernel<R, CH, kWaves>;
+        attr_rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        int nb = 1, n_cu = 256, cur = 0;
+        if (attr_rc == hipSuccess && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kWaves, kLds) != hipSuccess) nb = 1;
+        if (hipGetDevice(&cur) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cur);
+        per_cu[dev] = nb < 1 ? 1 : nb;
+        cus[dev] = n_cu;
     });
     AFG_HIP_CHECK(attr_rc);
-    hipLaunchKernelGGL(vorbis_walk_kernel<kWalkWaves>, dim3(groups), dim3(64 * kWalkWaves), kWalkLds, stream, segs, n_segs,
-                       streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter);
+    // persistent wavefronts: as many workgroups as the device holds at once, each drawing segments from the counter
+    const uint32_t need = (n_segs + kWaves - 1) / kWaves, room = (uint32_t)(per_cu[dev] * cus[dev]);
+    hipLaunchKernelGGL((vorbis_walk_kernel<R, CH, kWaves>), dim3(need < room ? need : room), dim3(64 * kWaves), kLds, stream, segs,
+                       n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter);
     return AFG_OK;
+}
+
+template <int R>
+void build_tables_r(float *dst, const float *window)
+{
+    using G = Geo<R>;
+    const double two_pi = 6.283185307179586476925286766559;
+    auto put = [&](int slot, double angle) {
+        dst[2 * slot] = (float)std::cos(angle);
+        dst[2 * slot + 1] = (float)-std::sin(angle);
+    };
+    for (int k = 0; k < G::kPts; k++) put(k, two_pi * (k + 0.125) / (double)G::kN);
+    for (int k = 1; k < R; k++)
+        for (int j = 0; j < 64; j++) put(G::kTw1 + (k - 1) * 64 + j, two_pi * (double)(j * k) / (double)G::kPts);
+    if (R == 8) {
+        for (int k1 = 1; k1 < 8; k1++)
+            for (int n0 = 0; n0 < 8; n0++) put(G::kTw2 + (k1 - 1) * 8 + n0, two_pi * (double)(n0 * k1) / 64.0);
+    } else {
+        for (int k2 = 1; k2 < 4; k2++)
+            for (int m = 0; m < 16; m++) put(G::kTw2 + (k2 - 1) * 16 + m, two_pi * (double)(m * k2) / 64.0);
+    }
+    if (R == 4)
+        for (int k3 = 1; k3 < 4; k3++)
+            for (int n4 = 0; n4 < 4; n4++) put(G::kTw3 + (k3 - 1) * 4 + n4, two_pi * (double)(n4 * k3) / 16.0);
+    std::memcpy(dst + 2 * G::kTwEnd, window, sizeof(float) * (G::kN / 2));
+}
+
+}  // namespace
+
+int walk_shape(int channels, int blocksize0, int blocksize1)
+{
+    if (channels < 1 || channels > 2 || blocksize0 > 512 || blocksize0 >= blocksize1) return -1;
+    const int size = blocksize1 == 1024 ? 0 : blocksize1 == 2048 ? 1 : blocksize1 == 4096 ? 2 : -1;
+    return size < 0 ? -1 : 2 * size + (channels - 1);
+}
+
+size_t walk_table_floats(int shape)
+{
+    return shape < 2 ? Geo<4>::kTabFloats : shape < 4 ? Geo<8>::kTabFloats : Geo<16>::kTabFloats;
+}
+
+void walk_build_tables(int shape, float *dst, const float *window)
+{
+    if (shape < 2) build_tables_r<4>(dst, window);
+    else if (shape < 4) build_tables_r<8>(dst, window);
+    else build_tables_r<16>(dst, window);
+}
+
+int walk_launch(int shape, const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *streams, const uint8_t *pflags,
+                const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
+                const float *spec, float *out, uint32_t *counter, hipStream_t stream)
+{
+#define AFG_WALK_SHAPE(S, R, CH) \
+    case S: return launch_shape<R, CH>(segs, n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter, stream)
+    switch (shape) {
+        AFG_WALK_SHAPE(0, 4, 1);
+        AFG_WALK_SHAPE(1, 4, 2);
+        AFG_WALK_SHAPE(2, 8, 1);
+        AFG_WALK_SHAPE(3, 8, 2);
+        AFG_WALK_SHAPE(4, 16, 1);
+        AFG_WALK_SHAPE(5, 16, 2);
+    }
+#undef AFG_WALK_SHAPE
+    afg::set_error("afg_vorbis_transform_hip: walk shape %d", shape);
+    return AFG_ERR_INVALID;
 }
 
 }  // namespace afg_vorbis

@@ -44,7 +44,7 @@ def test_vorbis_long_short_mix(gpu, seg):
     assert compare(got, want) == 0
 
 
-@pytest.mark.parametrize("bs", [(256, 256), (256, 512), (512, 1024), (1024, 4096), (2048, 8192)])
+@pytest.mark.parametrize("bs", [(256, 256), (256, 512), (512, 1024), (1024, 4096), (2048, 8192), (512, 2048), (1024, 2048), (2048, 2048)])
 def test_vorbis_blocksizes(gpu, bs):
     packets = [9, 6]
     channels = [2, 1]
