@@ -693,8 +693,18 @@ __device__ __forceinline__ void walk_body(
 }
 
 
+// Wavefronts per workgroup of each shape and the wavefronts per SIMD it is compiled for: what the LDS of a CU holds
+// (tables once per workgroup + one transform area per wavefront) at the register budget that pays.  The small shapes
+// have little work per packet beside the fixed cost of a packet (flags, bounds, three or four LDS round trips): four
+// wavefronts per SIMD hide it (mono 1024: 11.5 -> 8.4 ms per C3-sized batch; a handful of spilled registers).
+template <int R, int CH> struct Shape { static constexpr int kWaves = 8, kPerSimd = 2; };
+template <> struct Shape<4, 1> { static constexpr int kWaves = 16, kPerSimd = 4; };
+template <> struct Shape<4, 2> { static constexpr int kWaves = 16, kPerSimd = 4; };
+template <> struct Shape<8, 1> { static constexpr int kWaves = 16, kPerSimd = 4; };
+template <> struct Shape<16, 2> { static constexpr int kWaves = 7, kPerSimd = 2; };      // 7 x 18432 + 24448 bytes of 160 KB
+
 template <int R, int CH, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void vorbis_walk_kernel(
+__global__ __launch_bounds__(64 * WAVES, (Shape<R, CH>::kPerSimd)) void vorbis_walk_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off,
     const float *tables, const float *__restrict__ walk_tables, const float *__restrict__ spec, float *__restrict__ out,
@@ -730,11 +740,6 @@ __global__ __launch_bounds__(64 * WAVES) void vorbis_walk_kernel(
         walk_body<R, CH>(U, T, seg, st, pflags, spec_off, out_off, tables, spec, out);
     }
 }
-
-// Wavefronts per workgroup of each shape: what the LDS of a CU holds (tables once per workgroup + one transform area per
-// wavefront) at the register budget the shape compiles to.
-template <int R, int CH> struct Shape { static constexpr int kWaves = 8; };
-template <> struct Shape<16, 2> { static constexpr int kWaves = 7; };      // 7 x 18432 + 24448 bytes of 160 KB
 
 template <int R, int CH>
 constexpr size_t shape_lds() { return sizeof(float) * (Geo<R>::kTabFloats + (size_t)Shape<R, CH>::kWaves * CH * 2 * Geo<R>::kChanF2); }

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="", help="comma-separated indices into SHAPES")
     args = ap.parse_args()
     import afgpu
     import oraclelib
@@ -34,7 +35,8 @@ def main():
     oraclelib.build()
     dev = torch.device("cuda:0")
     rows = []
-    for ch, bs0, bs1 in SHAPES:
+    only = [int(x) for x in args.only.split(",")] if args.only else range(len(SHAPES))
+    for ch, bs0, bs1 in [SHAPES[i] for i in only]:
         packets = 2584 * 2048 * 2 // (bs1 * ch)          # the samples of a C3 file
         plan, spec = synthetic.vorbis_batch_device(0x0662, args.files, packets, dev, bs0=bs0, bs1=bs1, channels=ch)
         out = torch.empty(plan.out_floats, dtype=torch.float32, device=dev)
