@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void vorbis_wave2_body(
 #endif
 constexpr int kWavesPerGroup = AFG_VORBIS_GROUP_WAVES;
 constexpr int kWaveStride = 2 * kWaveLds;             // transform areas of two channels: previous_window is in registers
-constexpr uint32_t kCounterSets = 32, kCountersPerLaunch = 1 + kWalkShapes + 1;   // (padded to 8)
+constexpr uint32_t kCounterSets = 32, kCountersPerLaunch = 1 + kWalkShapes;
 constexpr uint32_t kBothChannels = 0xffffffffu;       // VorbisSeg.pad of a wavefront that walks both channels of a stereo stream
 
 #ifndef AFG_VORBIS_WAVES_PER_EU
@@ -1261,7 +1261,10 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
         const int shape = single_only ? -1 : walk_shape((int)channels[s], bs[0], bs[1]);
         for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
             uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
-            if (shape >= 0) walk_segs[shape].push_back(VorbisSeg{ s, p0, cnt, 0 });
+            if (shape >= 6)      // one per channel or pair of channels
+                for (uint32_t c = 0; c < channels[s]; c += (uint32_t)walk_shape_channels(shape)) walk_segs[shape].push_back(VorbisSeg{ s, p0, cnt, c });
+            else if (shape >= 0)
+                walk_segs[shape].push_back(VorbisSeg{ s, p0, cnt, 0 });
             auto &wave_list = shape >= 0 ? wave_walk : wave_segs;
             if (fast && channels[s] == 2 && !single_only)
                 wave_list.push_back(VorbisSeg{ s, p0, cnt, kBothChannels });                                  // both channels, interleaved
@@ -1314,7 +1317,7 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     if (!rc) rc = p->d_walk_segs.upload(all_walk.data(), all_walk.size() * sizeof(VorbisSeg));
     for (int k = 0; k < kWalkShapes && !rc; k++) {
         if (p->walk_first[k + 1] == p->walk_first[k]) continue;
-        const int n = 1024 << (k >> 1);
+        const int n = walk_shape_blocksize(k);
         std::vector<float> wt(walk_table_floats(k));
         walk_build_tables(k, wt.data(), tables.data() + tab_of[n] + n + n / 4);
         rc = p->d_walk_tables[k].upload(wt.data(), wt.size() * sizeof(float));

@@ -433,22 +433,33 @@ __device__ __forceinline__ float y_of_u(const float *uf, int m)
     return -uf[m - 3 * N / 4];
 }
 
-// two frames of all channels: 16 bytes of a stereo stream, 8 of a mono one
-template <int CH>
-__device__ __forceinline__ void store_pair(float *o, int pair, const float (&f0)[CH], const float (&f1)[CH])
+// two frames of all channels: 16 bytes of a stereo stream, 8 of a mono one; ST (CH channels of a stream with more than
+// two): these channels' 4- or 8-byte column of the interleaved frames, `stride` floats apart, cached -- the other columns'
+// wavefronts fill the lines in L2
+template <int CH, bool ST>
+__device__ __forceinline__ void store_pair(float *o, int pair, const float (&f0)[CH], const float (&f1)[CH], int stride)
 {
-    if constexpr (CH == 2) __builtin_nontemporal_store((f4{ f0[0], f0[1], f1[0], f1[1] }), (f4 *)o + pair);
+    if constexpr (ST && CH == 2) {
+        *(f2 *)(o + (2 * pair) * stride) = f2{ f0[0], f0[1] };
+        *(f2 *)(o + (2 * pair + 1) * stride) = f2{ f1[0], f1[1] };
+    } else if constexpr (ST) {
+        o[(2 * pair) * stride] = f0[0];
+        o[(2 * pair + 1) * stride] = f1[0];
+    } else if constexpr (CH == 2) __builtin_nontemporal_store((f4{ f0[0], f0[1], f1[0], f1[1] }), (f4 *)o + pair);
     else __builtin_nontemporal_store((f2{ f0[0], f1[0] }), (f2 *)o + pair);
 }
-template <int CH>
-__device__ __forceinline__ void store_frame(float *o, int frame, const float (&v)[CH])
+template <int CH, bool ST>
+__device__ __forceinline__ void store_frame(float *o, int frame, const float (&v)[CH], int stride)
 {
-    if constexpr (CH == 2) __builtin_nontemporal_store((f2{ v[0], v[1] }), (f2 *)o + frame);
+    if constexpr (ST && CH == 2) *(f2 *)(o + frame * stride) = f2{ v[0], v[1] };
+    else if constexpr (ST) o[frame * stride] = v[0];
+    else if constexpr (CH == 2) __builtin_nontemporal_store((f2{ v[0], v[1] }), (f2 *)o + frame);
     else __builtin_nontemporal_store(v[0], o + frame);
 }
 
-// One wavefront walks the CH channels of a segment whose long blocks have 256 R samples.
-template <int R, int CH>
+// One wavefront walks the CH channels of a segment whose long blocks have 256 R samples; ST: channels seg.pad .. seg.pad +
+// CH - 1 of a stream with more than two (pairs when the count is even: 8-byte columns need even frame strides).
+template <int R, int CH, bool ST>
 __device__ __forceinline__ void walk_body(
     f2 *U, const f2 *T, const VorbisSeg &seg, const VorbisStream &st, const uint8_t *__restrict__ pflags,
     const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off, const float *tables,
@@ -460,6 +471,7 @@ __device__ __forceinline__ void walk_body(
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
     const uint32_t tab0 = st.tab[0];
     const float *const lwin = (const float *)(T + G::kTwEnd);    // window of the long block (LDS)
+    const int stride = ST ? (int)st.nch : CH, chan = ST ? (int)seg.pad : 0;
 
     int previous_length = 0;
     const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
@@ -504,7 +516,7 @@ __device__ __forceinline__ void walk_body(
     auto issue = [&](int p) {
         const unsigned flp = p < p_end ? flags_of(p) : 0u;
         if (flp & AFG_VORBIS_LONG) {
-            const f2 *src = (const f2 *)(spec + lane64(so_reg, p)) + group_of(fresh_lane());
+            const f2 *src = (const f2 *)(spec + lane64(so_reg, p)) + chan * kPts + group_of(fresh_lane());
             // AFG_VORBIS_NZ_EIGHTHS: load r of a channel covers bins 128 r .. 128 r + 127 of n/2 = 128 R, so a load whose
             // bins all lie in the declared-empty eighths is a whole instruction that is not issued (a scalar test)
             const int nz = (int)(flp >> 4) ? (int)(flp >> 4) - 1 : 8;
@@ -535,7 +547,7 @@ __device__ __forceinline__ void walk_body(
         const bool emit = (p >= (int)seg.p0) && previous_length > 0;
         const int pn = previous_length;
         const int nout = right - left, plen = right_end - right;
-        float *const o = out + lane64(oo_reg, p);        // interleaved frames; 16-byte aligned (checked at launch)
+        float *const o = out + lane64(oo_reg, p) + chan;   // interleaved frames; 16-byte aligned (checked at launch) unless ST
         auto next = [&]() { issue(p + 1); };
         // previous_window sample jj of channel c (jj < 256): cb[c][jj >> 6], a register: spelled out
         auto carried = [&](int c, int jj) -> float {
@@ -606,8 +618,8 @@ __device__ __forceinline__ void walk_body(
                         hi1[c] = -a0 * w1.y - b0 * w0.x;
                         hi0[c] = -a1 * w1.x - b1 * w0.y;
                     }
-                    store_pair<CH>(o, j + 64 * i, lo0, lo1);
-                    store_pair<CH>(o, (kPts - 1) - j - 64 * i, hi0, hi1);
+                    store_pair<CH, ST>(o, j + 64 * i, lo0, lo1, stride);
+                    store_pair<CH, ST>(o, (kPts - 1) - j - 64 * i, hi0, hi1, stride);
                 }
             }
             if (!(wprev && wnext)) {
@@ -624,7 +636,7 @@ __device__ __forceinline__ void walk_body(
 #pragma unroll
                             for (int c = 0; c < CH; c++) v[c] = v[c] * wa + carried(c, jj) * wb;
                         }
-                        store_frame<CH>(o, jj, v);
+                        store_frame<CH, ST>(o, jj, v, stride);
                     }
                 }
                 if (!wnext) {
@@ -651,9 +663,9 @@ __device__ __forceinline__ void walk_body(
             // short block: the reference's own transform (vorbis_core.h) over LDS, previous_window in cb
             const float *Tn = tables + tab0;
             const float *A = Tn, *B = Tn + n / 2, *Ct = Tn + n;
-            const float *src = spec + lane64(so_reg, p);
-            float *const sm = (float *)U;
             const int n2 = n >> 1;
+            const float *src = spec + lane64(so_reg, p) + chan * n2;
+            float *const sm = (float *)U;
             for (int k = lane; k < n2; k += 64) {
 #pragma unroll
                 for (int c = 0; c < CH; c++) sm[c * (2 * kChanF2) + k] = src[c * n2 + k];
@@ -677,7 +689,7 @@ __device__ __forceinline__ void walk_body(
 #pragma unroll
                         for (int c = 0; c < CH; c++) v[c] = v[c] * wa + carried(c, jj) * wb;
                     }
-                    store_frame<CH>(o, jj, v);
+                    store_frame<CH, ST>(o, jj, v, stride);
                 }
             }
 #pragma unroll
@@ -703,7 +715,7 @@ template <> struct Shape<4, 2> { static constexpr int kWaves = 16, kPerSimd = 4;
 template <> struct Shape<8, 1> { static constexpr int kWaves = 16, kPerSimd = 4; };
 template <> struct Shape<16, 2> { static constexpr int kWaves = 7, kPerSimd = 2; };      // 7 x 18432 + 24448 bytes of 160 KB
 
-template <int R, int CH, int WAVES>
+template <int R, int CH, bool ST, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (Shape<R, CH>::kPerSimd)) void vorbis_walk_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off,
@@ -730,21 +742,40 @@ __global__ __launch_bounds__(64 * WAVES, (Shape<R, CH>::kPerSimd)) void vorbis_w
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     f2 *const U = (f2 *)(lds + G::kTabFloats) + wave * (CH * G::kChanF2);
     const f2 *const T = (const f2 *)lds;
-    for (;;) {
-        uint32_t sidx = 0;
-        if ((threadIdx.x & 63) == 0) sidx = atomicAdd(next_seg, 1u);
-        sidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sidx);
-        if (sidx >= n_segs) return;
-        const VorbisSeg seg = segs[sidx];
-        const VorbisStream st = streams[seg.stream];
-        walk_body<R, CH>(U, T, seg, st, pflags, spec_off, out_off, tables, spec, out);
+    if constexpr (ST) {
+        // a workgroup draws WAVES consecutive items at a time -- the channels of a segment follow each other -- so that the
+        // wavefronts filling the columns of one run of frames share a CU's L2 slice and a moment in time
+        __shared__ uint32_t first;
+        for (;;) {
+            if (threadIdx.x == 0) first = atomicAdd(next_seg, (uint32_t)WAVES);
+            __syncthreads();
+            const uint32_t base = first;
+            __syncthreads();
+            if (base >= n_segs) return;
+            const uint32_t sidx = base + wave;
+            if (sidx < n_segs) {
+                const VorbisSeg seg = segs[sidx];
+                const VorbisStream st = streams[seg.stream];
+                walk_body<R, CH, ST>(U, T, seg, st, pflags, spec_off, out_off, tables, spec, out);
+            }
+        }
+    } else {
+        for (;;) {
+            uint32_t sidx = 0;
+            if ((threadIdx.x & 63) == 0) sidx = atomicAdd(next_seg, 1u);
+            sidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sidx);
+            if (sidx >= n_segs) return;
+            const VorbisSeg seg = segs[sidx];
+            const VorbisStream st = streams[seg.stream];
+            walk_body<R, CH, ST>(U, T, seg, st, pflags, spec_off, out_off, tables, spec, out);
+        }
     }
 }
 
 template <int R, int CH>
 constexpr size_t shape_lds() { return sizeof(float) * (Geo<R>::kTabFloats + (size_t)Shape<R, CH>::kWaves * CH * 2 * Geo<R>::kChanF2); }
 
-template <int R, int CH>
+template <int R, int CH, bool ST>
 int launch_shape(const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *streams, const uint8_t *pflags,
                  const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
                  const float *spec, float *out, uint32_t *counter, hipStream_t stream)
@@ -759,7 +790,7 @@ int launch_shape(const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *str
     if (int rc = afg::device_slot(&dev, "afg_vorbis_transform_hip")) return rc;
     hipError_t attr_rc = hipSuccess;
     std::call_once(attr_once[dev], [&] {
-        const void *fn = (const void *)vorbis_walk_kernel<R, CH, kWaves>;
+        const void *fn = (const void *)vorbis_walk_kernel<R, CH, ST, kWaves>;
         attr_rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
         int nb = 1, n_cu = 256, cur = 0;
         if (attr_rc == hipSuccess && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kWaves, kLds) != hipSuccess) nb = 1;
@@ -770,7 +801,7 @@ int launch_shape(const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *str
     AFG_HIP_CHECK(attr_rc);
     // persistent wavefronts: as many workgroups as the device holds at once, each drawing segments from the counter
     const uint32_t need = (n_segs + kWaves - 1) / kWaves, room = (uint32_t)(per_cu[dev] * cus[dev]);
-    hipLaunchKernelGGL((vorbis_walk_kernel<R, CH, kWaves>), dim3(need < room ? need : room), dim3(64 * kWaves), kLds, stream, segs,
+    hipLaunchKernelGGL((vorbis_walk_kernel<R, CH, ST, kWaves>), dim3(need < room ? need : room), dim3(64 * kWaves), kLds, stream, segs,
                        n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter);
     return AFG_OK;
 }
@@ -804,20 +835,27 @@ void build_tables_r(float *dst, const float *window)
 
 int walk_shape(int channels, int blocksize0, int blocksize1)
 {
-    if (channels < 1 || channels > 2 || blocksize0 > 512 || blocksize0 >= blocksize1) return -1;
+    if (channels < 1 || blocksize0 > 512 || blocksize0 >= blocksize1) return -1;
     const int size = blocksize1 == 1024 ? 0 : blocksize1 == 2048 ? 1 : blocksize1 == 4096 ? 2 : -1;
-    return size < 0 ? -1 : 2 * size + (channels - 1);
+    if (size < 0) return -1;
+    return channels <= 2 ? 2 * size + (channels - 1) : (channels & 1) ? 6 + size : 9 + size;
 }
+
+int walk_shape_channels(int shape) { return shape < 6 ? (shape & 1) + 1 : shape < 9 ? 1 : 2; }
+
+int walk_shape_blocksize(int shape) { return 1024 << (shape < 6 ? shape >> 1 : (shape - 6) % 3); }
 
 size_t walk_table_floats(int shape)
 {
-    return shape < 2 ? Geo<4>::kTabFloats : shape < 4 ? Geo<8>::kTabFloats : Geo<16>::kTabFloats;
+    const int n = walk_shape_blocksize(shape);
+    return n == 1024 ? Geo<4>::kTabFloats : n == 2048 ? Geo<8>::kTabFloats : Geo<16>::kTabFloats;
 }
 
 void walk_build_tables(int shape, float *dst, const float *window)
 {
-    if (shape < 2) build_tables_r<4>(dst, window);
-    else if (shape < 4) build_tables_r<8>(dst, window);
+    const int n = walk_shape_blocksize(shape);
+    if (n == 1024) build_tables_r<4>(dst, window);
+    else if (n == 2048) build_tables_r<8>(dst, window);
     else build_tables_r<16>(dst, window);
 }
 
@@ -825,15 +863,21 @@ int walk_launch(int shape, const VorbisSeg *segs, uint32_t n_segs, const VorbisS
                 const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
                 const float *spec, float *out, uint32_t *counter, hipStream_t stream)
 {
-#define AFG_WALK_SHAPE(S, R, CH) \
-    case S: return launch_shape<R, CH>(segs, n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter, stream)
+#define AFG_WALK_SHAPE(S, R, CH, ST) \
+    case S: return launch_shape<R, CH, ST>(segs, n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter, stream)
     switch (shape) {
-        AFG_WALK_SHAPE(0, 4, 1);
-        AFG_WALK_SHAPE(1, 4, 2);
-        AFG_WALK_SHAPE(2, 8, 1);
-        AFG_WALK_SHAPE(3, 8, 2);
-        AFG_WALK_SHAPE(4, 16, 1);
-        AFG_WALK_SHAPE(5, 16, 2);
+        AFG_WALK_SHAPE(0, 4, 1, false);
+        AFG_WALK_SHAPE(1, 4, 2, false);
+        AFG_WALK_SHAPE(2, 8, 1, false);
+        AFG_WALK_SHAPE(3, 8, 2, false);
+        AFG_WALK_SHAPE(4, 16, 1, false);
+        AFG_WALK_SHAPE(5, 16, 2, false);
+        AFG_WALK_SHAPE(6, 4, 1, true);
+        AFG_WALK_SHAPE(7, 8, 1, true);
+        AFG_WALK_SHAPE(8, 16, 1, true);
+        AFG_WALK_SHAPE(9, 4, 2, true);
+        AFG_WALK_SHAPE(10, 8, 2, true);
+        AFG_WALK_SHAPE(11, 16, 2, true);
     }
 #undef AFG_WALK_SHAPE
     afg::set_error("afg_vorbis_transform_hip: walk shape %d", shape);

@@ -180,7 +180,9 @@ def test_walk_declared_zero_tail(gpu, eighths):
 
 # ---------------------------------------------------------------- round 5: mono streams, blocksize_1 = 1024 and 4096
 SHAPES = [(1, 256, 2048), (1, 512, 2048), (2, 256, 1024), (1, 256, 1024), (2, 512, 1024), (2, 512, 4096), (1, 512, 4096),
-          (2, 256, 4096), (1, 256, 4096)]
+          (2, 256, 4096), (1, 256, 4096),
+          # more than two channels: one wavefront per channel, each storing its own column of the interleaved frames
+          (3, 256, 2048), (6, 256, 2048), (6, 512, 1024), (4, 512, 4096), (8, 256, 2048)]
 
 
 def legal_flags(longs):
@@ -270,7 +272,8 @@ def test_walk_shape_tdac_reconstruction(gpu, ch, n):
 
 
 @pytest.mark.parametrize("eighths", [0, 1, 3, 6, 8])
-@pytest.mark.parametrize("ch,bs0,bs1", [(1, 256, 2048), (2, 256, 1024), (1, 256, 1024), (2, 512, 4096), (1, 512, 4096)])
+@pytest.mark.parametrize("ch,bs0,bs1", [(1, 256, 2048), (2, 256, 1024), (1, 256, 1024), (2, 512, 4096), (1, 512, 4096),
+                                        (6, 256, 2048), (3, 256, 1024)])
 def test_walk_shape_declared_zero_tail(gpu, ch, bs0, bs1, eighths):
     from afgpu import VORBIS_NZ_EIGHTHS
     import torch
@@ -300,12 +303,12 @@ def test_walk_shape_declared_zero_tail(gpu, ch, bs0, bs1, eighths):
 
 
 def test_walk_every_shape_in_one_plan(gpu):
-    """streams of every shape the walk takes and of shapes it does not (three channels, 8192-sample blocks, equal block
-    sizes, blocksize_0 = 1024) in one plan: each goes to its own kernel and the planes are written once"""
-    ch = [2, 1, 2, 1, 2, 1, 3, 2, 1, 2, 2, 1]
-    bs0 = [256, 256, 256, 512, 512, 256, 256, 256, 512, 1024, 512, 1024]
-    bs1 = [2048, 2048, 1024, 1024, 4096, 4096, 2048, 8192, 512, 2048, 2048, 2048]
-    packets = [23, 31, 40, 17, 19, 26, 9, 5, 30, 12, 44, 21]
+    """streams of every shape the walk takes and of shapes it does not (8192-sample blocks, equal block sizes,
+    blocksize_0 = 1024) in one plan: each goes to its own kernel and the planes are written once"""
+    ch = [2, 1, 2, 1, 2, 1, 3, 2, 1, 2, 2, 1, 5, 6, 4]
+    bs0 = [256, 256, 256, 512, 512, 256, 256, 256, 512, 1024, 512, 1024, 1024, 256, 256]
+    bs1 = [2048, 2048, 1024, 1024, 4096, 4096, 2048, 8192, 512, 2048, 2048, 2048, 2048, 1024, 4096]
+    packets = [23, 31, 40, 17, 19, 26, 9, 5, 30, 12, 44, 21, 8, 15, 11]
     pflags, spec = synthetic.vorbis_batch(77, packets, ch, bs0, bs1, p_short_run=0.15)
     for seg in (4, 16):
         got, want = run_both(gpu, packets, ch, bs0, bs1, pflags, spec, seg)

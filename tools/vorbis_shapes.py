@@ -17,7 +17,8 @@ sys.path.insert(0, os.path.join(ROOT, "audio-formats_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-SHAPES = [(2, 256, 2048), (1, 256, 2048), (2, 256, 1024), (1, 256, 1024), (2, 512, 4096), (1, 512, 4096), (2, 256, 4096)]
+SHAPES = [(2, 256, 2048), (1, 256, 2048), (2, 256, 1024), (1, 256, 1024), (2, 512, 4096), (1, 512, 4096), (2, 256, 4096),
+          (6, 256, 2048), (3, 256, 1024), (6, 512, 4096)]
 
 
 def main():
