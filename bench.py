@@ -224,6 +224,7 @@ def other_workloads(args):
       flac_int32_rows  C4 with int32 residual rows (8 B per sample moved) beside the headline's int16 rows
       celt_dense  8192 x Opus/CELT stereo, 200 frames of 960: the CELT kernel on a device-filling batch
       qoa         4096 x QOA stereo 4 s
+      vorbis_shapes  C3-sized batches of the other Vorbis stream shapes (mono, blocksize_1 1024 / 4096, 3 and 6 channels)
       device_inclusive  SURVEY 8d (b): parsed records in page-locked memory -> H2D + kernels + D2H, overlapped, per headline codec
       *_e2e       SURVEY 8d (c): file bytes in host memory -> afg_batch_decode (host parse, H2D, kernels, D2H) -> floats in
                   host memory; PCIe-inclusive, never `value`.  256 DISTINCT generated files per codec (every blob its own
@@ -283,6 +284,9 @@ def other_workloads(args):
         for k, v in d.items():
             out[k] = v
         out["codecs_wall_s"] = wall
+    # the other stream shapes of the Vorbis walk (mono, 1024 / 4096-sample long blocks, more than two channels), C3-sized
+    d, err, wall = child([os.path.join(ROOT, "tools", "vorbis_shapes.py"), "--steps", "5", "--files", str(args.files)], 300)
+    out["vorbis_shapes"] = {"error": err} if d is None else dict(d["vorbis_shapes"], wall_s=wall, error=d["vorbis_shapes"]["error"] or err)
     return out
 
 

@@ -64,7 +64,14 @@ def main():
     if args.out:
         with open(args.out, "w") as f:
             json.dump({"shapes": rows}, f, indent=1)
+    bad = [f"{r['channels']}ch {r['blocksize_1']}" for r in rows
+           if not r["rms_error"] <= 1e-5 or (r["numeric_mode"] == "exact" and r["bitwise_mismatches"])]
+    print(json.dumps({"vorbis_shapes": {"workload": f"{args.files} files per shape, the samples of 2584 stereo 2048-sample packets each",
+                                        "shapes": [{k: r[k] for k in ("channels", "blocksize_0", "blocksize_1", "samples_per_step", "avg_kernel_ms",
+                                                                     "samples_per_s", "frac", "numeric_mode", "rms_error", "rms_signal")} for r in rows],
+                                        "error": ("parity: " + ", ".join(bad)) if bad else None}}))
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
