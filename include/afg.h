@@ -53,9 +53,9 @@ int         afg_device_count(void);        /* number of HIP devices visible, <0 
  *                          for; lets the Opus/CELT stage re-associate the de-emphasis recurrence (dopus.d:3695-3701) into a
  *                          prefix sum inside the frame walk, fuse multiply-adds there, and cut a stream into independently
  *                          walked segments wherever the post-filter is provably idle (dopus.d:3294-3296, :3333); lets the
- *                          Vorbis stage compute inverse_mdct (stb_vorbis2.d:1941-2242) of 2048-sample blocks of stereo streams
- *                          as ONE 512-point complex FFT with fused multiply-adds instead of scheduling the reference's 8-step
- *                          algorithm, and write window + overlap (:2606-2657) on the transform's DCT-IV (csrc/vorbis_walk.hip);
+ *                          Vorbis stage compute inverse_mdct (stb_vorbis2.d:1941-2242) of 1024-, 2048- and 4096-sample long
+ *                          blocks as ONE complex FFT of n/4 points with fused multiply-adds instead of scheduling the reference's
+ *                          8-step algorithm, and write window + overlap (:2606-2657) on the transform's DCT-IV (csrc/vorbis_walk.hip);
  *                          lets the MP3 stage fuse multiply-adds and sum the polyphase window's sixteen products per output
  *                          (minimp3.d:1371-1405) in one chain (csrc/mp3_tolerance.hip).
  * FLAC and QOA (integer work) compute the same bits in both modes.  The environment variable AFG_NUMERIC=exact|tolerance

@@ -144,3 +144,30 @@ def test_c5_wave_default_mode(gpu):
         part_got, _ = decode(shard)
         for fid, (name, arr) in part_got.items():
             assert np.array_equal(arr.view(np.uint32), whole[fid][1].view(np.uint32)), (name, fid)
+
+
+def test_generated_vorbis_stream_shapes_default_mode(gpu):
+    """Generated Ogg files of every stream shape the tolerance-mode walk has a kernel for (mono, 1024- and 4096-sample long
+    blocks, three .. six channels) and of two it has not, from bytes to PCM in one batch: within 1e-5 RMS (absolute: the
+    generator is calibrated to rms 0.05) of the oracle's decode, and not its bits where the walk ran."""
+    import vorbis_bitstream as vb
+    shapes = [(1, (256, 2048)), (2, (256, 1024)), (1, (256, 1024)), (2, (512, 4096)), (1, (256, 4096)), (3, (256, 1024)),
+              (6, (256, 2048)), (4, (512, 4096)), (5, (512, 2048)), (2, (1024, 2048)), (2, (2048, 8192))]
+    files, wants = [], []
+    for k, (ch, bs) in enumerate(shapes):
+        d = vb.make_file(1700 + k, channels=ch, bs=bs, n_packets=30, residue_types=[(0, 1), (1, 2), (2, 0)][k % 3])
+        rec = oraclelib.vorbis_decode_file(d)
+        assert rec is not None and len(rec["pflags"]) >= 20
+        files.append(d)
+        wants.append(oraclelib.vorbis_file_pcm(rec))
+    out = afgpu.batch_decode(files, n_threads=2)
+    walked = 0
+    for (ch, bs), item, want in zip(shapes, out, wants):
+        assert item["status"] == 0 and item["frames"] == len(want) and item["channels"] == ch
+        assert rms(item["pcm"], want) <= 1e-5, (ch, bs)
+        same = np.array_equal(item["pcm"].view(np.uint32), want.view(np.uint32))
+        if bs[0] <= 512 and bs[1] in (1024, 2048, 4096):
+            walked += not same
+        else:
+            assert same, (ch, bs)                # the bit-exact kernels
+    assert walked >= 7
