@@ -658,6 +658,11 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         opus_recs += p.opus.frames.size() * (size_t)p.opus.channels;
         opus_coefs += p.opus.coeffs.size();
         opus_out += (size_t)p.opus.pcm_frames * (size_t)p.opus.channels;
+        // The transform stage walks sequences 2p and 2p + 1 together when they are the two channels of a stream (one
+        // wavefront, half each: afg.h).  A stereo file behind an odd number of mono files would sit across two such
+        // slots -- walked one channel at a time, and, in AFG_NUMERIC_TOLERANCE, to samples that depend on what else is
+        // in the batch -- so an empty sequence goes in front of it.
+        if (p.opus.channels == 2 && (opus_seqs & 1)) opus_seqs++;
         opus_seqs += (size_t)p.opus.channels;
     }
     out.plane_floats = flac_out + qoa_out + mp3_out + ogg_out + opus_out;
@@ -1039,6 +1044,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 for (size_t i = 0; i < nf; i++) {
                     const Parsed &p = parsed[i];
                     if (fmt_of(p) != AFG_FORMAT_OPUS) continue;
+                    if (p.opus.channels == 2 && (seq & 1)) hb[seq++] = opus_rec_base[i];          // the empty sequence (above)
                     for (int c = 0; c < p.opus.channels; c++) hb[seq++] = opus_rec_base[i] + (size_t)c * p.opus.frames.size();
                 }
                 hb[seq] = opus_recs;
@@ -1870,12 +1876,32 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
             for (size_t i = 0; i < (size_t)n_files; i++) {
                 if (!opus_open[i]) continue;
                 const afg_opus::File &m = parsed[i].opus;
-                rec_at[i] = recs_total; coef_at[i] = coefs_total; seq_at[i] = seqs_total;
+                rec_at[i] = recs_total; coef_at[i] = coefs_total;
                 opus_pcm_at[i] = coefs_total;                     // one PCM float per coefficient
                 recs_total += m.bound_frames * (size_t)m.channels;
                 coefs_total += m.bound_coeffs;
-                seqs_total += (size_t)m.channels;
                 n_opus++;
+            }
+            // Channel sequences.  The transform stage walks sequences 2p and 2p + 1 of a launch together when they are the two
+            // channels of a stream (one wavefront, half each: afg.h), so a stereo file starts on an even index of its launch:
+            // an empty sequence goes in front of it after an odd number of mono files, and in front of a chunk (a launch, below)
+            // that would start on an odd one.  Without it such a file is walked one channel at a time -- slower, and in
+            // AFG_NUMERIC_TOLERANCE to samples that depend on what else is in the batch (tools/soak_damaged.py found one).
+            const size_t target = std::max<size_t>((coefs_total + 7) / 8, (size_t)4 << 20);      // coefficients per chunk
+            std::vector<uint8_t> seq_pad((size_t)n_files, 0);
+            for (size_t f0 = 0; f0 < (size_t)n_files;) {
+                size_t f1 = f0, acc = 0;
+                while (f1 < (size_t)n_files && acc < target) { if (opus_open[f1]) acc += parsed[f1].opus.bound_coeffs; f1++; }
+                bool first = true;
+                for (size_t i = f0; i < f1; i++) {
+                    if (!opus_open[i]) continue;
+                    const size_t C = (size_t)parsed[i].opus.channels;
+                    if ((seqs_total & 1) && (first || C == 2)) { seq_pad[i] = 1; seqs_total++; }
+                    seq_at[i] = seqs_total;
+                    seqs_total += C;
+                    first = false;
+                }
+                f0 = f1;
             }
             if (n_opus && seqs_total <= 0xffffffffull) {
                 const size_t base_bytes = ((seqs_total + 1) * sizeof(uint64_t) + 15) & ~(size_t)15;
@@ -1895,6 +1921,7 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 for (size_t i = 0; i < (size_t)n_files; i++) {
                     if (!opus_open[i]) continue;
                     const afg_opus::File &m = parsed[i].opus;
+                    if (seq_pad[i]) hb[seq_at[i] - 1] = rec_at[i];                                  // the empty sequence
                     for (int c = 0; c < m.channels; c++) hb[seq_at[i] + (size_t)c] = rec_at[i] + (size_t)c * m.bound_frames;
                 }
                 hb[seqs_total] = recs_total;
@@ -1904,7 +1931,6 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
                 if (e == hipSuccess) e = hipMemcpyAsync(d_in.p, hb, base_bytes, hipMemcpyHostToDevice, up);
                 int rc = AFG_OK;
-                const size_t target = std::max<size_t>((coefs_total + 7) / 8, (size_t)4 << 20);
                 for (size_t f0 = 0; f0 < (size_t)n_files && !rc && e == hipSuccess;) {
                     size_t f1 = f0, acc = 0;
                     while (f1 < (size_t)n_files && acc < target) { if (opus_open[f1]) acc += parsed[f1].opus.bound_coeffs; f1++; }

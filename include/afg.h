@@ -331,7 +331,12 @@ typedef struct afg_celt_frame {
 
 /* Channel sequence k owns records [rec_base[k], rec_base[k+1]) (n_chan + 1 entries).
  * d_states: NULL (zero state: a fresh decoder) or n_chan * AFG_CELT_STATE_FLOATS words read
- * before the first and rewritten after the last frame of each sequence (chunked decoding). */
+ * before the first and rewritten after the last frame of each sequence (chunked decoding).
+ * Sequences 2p and 2p + 1 are walked by one wavefront, half each, when they are the two channels of a stereo stream
+ * (equally long, records of equal geometry, out_stride 2, out_off even and out_off + 1): put a stereo stream's channels on
+ * an even and the following odd index -- an empty sequence (rec_base[k] == rec_base[k+1]) after an odd number of mono
+ * streams does it, as afg_batch_decode does.  Any layout is decoded correctly; in AFG_NUMERIC_TOLERANCE the two forms
+ * of the walk round differently (both within the tolerance), in AFG_NUMERIC_EXACT they are the same bits. */
 int afg_celt_transform_hip(uint32_t n_chan, const uint64_t *d_rec_base, const afg_celt_frame *d_recs,
                            const float *d_coeffs, float *d_out, float *d_states, void *hip_stream);
 

@@ -4,6 +4,8 @@ afgo_celt_transform -> gain -> afgo_opus_output, clipped to the declared length)
 
 Reference behaviour: stream.d:429-487 (Opus read loop, length clamp, int16 / 32767), :1596-1614 (Opus is probed first,
 48 kHz, length = smpduration), dopus.d:6688-6691 (gain), :8062-8110 (readFrame), :3680-3702 (transform)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -264,3 +266,80 @@ def test_encoder_made_files_default_mode(gpu):
         assert r["status"] == 0 and r["frames"] == len(pcm)
         d = np.abs(r["pcm"].astype(np.float64) - pcm)
         assert d.max() <= ONE_STEP and np.sqrt(np.mean(d ** 2)) <= 1e-5 and (d > 0).mean() < 0.01
+
+
+@pytest.mark.numeric_tolerance
+def test_batch_composition_does_not_change_a_files_samples(gpu):
+    """A stereo file decodes to the same bits alone, behind a mono file and behind two (the transform stage walks the two
+    channels of a stream in one wavefront when they sit on an even / odd pair of channel sequences: afg_batch_decode keeps
+    stereo files there with an empty sequence after an odd number of mono ones; found by tools/soak_damaged.py)."""
+    rng = np.random.default_rng(77)
+    stereo = [ob.random_celt_file(rng, 2, 14, pcm_rms=0.05)[0] for _ in range(2)]
+    mono = [ob.random_celt_file(rng, 1, 9, pcm_rms=0.05)[0] for _ in range(3)]
+    alone = [afgpu.batch_decode([d])[0]["pcm"] for d in stereo]
+    mono_alone = [afgpu.batch_decode([d])[0]["pcm"] for d in mono]
+    for batch, where, monos in (([mono[0], stereo[0]], {1: 0}, {0: 0}), ([mono[0], mono[1], stereo[1]], {2: 1}, {0: 0, 1: 1}),
+                                ([stereo[0], mono[2], stereo[1], mono[0], mono[1], stereo[0]], {0: 0, 2: 1, 5: 0}, {1: 2, 3: 0, 4: 1})):
+        out = afgpu.batch_decode(batch)
+        for i, k in where.items():
+            assert out[i]["status"] == 0
+            assert np.array_equal(out[i]["pcm"].view(np.uint32), alone[k].view(np.uint32)), (len(batch), i)
+        for i, k in monos.items():
+            assert np.array_equal(out[i]["pcm"].view(np.uint32), mono_alone[k].view(np.uint32)), (len(batch), i)
+
+
+@pytest.mark.numeric_tolerance
+def test_the_soak_pair_that_found_it(gpu):
+    """tests/golden/soak_r05_{mono,stereo}.opus: two damaged generated files of one soak batch (tools/soak_damaged.py, round 67
+    of seed 2024).  Behind the mono one the stereo file's channels sat on an odd / even pair of sequences, were walked
+    one at a time and came out one int16 step away from the file decoded alone, at one sample."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    mono = open(os.path.join(here, "soak_r05_mono.opus"), "rb").read()
+    stereo = open(os.path.join(here, "soak_r05_stereo.opus"), "rb").read()
+    alone = afgpu.batch_decode([stereo])[0]["pcm"]
+    for batch, at in (([mono, stereo], 1), ([mono, mono, stereo], 2), ([stereo, mono, stereo], 2), ([mono, stereo, mono, stereo], 3)):
+        got = afgpu.batch_decode(batch)[at]
+        assert got["status"] == 0 and np.array_equal(got["pcm"].view(np.uint32), alone.view(np.uint32)), len(batch)
+    want = oraclelib.opus_file_pcm(oraclelib.opus_decode_file(stereo))
+    assert np.abs(alone - want).max() <= 1 / 32767 + 1.2e-7 and (alone != want).sum() <= 2
+
+
+@pytest.mark.numeric_tolerance
+def test_an_empty_sequence_restores_the_stereo_walk(gpu):
+    """afg.h: sequences 2p and 2p + 1 are walked together when they are a stream's two channels.  Device level, floats before
+    the int16 conversion: a stereo stream behind a mono one and an EMPTY sequence gets the bits it gets alone; without the
+    empty sequence it is walked one channel at a time -- other bits, the same tolerance."""
+    import torch
+    from oraclelib import opus_channel_records
+    rng = np.random.default_rng(5)
+    pm = afgpu.opus_parse(ob.random_celt_file(rng, 1, 9, pcm_rms=0.05)[0])
+    ps = afgpu.opus_parse(ob.random_celt_file(rng, 2, 12, pcm_rms=0.05)[0])
+
+    def run(parts, pad_before=()):
+        bases, recs_all, coefs, spans, co, oo, nrec = [0], [], [], [], 0, 0, 0
+        for k, p in enumerate(parts):
+            base, recs = opus_channel_records(p)
+            recs = recs.copy(); recs["coef_off"] += np.uint64(co); recs["out_off"] += np.uint64(oo)
+            if k in pad_before:
+                bases.append(nrec)                                    # rec_base[k] == rec_base[k+1]: no records
+            bases += [nrec + int(b) for b in base[1:]]
+            recs_all.append(recs); coefs.append(p["coeffs"]); spans.append((oo, p["pcm_frames"] * p["channels"]))
+            nrec += len(recs); co += len(p["coeffs"]); oo += p["pcm_frames"] * p["channels"]
+        rec_base = np.array(bases, np.uint64)
+        d_out = torch.full((oo,), float("nan"), dtype=torch.float32, device=gpu)
+        afgpu.celt_transform(len(rec_base) - 1, torch.from_numpy(rec_base.view(np.int64)).to(gpu),
+                             torch.from_numpy(np.concatenate(recs_all).view(np.uint8).copy()).to(gpu),
+                             torch.from_numpy(np.concatenate(coefs)).to(gpu), d_out)
+        torch.cuda.synchronize()
+        o = d_out.cpu().numpy()
+        assert not np.isnan(o).any()
+        return [o[a:a + n] for a, n in spans]
+
+    alone = run([ps])[0]
+    padded = run([pm, ps], pad_before=(1,))
+    split = run([pm, ps])
+    assert np.array_equal(padded[1].view(np.uint32), alone.view(np.uint32))
+    assert np.array_equal(padded[0].view(np.uint32), split[0].view(np.uint32))           # the mono stream does not care
+    differ = int((split[1].view(np.uint32) != alone.view(np.uint32)).sum())
+    assert differ > 0, "the one-channel walk gave the paired walk's bits: nothing was tested"
+    assert float(np.sqrt(np.mean((split[1].astype(np.float64) - alone) ** 2))) <= 1e-6          # far inside the tolerance
