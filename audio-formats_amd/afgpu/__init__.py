@@ -741,10 +741,11 @@ class BatchDecoded:
         self._res = BatchResult()
         self._open = False
         self.n_threads = n_threads
-        self.items = []
+        self._items = None
 
     def run(self):
-        """The timed part: host parse + device restore + copy back (no Python-side copies)."""
+        """The timed part: host parse + device restore + copy back -- the C call and nothing else (the per-file views of
+        `items` are made when they are first asked for: two thousand numpy views cost more than some of these calls)."""
         self.close()
         opts = BatchOpts(C.sizeof(BatchOpts), self.n_threads, 0, None)
         if self.devices == "all":
@@ -754,22 +755,29 @@ class BatchDecoded:
             opts.n_devices, opts.devices = len(self.devices), devs
         check(lib().afg_batch_decode_ex(self._ptrs, self._lens, len(self._bufs), C.byref(opts), C.byref(self._res)))
         self._open = True
-        self.items = []
-        for i in range(self._res.n_files):
-            it = self._res.items[i]
-            cnt = it.frames * it.channels
-            pcm = (np.ctypeslib.as_array(it.pcm, shape=(cnt,)).reshape(-1, max(1, it.channels))
-                   if cnt and it.pcm else None)
-            self.items.append({"status": it.status, "message": None if it.message is None else it.message.decode(),
-                               "format": it.format, "channels": it.channels, "samplerate": it.samplerate,
-                               "frames": it.frames, "pcm": pcm})
+        self._items = None
         return self
+
+    @property
+    def items(self):
+        if self._items is None:
+            self._items = []
+            if self._open:
+                for i in range(self._res.n_files):
+                    it = self._res.items[i]
+                    cnt = it.frames * it.channels
+                    pcm = (np.ctypeslib.as_array(it.pcm, shape=(cnt,)).reshape(-1, max(1, it.channels))
+                           if cnt and it.pcm else None)
+                    self._items.append({"status": it.status, "message": None if it.message is None else it.message.decode(),
+                                        "format": it.format, "channels": it.channels, "samplerate": it.samplerate,
+                                        "frames": it.frames, "pcm": pcm})
+        return self._items
 
     def close(self):
         if self._open:
             lib().afg_batch_free(C.byref(self._res))
             self._open = False
-            self.items = []
+        self._items = None
 
     def __enter__(self):
         return self.run() if not self._open else self

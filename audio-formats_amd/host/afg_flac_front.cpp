@@ -165,9 +165,53 @@ bool flac_residual(BitReader &br, uint32_t block_size, uint32_t order, int32_t *
             // inside the window (a run of 50 zeros), the last bytes of the buffer -- takes the bit reader.  Same values.
             const size_t bytes = br.nbits >> 3;
             size_t pos = br.pos;
+            uint32_t j = 0;
+            // Groups first: one load of eight bytes (at least 57 stream bits) feeds `per` symbols -- as many as fit nearly always
+            // at this parameter (a symbol is k + 1 bits and a quotient that averages one to two) -- so the load, the byte
+            // swap and the shift by the bit offset are paid once per group and the chain from symbol to symbol is a count of
+            // leading zeros and a shift.  The trip count is fixed per partition (a predictable loop); a symbol that does
+            // not end inside the window, which is rare, goes through the bit reader and the groups resume behind it.
+            {
+                const unsigned per = k <= 5 ? 6u : 57u / (k + 4);
+                while (j + per <= count) {
+                    const size_t bp = pos >> 3;
+                    if (bp + 8 > bytes) break;
+                    const unsigned s = (unsigned)(pos & 7);
+                    uint64_t x;
+                    std::memcpy(&x, br.p + bp, 8);
+                    uint64_t w = __builtin_bswap64(x) << s;
+                    unsigned left = 64 - s;
+                    int32_t *const o = dst + i;
+                    unsigned n = 0;
+                    for (; n < per; n++) {
+                        if (!w) break;
+                        const unsigned lz = (unsigned)__builtin_clzll(w);
+                        const unsigned need = lz + 1 + k;
+                        if (need > left) break;
+                        const uint32_t low = k ? (uint32_t)((w << (lz + 1)) >> (64 - k)) : 0u;      // (lz + 1 <= 63 when k > 0)
+                        w = need < 64 ? w << need : 0;
+                        left -= need;
+                        const uint32_t v = (lz << k) | low;
+                        o[n] = (int32_t)((v >> 1) ^ (~(v & 1) + 1));                              // zig-zag, :1224
+                    }
+                    pos += (64 - s) - left;
+                    i += n;
+                    j += n;
+                    if (n < per) {
+                        uint32_t q;
+                        br.pos = pos;
+                        if (!br.unary(q)) return false;
+                        const uint32_t low = (uint32_t)br.bits(k);
+                        pos = br.pos;
+                        const uint32_t v = (q << k) | low;
+                        dst[i++] = (int32_t)((v >> 1) ^ (~(v & 1) + 1));
+                        j++;
+                    }
+                }
+            }
             uint64_t w = 0;
             unsigned avail = 0;
-            for (uint32_t j = 0; j < count; j++) {
+            for (; j < count; j++) {
                 if (avail < 48) {
                     const size_t bp = pos >> 3;
                     const unsigned s = (unsigned)(pos & 7);
