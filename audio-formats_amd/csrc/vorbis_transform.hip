@@ -41,28 +41,44 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef AFG_VORBIS_CHAN_WIDE
+#define AFG_VORBIS_CHAN_WIDE 2048    // long blocks from this size up: a 256-thread workgroup per channel
+#endif
 
 using namespace afg_vorbis;
 
-__global__ __launch_bounds__(kThreads) void vorbis_transform_kernel(
-    const VorbisSeg *__restrict__ segs, const VorbisStream *__restrict__ streams,
+// General path (round 5; round 1's version gave a 256-thread workgroup to a segment and walked its channels one after
+// the other with block-wide barriers between the reference's steps: 54-109 ms per C3-sized batch): ONE WAVEFRONT walks one
+// channel of a segment -- the channels of a stream meet only in the interleave of the output, a strided store -- with the
+// reference's own transform over LDS (vorbis_core.h: inverse_mdct_lds, program-ordered LDS accesses instead of barriers),
+// any block sizes, any number of channels.  Per wavefront: the channel buffer (n floats), inverse_mdct's scratch (n/2) and
+// previous_window (n/2) of the stream's long block size.  Arithmetic per output is the reference's, operation for operation.
+// T threads walk one channel of a segment, CPG channels per workgroup: (64, up to 8) -- wavefronts that never meet, for block
+// sizes up to 1024 -- or (256, 1), a workgroup per channel with block-wide barriers between the passes, for the long
+// blocks whose passes have work for four wavefronts (one wavefront alone: 4096-sample blocks 75 ms per C3-sized batch,
+// 32 KB of LDS each; four: see DESIGN 3.2).
+template <int T, int CPG>
+__global__ __launch_bounds__(T * CPG) void vorbis_channel_kernel(
+    const VorbisSeg *__restrict__ segs, uint32_t n_segs, uint32_t chan_floats, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off,
     const uint64_t *__restrict__ out_off, const float *__restrict__ tables,
     const float *__restrict__ spec, float *__restrict__ out)
 {
+    static_assert(T == 64 || CPG == 1, "block-wide barriers: one channel per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const VorbisSeg seg = segs[blockIdx.x];
+    const int tid = threadIdx.x & (T - 1);
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));
+    const uint32_t sidx = blockIdx.x * CPG + slot;
+    if (sidx >= n_segs) return;
+    const VorbisSeg seg = segs[sidx];
     const VorbisStream st = streams[seg.stream];
-    const int C = (int)st.nch;
+    const int C = (int)st.nch, c = (int)seg.pad;
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
     const uint32_t tab0 = st.tab[0], tab1 = st.tab[1];
-    const int nmax = bs1;
 
-    float *chan = smem;                          // C * nmax   (channel_buffers)
-    float *buf2 = chan + C * nmax;               // nmax / 2   (temp buffer of inverse_mdct)
-    float *prevw = buf2 + nmax / 2;              // C * nmax/2 (previous_window)
+    float *chan = smem + (size_t)slot * chan_floats;      // bs1       (channel_buffers[c])
+    float *buf2 = chan + bs1;                             // bs1 / 2   (temp buffer of inverse_mdct)
+    float *prevw = buf2 + bs1 / 2;                        // bs1 / 2   (previous_window[c])
 
     int previous_length = 0;
     const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
@@ -76,39 +92,68 @@ __global__ __launch_bounds__(kThreads) void vorbis_transform_kernel(
         const int n2 = n >> 1;
         const int which = (fl & AFG_VORBIS_LONG) ? 1 : 0;
         const int ld = 31 - __clz(n);
-        const float *T = tables + (which ? tab1 : tab0);            // (a runtime index into the struct would put it in scratch memory)
-        const float *A = T, *B = T + n2, *Ct = T + n;
+        const float *Tb = tables + (which ? tab1 : tab0);           // (a runtime index into the struct would put it in scratch memory)
+        const float *A = Tb, *B = Tb + n2, *Ct = Tb + n;
 
         // spectrum -> LDS (coalesced rows)
-        const float *src = spec + spec_off[gp];
-        for (int c = 0; c < C; c++)
-            for (int k = tid; k < n2; k += kThreads) chan[c * nmax + k] = src[c * n2 + k];
-        __syncthreads();
+        const float *src = spec + spec_off[gp] + (size_t)c * (size_t)n2;
+        for (int k = tid; k < n2; k += T) chan[k] = src[k];
+        pass_sync<T>();
 
-        for (int c = 0; c < C; c++) inverse_mdct_lds<kThreads>(chan + c * nmax, buf2, n, ld, A, B, Ct);   // :2526-2527
+        inverse_mdct_lds<T>(chan, buf2, n, ld, A, B, Ct);           // :2526-2527
 
         // vorbis_finish_frame, :2606-2657
         const bool emit = (p >= (int)seg.p0) && previous_length > 0;
         if (emit) {
             const int pn = previous_length;
             const float *w = tables + ((pn * 2 == bs1) ? tab1 : tab0) + (pn * 2) + (pn * 2 / 4);   // window of size 2*pn (:2245-2251)
-            float *o = out + out_off[gp];
-            const int total = (right - left) * C;
-            for (int idx = tid; idx < total; idx += kThreads) {
-                const int jj = idx / C, c = idx - jj * C;
-                float vcur = chan[c * nmax + left + jj];
-                if (jj < pn) vcur = vcur * w[jj] + prevw[c * (nmax / 2) + jj] * w[pn - 1 - jj];   // :2624-2626
-                o[idx] = vcur;                                                                   // :3927-3952
+            float *o = out + out_off[gp] + c;
+            const int nout = right - left;
+            for (int jj = tid; jj < nout; jj += T) {
+                float vcur = chan[left + jj];
+                if (jj < pn) vcur = vcur * w[jj] + prevw[jj] * w[pn - 1 - jj];   // :2624-2626
+                o[(size_t)jj * (size_t)C] = vcur;                                  // :3927-3952
             }
         }
-        __syncthreads();
+        pass_sync<T>();
         // last half of this data becomes previous window, :2633-2643
         previous_length = right_end - right;
-        for (int c = 0; c < C; c++)
-            for (int k = tid; k < previous_length; k += kThreads)
-                prevw[c * (nmax / 2) + k] = chan[c * nmax + right + k];
-        __syncthreads();
+        for (int k = tid; k < previous_length; k += T) prevw[k] = chan[right + k];
+        pass_sync<T>();
     }
+}
+
+// the general path's launch shape for a stream set whose longest block has n samples
+struct ChannelShape { int threads, per_group; };
+inline ChannelShape channel_shape(uint32_t nmax) { return nmax >= AFG_VORBIS_CHAN_WIDE ? ChannelShape{ 256, 1 } : nmax > 1024 ? ChannelShape{ 64, 5 } : ChannelShape{ 64, 8 }; }
+
+template <int T, int CPG>
+int channel_launch(bool set_attr, uint32_t n_segs, uint32_t nmax, hipStream_t stream, const VorbisSeg *segs, const VorbisStream *streams,
+                   const uint8_t *pflags, const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *spec,
+                   float *out)
+{
+    const size_t lds = (size_t)CPG * 2 * nmax * sizeof(float);
+    if (set_attr) {
+        const hipError_t e = hipFuncSetAttribute((const void *)vorbis_channel_kernel<T, CPG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            afg::set_error("hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e));
+            return AFG_ERR_HIP;
+        }
+        return AFG_OK;
+    }
+    hipLaunchKernelGGL((vorbis_channel_kernel<T, CPG>), dim3((n_segs + CPG - 1) / CPG), dim3(T * CPG), lds, stream, segs, n_segs, 2 * nmax,
+                       streams, pflags, spec_off, out_off, tables, spec, out);
+    return AFG_OK;
+}
+
+// set_attr: the dynamic-LDS attribute of the instantiation this stream set uses (plan creation); else the launch
+int channel_dispatch(bool set_attr, uint32_t n_segs, uint32_t nmax, hipStream_t stream, const VorbisSeg *segs, const VorbisStream *streams,
+                     const uint8_t *pflags, const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *spec, float *out)
+{
+    const ChannelShape sh = channel_shape(nmax);
+    if (sh.threads == 256) return channel_launch<256, 1>(set_attr, n_segs, nmax, stream, segs, streams, pflags, spec_off, out_off, tables, spec, out);
+    if (sh.per_group == 5) return channel_launch<64, 5>(set_attr, n_segs, nmax, stream, segs, streams, pflags, spec_off, out_off, tables, spec, out);
+    return channel_launch<64, 8>(set_attr, n_segs, nmax, stream, segs, streams, pflags, spec_off, out_off, tables, spec, out);
 }
 
 
@@ -1147,7 +1192,7 @@ struct afg_vorbis_plan {
     uint64_t n_packets = 0;
     uint64_t spec_floats = 0;
     uint64_t out_floats = 0;
-    size_t lds_bytes = 0;
+    uint32_t chan_nmax = 0;         // longest block among the streams of the general path (d_segs)
     std::vector<uint64_t> h_spec_off, h_out_off;
     uint32_t n_wave_segs = 0;      // segments of streams on the wave-level fast path
     // AFG_NUMERIC_TOLERANCE (vorbis_walk.hip): the segments of the streams the walk takes, one run per shape in
@@ -1197,7 +1242,7 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     if (!p) return AFG_ERR_OOM;
 
     uint64_t pkt = 0, so = 0, oo = 0, so_extent = 0;
-    size_t lds = 0;
+    uint32_t chan_nmax = 0;
     for (uint32_t s = 0; s < n_streams; s++) {
         if (spec_base) so = spec_base[s];
         const int bs[2] = { blocksize0[s], blocksize1[s] };
@@ -1233,8 +1278,7 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
         st.tab[0] = tab_of[bs[0]];
         st.tab[1] = tab_of[bs[1]];
         const bool fast = (bs[1] == kNL) && (bs[0] <= kNL / 2) && channels[s] <= 2;
-        const size_t need = sizeof(float) * ((size_t)channels[s] * bs[1] + bs[1] / 2 + (size_t)channels[s] * bs[1] / 2);
-        if (!fast) lds = need > lds ? need : lds;
+        if (!fast) chan_nmax = std::max<uint32_t>(chan_nmax, (uint32_t)bs[1]);
 
         int prev_len = 0;
         for (uint32_t q = 0; q < packets[s]; q++, pkt++) {
@@ -1271,13 +1315,8 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
             else if (fast)
                 for (uint32_t c = 0; c < channels[s]; c++) wave_list.push_back(VorbisSeg{ s, p0, cnt, c });   // one per channel
             else
-                (shape >= 0 ? segs_walk : segs).push_back(VorbisSeg{ s, p0, cnt, 0 });
+                for (uint32_t c = 0; c < channels[s]; c++) (shape >= 0 ? segs_walk : segs).push_back(VorbisSeg{ s, p0, cnt, c });   // one per channel
         }
-    }
-    if (lds > 160 * 1024) {
-        afg::set_error("afg_vorbis_plan_create: %zu bytes of LDS needed (channels x blocksize too large)", lds);
-        delete p;
-        return AFG_ERR_UNSUPPORTED;
     }
     p->n_wave_walk = (uint32_t)wave_walk.size();
     wave_segs.insert(wave_segs.begin(), wave_walk.begin(), wave_walk.end());
@@ -1296,7 +1335,7 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     p->n_packets = pkt;
     p->spec_floats = so_extent;
     p->out_floats = oo;
-    p->lds_bytes = lds;
+    p->chan_nmax = chan_nmax;
     int rc = p->d_segs.upload(segs.data(), segs.size() * sizeof(VorbisSeg));
     if (!rc) rc = p->d_wave_segs.upload(wave_segs.data(), wave_segs.size() * sizeof(VorbisSeg));
     if (!rc) rc = p->d_streams.upload(streams.data(), streams.size() * sizeof(VorbisStream));
@@ -1330,14 +1369,7 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
             rc = AFG_ERR_HIP;
         }
     }
-    if (!rc && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)vorbis_transform_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            afg::set_error("hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e));
-            rc = AFG_ERR_HIP;
-        }
-    }
+    if (!rc && p->n_segs) rc = channel_dispatch(true, 0, chan_nmax, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc) {
         afg_vorbis_plan_destroy(p);
         return rc;
@@ -1412,11 +1444,11 @@ int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, f
         }
     }
     if (n_segs)
-        hipLaunchKernelGGL(vorbis_transform_kernel, dim3(n_segs), dim3(kThreads), plan->lds_bytes,
-                           (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_segs.ptr,
-                           (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
-                           (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
-                           (const float *)plan->d_tables.ptr, d_spec, d_out);
+        if (int rc = channel_dispatch(false, n_segs, plan->chan_nmax, (hipStream_t)hip_stream, (const VorbisSeg *)plan->d_segs.ptr,
+                                      (const VorbisStream *)plan->d_streams.ptr, (const uint8_t *)plan->d_pflags.ptr,
+                                      (const uint64_t *)plan->d_spec_off.ptr, (const uint64_t *)plan->d_out_off.ptr,
+                                      (const float *)plan->d_tables.ptr, d_spec, d_out))
+            return rc;
     AFG_HIP_CHECK(hipGetLastError());
     return AFG_OK;
 }

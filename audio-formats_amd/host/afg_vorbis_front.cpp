@@ -992,12 +992,10 @@ bool open_stream(const uint8_t *data, size_t size, File &f, Demux &dm, Setup &st
         f.blocksize1 = 1 << log1;
         if (!(h[29] & 1)) return false;
         // What the transform stage cannot take is refused here, per file (a plan that fails would fail its whole chunk of
-        // the batch): block sizes 64 / 128 (the reference's inverse_mdct is wrong for them, stb_vorbis2.d:2053-2090) and
-        // streams whose general-path working set exceeds the 160 KiB of LDS (6+ channels at block size 8192).
+        // the batch): block sizes 64 / 128 (the reference's inverse_mdct is wrong for them, stb_vorbis2.d:2053-2090).
+        // (Until round 5 also streams of 6+ channels at block size 8192: the general path kept all channels of a segment
+        // in one workgroup's LDS; it is one wavefront per channel now.)
         if (f.blocksize0 < 256) return false;
-        const bool fast = f.blocksize1 == 2048 && f.blocksize0 <= 1024 && f.channels <= 2;
-        const size_t lds = sizeof(float) * ((size_t)f.channels * f.blocksize1 + f.blocksize1 / 2 + (size_t)f.channels * f.blocksize1 / 2);
-        if (!fast && lds > 160 * 1024) return false;
     }
     st.channels = f.channels;
     st.rate = f.sample_rate;

@@ -58,7 +58,7 @@ def parse_args(argv=None):
                     help="skip `other_workloads` (the side-by-side step; the C5 corpus, dense CELT, QOA and the end-to-end batches, each in "
                          "a child process after the headline measurement; only at N = 1 with the default config)")
     ap.add_argument("--oversubscribe", action="store_true",
-                    help="testing only: ranks beyond the visible devices share them (rank % devices); the line says so")
+                    help="testing only: ranks beyond the visible devices share them (rank %% devices); the line says so")
     return ap.parse_args(argv)
 
 

@@ -65,6 +65,18 @@ def test_vorbis_multichannel_and_empty(gpu):
     assert compare(got, want) == 0
 
 
+def test_vorbis_many_channels_long_blocks(gpu):
+    """16 channels of 2048-sample blocks, 8 of 8192: round 1's general kernel kept all channels of a segment in one
+    workgroup's LDS and refused these; one wavefront per channel takes them."""
+    packets = [7, 5, 6]
+    channels = [16, 8, 3]
+    bs0 = [256, 256, 2048]
+    bs1 = [2048, 8192, 8192]
+    pflags, spec = synthetic.vorbis_batch(31, packets, channels, bs0, bs1, p_short_run=0.25)
+    got, want = run_both(gpu, packets, channels, bs0, bs1, pflags, spec, 3)
+    assert compare(got, want) == 0
+
+
 def test_vorbis_rejects_broken_reference_sizes(gpu):
     import afgpu
     with pytest.raises(afgpu.AfgError):
