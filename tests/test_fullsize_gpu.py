@@ -209,3 +209,41 @@ def test_fullsize_c5_wave(gpu):
         del first
     del wl
     torch.cuda.empty_cache()
+
+
+@pytest.mark.numeric_tolerance
+@pytest.mark.parametrize("ch,bs0,bs1", [(1, 256, 2048), (2, 256, 1024), (1, 256, 1024), (2, 512, 4096), (1, 512, 4096), (6, 256, 2048)])
+def test_full_size_vorbis_other_shapes_default_mode(gpu, ch, bs0, bs1):
+    """C3-sized batches (1024 files, the samples of 2584 stereo 2048-sample packets each: planes beyond 32-bit offsets) of
+    the other stream shapes the tolerance-mode walk has kernels for: first, middle and last file within 1e-5 RMS of the
+    oracle, every frame written, a second launch bit-identical."""
+    import torch
+    from afgpu import synthetic
+    if free_bytes() < 95e9:
+        pytest.skip("not enough free device memory for the full-size batch")
+    files = 1024
+    packets = 2584 * 2048 * 2 // (bs1 * ch)
+    plan, spec = synthetic.vorbis_batch_device(0x0662 + ch + bs1, files, packets, gpu, bs0=bs0, bs1=bs1, channels=ch)
+    out = torch.full((plan.out_floats,), float("nan"), dtype=torch.float32, device=gpu)
+    plan.transform(spec, out)
+    torch.cuda.synchronize()
+    assert out.numel() * 4 > 2 ** 32
+    so, oo = plan.offsets()
+    for f in (0, files // 2 + 1, files - 1):
+        p0, p1 = f * packets, (f + 1) * packets
+        s0, o0 = int(so[p0]), int(oo[p0])
+        s1 = int(so[p1]) if p1 < plan.total_packets else plan.spec_floats
+        o1 = int(oo[p1]) if p1 < plan.total_packets else plan.out_floats
+        want = oraclelib.vorbis_transform(plan.packets[f:f + 1], plan.channels[f:f + 1], plan.bs0[f:f + 1], plan.bs1[f:f + 1],
+                                          plan.pflags[p0:p1], so[p0:p1] - so[p0], oo[p0:p1] - oo[p0], spec[s0:s1].cpu().numpy(), o1 - o0)
+        got = out[o0:o1].cpu().numpy()
+        rms = float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)))
+        assert rms <= 1e-5, (f, rms)
+        assert (got.view(np.uint32) != want.view(np.uint32)).sum() > got.size // 10, "the exact kernel ran: this test would not be testing the walk"
+    assert bool(torch.isfinite(out).all())
+    first = out.clone()
+    plan.transform(spec, out)
+    torch.cuda.synchronize()
+    assert torch.equal(first, out)
+    del first, out, spec, plan
+    torch.cuda.empty_cache()
