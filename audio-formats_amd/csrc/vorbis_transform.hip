@@ -6,18 +6,20 @@
 // Every output sample is produced by the same float32 expression tree as the
 // reference (library built with -ffp-contract=off); only the schedule differs:
 //
-//   * one 256-thread workgroup walks `seg_packets` consecutive packets of one
-//     stream with all its channels resident in LDS; a segment that does not
-//     start at packet 0 first redoes the IMDCT of the preceding packet to get
-//     its right half (the only carried state, stb_vorbis2.d:2641-2643);
+//   * a thread group (one wavefront, or a 256-thread workgroup for long blocks on the general path) walks `seg_packets`
+//     consecutive packets of ONE CHANNEL of one stream (the fast path: both channels of a stereo stream) with its working
+//     set resident in LDS; a segment that does not start at packet 0 first redoes the IMDCT of the preceding packet to
+//     get its right half (the only carried state, stb_vorbis2.d:2641-2643);
 //   * every pass of the reference's in-place algorithm is a set of independent
-//     butterflies; passes are spread over the 256 threads with a barrier
-//     between passes.  Step 3's iter0 / inner_r / inner_s loops (:1720-1864)
+//     butterflies; passes are spread over the group's threads, ordered by the hardware's in-order LDS queue within a
+//     wavefront and by a barrier across wavefronts.  Step 3's iter0 / inner_r / inner_s loops (:1720-1864)
 //     are one formula: stage l, group i < 2^(l+1), butterfly b < n >> (l+4):
 //         p = n/2-1 - (n >> (l+2))*i - 2b,  q = p - (n >> (l+3)),  twiddle A[b << (l+3)]
 //   * spectra are read with coalesced row loads, PCM leaves as interleaved
-//     rows; twiddle/window tables (host-computed exactly as :851-881) are
-//     shared by all workgroups and served from L2.
+//     rows (a channel's column of them on the general path); twiddle/window tables (host-computed exactly as
+//     :851-881) are shared by all workgroups and served from L2 or staged in LDS.
+// Kernels: vorbis_wave_kernel (blocksize_1 = 2048, one or two channels: register passes), vorbis_channel_kernel (every
+// other stream).  The default numeric mode sends most streams to vorbis_walk.hip instead (afg_vorbis_transform_hip below).
 #include "afg_common.h"
 #ifndef AFG_VORBIS_NT_LOAD
 #define AFG_VORBIS_NT_LOAD 1   // nontemporal spectrum loads (0: plain -- A/B builds)
