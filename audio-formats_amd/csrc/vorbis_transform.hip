@@ -1205,6 +1205,7 @@ struct afg_vorbis_plan {
     afg::DeviceArray d_walk_segs, d_walk_tables[kWalkShapes];
     uint32_t tab2048 = 0;          // float offset of the n = 2048 table set
     afg::DeviceArray d_segs, d_wave_segs, d_streams, d_pflags, d_spec_off, d_out_off, d_tables;
+    afg::DeviceArray d_walk_pflags;   // d_pflags as the walk reads them (equal block sizes: every packet a long block between long blocks); empty: d_pflags
     // work counters of the persistent kernels: launch k uses (and first clears, on its stream) set k % kCounterSets -- one
     // counter for the wave kernel, one per walk shape -- so launches of one plan that overlap on different streams do not
     // share one
@@ -1238,6 +1239,9 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
 
     std::vector<VorbisStream> streams(n_streams);
     std::vector<VorbisSeg> segs, segs_walk, wave_segs, wave_walk, walk_segs[kWalkShapes];
+    std::vector<uint8_t> walk_pflags;
+    uint64_t total_packets = 0;
+    for (uint32_t s = 0; s < n_streams; s++) total_packets += packets[s];
     std::vector<float> tables;
     std::map<int, uint32_t> tab_of;
     auto p = new (std::nothrow) afg_vorbis_plan;
@@ -1305,6 +1309,13 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
             prev_len = right_end - right;
         }
         const int shape = single_only ? -1 : walk_shape((int)channels[s], bs[0], bs[1]);
+        if (shape >= 0 && bs[0] == bs[1]) {
+            // one block size: the packets' blockflag says "short" or "long" as the encoder pleased, the two windows are the
+            // same -- for the walk every one of them is a long block between long blocks (the same bounds, vorbis_core.h)
+            if (walk_pflags.empty()) walk_pflags.assign(pflags, pflags + total_packets);
+            for (uint64_t q = st.pkt_base; q < st.pkt_base + packets[s]; q++)
+                walk_pflags[q] |= (uint8_t)(AFG_VORBIS_LONG | AFG_VORBIS_PREV | AFG_VORBIS_NEXT);
+        }
         for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
             uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
             if (shape >= 6)      // one per channel or pair of channels
@@ -1342,6 +1353,7 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     if (!rc) rc = p->d_wave_segs.upload(wave_segs.data(), wave_segs.size() * sizeof(VorbisSeg));
     if (!rc) rc = p->d_streams.upload(streams.data(), streams.size() * sizeof(VorbisStream));
     if (!rc) rc = p->d_pflags.upload(pflags, (size_t)pkt);
+    if (!rc && !walk_pflags.empty()) rc = p->d_walk_pflags.upload(walk_pflags.data(), walk_pflags.size());
     if (!rc) rc = p->d_spec_off.upload(p->h_spec_off.data(), p->h_spec_off.size() * sizeof(uint64_t));
     if (!rc) rc = p->d_out_off.upload(p->h_out_off.data(), p->h_out_off.size() * sizeof(uint64_t));
     if (!rc) rc = p->d_tables.upload(tables.data(), tables.size() * sizeof(float));
@@ -1389,6 +1401,7 @@ void afg_vorbis_plan_destroy(afg_vorbis_plan *plan)
     plan->d_wave_segs.release();
     plan->d_streams.release();
     plan->d_pflags.release();
+    plan->d_walk_pflags.release();
     plan->d_spec_off.release();
     plan->d_out_off.release();
     plan->d_tables.release();
@@ -1430,7 +1443,7 @@ int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, f
             const uint32_t first = plan->walk_first[k], count = plan->walk_first[k + 1] - first;
             if (!count) continue;
             if (int rc = walk_launch(k, (const VorbisSeg *)plan->d_walk_segs.ptr + first, count, (const VorbisStream *)plan->d_streams.ptr,
-                                     (const uint8_t *)plan->d_pflags.ptr, (const uint64_t *)plan->d_spec_off.ptr,
+                                     (const uint8_t *)(plan->d_walk_pflags.ptr ? plan->d_walk_pflags.ptr : plan->d_pflags.ptr), (const uint64_t *)plan->d_spec_off.ptr,
                                      (const uint64_t *)plan->d_out_off.ptr, (const float *)plan->d_tables.ptr,
                                      (const float *)plan->d_walk_tables[k].ptr, d_spec, d_out, counter + 1 + k, (hipStream_t)hip_stream))
                 return rc;

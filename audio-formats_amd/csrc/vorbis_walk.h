@@ -6,7 +6,7 @@
 namespace afg_vorbis {
 
 constexpr int kWalkShapes = 12;
-// The walk's kernel for a stream with blocksize_1 in {1024, 2048, 4096} and blocksize_0 <= 512, < blocksize_1; with
+// The walk's kernel for a stream with blocksize_1 in {1024, 2048, 4096} and blocksize_0 <= 512 (or = blocksize_1); with
 // size = log2(blocksize_1) - 10:  2 size + (channels - 1) for mono / stereo streams (one wavefront walks every channel of
 // a segment); 6 + size for an odd number of channels above two (one wavefront per channel: VorbisSeg.pad), 9 + size for an
 // even one (one wavefront per pair of channels, VorbisSeg.pad the first); -1 for every other stream.

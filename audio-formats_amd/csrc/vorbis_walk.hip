@@ -861,7 +861,8 @@ void build_tables_r(float *dst, const float *window)
 
 int walk_shape(int channels, int blocksize0, int blocksize1)
 {
-    if (channels < 1 || blocksize0 > 512 || blocksize0 >= blocksize1) return -1;
+    // (equal block sizes: every packet is a long block between long blocks to the walk -- the plan rewrites its flags)
+    if (channels < 1 || (blocksize0 > 512 && blocksize0 != blocksize1) || blocksize0 > blocksize1) return -1;
     const int size = blocksize1 == 1024 ? 0 : blocksize1 == 2048 ? 1 : blocksize1 == 4096 ? 2 : -1;
     if (size < 0) return -1;
     return channels <= 2 ? 2 * size + (channels - 1) : (channels & 1) ? 6 + size : 9 + size;

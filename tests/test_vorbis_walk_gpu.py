@@ -182,7 +182,9 @@ def test_walk_declared_zero_tail(gpu, eighths):
 SHAPES = [(1, 256, 2048), (1, 512, 2048), (2, 256, 1024), (1, 256, 1024), (2, 512, 1024), (2, 512, 4096), (1, 512, 4096),
           (2, 256, 4096), (1, 256, 4096),
           # more than two channels: one wavefront per channel, each storing its own column of the interleaved frames
-          (3, 256, 2048), (6, 256, 2048), (6, 512, 1024), (4, 512, 4096), (8, 256, 2048), (16, 256, 2048)]
+          (3, 256, 2048), (6, 256, 2048), (6, 512, 1024), (4, 512, 4096), (8, 256, 2048), (16, 256, 2048),
+          # one block size (libvorbis' lowest 16 / 22 kHz modes): every packet a long block between long blocks
+          (2, 1024, 1024), (1, 1024, 1024), (2, 2048, 2048), (3, 1024, 1024)]
 
 
 def legal_flags(longs):
