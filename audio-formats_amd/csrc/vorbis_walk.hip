@@ -33,9 +33,10 @@
 //
 // Packets that are not "long between two long blocks" (short blocks, the long blocks beside them) take the reference's
 // own arithmetic for the parts that differ: short blocks run vorbis_core.h's inverse_mdct_lds, long blocks with a short
-// neighbour scatter u to LDS and window through a y(m) accessor.  One wavefront walks all channels (1 or 2) of a segment.
-// Streams this walk does not take (more than two channels, other long block sizes, blocksize_0 > 512 or = blocksize_1)
-// stay on the bit-exact kernels, which are within any tolerance.
+// neighbour scatter u to LDS and window through a y(m) accessor.  One wavefront walks all channels (1 or 2) of a segment;
+// of a stream with more channels, one channel or one pair of channels (their column of the interleaved frames).
+// Streams this walk does not take (other long block sizes, blocksize_0 > 512 unless it is blocksize_1 itself) stay on the
+// bit-exact kernels, which are within any tolerance.
 //
 // Compiled with -ffp-contract=fast (Makefile): multiply-adds fuse.  Error against the oracle on the C3 workload (N(0,1)
 // spectra, output RMS 6.8): 1e-6 RMS, i.e. 1.5e-7 of the signal (tests/test_vorbis_walk_gpu.py).
