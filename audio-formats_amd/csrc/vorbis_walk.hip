@@ -207,7 +207,9 @@ __device__ __forceinline__ void load_lane_tw(LaneTw<R> &tw, const f2 *T)
         for (int k = 1; k < 8; k++) tw.w2[k - 1] = T[G::kTw2 + (lane >> 3) + 8 * (k - 1)];
     }
 }
-template <int R, int CH> constexpr bool kTwRegs = R == 8 && CH == 2;
+// which of them: the pre- / post-twiddle w (R values), the pass-1 twiddles (R - 1), pass 2's (R = 8)
+template <int R, int CH> constexpr bool kTwRegs = R == 8 && CH == 2;                           // all three sets
+template <int R, int CH> constexpr bool kTwRegsW = kTwRegs<R, CH> || (R == 16 && CH == 1);             // w only (mono 4096: 197 -> 245 registers, +0.6 %)
 
 // The passes between the pre- and the post-twiddle: e[c][r] = point j + 64 r in, e[c][s] = bin j + 64 s out (not yet
 // multiplied by w).  U: the wavefront's transform area (channel c at U + c kChanF2); T: the table block.
@@ -430,7 +432,7 @@ __device__ __forceinline__ void fft_lanes(f2 (&xin)[CH][R], f2 (&P)[CH][R], f2 *
         const f2 *W = T + j;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const f2 w = kTwRegs<R, CH> ? tw.w[r] : W[64 * r];
+            const f2 w = kTwRegsW<R, CH> ? tw.w[r] : W[64 * r];
 #pragma unroll
             for (int c = 0; c < CH; c++) e[c][r] = cmul(xin[c][r], w);
         }
@@ -442,7 +444,7 @@ __device__ __forceinline__ void fft_lanes(f2 (&xin)[CH][R], f2 (&P)[CH][R], f2 *
         const f2 *W = T + j;
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const f2 w = kTwRegs<R, CH> ? tw.w[k] : W[64 * k];
+            const f2 w = kTwRegsW<R, CH> ? tw.w[k] : W[64 * k];
 #pragma unroll
             for (int c = 0; c < CH; c++) P[c][k] = cmul(e[c][k], w);
         }
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(64 * WAVES, (Shape<R, CH>::kPerSimd)) void vorbis_w
     f2 *const U = (f2 *)(lds + G::kTabFloats) + wave * (CH * G::kChanF2);
     const f2 *const T = (const f2 *)lds;
     LaneTw<R> tw;
-    if constexpr (kTwRegs<R, CH>) load_lane_tw<R>(tw, T);
+    if constexpr (kTwRegsW<R, CH>) load_lane_tw<R>(tw, T);
     if constexpr (ST) {
         // a workgroup draws WAVES consecutive items at a time -- the channels of a segment follow each other -- so that the
         // wavefronts filling the columns of one run of frames share a CU's L2 slice and a moment in time
