@@ -1540,7 +1540,7 @@ int afg_mp3_parse_q(const uint8_t *data, size_t length, afg_mp3_parsed_q *out)
         }
         if (own->q_unsupported) {
             own_guard.reset();
-            afg::set_error("afg_mp3_parse_q: the stream holds MPEG-2.5 8 kHz mixed blocks, which the device requantiser does not cover");
+            afg::set_error("afg_mp3_parse_q: the stream holds granules the device requantiser does not cover (MPEG-2.5 8 kHz mixed blocks, or a mono frame with the intensity bit set)");
             return AFG_ERR_UNSUPPORTED;
         }
         afg_mp3_parsed &b = out->base;

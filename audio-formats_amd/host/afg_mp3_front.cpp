@@ -862,6 +862,11 @@ FrameResult frame(Decoder &d, const uint8_t *p, int avail, File *out, bool *fres
                     rec.table[ch] = (uint8_t)((tab[ch] < 0 ? 0 : tab[ch]) | (g[ch].n_short ? 0x80 : 0));
                     fl[ch] = AFG_MP3_FLAGS(g[ch].block_type, n_long_bands, g[ch].n_short ? n_long_bands - 1 : 31);
                 }
+                // The reference tests the intensity bit of the header whatever the channel mode (HDR_TEST_I_STEREO,
+                // minimp3.d:100): a MONO frame that carries it -- damaged files do -- has L3_intensity_stereo run over its one
+                // channel and the scratch row behind it (:1207-1210).  The float front-end does the same; the device
+                // requantiser has no such case: the file takes the float path.
+                if (nch == 1 && hd.intensity()) out->q_unsupported = true;
                 // a line of the right channel is nonzero exactly when its value is and its band's scale is (the
                 // requantised magnitude of a nonzero value is at least 1)
                 if (hd.intensity()) {

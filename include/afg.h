@@ -137,8 +137,10 @@ int afg_mp3_transform_hip(const afg_mp3_plan *plan, const float *d_coef, const u
  *  The host keeps Huffman decoding and the scalefactor arithmetic (L3_decode_scalefactors, :616-719: 39 floats per
  *  granule-channel) and decides the stereo plan (which band is mid/side or intensity coded, with which factors); the
  *  device turns int16 values into exactly the floats L3_decode holds in grbuf at :1226 -- 2 bytes per line cross the
- *  bus instead of 4.  MPEG-2.5 8 kHz mixed blocks are not covered (their reorder walks outside the channel,
- *  :1218-1223): afg_mp3_parse_q reports AFG_ERR_UNSUPPORTED for such a file and the float path takes it.
+ *  bus instead of 4.  Two cases are not covered: MPEG-2.5 8 kHz mixed blocks (their reorder walks outside the channel,
+ *  :1218-1223) and a MONO frame whose header carries the intensity-stereo bit (the reference runs L3_intensity_stereo over
+ *  the one channel and the scratch row behind it, :100, :1207-1210: damaged files).  afg_mp3_parse_q reports
+ *  AFG_ERR_UNSUPPORTED for such a file and the float path takes it.
  * -------------------------------------------------------------------------- */
 #define AFG_MP3_NO_SDESC 0xffffffffu
 

@@ -109,3 +109,18 @@ def test_mpeg25_8khz_mixed_blocks_are_refused_not_mangled():
             refused += 1
             afgpu.mp3_parse(data)
     assert refused >= 1
+
+
+def test_a_mono_frame_with_the_intensity_bit_takes_the_float_path():
+    """tests/golden/soak_r05_mono_intensity.mp3 (a damaged generated file, found by tools/soak_damaged.py seed 7): mono frames
+    whose header has the intensity-stereo bit set.  The reference runs L3_intensity_stereo on them all the same
+    (minimp3.d:100, :1207-1210), which the float front-end restates and the oracle pins; the quantised records cannot say it,
+    so afg_mp3_parse_q hands the file to the float path -- it used to record the granules as plain mono and the batch decoded
+    1 000 frames of the file to other samples than the stream surface and the oracle."""
+    import oraclelib
+    data = open(os.path.join(os.path.dirname(__file__), "golden", "soak_r05_mono_intensity.mp3"), "rb").read()
+    with pytest.raises(afgpu.AfgError):
+        afgpu.mp3_parse_q(data)
+    info, runs, coef, flags, copies = afgpu.mp3_parse(data)
+    want = oraclelib.mp3_decode_file(data)
+    assert info["channels"] == 1 and np.array_equal(coef.view(np.uint32), want["coef"].view(np.uint32))

@@ -92,3 +92,20 @@ def test_a_file_outside_the_requantisers_coverage_sends_the_batch_down_the_float
         assert x["status"] == 0 and x["frames"] * x["channels"] == len(want["pcm"])
         if x["frames"]:
             assert np.array_equal(x["pcm"].reshape(-1).view(np.uint32), want["pcm"].view(np.uint32))
+
+
+def test_a_mono_frame_with_the_intensity_bit_in_a_batch(gpu, monkeypatch):
+    """tests/golden/soak_r05_mono_intensity.mp3 (tests/test_mp3_requant.py) among ordinary files: the batch takes the float
+    path and every file decodes to the oracle's samples."""
+    import os
+    monkeypatch.delenv("AFG_MP3_FLOAT_UPLOAD", raising=False)
+    odd = open(os.path.join(os.path.dirname(__file__), "golden", "soak_r05_mono_intensity.mp3"), "rb").read()
+    blobs = files()[:3] + [odd] + files()[3:6]
+    got = afgpu.batch_decode(blobs, n_threads=4)
+    for blob, x in zip(blobs, got):
+        want = oraclelib.mp3_decode_file(blob)
+        assert x["status"] == 0 and x["frames"] * x["channels"] == len(want["pcm"])
+        if x["frames"]:
+            assert np.array_equal(x["pcm"].reshape(-1).view(np.uint32), want["pcm"].view(np.uint32))
+    alone = afgpu.batch_decode([odd])[0]
+    assert np.array_equal(alone["pcm"].view(np.uint32), got[3]["pcm"].view(np.uint32))

@@ -220,7 +220,7 @@ def run(rounds, seed=2024, streams=True):
 
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    n_ok, n_rejected, bad = run(rounds)
+    n_ok, n_rejected, bad = run(rounds, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
     print("rounds", rounds, "decoded", n_ok, "rejected", n_rejected, "bad", bad, "| product refused what the oracle decodes:", run.refused,
           "| FLAC streams ended at a stale-buffer frame:", run.flac_stale, "| Ogg streams ended at an inconsistent window:", run.ogg_window_cut, "| Ogg files the reference stops after its length scan (held against upstream's seek):", run.ogg_eof_quirk,
           "of which end one phantom packet early:", OGG_WINDOW_CUT["phantom"], "| damaged MP3 / Ogg files decoding over full scale:", run.over_full_scale)
