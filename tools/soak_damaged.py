@@ -110,6 +110,14 @@ def want_opus(data):
     return None if isinstance(rec, int) or rec.get("error") else oraclelib.opus_file_pcm(rec)
 
 
+def dump_bad(tag, r, kind, d):
+    """AFG_SOAK_DUMP=<dir>: keep the bytes of a file the soak flags"""
+    where = os.environ.get("AFG_SOAK_DUMP")
+    if where:
+        with open(os.path.join(where, f"{tag}_{r}_{kind}_{len(d)}.bin"), "wb") as fh:
+            fh.write(d)
+
+
 def run(rounds, seed=2024, streams=True):
     """-> (decoded, rejected, disagreements); run.refused / run.flac_stale / run.ogg_window_cut: the counted divergence classes"""
     global rng
@@ -192,14 +200,24 @@ def run(rounds, seed=2024, streams=True):
             diff = got[:n].astype(np.float64) - w[:n]
             if kind == "opus":
                 # the decoder's int16 / 32767: the same values, or (default mode) a rare neighbour
-                if len(got) != len(w) or (n and np.abs(diff).max() > 1 / 32767 + 1.2e-7):
+                far = np.abs(diff) > 1 / 32767 + 1.2e-7
+                # Damage that lands in the band energies can put the decoder's floats 1e9 times over full scale (the int16
+                # conversion clips them): float32 carries 1.2e-7 of THAT, so where the clipped waveform passes through the
+                # int16 range a default-mode sample may land anywhere.  Such a file (the oracle's output sits at the rails
+                # for more than 0.5 % of its samples; counted) is held to 0.1 % of its samples; exact mode stays bit-exact.
+                railed = n and float(np.mean(np.abs(w[:n]) >= 32766.5 / 32767)) > 0.005
+                if railed:
+                    run.over_full_scale += 1
+                if len(got) != len(w) or (n and far.any() and not (railed and far.mean() <= 0.001 and afgpu.get_numeric_mode() == afgpu.NUMERIC_TOLERANCE)):
                     print("opus mismatch", len(got), len(w), float(np.abs(diff).max()) if n else None); bad += 1
+                    dump_bad("mismatch", r, kind, d)
             elif kind in ("ogg", "mp3"):
                 if len(got) != len(w):
                     if kind == "ogg" and OGG_PHANTOM.get(len(d)) == len(got):
                         OGG_WINDOW_CUT["phantom"] += 1
                     else:
                         print(kind, "length", len(got), len(w)); bad += 1
+                        dump_bad("length", r, kind, d)
                 rms = float(np.sqrt(np.mean(diff ** 2))) if n else 0.0
                 sig = float(np.sqrt(np.mean(w[:n].astype(np.float64) ** 2))) if n else 0.0
                 # absolute 1e-5 of full scale: the generators keep the undamaged signal inside it (round 5).  Damage that lands in
@@ -209,6 +227,7 @@ def run(rounds, seed=2024, streams=True):
                     run.over_full_scale += 1
                 if rms > 1e-5 * max(1.0, sig):
                     print(kind, "mismatch", len(got), len(w), rms, "signal rms", sig); bad += 1
+                    dump_bad("mismatch", r, kind, d)
             else:
                 if len(got) != len(w) or not np.array_equal(got.view(np.uint32), w.astype(np.float32).view(np.uint32)):
                     print(kind, "mismatch", len(got), len(w)); bad += 1
@@ -223,5 +242,5 @@ if __name__ == "__main__":
     n_ok, n_rejected, bad = run(rounds, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
     print("rounds", rounds, "decoded", n_ok, "rejected", n_rejected, "bad", bad, "| product refused what the oracle decodes:", run.refused,
           "| FLAC streams ended at a stale-buffer frame:", run.flac_stale, "| Ogg streams ended at an inconsistent window:", run.ogg_window_cut, "| Ogg files the reference stops after its length scan (held against upstream's seek):", run.ogg_eof_quirk,
-          "of which end one phantom packet early:", OGG_WINDOW_CUT["phantom"], "| damaged MP3 / Ogg files decoding over full scale:", run.over_full_scale)
+          "of which end one phantom packet early:", OGG_WINDOW_CUT["phantom"], "| damaged MP3 / Ogg / Opus files decoding over full scale:", run.over_full_scale)
     sys.exit(1 if bad else 0)
