@@ -19,11 +19,17 @@ struct BitReader {
     const uint8_t *p;
     size_t nbits, pos = 0;
     bool fail = false;
-    BitReader(const uint8_t *data, size_t bytes) : p(data), nbits(bytes * 8) {}
+    size_t real_bytes;             // bytes that exist behind p (nbits can come to lie past them: rice_low)
+    unsigned phase;                // bits of a 32-bit line in front of p: the reference's reader takes the stream in lines
+                                   // counted from the first frame (drflac.d:707-780)
+    bool phantom = false;
+    BitReader(const uint8_t *data, size_t bytes, size_t lead_bytes = 0)
+        : p(data), nbits(bytes * 8), real_bytes(bytes), phase((unsigned)(lead_bytes & 3) * 8) {}
+    uint32_t at(size_t i) const { return i < real_bytes ? p[i] : 0u; }
     uint32_t bit()
     {
         if (pos >= nbits) { fail = true; return 0; }
-        uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1u;
+        uint32_t b = (at(pos >> 3) >> (7 - (pos & 7))) & 1u;
         pos++;
         return b;
     }
@@ -36,10 +42,28 @@ struct BitReader {
         unsigned have = 0;
         uint64_t acc = 0;
         unsigned skip = (unsigned)(pos & 7);
-        while (have < n + skip) { acc = (acc << 8) | p[byte++]; have += 8; }
+        while (have < n + skip) { acc = (acc << 8) | at(byte++); have += 8; }
         v = (acc >> (have - n - skip)) & ((n == 64) ? ~0ull : ((1ull << n) - 1));
         pos += n;
         return v;
+    }
+    // The low k bits of a Rice symbol whose stop bit has just been read, as the reference's fused loop gets them
+    // (drflac.d:1166-1236): when the symbol reaches the end of the 32-bit line its stop bit sits in, the loop fetches the NEXT
+    // line -- even for zero bits of it ("riceLength < bits remaining", else the straddling branch).  Two things follow at the
+    // end of a stream.  A symbol that ends on the last bit of the data fails (there is no next line).  And when the next line
+    // is the partial last one (1-3 bytes), that branch overwrites the count of bits the line holds with the count it has
+    // just taken from it: the line is a whole one from then on, its missing bytes zeros.  Files cut short get there.
+    bool rice_low(unsigned k, uint32_t &low)
+    {
+        const size_t s = pos - 1 + phase, end_all = nbits + phase;     // stop bit and end of the stream, in line coordinates
+        size_t le = ((s >> 5) + 1) << 5;                                // end of the stop bit's line
+        if (le > end_all) le = end_all;
+        if (s + 1 + k >= le) {
+            if (le >= end_all) { fail = true; pos = nbits; low = 0; return false; }
+            if (!phantom && le + 32 > real_bytes * 8 + phase) { phantom = true; nbits = le + 32 - phase; }
+        }
+        low = (uint32_t)bits(k);
+        return !fail;
     }
     int64_t sbits(unsigned n)      // two's complement, drflac__read_int32 (drflac.d:858-870)
     {
@@ -54,7 +78,7 @@ struct BitReader {
         for (;;) {
             if (pos >= nbits) { fail = true; return false; }
             unsigned skip = (unsigned)(pos & 7);
-            uint32_t byte = (uint32_t)(p[pos >> 3] << skip) & 0xffu;
+            uint32_t byte = (uint32_t)(at(pos >> 3) << skip) & 0xffu;
             if (byte) {
                 unsigned lz = (unsigned)__builtin_clz(byte) - 24;
                 zeros += lz;
@@ -163,7 +187,8 @@ bool flac_residual(BitReader &br, uint32_t block_size, uint32_t order, int32_t *
             // by a shift (the dependent chain per symbol is clz + shift, not load + swap + clz); it is topped up from
             // memory whenever eight whole bytes are left at the position.  Anything else -- a symbol that does not end
             // inside the window (a run of 50 zeros), the last bytes of the buffer -- takes the bit reader.  Same values.
-            const size_t bytes = br.nbits >> 3;
+            // (the last bytes of the stream go symbol by symbol through BitReader::rice_low: what the reference does there)
+            const size_t bytes = br.real_bytes > 12 ? br.real_bytes - 12 : 0;
             size_t pos = br.pos;
             uint32_t j = 0;
             // Groups first: one load of eight bytes (at least 57 stream bits) feeds `per` symbols -- as many as fit nearly always
@@ -198,10 +223,9 @@ bool flac_residual(BitReader &br, uint32_t block_size, uint32_t order, int32_t *
                     i += n;
                     j += n;
                     if (n < per) {
-                        uint32_t q;
+                        uint32_t q, low;
                         br.pos = pos;
-                        if (!br.unary(q)) return false;
-                        const uint32_t low = (uint32_t)br.bits(k);
+                        if (!br.unary(q) || !br.rice_low(k, low)) return false;
                         pos = br.pos;
                         const uint32_t v = (q << k) | low;
                         dst[i++] = (int32_t)((v >> 1) ^ (~(v & 1) + 1));
@@ -235,8 +259,7 @@ bool flac_residual(BitReader &br, uint32_t block_size, uint32_t order, int32_t *
                     pos += need;
                 } else {
                     br.pos = pos;
-                    if (!br.unary(q)) return false;
-                    low = (uint32_t)br.bits(k);
+                    if (!br.unary(q) || !br.rice_low(k, low)) return false;
                     pos = br.pos;
                     avail = 0;
                 }
@@ -431,7 +454,7 @@ int flac_parse_frames(const uint8_t *d, size_t n, const FlacInfo &fi, FlacRecord
     *ended = false;
     if (fi.first_frame + *pos >= n) { *ended = true; return 0; }
     const size_t avail = n - fi.first_frame - *pos;
-    BitReader br(d + fi.first_frame + *pos, avail);
+    BitReader br(d + fi.first_frame + *pos, avail, *pos);
     int got = 0;
     while (got < max_frames) {
         if (br.byte_pos() + 2 >= avail) { *ended = true; break; }

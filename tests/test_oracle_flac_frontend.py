@@ -9,6 +9,8 @@ and fused Rice + prediction loop, drflac.d:680-1043, :1143-1328, :1444-1695, :28
     below where the product stops a frame early on purpose.
 
 No device: the product side here is host code + the oracle's restore stage."""
+import os
+
 import numpy as np
 import pytest
 
@@ -230,3 +232,40 @@ def test_qoa_product_parser_equals_the_oracle_reader_on_damaged_files():
         np.testing.assert_array_equal(p, o["pcm"], err_msg=f"case {it}")
         same += 1
     assert same >= 300, (same, refused)
+
+
+def _product_vs_oracle(data):
+    """afg_flac_parse's records through the restore oracle against the oracle front-end's delivery; -> (ok, frames)"""
+    import afgpu
+    o = oraclelib.flac_decode_file(data)
+    want = None if isinstance(o, int) else o["pcm"]
+    if want is not None and o["flags"] and o["first_flag_sample"] is not None:
+        want = want[:o["first_flag_sample"]]                   # the product ends the stream at a stale-buffer frame (DESIGN 4)
+    try:
+        info, frames, subframes, res = afgpu.flac_parse(data)
+        got = oraclelib.flac_transform(frames, subframes, res, info["out_samples"])
+    except afgpu.AfgError:
+        got = np.zeros(0, np.int32)
+    want = np.zeros(0, np.int32) if want is None else want
+    return len(got) == len(want) and np.array_equal(got, want), len(got)
+
+
+def test_the_end_of_a_stream_as_the_references_rice_loop_reads_it():
+    """drflac.d:1166-1236: the fused Rice loop fetches the next 32-bit line whenever a symbol reaches the end of the line its
+    stop bit sits in -- so a symbol that ends on the LAST bit of the data fails, and a partial last line (1-3 bytes) fetched
+    that way counts as a whole one, its missing bytes zeros.  Files cut short get there: tests/golden/soak_r05_cut_{a,b}.flac
+    are the two of 2 000 damaged files (tools/soak_damaged.py, seed 13) on which the product's reader -- a plain positional
+    one until then -- delivered a frame more, or less, than the reference; and every cut point in the last 300 bytes of two
+    encoder-made files."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name in ("soak_r05_cut_a.flac", "soak_r05_cut_b.flac"):
+        ok, n = _product_vs_oracle(open(os.path.join(here, name), "rb").read())
+        assert ok and n > 0, name
+    import flac_bitstream as fb
+    from test_flac_frontend import make_pcm
+    rng = np.random.default_rng(17)
+    for k in range(2):
+        base, _ = fb.encode_file(make_pcm(int(rng.integers(5000, 9000)), 1 + k, 16, int(rng.integers(0, 1 << 30))), 16, 4096, orders=(8, 12, 2))
+        for cut in range(len(base) - 300, len(base) + 1):
+            ok, _ = _product_vs_oracle(base[:cut])
+            assert ok, (k, cut, len(base))

@@ -231,6 +231,7 @@ def run(rounds, seed=2024, streams=True):
             else:
                 if len(got) != len(w) or not np.array_equal(got.view(np.uint32), w.astype(np.float32).view(np.uint32)):
                     print(kind, "mismatch", len(got), len(w)); bad += 1
+                    dump_bad("mismatch", r, kind, d)
     run.flac_stale = FLAC_STALE["n"]
     run.ogg_window_cut = OGG_WINDOW_CUT["n"]
     run.ogg_eof_quirk = OGG_WINDOW_CUT["eof"]
