@@ -36,7 +36,17 @@ struct BitReader {
     uint64_t bits(unsigned n)      // n <= 57
     {
         if (n == 0) return 0;
-        if (pos + n > nbits) { fail = true; pos = nbits; return 0; }
+        if (pos + n > nbits) {
+            // drflac__read_uint32 (drflac.d:834-856): a read that runs from a whole line into the partial last line (1-3 bytes)
+            // adds what it takes there to the line's count of consumed bits, which started at 32 minus the line's own -- when
+            // it takes more than the line holds the count passes 32, "bits remaining" (an unsigned difference) becomes
+            // enormous, and every later read of this kind succeeds with zeros.  The frame in hand is delivered, the sync
+            // code of the next one is not found.  (A stream that ends on a line boundary, or a read that starts inside the
+            // last line, fails as one expects.)
+            const size_t end_all = real_bytes * 8 + phase, last = end_all & ~(size_t)31;
+            if (!phantom && nbits == real_bytes * 8 && (end_all & 31) != 0 && pos + phase < last && n <= 32) nbits = (size_t)1 << 62;
+            else { fail = true; pos = nbits; return 0; }
+        }
         uint64_t v = 0;
         size_t byte = pos >> 3;
         unsigned have = 0;
@@ -76,7 +86,7 @@ struct BitReader {
     {
         zeros = 0;
         for (;;) {
-            if (pos >= nbits) { fail = true; return false; }
+            if (pos >= nbits || (pos >> 3) >= real_bytes + 4) { fail = true; return false; }      // (zeros without end: no set bit will come)
             unsigned skip = (unsigned)(pos & 7);
             uint32_t byte = (uint32_t)(at(pos >> 3) << skip) & 0xffu;
             if (byte) {

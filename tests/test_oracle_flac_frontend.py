@@ -256,9 +256,12 @@ def test_the_end_of_a_stream_as_the_references_rice_loop_reads_it():
     that way counts as a whole one, its missing bytes zeros.  Files cut short get there: tests/golden/soak_r05_cut_{a,b}.flac
     are the two of 2 000 damaged files (tools/soak_damaged.py, seed 13) on which the product's reader -- a plain positional
     one until then -- delivered a frame more, or less, than the reference; and every cut point in the last 300 bytes of two
-    encoder-made files."""
+    encoder-made files.  soak_r05_cut_c.flac (seed 41) is drflac__read_uint32's side of it (:834-856): a read that runs from
+    a whole line into the partial last line and takes more than it holds pushes the count of consumed bits past 32, the
+    unsigned "bits remaining" becomes enormous and every later read succeeds with zeros -- a verbatim subframe 12 000 bits
+    longer than the file is delivered, padded with zeros."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    for name in ("soak_r05_cut_a.flac", "soak_r05_cut_b.flac"):
+    for name in ("soak_r05_cut_a.flac", "soak_r05_cut_b.flac", "soak_r05_cut_c.flac"):
         ok, n = _product_vs_oracle(open(os.path.join(here, name), "rb").read())
         assert ok and n > 0, name
     import flac_bitstream as fb
