@@ -30,7 +30,7 @@ def damage(data, lo):
             d[p] ^= 1 << int(rng.integers(0, 8))
         else:
             d[p] = int(rng.integers(0, 256))
-    if rng.random() < 0.2:
+    if rng.random() < float(os.environ.get("AFG_SOAK_CUT", "0.2")):          # cut short (AFG_SOAK_CUT: how often)
         d = d[:int(rng.integers(max(lo, len(d) // 2), len(d)))]
     return bytes(d)
 
