@@ -118,6 +118,9 @@ def dump_bad(tag, r, kind, d):
             fh.write(d)
 
 
+WIDE = bool(os.environ.get("AFG_SOAK_WIDE"))
+
+
 def run(rounds, seed=2024, streams=True):
     """-> (decoded, rejected, disagreements); run.refused / run.flac_stale / run.ogg_window_cut: the counted divergence classes"""
     global rng
@@ -138,11 +141,24 @@ def run(rounds, seed=2024, streams=True):
                 d = damage(base, 8)
                 w = want_qoa(d)
             elif kind == "flac":
-                base, _ = fb.encode_file(make_pcm(int(rng.integers(2000, 20000)), 2, 16, int(rng.integers(0, 1 << 30))), 16, 4096, orders=(8, 12, 2))
-                d = damage(base, 42)
+                if WIDE:                                             # AFG_SOAK_WIDE=1: other sample widths, block sizes, channel counts
+                    bps = (16, 24, 8, 12, 20)[int(rng.integers(0, 5))]
+                    base, _ = fb.encode_file(make_pcm(int(rng.integers(1500, 12000)), int(rng.integers(1, 4)), bps, int(rng.integers(0, 1 << 30))), bps,
+                                             (4096, 1152, 576, 2304, 4608)[int(rng.integers(0, 5))], orders=(8, 12, 2, 32)[:int(rng.integers(2, 5))],
+                                             use_fixed_every=(1000, 3)[int(rng.integers(0, 2))])
+                else:
+                    base, _ = fb.encode_file(make_pcm(int(rng.integers(2000, 20000)), 2, 16, int(rng.integers(0, 1 << 30))), 16, 4096, orders=(8, 12, 2))
+                d = damage(base, 42 if not WIDE else (42, 8)[int(rng.integers(0, 2))])
                 w = want_flac(d)
             elif kind == "mp3":
-                base = mb.make_file(int(rng.integers(0, 1 << 20)), n_frames=int(rng.integers(8, 40)), mode=("stereo", "ms", "mono")[int(rng.integers(0, 3))])[0]
+                if WIDE:                                             # MPEG-2 / 2.5 rates, intensity stereo, free choice of the sampling rate
+                    # (not MPEG-2.5 at 8 kHz: its mixed blocks make L3_reorder read the reference's uninitialised stack scratch,
+                    #  minimp3.d:1218-1223 -- what comes out depends on what the thread decoded before, in the oracle as in the product)
+                    version = ("mpeg1", "mpeg2", "mpeg25")[int(rng.integers(0, 3))]
+                    base = mb.make_file(int(rng.integers(0, 1 << 20)), n_frames=int(rng.integers(8, 30)), version=version, sr=int(rng.integers(0, 2 if version == "mpeg25" else 3)),
+                                        mode=("stereo", "ms", "mono", "intensity", "ms+intensity")[int(rng.integers(0, 5))])[0]
+                else:
+                    base = mb.make_file(int(rng.integers(0, 1 << 20)), n_frames=int(rng.integers(8, 40)), mode=("stereo", "ms", "mono")[int(rng.integers(0, 3))])[0]
                 d = damage(base, 4)
                 w = want_mp3(d)
             elif kind == "opus":
