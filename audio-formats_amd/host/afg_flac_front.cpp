@@ -346,7 +346,7 @@ bool flac_frame(BitReader &br, const FlacInfo &fi, FlacRecords &rec)
         if (hdr & 1) {
             uint32_t z;
             if (!br.unary(z)) return false;
-            wasted = z + 1;
+            wasted = (uint8_t)((uint8_t)z + 1);                    // (the reference keeps the count in a byte: 276 zeros are 21 wasted bits, :1563)
         }
         unsigned sbps = bps;                                       // side channels carry one extra bit, :1578-1585
         if ((asg == AFG_FLAC_LEFT_SIDE || asg == AFG_FLAC_MID_SIDE) && c == 1) sbps++;

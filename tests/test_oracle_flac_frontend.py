@@ -272,3 +272,32 @@ def test_the_end_of_a_stream_as_the_references_rice_loop_reads_it():
         for cut in range(len(base) - 300, len(base) + 1):
             ok, _ = _product_vs_oracle(base[:cut])
             assert ok, (k, cut, len(base))
+
+
+def test_wasted_bits_are_counted_in_a_byte():
+    """drflac.d:1563: wastedBitsPerSample = cast(ubyte)(cast(ubyte)count + 1) -- 276 zeros in front of the stop bit are 21
+    wasted bits, not 277 (found by the soak's wider generators: a damaged 24-bit file; the product had refused the frame).
+    A hand-made stream: one frame of 16 samples, one constant subframe with that count."""
+    bits = []
+
+    def put(v, n):
+        bits.extend((v >> (n - 1 - i)) & 1 for i in range(n))
+    # STREAMINFO: block sizes 16 / 16, frame sizes 0 / 0, 44100 Hz, 1 channel, 24 bits, 16 samples, MD5 0
+    put(16, 16); put(16, 16); put(0, 24); put(0, 24); put(44100, 20); put(0, 3); put(23, 5); put(16, 36); put(0, 128)
+    info = bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+    bits.clear()
+    # frame header: sync, reserved, fixed blocking, block size code 6 (8-bit value follows), rate from STREAMINFO,
+    # channel assignment 0 (mono), sample size from STREAMINFO, reserved, frame number 0, block size - 1, CRC-8
+    put(0x3FFE, 14); put(0, 1); put(0, 1); put(6, 4); put(0, 4); put(0, 4); put(0, 3); put(0, 1); put(0, 8); put(15, 8); put(0xAB, 8)
+    put(0x01, 8)                      # subframe: constant, wasted-bits flag
+    put(0, 276); put(1, 1)            # the count
+    put(0b101, 3)                     # 24 - 21 = 3 bits of constant: -3
+    while len(bits) % 8: bits.append(0)
+    put(0x1234, 16)                   # CRC-16 (not verified)
+    frame = bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+    data = b"fLaC" + bytes([0x80, 0, 0, 34]) + info + frame
+    o = oraclelib.flac_decode_file(data)
+    assert not isinstance(o, int) and o["n_frames"] == 1 and o["flags"] == 0
+    assert (o["pcm"] == (-3 << 21 << 8)).all() and len(o["pcm"]) == 16
+    ok, n = _product_vs_oracle(data)
+    assert ok and n == 16

@@ -191,7 +191,7 @@ def run(rounds, seed=2024, streams=True):
                     continue
                 print("product rejected", kind, out["message"]); bad += 1; continue
             n_ok += 1
-            got = out["pcm"]
+            got = out["pcm"] if out["pcm"] is not None else np.zeros((0, max(1, out["channels"])), np.float32)
             if streams and out["frames"] > 0:
                 # the same bytes pulled through the AudioStream surface in odd-sized reads: chunked decoding must deliver the
                 # batch path's samples bit for bit
