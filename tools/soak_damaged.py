@@ -81,11 +81,11 @@ def want_ogg(data):
         # fields read as zeros, "no segments", and the next packet takes the PREVIOUS page's first lacing value and reads
         # zeros past the end -- a short block of silence.  The product stops at the cut header: either length is accepted
         # for such a file (counted), the samples before it must agree.
+        # (likewise a packet that continues onto a page that is not there: upstream decodes the part it has, the product ends
+        #  the stream in front of it)
         n = len(rec["pflags"])
         if n and not rec["pflags"][-1] & 1 and rec["take_count"][-1] > 0:
-            ch, n2 = rec["channels"], rec["blocksize0"] // 2
-            if not np.any(rec["spec"][-ch * n2:]):
-                OGG_PHANTOM[len(data)] = int(rec["pcm_frames"]) - int(rec["take_count"][-1])
+            OGG_PHANTOM[len(data)] = int(rec["pcm_frames"]) - int(rec["take_count"][-1])
     pcm = oraclelib.vorbis_file_pcm(rec)
     bs0, bs1, prev = rec["blocksize0"], rec["blocksize1"], 0
     for q, fl in enumerate(rec["pflags"]):
