@@ -1001,21 +1001,38 @@ bool open_stream(const uint8_t *data, size_t size, File &f, Demux &dm, Setup &st
     st.rate = f.sample_rate;
     st.bs[0] = f.blocksize0;
     st.bs[1] = f.blocksize1;
-    {   // comment header (:2736-2786): type 3, "vorbis", framing bit after the comments
+    {   // comment header (:2736-2786): type 3, "vorbis", vendor, comments, framing bit.  The reference reads it with
+        // get8_packet, which answers EOP (-1) past the end of the packet, and get32_packet, which adds four such answers up
+        // (:1199-1207): lengths that a damaged byte has made longer than the packet run into the end, the framing "byte" read
+        // there is 0xff, and the header passes.  What fails is an allocation: setup_malloc of a size that is not positive
+        // (a length of -1 or less -- which is also what four EOPs add up to).  Sizes up to 2 GB are taken to succeed.
         const Packet &p = dm.packets[1];
         if (!p.complete) return false;
         Bits br(data, dm.pieces.data() + p.first_piece, p.n_pieces);
-        if (br.get(8) != 3) return false;
+        auto g8 = [&]() -> int { return br.exhausted() ? -1 : (int)br.get(8); };
+        auto g32 = [&]() -> int32_t {
+            uint32_t x = (uint32_t)g8();
+            x += (uint32_t)g8() << 8;
+            x += (uint32_t)g8() << 16;
+            x += (uint32_t)g8() << 24;
+            return (int32_t)x;
+        };
+        auto allocates = [](int32_t sz) { return (int32_t)(((uint32_t)sz + 3u) & ~3u) > 0; };      // setup_malloc (:556-567)
+        auto skip = [&](int32_t len) { for (int32_t i = 0; i < len && !br.exhausted(); i++) br.get(8); };
+        if (g8() != 3) return false;
         for (const char *c = "vorbis"; *c; c++)
-            if (br.get(8) != (uint8_t)*c) return false;
-        uint32_t len = br.get(32);
-        for (uint32_t i = 0; i < len && !br.invalid; i++) br.get(8);
-        const uint32_t ncomm = br.get(32);
-        for (uint32_t k = 0; k < ncomm && !br.invalid; k++) {
-            len = br.get(32);
-            for (uint32_t i = 0; i < len && !br.invalid; i++) br.get(8);
+            if ((uint8_t)g8() != (uint8_t)*c) return false;
+        int32_t len = g32();
+        if (!allocates((int32_t)((uint32_t)len + 1u))) return false;
+        skip(len);
+        const int32_t ncomm = g32();
+        if (ncomm > 0 && !allocates((int32_t)(8u * (uint32_t)ncomm))) return false;
+        for (int32_t k = 0; k < ncomm; k++) {
+            len = g32();
+            if (!allocates((int32_t)((uint32_t)len + 1u))) return false;
+            skip(len);
         }
-        if (!(br.get(8) & 1)) return false;
+        if (!((uint8_t)g8() & 1)) return false;
     }
     {   // setup header
         const Packet &p = dm.packets[2];

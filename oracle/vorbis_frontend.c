@@ -784,15 +784,23 @@ static int start_decoder(vorb *f)
     if (get8_packet(f) != 3) return verror(f, 8);
     for (i = 0; i < 6; ++i) header[i] = (uint8_t)get8_packet(f);
     if (memcmp(header, "vorbis", 6)) return verror(f, 8);
+    /* (the vendor string and the comments are copied into setup_malloc'ed memory, vb:2741-2765; setup_malloc (vb:556-567)
+       rounds its int size up to a multiple of four and answers NULL for one that is not positive -- the open fails with
+       outofmem.  Positive sizes are taken to succeed.) */
+#define AFGO_ALLOCATES(sz) ((int32_t)(((uint32_t)(sz) + 3u) & ~3u) > 0)
     len = get32_packet(f);
+    if (!AFGO_ALLOCATES((uint32_t)len + 1u)) return verror(f, 3);
     for (i = 0; i < len; ++i) get8_packet(f);
     {
         int n_comments = get32_packet(f);
+        if (n_comments > 0 && !AFGO_ALLOCATES(8u * (uint32_t)n_comments)) return verror(f, 3);
         for (i = 0; i < n_comments; ++i) {
             len = get32_packet(f);
+            if (!AFGO_ALLOCATES((uint32_t)len + 1u)) return verror(f, 3);
             for (j = 0; j < len; ++j) get8_packet(f);
         }
     }
+#undef AFGO_ALLOCATES
     x = (uint8_t)get8_packet(f);
     if (!(x & 1)) return verror(f, 8);
     if (!skip_bytes(f, f->bytes_in_seg)) return verror(f, 8);

@@ -223,3 +223,23 @@ def test_residue_records_of_damaged_files():
             pos = int(rng.integers(4000, len(v)))
             v[pos] ^= 1 << int(rng.integers(0, 8))
         same_spectra_through_records(bytes(v))
+
+
+def test_a_comment_header_whose_lengths_overrun_the_packet():
+    """stb_vorbis2.d:2736-2770: the comment header is read with get8_packet / get32_packet, which answer EOP (-1) past the end
+    of the packet -- a vendor length that a flipped bit has made 512 MB runs into the end, the comment count read there is
+    negative, the framing "byte" 0xff: the header passes and the stream decodes (tests/golden/soak_r05_vendor_length.ogg, a
+    damaged generated file).  What fails in the reference is an allocation of a size that is not positive: a vendor or
+    comment length of -1 or less."""
+    import struct
+    here = os.path.dirname(os.path.abspath(__file__))
+    data = open(os.path.join(here, "golden", "soak_r05_vendor_length.ogg"), "rb").read()
+    got, want = same_records(data)
+    assert want is not None and len(want["pflags"]) == 24 and want["pcm_frames"] > 10000
+    # the same file with the vendor length set to -1 and to 0x7fffffff (len + 1 wraps): refused by both
+    at = data.index(b"\x03vorbis") + 7
+    for bad in (-1, 0x7fffffff, -2000):
+        blob = data[:at] + struct.pack("<i", bad) + data[at + 4:]
+        assert oraclelib.vorbis_decode_file(blob) is None
+        with pytest.raises(afgpu.AfgError):
+            afgpu.vorbis_parse(blob)
