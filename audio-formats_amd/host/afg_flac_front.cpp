@@ -120,7 +120,6 @@ bool flac_open(const uint8_t *d, size_t n, FlacInfo &fi)
         const unsigned type = d[pos] & 0x7f;
         const size_t len = ((size_t)d[pos + 1] << 16) | ((size_t)d[pos + 2] << 8) | d[pos + 3];
         pos += 4;
-        if (pos + len > n) return false;
         if (pos == 8 && (type != 0 || len != 34)) return false;    // the first block is STREAMINFO, 34 bytes (drflac.d:2139-2141)
         if (type == 0 && pos == 8) {
             BitReader br(d + pos, len);
@@ -133,11 +132,17 @@ bool flac_open(const uint8_t *d, size_t n, FlacInfo &fi)
             fi.total_samples = br.bits(36);
             got = true;
         }
-        pos += len;
+        // The blocks behind STREAMINFO are skipped by a seek that never fails and stops at the end of the data
+        // (drflac.d:2103-2106, stream.d:2227-2239): a block longer than the file is no error -- if it is the last one the
+        // stream opens and holds no frames (a STREAMINFO whose last-block flag a damaged byte cleared makes the first
+        // frame's bytes such a block).
+        pos = len > n - pos ? n : pos + len;
         if (last) break;
     }
     fi.first_frame = pos;
-    return got && fi.sample_rate != 0 && fi.bps >= 4;
+    // (STREAMINFO's rate and sample size are not validated by the reference: a damaged 0 Hz or 3-bit claim opens, frames
+    //  decode by their own headers and drflac_read_s32 shifts by 32 minus the claim, :2883)
+    return got;
 }
 
 
