@@ -119,6 +119,7 @@ def dump_bad(tag, r, kind, d):
 
 
 WIDE = bool(os.environ.get("AFG_SOAK_WIDE"))
+HDR = bool(os.environ.get("AFG_SOAK_HDR"))          # the damage may land in the headers too
 
 
 def run(rounds, seed=2024, streams=True):
@@ -148,7 +149,7 @@ def run(rounds, seed=2024, streams=True):
                                              use_fixed_every=(1000, 3)[int(rng.integers(0, 2))])
                 else:
                     base, _ = fb.encode_file(make_pcm(int(rng.integers(2000, 20000)), 2, 16, int(rng.integers(0, 1 << 30))), 16, 4096, orders=(8, 12, 2))
-                d = damage(base, 42 if not WIDE else (42, 8)[int(rng.integers(0, 2))])
+                d = damage(base, 4 if HDR else 42 if not WIDE else (42, 8)[int(rng.integers(0, 2))])
                 w = want_flac(d)
             elif kind == "mp3":
                 if WIDE:                                             # MPEG-2 / 2.5 rates, intensity stereo, free choice of the sampling rate
@@ -163,7 +164,7 @@ def run(rounds, seed=2024, streams=True):
                 w = want_mp3(d)
             elif kind == "opus":
                 base = ob.random_celt_file(rng, int(rng.integers(1, 3)), int(rng.integers(10, 40)), pcm_rms=0.05)[0]
-                d = damage(base, len(base) // 2)
+                d = damage(base, 28 if HDR else len(base) // 2)
                 w = want_opus(d)
             else:
                 base = None
@@ -175,7 +176,7 @@ def run(rounds, seed=2024, streams=True):
                         base = vb.make_file(int(rng.integers(0, 1 << 20)), channels=ch, bs=bs, n_packets=30, force_long_only=bool(rng.integers(0, 2)))
                     except ValueError:
                         pass
-                d = damage(base, len(base) // 3)
+                d = damage(base, 60 if HDR else len(base) // 3)
                 w = want_ogg(d)
             files.append(d); wants.append(w); kinds.append(kind)
         res = afgpu.batch_decode(files, n_threads=4)
