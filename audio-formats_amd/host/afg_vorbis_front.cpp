@@ -130,6 +130,20 @@ struct Bits {
     int have = 0;
     bool dry = false;        // no more bytes
     bool invalid = false;    // a fixed-width read ran past the end (valid_bits == INVALID_BITS)
+    // The reference fetches the packet a byte at a time (:1126-1184) and its accumulator is zero above the bits fetched:
+    // `sv` is ITS count of fetched, unread bits at this point of the packet.  Only a word that is not in the book looks
+    // at it (miss() below: the search over the sorted words compares all 32 bits of the accumulator).
+    int sv = 0;
+    void sv_take(int n)
+    {
+        if (sv < n) sv += 8 * ((n - sv + 7) / 8);
+        sv -= n;
+    }
+    void sv_prefetch()                                   // prep_huffman, :1186-1198
+    {
+        fill();
+        while (sv <= 24 && sv + 8 <= have) sv += 8;
+    }
     Bits(const uint8_t *data, const Piece *p, size_t np) : d(data), pc(p), n_pieces(np) {}
     void fill()
     {
@@ -155,6 +169,7 @@ struct Bits {
         const uint32_t v = (uint32_t)(acc & ((n >= 32) ? 0xffffffffull : ((1ull << n) - 1)));
         acc >>= n;
         have -= n;
+        sv_take(n);
         return v;
     }
     bool exhausted() { fill(); return have == 0; }
@@ -180,6 +195,12 @@ struct Book {
     // vector of a different entry (:1344-1444 with :2987-2997).  The same happens here.
     std::vector<int32_t> rank;                // empty: index by symbol
     int vec(int sym) const { return rank.empty() ? sym : rank[(size_t)sym]; }
+    // The reference's sorted word list (:776-828): every word of a book that stays sparse, the words of more than 10
+    // bits of any other; left-aligned, ascending.  A stream word that is NOT in the book (possible only in a book whose
+    // lengths leave the tree incomplete) is read by the reference as the nearest listed word below it (:1211-1240).
+    std::vector<uint32_t> sorted_word;
+    std::vector<int32_t> sorted_sym;
+    bool search = false;                      // the reference decodes a table miss by that search (else: exact match only)
 };
 constexpr int kFast = 10;
 constexpr int32_t kNone = 0x7fffffff;
@@ -234,6 +255,21 @@ void leaf_order(const Book &b, int32_t node, std::vector<int32_t> &order)
     }
 }
 
+void leaf_words(const Book &b, int32_t node, uint32_t prefix, int depth, bool all, std::vector<uint32_t> &words,
+                std::vector<int32_t> &syms)
+{
+    for (int v = 0; v < 2; v++) {
+        const int32_t c = b.tree[(size_t)node].child[v];
+        if (c == kNone) continue;
+        const uint32_t p = prefix | ((uint32_t)v << (31 - depth));
+        if (c >= 0) { leaf_words(b, c, p, depth + 1, all, words, syms); continue; }
+        const int sym = -(c + 1);
+        if (!all && b.len[(size_t)sym] <= kFast) continue;
+        words.push_back(p);
+        syms.push_back(sym);
+    }
+}
+
 bool build_decoder(Book &b)
 {
     b.fast.assign(1 << kFast, -1);
@@ -271,31 +307,69 @@ bool build_decoder(Book &b)
     return true;
 }
 
+// valid_bits = 0: the reference drops the bits it has fetched -- the bytes behind them are still to come (a word that is
+// not in the book can fail in the middle of a packet, and the floor decode reads on, :3132-3150)
+inline int no_symbol(Bits &br)
+{
+    br.acc = br.sv >= 64 ? 0 : br.acc >> br.sv;
+    br.have -= br.sv;
+    br.sv = 0;
+    return -1;
+}
+
+// codebook_decode_scalar_raw's search (:1211-1240): the last listed word that is <= the 32 accumulator bits, taken
+// with ITS length whether or not it is a prefix of them
+int search_symbol(Bits &br, const Book &b)
+{
+    uint32_t a = (uint32_t)br.acc;
+    if (br.sv < 32) a &= (1u << br.sv) - 1;
+    uint32_t code = 0;
+    for (int i = 0; i < 32; i++) code |= ((a >> i) & 1u) << (31 - i);
+    int x = 0, n = (int)b.sorted_word.size();
+    while (n > 1) {
+        const int m = x + (n >> 1);
+        if (b.sorted_word[(size_t)m] <= code) { x = m; n -= n >> 1; }
+        else n >>= 1;
+    }
+    const int sym = b.sorted_sym[(size_t)x];
+    const int l = b.len[(size_t)sym];
+    if (br.sv < l) return no_symbol(br);
+    br.acc >>= l;
+    br.have -= l;
+    br.sv -= l;
+    return sym;
+}
+
 // one symbol, or -1 at the end of the packet / on a word that is not in the book (:1211-1286)
 int symbol(Bits &br, const Book &b)
 {
     if (!b.usable) return -1;
     if (br.have < 32) br.fill();
+    if (br.sv < kFast) br.sv_prefetch();
     int32_t e = b.fast[(size_t)(br.acc & ((1u << kFast) - 1))];
     if (e >= 0) {
         const int l = b.len[(size_t)e];
-        if (br.have < l) { br.have = 0; br.acc = 0; return -1; }
+        if (br.sv < l) return no_symbol(br);
         br.acc >>= l;
         br.have -= l;
+        br.sv -= l;
         return e;
     }
-    if (e == -1) { br.have = 0; br.acc = 0; return -1; }
+    br.sv_prefetch();
+    if (b.search) return search_symbol(br, b);
+    if (e == -1) return no_symbol(br);
     int32_t node = -(e + 2);
     int used = kFast;
     for (;;) {
-        if (used >= br.have) { br.have = 0; br.acc = 0; return -1; }
+        if (used >= br.sv) return no_symbol(br);
         const int v = (int)((br.acc >> used) & 1);
         used++;
         const int32_t nx = b.tree[(size_t)node].child[v];
-        if (nx == kNone) { br.have = 0; br.acc = 0; return -1; }
+        if (nx == kNone) return no_symbol(br);
         if (nx < 0) {
             br.acc >>= used;
             br.have -= used;
+            br.sv -= used;
             return -(nx + 1);
         }
         node = nx;
@@ -392,6 +466,8 @@ bool read_setup(Bits &br, Setup &st)
             b.rank.assign((size_t)b.entries, 0);
             for (size_t k = 0; k < order.size(); k++) b.rank[(size_t)order[k]] = (int32_t)k;
         }
+        leaf_words(b, 0, 0u, 0, stays_sparse, b.sorted_word, b.sorted_sym);
+        b.search = b.entries > 8 ? !b.sorted_word.empty() : stays_sparse;     // :1214
         b.lookup = (int)br.get(4);
         if (b.lookup > 2) return false;
         if (b.lookup > 0) {
