@@ -11,9 +11,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-def soak(seed):
+def soak(seed, headers=False):
     import soak_damaged
-    ok, rejected, bad = soak_damaged.run(4, seed)
+    before = soak_damaged.HDR
+    soak_damaged.HDR = headers
+    try:
+        ok, rejected, bad = soak_damaged.run(4, seed)
+    finally:
+        soak_damaged.HDR = before
     assert bad == 0 and ok >= 20
 
 
@@ -24,3 +29,9 @@ def test_damaged_files_exact_mode(gpu):
 @pytest.mark.numeric_tolerance
 def test_damaged_files_default_mode(gpu):
     soak(8)
+
+
+@pytest.mark.numeric_tolerance
+def test_files_with_damaged_headers_too(gpu):
+    """AFG_SOAK_HDR: the damage may land in the stream headers (the class that found the incomplete Vorbis code books)"""
+    soak(9, headers=True)
