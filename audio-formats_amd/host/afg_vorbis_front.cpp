@@ -134,10 +134,11 @@ struct Bits {
     // `sv` is ITS count of fetched, unread bits at this point of the packet.  Only a word that is not in the book looks
     // at it (miss() below: the search over the sorted words compares all 32 bits of the accumulator).
     int sv = 0;
-    void sv_take(int n)
+    void sv_take(int n)                                  // (called after `have -= n`: sv <= have, equal modulo 8)
     {
         if (sv < n) sv += 8 * ((n - sv + 7) / 8);
         sv -= n;
+        if (sv > have) sv = have;
     }
     void sv_prefetch()                                   // prep_huffman, :1186-1198
     {
@@ -164,6 +165,7 @@ struct Bits {
             invalid = true;
             have = 0;
             acc = 0;
+            sv = 0;
             return 0;
         }
         const uint32_t v = (uint32_t)(acc & ((n >= 32) ? 0xffffffffull : ((1ull << n) - 1)));

@@ -245,14 +245,17 @@ def test_a_comment_header_whose_lengths_overrun_the_packet():
             afgpu.vorbis_parse(blob)
 
 
-@pytest.mark.parametrize("name", ["soak_r05_book_miss_sorted_a.ogg", "soak_r05_book_miss_sorted_b.ogg", "soak_r05_book_miss_linear.ogg"])
+@pytest.mark.parametrize("name", ["soak_r05_book_miss_sorted_a.ogg", "soak_r05_book_miss_sorted_b.ogg", "soak_r05_book_miss_linear.ogg",
+                                  "soak_r05_read_past_packet_end.ogg"])
 def test_code_books_whose_lengths_leave_the_tree_incomplete(name):
     """A flipped bit in a code-word length of the setup header: the book still opens (stb_vorbis2.d:691-737 refuses only a
     length list with too many words), and the stream now holds words that are not in it.  The reference reads such a word
     through its sorted list as the nearest listed word below it, taken with that word's length (:1211-1240: books of more
     than 8 entries that list any word -- the `sorted` files), or fails the symbol, drops the bits it has fetched and reads on
     from the next byte (:1242-1262 -- the `linear` file, where the floor decode continues behind the failure).  Damaged
-    generated files found by the header-damage soak (tools/soak_damaged.py, AFG_SOAK_HDR=1)."""
+    generated files found by the header-damage soak (tools/soak_damaged.py, AFG_SOAK_HDR=1).  The last file is the other end of
+    the fetched-bit count the search needs: a fixed-width read that runs past the end of a packet (valid_bits = INVALID_BITS)
+    followed by a symbol decode, which must then fail (:1154-1198)."""
     here = os.path.dirname(os.path.abspath(__file__))
     data = open(os.path.join(here, "golden", name), "rb").read()
     got, want = same_records(data)
