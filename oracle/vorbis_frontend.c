@@ -1378,13 +1378,7 @@ static uint32_t stream_length_in_samples(vorb *f)
 
 static void free_all(vorb *f)
 {
-    for (int i = 0; i < f->codebook_count && f->codebooks; i++) {
-        Codebook *c = f->codebooks + i;
-        free(c->codeword_lengths); free(c->multiplicands); free(c->codewords); free(c->sorted_codewords); free(c->sorted_values_base);
-    }
-    free(f->codebooks);
-    free(f->floor_config);
-    for (int i = 0; i < f->residue_count && f->residue_config; i++) {
+    for (int i = 0; i < f->residue_count && f->residue_config; i++) {      /* (reads the class book's entry count: first) */
         Residue *r = f->residue_config + i;
         if (r->classdata && f->codebooks)
             for (int j = 0; j < f->codebooks[r->classbook].entries; j++) free(r->classdata[j]);
@@ -1392,6 +1386,12 @@ static void free_all(vorb *f)
         free(r->residue_books);
     }
     free(f->residue_config);
+    for (int i = 0; i < f->codebook_count && f->codebooks; i++) {
+        Codebook *c = f->codebooks + i;
+        free(c->codeword_lengths); free(c->multiplicands); free(c->codewords); free(c->sorted_codewords); free(c->sorted_values_base);
+    }
+    free(f->codebooks);
+    free(f->floor_config);
     for (int i = 0; i < f->mapping_count && f->mapping; i++) free(f->mapping[i].chan);
     free(f->mapping);
     for (int i = 0; i < MAX_CH; i++) { free(f->channel_buffers[i]); free(f->finalY[i]); }
