@@ -62,7 +62,7 @@ uint32_t rd32(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) | ((uint32
 // pattern, bad version, truncated page, a fresh packet on a page flagged "continued").
 void demux(const uint8_t *d, size_t n, Demux &dm)
 {
-    size_t pos = 0;
+    size_t pos = 0, n_page = 0;
     bool open_packet = false;
     Packet cur;
     while (pos + 27 <= n) {
@@ -76,7 +76,11 @@ void demux(const uint8_t *d, size_t n, Demux &dm)
         if (lo != 0xffffffffu || hi != 0xffffffffu)
             for (int i = nseg - 1; i >= 0; --i)
                 if (lac[i] < 255) { last_complete = i; break; }
-        if (open_packet != ((flags & 1) != 0)) {
+        // (the page the comment header starts on is opened by start_decoder itself, stb_vorbis2.d:2732, not by start_packet :1056-1069: nobody
+        //  looks at its "continued" flag)
+        const bool unchecked = n_page == 1 && !open_packet;
+        n_page++;
+        if (!unchecked && open_packet != ((flags & 1) != 0)) {
             // continued flag without an open packet, or an open packet on a page that does not continue it
             if (open_packet) { cur.complete = false; dm.packets.push_back(cur); }
             break;

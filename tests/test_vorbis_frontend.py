@@ -261,3 +261,15 @@ def test_code_books_whose_lengths_leave_the_tree_incomplete(name):
     got, want = same_records(data)
     assert want is not None and len(want["pflags"]) == 8
     same_spectra_through_records(data)
+
+
+def test_the_continued_flag_of_the_comment_headers_page_is_not_looked_at():
+    """stb_vorbis2.d:2732: start_decoder opens the second page itself (start_page, then start_packet with a page already
+    open), so the check start_packet makes when IT turns a page (:1056-1069 and :1071-1090, "continued packet flag invalid") never sees
+    that page's flag.  A generated file with that one bit set decodes in the reference; on any later page the same bit
+    ends the stream."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    data = open(os.path.join(here, "golden", "soak_r05_comment_page_continued.ogg"), "rb").read()
+    assert data[58:62] == b"OggS" and data[58 + 5] & 1
+    got, want = same_records(data)
+    assert want is not None and len(want["pflags"]) == 8
