@@ -1010,7 +1010,12 @@ bool find_page(const uint8_t *d, size_t n, size_t from, size_t &start, size_t &e
 {
     crc_init();
     for (size_t p = from; p + 27 <= n; p++) {
-        if (d[p] != 0x4f || std::memcmp(d + p, "OggS", 4) || d[p + 4] != 0) continue;
+        if (d[p] != 0x4f) continue;
+        // `if (retry_loc - 25 > f.stream_len) return 0` (stb_vorbis2.d:3407) with retry_loc = p + 1, unsigned: an 'O' in the
+        // first 24 bytes of the data ends the search -- the length scan of a short file whose headers end inside a page
+        // (first_audio_page_offset = 0) starts there and so reports no length
+        if (p < 24) return false;
+        if (std::memcmp(d + p, "OggS", 4) || d[p + 4] != 0) continue;
         const int nseg = d[p + 26];
         if (p + 27 + (size_t)nseg > n) return false;
         size_t len = 0;

@@ -273,3 +273,14 @@ def test_the_continued_flag_of_the_comment_headers_page_is_not_looked_at():
     assert data[58:62] == b"OggS" and data[58 + 5] & 1
     got, want = same_records(data)
     assert want is not None and len(want["pflags"]) == 8
+
+
+def test_no_stream_length_when_the_page_search_starts_at_the_top_of_the_file():
+    """stb_vorbis2.d:3407: `if (retry_loc - 25 > f.stream_len) return 0` is unsigned, so a page search that meets an 'O' in
+    the first 24 bytes of the file gives up.  The length scan starts at first_audio_page_offset when the file is shorter
+    than 64 KB, and that is 0 when the setup header does not end its page (here: a damaged lacing value cuts it one byte
+    short): such a file reports no length (0) although its last page carries one."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    data = open(os.path.join(here, "golden", "soak_r05_headers_end_inside_a_page.ogg"), "rb").read()
+    got, want = same_records(data)
+    assert want is not None and want["total_samples"] == 0 and got["total_samples"] == 0
