@@ -57,6 +57,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-others", action="store_true",
                     help="skip `other_workloads` (the side-by-side step; the C5 corpus, dense CELT, QOA and the end-to-end batches, each in "
                          "a child process after the headline measurement; only at N = 1 with the default config)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the full record as the (only) stdout line instead of the compact line (what this script's own child "
+                         "runs and the tools that post-process a run read)")
+    ap.add_argument("--full-record", default="", help="where the full record goes (default: gpurun_out/bench_full.json under the repo)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: ranks beyond the visible devices share them (rank %% devices); the line says so")
     return ap.parse_args(argv)
@@ -247,7 +251,7 @@ def other_workloads(args):
             return None, f"exit code {r.returncode}: {r.stderr.decode()[-400:]}", time.perf_counter() - t0
         return json.loads(lines[-1]), (None if r.returncode == 0 else f"exit code {r.returncode}"), time.perf_counter() - t0
 
-    d, err, wall = child([os.path.abspath(__file__), "--config", "c5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+    d, err, wall = child([os.path.abspath(__file__), "--config", "c5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--full-line",
                           "--c5-files", str(args.c5_files)], 420)
     if d is None:
         out["c5"] = {"error": err}
@@ -264,7 +268,7 @@ def other_workloads(args):
     t0 = time.perf_counter()
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "5", "--warmup", "1", "--no-cpu-baseline",
-                            "--no-others", "--files", str(args.files)], env=env32, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+                            "--no-others", "--full-line", "--files", str(args.files)], env=env32, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
         d = json.loads(lines[-1]) if lines else None
         err = None if (d is not None and r.returncode == 0) else f"exit code {r.returncode}: {r.stderr.decode()[-300:]}"
@@ -312,6 +316,135 @@ def other_parity_failures(others):
         if rec.get("all_ok") is False:
             bad.append(f"{name}: not all files decoded")
     return bad
+
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the printed line: compact (what the driver parses); the full record goes to a file
+# ----------------------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 6000            # characters; the driver keeps an 8 KB tail of stdout and parses its last JSON line
+
+
+def _sig(x, digits=5):
+    """Numbers to `digits` significant figures (ints and everything else unchanged): the line is a summary."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{digits}g}")
+
+
+def _pick(d, keys):
+    return {k: _sig(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(full, full_record_path=None):
+    """The one JSON line `bench.py` prints: the contract's keys, `roofline`, `cpu_baseline`, parity per codec and ONE
+    number (or a short tuple of numbers) per `other_workloads` leg.  Everything else -- notes, per-window timings, per-file
+    lists, workload prose -- is in the full record (`full_record_path`).  Never longer than COMPACT_LIMIT characters:
+    optional blocks are dropped from the end until it fits."""
+    r = full.get("roofline") or {}
+    out = {k: _sig(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                          "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg[k] for k in ("workload", "name", "samples_per_step", "files_per_gpu", "files", "waves_per_gpu", "parallelism") if k in cfg}
+    if len(out["config"].get("workload", "")) > 330:
+        out["config"]["workload"] = out["config"]["workload"][:327] + "..."
+    roof = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "frac_by_traffic", "kernel", "codec", "avg_kernel_ms",
+                     "algorithmic_bytes_per_launch", "measured_copy_GBs"))
+    if "kernel" in roof:
+        roof["kernel"] = str(roof["kernel"]).split(" ")[0]
+    roof.setdefault("traffic", None)
+    roof["kernels"] = [dict(_pick(k, ("codec", "avg_kernel_ms", "frac", "traffic", "algorithmic_bytes_per_launch", "samples_per_launch")),
+                            kernel=str(k.get("kernel", "")).split(" ")[0]) for k in r.get("kernels", [])]
+    if r.get("whole_step"):
+        roof["whole_step"] = _pick(r["whole_step"], ("algorithmic_bytes", "kernel_ms", "frac"))
+    for leg in ("mp3_full_fetch", "vorbis_full_fetch", "celt_alone"):
+        if r.get(leg):
+            roof[leg] = _pick(r[leg], ("avg_kernel_ms", "frac"))
+    out["roofline"] = roof
+    cpu = full.get("cpu_baseline")
+    out["cpu_baseline"] = None if cpu is None else dict(_pick(cpu, ("value", "unit", "cores", "kind", "single_thread_value")),
+                                                        sample=str(cpu.get("sample", ""))[:160])
+    out["parity"] = {c: _pick(p, ("mismatches", "rms_error", "rms_signal", "samples")) for c, p in (full.get("parity") or {}).items()}
+    if full.get("oversubscribed"):
+        out["oversubscribed"] = full["oversubscribed"]
+    ow = full.get("other_workloads") or {}
+    others = {}
+    for name, rec in ow.items():
+        if not isinstance(rec, dict):
+            continue
+        if rec.get("error") and len([k for k in rec if k != "error"]) == 0:
+            others[name] = {"error": str(rec["error"])[:120]}
+            continue
+        if name == "c5":
+            e = _pick(rec, ("value", "ms_per_step", "samples_per_step", "n_gpus", "efficiency_vs_n1"))
+            e["kernel_ms"] = {k.get("codec"): _sig(k.get("avg_kernel_ms"), 4) for k in rec.get("kernels", [])}
+            if isinstance(rec.get("celt_alone"), dict):
+                e["celt_alone_ms"] = _sig(rec["celt_alone"].get("avg_kernel_ms"), 4)
+            par = rec.get("parity") or {}
+            e["mismatches"] = sum(int(p.get("mismatches") or 0) for p in par.values() if isinstance(p, dict))
+        elif name.endswith("_e2e"):
+            e = {"value": _sig(rec.get("samples_per_s_end_to_end")), "cpu": _sig((rec.get("cpu_baseline_e2e") or {}).get("value")),
+                 "vs_cpu": _sig(rec.get("vs_cpu_baseline_e2e"), 4), "ok": rec.get("all_ok")}
+            par = rec.get("parity") or {}
+            blocks = list(par.values()) if par and all(isinstance(v, dict) for v in par.values()) else [par]
+            e["mismatches"] = sum(int(b.get("mismatches") or 0) for b in blocks)
+        elif name == "device_inclusive":
+            e = {c: _sig(v.get("samples_per_s_device_inclusive")) for c, v in rec.items() if isinstance(v, dict)}
+        elif name in ("vorbis_shapes", "flac_shapes"):
+            e = {"shapes": [[s.get("label") or f"{s.get('channels')}ch/{s.get('blocksize_0')}/{s.get('blocksize_1')}", _sig(s.get("avg_kernel_ms"), 4),
+                             _sig(s.get("frac"), 3)] for s in rec.get("shapes", [])], "cols": ["shape", "kernel_ms", "frac"]}
+            bad = [s for s in rec.get("shapes", []) if s.get("mismatches") or (s.get("rms_error") is not None and not s["rms_error"] <= 1e-5)]
+            e["parity_failures"] = len(bad)
+        elif name == "c234_side_by_side":
+            e = _pick(rec, ("ms_per_step", "value", "frac_of_peak"))
+            e["mismatches"] = sum(int(m or 0) for m in (rec.get("mismatches_by_codec") or {}).values())
+        else:
+            e = _pick(rec, ("avg_kernel_ms", "frac", "samples_per_s", "mismatches", "bitwise_mismatches", "rms_vs_oracle", "int16_flip_rate"))
+            if isinstance(rec.get("parity"), dict) and "mismatches" in rec["parity"]:
+                e["mismatches"] = rec["parity"]["mismatches"]
+        if rec.get("error"):
+            e["error"] = str(rec["error"])[:120]
+        others[name] = e
+    if others:
+        out["other_workloads"] = others
+    if full_record_path:
+        out["full_record"] = full_record_path
+    # the bound is a contract: shed optional detail, least important first, until the line fits
+    shed = [("other_workloads", "vorbis_shapes"), ("other_workloads", "flac_shapes"), ("other_workloads", "device_inclusive"),
+            ("other_workloads", None), ("roofline", "whole_step"), ("roofline", "mp3_full_fetch"), ("roofline", "vorbis_full_fetch")]
+    text = json.dumps(out)
+    while len(text) > COMPACT_LIMIT and shed:
+        top, sub = shed.pop(0)
+        if top in out:
+            if sub is None:
+                out.pop(top)
+            elif isinstance(out[top], dict):
+                out[top].pop(sub, None)
+        text = json.dumps(out)
+    if len(text) > COMPACT_LIMIT:
+        out["config"]["workload"] = out["config"].get("workload", "")[:120]
+        out["roofline"]["kernels"] = out["roofline"]["kernels"][:4]
+        text = json.dumps(out)
+    return text
+
+
+def emit(args, full):
+    """Full record -> file (and stdout for `--full-line`); compact line -> the last (normally the only) stdout line."""
+    if args.full_line:
+        print(json.dumps(full), flush=True)
+        return
+    path = args.full_record or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    rel = None
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(full, fh, indent=1)
+        rel = os.path.relpath(path, ROOT)
+    except OSError as e:
+        sys.stderr.write(f"bench.py: full record not written ({e})\n")
+    print(compact_line(full, rel), flush=True)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -583,18 +716,24 @@ def run_rank(args, world, rank, local_rank):
                         "traffic": tb, "frac_by_traffic": (tb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None,
                         "traffic_source": ("profiles/" + pmc_file[name]) if tb else None})
         if k.get("survey_bytes") and k["survey_bytes"] != k["alg_bytes"]:
-            # FLAC with int16 residual rows: the launch reads 2 B / sample where SURVEY 8(d) counts 4.  `frac` above is
-            # priced on the bytes this input format moves; the 8 B / sample figure is shown for comparison with round 1 only.
-            kernels[-1]["launch"] = ("the populated instantiations of flac_restore1_kernel (here LPC order <= 8 and <= 12) run side by side on two "
-                                     "streams: a kernel trace lists each with about this duration, and they overlap")
-            kernels[-1]["input_rows"] = "int16 residual rows (6 B / sample moved)"
-            kernels[-1]["bytes_at_8B_per_sample"] = int(k["survey_bytes"])
-            kernels[-1]["frac_at_8B_per_sample"] = k["survey_bytes"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # `frac` above is priced on the bytes this launch has to move; SURVEY 8(d)'s per-unit figure is shown beside it
+            kernels[-1]["bytes_at_survey_8d"] = int(k["survey_bytes"])
+            kernels[-1]["frac_at_survey_8d"] = k["survey_bytes"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if name == "flac":
+                # int16 residual rows: the launch reads 2 B / sample where SURVEY 8(d) counts 4 (8 B / sample with the store)
+                kernels[-1]["launch"] = ("the populated instantiations of flac_restore1_kernel (here LPC order <= 8 and <= 12) run side by side on two "
+                                         "streams: a kernel trace lists each with about this duration, and they overlap")
+                kernels[-1]["input_rows"] = "int16 residual rows (6 B / sample moved)"
+            elif name == "vorbis":
+                kernels[-1]["input_rows"] = ("packet flags declare the non-zero eighths of each long block's spectrum (AFG_VORBIS_NZ_EIGHTHS): "
+                                             "the zero tail above the residue's end is not fetched")
+            elif name == "mp3":
+                kernels[-1]["input_rows"] = "flag words declare the non-zero subbands of each block (AFG_MP3_NZ_BANDS): the zero tail is not fetched"
     dom = max(kernels, key=lambda d: d["avg_kernel_ms"])
     step_ms = sum(d["avg_kernel_ms"] for d in kernels)
     step_bytes = sum(d["algorithmic_bytes_per_launch"] for d in kernels)
     roofline = {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
-                "traffic": dom["traffic"], "frac_by_traffic": dom["frac_by_traffic"],
+                "traffic": dom["traffic"], "traffic_from": dom["traffic_source"], "frac_by_traffic": dom["frac_by_traffic"],
                 "kernel": dom["kernel"], "codec": dom["codec"], "avg_kernel_ms": dom["avg_kernel_ms"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                 "note": "dominant kernel = the codec with the largest share of a step's time; every kernel of the step is listed in `kernels`",
@@ -633,7 +772,7 @@ def run_rank(args, world, rank, local_rank):
     if extra.get("side_by_side"):
         line.setdefault("other_workloads", {})["c234_side_by_side"] = extra["side_by_side"]
         failed += [f"side_by_side:{n}" for n, m in extra["side_by_side"]["mismatches_by_codec"].items() if m]
-    print(json.dumps(line), flush=True)
+    emit(args, line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

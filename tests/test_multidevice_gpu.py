@@ -272,7 +272,7 @@ def test_bench_launches_its_own_ranks(gpu):
     assert line["value"] > 0 and {k["codec"] for k in line["roofline"]["kernels"]} == {"mp3", "vorbis", "flac", "celt"}
     # the default configuration at N > 1: the weak-scaling headline step, then BASELINE configs[4] (strong scaling) on the same ranks
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--files", "8", "--c5-files", "96",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-full-fetch"]
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-full-fetch", "--full-line"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
