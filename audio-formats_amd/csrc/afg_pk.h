@@ -44,3 +44,17 @@ AFG_PK(pk_mul_hl_hh, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[1,1]")            
 AFG_PK(pk_mul_lnh_ll, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]")          // (-a.x*b.y ,  a.x*b.x)
 AFG_PK(pk_mul_hnh_hl, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]")          // (-a.y*b.y ,  a.y*b.x)
 #undef AFG_PK
+
+// three-operand forms (fused: tolerance-mode kernels only)
+#define AFG_PK3(name, op, mods)                                                             \
+    __device__ __forceinline__ f2 name(f2 a, f2 b, f2 c)                                    \
+    {                                                                                       \
+        f2 r;                                                                               \
+        asm(op " %0, %1, %2, %3 " mods : "=v"(r) : "v"(a), "v"(b), "v"(c));                 \
+        return r;                                                                           \
+    }
+AFG_PK3(pk_fma_nhh_hl, "v_pk_fma_f32", "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]")   // (-a.y*b.y + c.x ,  a.y*b.x + c.y)
+#undef AFG_PK3
+
+// complex product in two packed instructions (fused multiply-adds: not the reference's rounding)
+__device__ __forceinline__ f2 pk_cmul_fused(f2 a, f2 w) { return pk_fma_nhh_hl(a, w, pk_mul_ll_lh(a, w)); }

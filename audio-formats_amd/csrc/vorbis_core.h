@@ -57,11 +57,16 @@ __device__ __forceinline__ void iter_54(float *z)
 // A workgroup of one wavefront -- or wavefronts that never share data -- only needs its own LDS
 // accesses ordered, which the hardware does in program order: a compiler-level ordering point is
 // enough, and unlike __syncthreads() it does not drain the spectrum loads that are in flight.
+// That point has to be a fence: wave_barrier alone is declared to touch no memory, so the compiler may move or forward LDS
+// accesses across it.  A wavefront-scope fence on the LDS address space emits no instruction and no wait.
 template <int kThreads>
 __device__ __forceinline__ void pass_sync()
 {
     if (kThreads > 64) __syncthreads();
-    else __builtin_amdgcn_wave_barrier();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 template <int kThreads>

@@ -1234,14 +1234,20 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
         return AFG_ERR_INVALID;
     }
     if (int rc = afg::require_device()) return rc;
-    if (seg_packets == 0) seg_packets = 16;
+    uint64_t total_packets = 0;
+    for (uint32_t s = 0; s < n_streams; s++) total_packets += packets[s];
+    if (seg_packets == 0) {
+        // A walk item re-reads (and re-transforms) the packet in front of it to rebuild the carried half block: 1 / seg_packets of
+        // the spectra are fetched twice.  Longer items do not pay that back on C3 (one box, 10 launches each: 16 packets 6.94 ms,
+        // 32 7.03, 64 7.11, 128 7.22, 256 7.46 -- the tail of a persistent launch is one item long): 16 stays.
+        const long v = afg::dev_option(afg::kDevVorbisSegPackets);
+        seg_packets = (v > 0 && v <= (1 << 20)) ? (uint32_t)v : 16u;
+    }
     const bool single_only = afg::dev_option(afg::kDevVorbisSingle) > 0;      // tests: the one-channel-per-wavefront walk
 
     std::vector<VorbisStream> streams(n_streams);
     std::vector<VorbisSeg> segs, segs_walk, wave_segs, wave_walk, walk_segs[kWalkShapes];
     std::vector<uint8_t> walk_pflags;
-    uint64_t total_packets = 0;
-    for (uint32_t s = 0; s < n_streams; s++) total_packets += packets[s];
     std::vector<float> tables;
     std::map<int, uint32_t> tab_of;
     auto p = new (std::nothrow) afg_vorbis_plan;

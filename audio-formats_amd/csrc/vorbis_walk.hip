@@ -41,10 +41,12 @@
 // Compiled with -ffp-contract=fast (Makefile): multiply-adds fuse.  Error against the oracle on the C3 workload (N(0,1)
 // spectra, output RMS 6.8): 1e-6 RMS, i.e. 1.5e-7 of the signal (tests/test_vorbis_walk_gpu.py).
 #include "afg_common.h"
+#include "afg_pk.h"
 #include "vorbis_core.h"
 #include "vorbis_walk.h"
 
 #include <mutex>
+#include <type_traits>
 
 #include <cmath>
 
@@ -52,8 +54,7 @@ namespace afg_vorbis {
 
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));           // (f2: afg_pk.h)
 
 // Geometry of one long block size: R points per lane.  Table block (walk_build_tables): W[N] | pass twiddles as float2,
 // then the window of the long block (n/2 floats).
@@ -72,7 +73,8 @@ struct Geo {
     static_assert(kTabFloats % 4 == 0, "staged in 16-byte pieces");
 };
 
-__device__ __forceinline__ f2 cmul(f2 a, f2 w) { return f2{ a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x }; }
+// complex product: a pair of packed instructions (round 6; four scalar ones before)
+__device__ __forceinline__ f2 cmul(f2 a, f2 w) { return pk_cmul_fused(a, w); }
 
 // 4-point DFT, forward, natural order in and out
 __device__ __forceinline__ void dft4(f2 &a0, f2 &a1, f2 &a2, f2 &a3)
@@ -150,6 +152,109 @@ __device__ __forceinline__ void dft16(f2 (&a)[16])
     for (int k = 0; k < 16; k++) a[k] = o[k];
 }
 
+// ---- channel-packed arithmetic (round 6) ----------------------------------------------------------------------------------
+// A stereo wavefront runs the same transform on both channels.  Held as c2 -- re = (ch0, ch1), im = (ch0, ch1), each a register
+// pair -- every real operation of the transform is ONE packed instruction for the two channels (v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32: 2 x 64 lanes per issue slot), twiddles and window taps are broadcast through op_sel, multiplications by +-i
+// are register renaming, and the windowed frames come out as (ch0, ch1) pairs: the order of the interleaved PCM.  Against
+// the complex-pair form (re, im of one channel per register pair, above: what a mono stream runs) a stereo long block needs
+// about 410 vector instructions instead of 725 -- the walk was issue-bound, not memory-bound (profiles/r06_pmc_vorbis_walk_kernel.json:
+// VALU busy 0.61 of a SIMD's cycles at two wavefronts, fetch 1.07 x the bytes needed).
+struct c2 { f2 re, im; };
+__device__ __forceinline__ c2 operator+(c2 a, c2 b) { return c2{ a.re + b.re, a.im + b.im }; }
+__device__ __forceinline__ c2 operator-(c2 a, c2 b) { return c2{ a.re - b.re, a.im - b.im }; }
+__device__ __forceinline__ c2 add_mi(c2 a, c2 b) { return c2{ a.re + b.im, a.im - b.re }; }       // a + (-i) b
+__device__ __forceinline__ c2 add_pi(c2 a, c2 b) { return c2{ a.re - b.im, a.im + b.re }; }       // a + i b
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{ v, v }; }
+// both channels' values times one complex factor
+__device__ __forceinline__ c2 cmulw(c2 a, f2 w)
+{
+    const f2 wr = w.xx, wi = w.yy;
+    return c2{ fma2(-a.im, wi, a.re * wr), fma2(a.im, wr, a.re * wi) };
+}
+
+__device__ __forceinline__ void dft4(c2 &a0, c2 &a1, c2 &a2, c2 &a3)
+{
+    const c2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    a1 = add_mi(d02, d13);
+    a3 = add_pi(d02, d13);
+}
+
+__device__ __forceinline__ void dft8(c2 (&a)[8])
+{
+    const f2 S = splat(0.70710678118654752440f);
+    const c2 b0 = a[0] + a[4], b4 = a[0] - a[4], b1 = a[1] + a[5], b5 = a[1] - a[5];
+    const c2 b2 = a[2] + a[6], b6 = a[2] - a[6], b3 = a[3] + a[7], b7 = a[3] - a[7];
+    const c2 c0 = b0 + b2, c2_ = b0 - b2, c1 = b1 + b3, c3 = b1 - b3;
+    a[0] = c0 + c1;
+    a[4] = c0 - c1;
+    a[2] = add_mi(c2_, c3);
+    a[6] = add_pi(c2_, c3);
+    const c2 d0 = add_mi(b4, b6), d2 = add_pi(b4, b6);
+    // p5 = b5 (1 - i), p7 = -b7 (1 + i) (both without their factor 1/sqrt 2): p5 = (b5.re + b5.im, b5.im - b5.re),
+    // p7 = (b7.im - b7.re, -(b7.re + b7.im)); q7 holds p7 with the sign of its imaginary part flipped
+    const c2 p5 = c2{ b5.re + b5.im, b5.im - b5.re }, q7 = c2{ b7.im - b7.re, b7.re + b7.im };
+    const c2 D1 = c2{ p5.re + q7.re, p5.im - q7.im }, D3 = c2{ p5.re - q7.re, p5.im + q7.im };
+    a[1] = c2{ fma2(D1.re, S, d0.re), fma2(D1.im, S, d0.im) };
+    a[5] = c2{ fma2(-D1.re, S, d0.re), fma2(-D1.im, S, d0.im) };
+    a[3] = c2{ fma2(D3.im, S, d2.re), fma2(-D3.re, S, d2.im) };
+    a[7] = c2{ fma2(-D3.im, S, d2.re), fma2(D3.re, S, d2.im) };
+}
+
+template <int M>
+__device__ __forceinline__ c2 mul_w16(c2 a)
+{
+    const f2 c1 = splat(0.92387953251128675613f), s1 = splat(0.38268343236508977173f), h = splat(0.70710678118654752440f);
+    if constexpr (M == 0) return a;
+    else if constexpr (M == 1) return c2{ fma2(a.im, s1, a.re * c1), fma2(-a.re, s1, a.im * c1) };
+    else if constexpr (M == 2) return c2{ (a.re + a.im) * h, (a.im - a.re) * h };
+    else if constexpr (M == 3) return c2{ fma2(a.im, c1, a.re * s1), fma2(-a.re, c1, a.im * s1) };
+    else if constexpr (M == 4) return c2{ a.im, -a.re };
+    else if constexpr (M == 6) return c2{ (a.im - a.re) * h, -((a.re + a.im) * h) };
+    else {
+        static_assert(M == 9, "exponent");
+        return c2{ -fma2(a.im, s1, a.re * c1), fma2(a.re, s1, -(a.im * c1)) };
+    }
+}
+
+__device__ __forceinline__ void dft16(c2 (&a)[16])
+{
+#pragma unroll
+    for (int nl = 0; nl < 4; nl++) dft4(a[nl], a[nl + 4], a[nl + 8], a[nl + 12]);
+    a[5] = mul_w16<1>(a[5]);
+    a[9] = mul_w16<2>(a[9]);
+    a[13] = mul_w16<3>(a[13]);
+    a[6] = mul_w16<2>(a[6]);
+    a[10] = mul_w16<4>(a[10]);
+    a[14] = mul_w16<6>(a[14]);
+    a[7] = mul_w16<3>(a[7]);
+    a[11] = mul_w16<6>(a[11]);
+    a[15] = mul_w16<9>(a[15]);
+    c2 o[16];
+#pragma unroll
+    for (int ka = 0; ka < 4; ka++) {
+        c2 x0 = a[4 * ka], x1 = a[4 * ka + 1], x2 = a[4 * ka + 2], x3 = a[4 * ka + 3];
+        dft4(x0, x1, x2, x3);
+        o[ka] = x0;
+        o[ka + 4] = x1;
+        o[ka + 8] = x2;
+        o[ka + 12] = x3;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = o[k];
+}
+
+// an ordering point for this wavefront's own LDS accesses: the hardware runs them in program order, the compiler is held by
+// the fence (wave_barrier alone is declared to touch no memory); no instruction, no wait
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void lane_swap32(float &x, float &y)      // x of lanes 32..63 <-> y of lanes 0..31
 {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -208,8 +313,13 @@ __device__ __forceinline__ void load_lane_tw(LaneTw<R> &tw, const f2 *T)
     }
 }
 // which of them: the pre- / post-twiddle w (R values), the pass-1 twiddles (R - 1), pass 2's (R = 8)
-template <int R, int CH> constexpr bool kTwRegs = R == 8 && CH == 2;                           // all three sets
-template <int R, int CH> constexpr bool kTwRegsW = kTwRegs<R, CH> || (R == 16 && CH == 1);             // w only (mono 4096: 197 -> 245 registers, +0.6 %)
+#ifndef AFG_WALK_TW
+#define AFG_WALK_TW 3       // stereo 2048: which sets live in registers (bit 0: w, bit 1: pass 1's, bit 2: pass 2's)
+#endif
+template <int R, int CH> constexpr bool kTwRegs1 = R == 8 && CH == 2 && (AFG_WALK_TW & 2);
+template <int R, int CH> constexpr bool kTwRegs2 = R == 8 && CH == 2 && (AFG_WALK_TW & 4);
+template <int R, int CH> constexpr bool kTwRegsW = (R == 8 && CH == 2 && (AFG_WALK_TW & 1)) || (R == 16 && CH == 1);   // (mono 4096: 197 -> 245 registers, +0.6 %)
+template <int R, int CH> constexpr bool kTwAny = kTwRegsW<R, CH> || kTwRegs1<R, CH> || kTwRegs2<R, CH>;
 
 // The passes between the pre- and the post-twiddle: e[c][r] = point j + 64 r in, e[c][s] = bin j + 64 s out (not yet
 // multiplied by w).  U: the wavefront's transform area (channel c at U + c kChanF2); T: the table block.
@@ -227,7 +337,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
             const f2 *W1 = T + G::kTw1 + j;
 #pragma unroll
             for (int k = 1; k < 8; k++) {
-                const f2 w = kTwRegs<R, CH> ? tw.w1[k - 1] : W1[64 * (k - 1)];
+                const f2 w = kTwRegs1<R, CH> ? tw.w1[k - 1] : W1[64 * (k - 1)];
 #pragma unroll
                 for (int c = 0; c < CH; c++) e[c][k] = cmul(e[c][k], w);
             }
@@ -236,7 +346,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
         for (int c = 0; c < CH; c++)
 #pragma unroll
             for (int k = 0; k < 8; k++) U[c * F + j + 68 * k] = e[c][k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         // pass 2: lane (n0, k0) = (lane >> 3, lane & 7) over n1 -> k1; reads U[n0 + 8 n1 + 68 k0], twiddle W64^(n0 k1),
         // writes V[k0 + 8 k1 + 72 n0] (the same area: all reads are issued before the first write)
         const int l2 = fresh_lane();
@@ -245,14 +355,14 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
         for (int c = 0; c < CH; c++)
 #pragma unroll
             for (int k = 0; k < 8; k++) e[c][k] = U[c * F + r2 + 8 * k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < CH; c++) dft8(e[c]);
         {
             const f2 *W2 = T + G::kTw2 + n0;
 #pragma unroll
             for (int k = 1; k < 8; k++) {
-                const f2 w = kTwRegs<R, CH> ? tw.w2[k - 1] : W2[8 * (k - 1)];
+                const f2 w = kTwRegs2<R, CH> ? tw.w2[k - 1] : W2[8 * (k - 1)];
 #pragma unroll
                 for (int c = 0; c < CH; c++) e[c][k] = cmul(e[c][k], w);
             }
@@ -261,14 +371,14 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
         for (int c = 0; c < CH; c++)
 #pragma unroll
             for (int k = 0; k < 8; k++) U[c * F + w2 + 8 * k] = e[c][k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         // pass 3: lane (k0 + 8 k1 = j) over n0 -> k2
         j = group_of(fresh_lane());
 #pragma unroll
         for (int c = 0; c < CH; c++)
 #pragma unroll
             for (int k = 0; k < 8; k++) e[c][k] = U[c * F + j + 72 * k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < CH; c++) dft8(e[c]);
     } else if constexpr (R == 16) {
@@ -288,7 +398,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
         for (int c = 0; c < CH; c++)
 #pragma unroll
             for (int k = 0; k < 16; k++) U[c * F + j + 72 * k] = e[c][k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         // pass 2: lane (n3, g) = (lane >> 2, lane & 3) takes the items k1 = g + 4 i, each a 4-point DFT over n2 -> k2:
         // reads U[n3 + 16 n2 + 72 k1], twiddle W64^(n3 k2), writes V[k1 + 16 k2 + 68 n3]
         const int l2 = fresh_lane();
@@ -299,7 +409,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int n2 = 0; n2 < 4; n2++) e[c][4 * i + n2] = U[c * F + r2 + 16 * n2 + 288 * i];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < CH; c++)
 #pragma unroll
@@ -321,14 +431,14 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) U[c * F + w2 + 4 * i + 16 * k] = e[c][4 * i + k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         // pass 3: lane j = k1 + 16 k2 over n3 -> k3
         j = group_of(fresh_lane());
 #pragma unroll
         for (int c = 0; c < CH; c++)
 #pragma unroll
             for (int k = 0; k < 16; k++) e[c][k] = U[c * F + j + 68 * k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < CH; c++) dft16(e[c]);
     } else {
@@ -349,7 +459,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
         for (int c = 0; c < CH; c++)
 #pragma unroll
             for (int k = 0; k < 4; k++) U[c * F + j + 80 * k] = e[c][k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         // pass 2: lane (m, k1) = (lane & 15, lane >> 4), m = n4 + 4 n3, over n2 -> k2: reads U[m + 16 n2 + 80 k1], twiddle
         // W64^(m k2), writes slot m + 16 kk + 4 (kk >> 1) of kk = k1 + 4 k2
         {
@@ -359,7 +469,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
             for (int c = 0; c < CH; c++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) e[c][k] = U[c * F + r2 + 16 * k];
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
 #pragma unroll
             for (int c = 0; c < CH; c++) dft4(e[c][0], e[c][1], e[c][2], e[c][3]);
             const f2 *W2 = T + G::kTw2 + m;
@@ -373,7 +483,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
             for (int c = 0; c < CH; c++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) U[c * F + w2 + 72 * k] = e[c][k];
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
         }
         // pass 3: lane (n4, kk) = (lane & 3, lane >> 2) over n3 -> k3: twiddle W16^(n4 k3), writes V[kk + 16 k3 + 72 n4]
         {
@@ -383,7 +493,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
             for (int c = 0; c < CH; c++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) e[c][k] = U[c * F + r3 + 4 * k];
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
 #pragma unroll
             for (int c = 0; c < CH; c++) dft4(e[c][0], e[c][1], e[c][2], e[c][3]);
             const f2 *W3 = T + G::kTw3 + n4;
@@ -397,7 +507,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
             for (int c = 0; c < CH; c++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) U[c * F + w3 + 16 * k] = e[c][k];
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
         }
         // pass 4: lane j = kk + 16 k3 over n4 -> k4
         j = group_of(fresh_lane());
@@ -405,7 +515,7 @@ __device__ __forceinline__ void fft_passes(f2 (&e)[CH][R], f2 *U, const f2 *T, c
         for (int c = 0; c < CH; c++)
 #pragma unroll
             for (int k = 0; k < 4; k++) e[c][k] = U[c * F + j + 72 * k];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < CH; c++) dft4(e[c][0], e[c][1], e[c][2], e[c][3]);
     }
@@ -451,6 +561,165 @@ __device__ __forceinline__ void fft_lanes(f2 (&xin)[CH][R], f2 (&P)[CH][R], f2 *
     }
 }
 
+// The same passes for a stereo pair held channel-packed (c2): the transform area holds a plane of real parts and a plane of
+// imaginary parts, each slot the two channels' values (8 bytes: the slot indices, and so the bank behaviour, are those of
+// fft_passes, tests/vorbis_walk_model.py).
+template <int R>
+__device__ __forceinline__ void fft_passes2(c2 (&e)[R], f2 *U, const f2 *T, const LaneTw<R> &tw)
+{
+    using G = Geo<R>;
+    constexpr int F = G::kChanF2;
+    f2 *const Ur = U, *const Ui = U + F;
+    int j = group_of(fresh_lane());
+    if constexpr (R == 8) {
+        dft8(e);
+        {
+            const f2 *W1 = T + G::kTw1 + j;
+#pragma unroll
+            for (int k = 1; k < 8; k++) e[k] = cmulw(e[k], kTwRegs1<R, 2> ? tw.w1[k - 1] : W1[64 * (k - 1)]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { Ur[j + 68 * k] = e[k].re; Ui[j + 68 * k] = e[k].im; }
+        wave_lds_sync();
+        const int l2 = fresh_lane();
+        const int n0 = l2 >> 3, r2 = n0 + 68 * (l2 & 7), w2 = (l2 & 7) + 72 * n0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = c2{ Ur[r2 + 8 * k], Ui[r2 + 8 * k] };
+        wave_lds_sync();
+        dft8(e);
+        {
+            const f2 *W2 = T + G::kTw2 + n0;
+#pragma unroll
+            for (int k = 1; k < 8; k++) e[k] = cmulw(e[k], kTwRegs2<R, 2> ? tw.w2[k - 1] : W2[8 * (k - 1)]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { Ur[w2 + 8 * k] = e[k].re; Ui[w2 + 8 * k] = e[k].im; }
+        wave_lds_sync();
+        j = group_of(fresh_lane());
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = c2{ Ur[j + 72 * k], Ui[j + 72 * k] };
+        wave_lds_sync();
+        dft8(e);
+    } else if constexpr (R == 16) {
+        dft16(e);
+        {
+            const f2 *W1 = T + G::kTw1 + j;
+#pragma unroll
+            for (int k = 1; k < 16; k++) e[k] = cmulw(e[k], W1[64 * (k - 1)]);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { Ur[j + 72 * k] = e[k].re; Ui[j + 72 * k] = e[k].im; }
+        wave_lds_sync();
+        const int l2 = fresh_lane();
+        const int n3 = l2 >> 2, r2 = n3 + 72 * (l2 & 3), w2 = (l2 & 3) + 68 * n3;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int n2 = 0; n2 < 4; n2++) e[4 * i + n2] = c2{ Ur[r2 + 16 * n2 + 288 * i], Ui[r2 + 16 * n2 + 288 * i] };
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 4; i++) dft4(e[4 * i], e[4 * i + 1], e[4 * i + 2], e[4 * i + 3]);
+        {
+            const f2 *W2 = T + G::kTw2 + n3;
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                const f2 w = W2[16 * (k - 1)];
+#pragma unroll
+                for (int i = 0; i < 4; i++) e[4 * i + k] = cmulw(e[4 * i + k], w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { Ur[w2 + 4 * i + 16 * k] = e[4 * i + k].re; Ui[w2 + 4 * i + 16 * k] = e[4 * i + k].im; }
+        wave_lds_sync();
+        j = group_of(fresh_lane());
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = c2{ Ur[j + 68 * k], Ui[j + 68 * k] };
+        wave_lds_sync();
+        dft16(e);
+    } else {
+        static_assert(R == 4, "points per lane");
+        dft4(e[0], e[1], e[2], e[3]);
+        {
+            const f2 *W1 = T + G::kTw1 + j;
+#pragma unroll
+            for (int k = 1; k < 4; k++) e[k] = cmulw(e[k], W1[64 * (k - 1)]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Ur[j + 80 * k] = e[k].re; Ui[j + 80 * k] = e[k].im; }
+        wave_lds_sync();
+        {
+            const int l2 = fresh_lane();
+            const int m = l2 & 15, k1 = l2 >> 4, r2 = m + 80 * k1, w2 = m + 16 * k1 + 4 * (k1 >> 1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[k] = c2{ Ur[r2 + 16 * k], Ui[r2 + 16 * k] };
+            wave_lds_sync();
+            dft4(e[0], e[1], e[2], e[3]);
+            const f2 *W2 = T + G::kTw2 + m;
+#pragma unroll
+            for (int k = 1; k < 4; k++) e[k] = cmulw(e[k], W2[16 * (k - 1)]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { Ur[w2 + 72 * k] = e[k].re; Ui[w2 + 72 * k] = e[k].im; }
+            wave_lds_sync();
+        }
+        {
+            const int l3 = fresh_lane();
+            const int n4 = l3 & 3, kk = l3 >> 2, r3 = n4 + 16 * kk + 4 * (kk >> 1), w3 = kk + 72 * n4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[k] = c2{ Ur[r3 + 4 * k], Ui[r3 + 4 * k] };
+            wave_lds_sync();
+            dft4(e[0], e[1], e[2], e[3]);
+            const f2 *W3 = T + G::kTw3 + n4;
+#pragma unroll
+            for (int k = 1; k < 4; k++) e[k] = cmulw(e[k], W3[4 * (k - 1)]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { Ur[w3 + 16 * k] = e[k].re; Ui[w3 + 16 * k] = e[k].im; }
+            wave_lds_sync();
+        }
+        j = group_of(fresh_lane());
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = c2{ Ur[j + 72 * k], Ui[j + 72 * k] };
+        wave_lds_sync();
+        dft4(e[0], e[1], e[2], e[3]);
+    }
+}
+
+// fft_lanes for a stereo pair: xin as loaded (one register pair per channel and point), P channel-packed
+template <int R, typename Next>
+__device__ __forceinline__ void fft_lanes2(f2 (&xin)[2][R], c2 (&P)[R], f2 *U, const f2 *T, const LaneTw<R> &tw, Next next)
+{
+    int j = group_of(fresh_lane());
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int r = 0; r < R / 2; r++) {
+            float a = xin[c][r].y, b = xin[c][R - 1 - r].y;
+            cross32(a, b);
+            xin[c][r].y = a;
+            xin[c][R - 1 - r].y = b;
+        }
+    c2 e[R];
+    {
+        const f2 *W = T + j;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const f2 w = kTwRegsW<R, 2> ? tw.w[r] : W[64 * r];
+            e[r] = cmulw(c2{ f2{ xin[0][r].x, xin[1][r].x }, f2{ xin[0][r].y, xin[1][r].y } }, w);
+        }
+    }
+    next();                                          // the spectrum registers are free: fetch the next packet's
+#ifndef AFG_WALK_EXP_NOFFT                                // (experiment: the memory floor of the walk -- loads, window, stores, no passes)
+    fft_passes2<R>(e, U, T, tw);
+#endif
+    j = group_of(fresh_lane());
+    {
+        const f2 *W = T + j;
+#pragma unroll
+        for (int k = 0; k < R; k++) P[k] = cmulw(e[k], kTwRegsW<R, 2> ? tw.w[k] : W[64 * k]);
+    }
+}
+
 // y[m] of a long block of n samples from its u (floats at uf[0..n/2)): the odd / even extension of the DCT-IV
 template <int N>
 __device__ __forceinline__ float y_of_u(const float *uf, int m)
@@ -474,6 +743,15 @@ __device__ __forceinline__ void store_pair(float *o, int pair, const float (&f0)
         o[(2 * pair + 1) * stride] = f1[0];
     } else if constexpr (CH == 2) __builtin_nontemporal_store((f4{ f0[0], f0[1], f1[0], f1[1] }), (f4 *)o + pair);
     else __builtin_nontemporal_store((f2{ f0[0], f1[0] }), (f2 *)o + pair);
+}
+// the same from channel-packed values: f0, f1 = (ch0, ch1) of two consecutive frames
+template <bool ST>
+__device__ __forceinline__ void store_pair2(float *o, int pair, f2 f0, f2 f1, int stride)
+{
+    if constexpr (ST) {
+        *(f2 *)(o + (2 * pair) * stride) = f0;
+        *(f2 *)(o + (2 * pair + 1) * stride) = f1;
+    } else __builtin_nontemporal_store((f4{ f0.x, f0.y, f1.x, f1.y }), (f4 *)o + pair);
 }
 template <int CH, bool ST>
 __device__ __forceinline__ void store_frame(float *o, int frame, const float (&v)[CH], int stride)
@@ -507,11 +785,21 @@ __device__ __forceinline__ void walk_body(
     // Carried state, per channel.  After a long block whose right window is long: cb[c][2 i], cb[c][2 i + 1] =
     // u[n/2-1 - 2k], u[n/2-2 - 2k] for k = j + 64 (R/2 + i) -- the b of frames 2k - n/4 and 2k - n/4 + 1 of the next block.
     // Otherwise previous_window itself (:2641-2643): sample lane + 64 i in cb[c][i] (64 .. 256 samples).
-    float cb[CH][R];
+    // (a stereo pair: channel-packed, cbs[i] = (ch0, ch1))
+    using CB = std::conditional_t<CH == 2, f2, float>;
+    CB cbs[R];
 #pragma unroll
-    for (int c = 0; c < CH; c++)
-#pragma unroll
-        for (int i = 0; i < R; i++) cb[c][i] = 0.0f;
+    for (int i = 0; i < R; i++) cbs[i] = CB(0.0f);
+    auto cbget = [&](int c, int i) -> float {
+        if constexpr (CH == 2) return c ? cbs[i].y : cbs[i].x;
+        else return cbs[i];
+    };
+    auto cbset = [&](int c, int i, float v) {
+        if constexpr (CH == 2) {
+            if (c) cbs[i].y = v;
+            else cbs[i].x = v;
+        } else cbs[i] = v;
+    };
 
     int fbase = 0;
     unsigned fl_reg = 0;
@@ -576,15 +864,9 @@ __device__ __forceinline__ void walk_body(
         const int nout = right - left, plen = right_end - right;
         float *const o = out + lane64(oo_reg, p) + chan;   // interleaved frames; 16-byte aligned (checked at launch) unless ST
         auto next = [&]() { issue(p + 1); };
-        // previous_window sample jj of channel c (jj < 256): cb[c][jj >> 6], a register: spelled out
-        auto carried = [&](int c, int jj) -> float {
-            const int i = jj >> 6;
-            return i == 0 ? cb[c][0] : i == 1 ? cb[c][1] : i == 2 ? cb[c][2] : cb[c][3];
-        };
 
         if (lng) {
             const bool wprev = (fl & AFG_VORBIS_PREV) != 0, wnext = (fl & AFG_VORBIS_NEXT) != 0;
-            f2 P[CH][R];
             if constexpr (R == 4) {
                 // a load covers two eighths of this size's spectrum (lanes 0..31 the first): an odd declaration leaves the
                 // upper lanes of its last load holding bins that must not be looked at
@@ -598,7 +880,24 @@ __device__ __forceinline__ void walk_body(
                             if (r == (nz >> 1)) xin[c][r] = low ? xin[c][r] : f2{ 0.0f, 0.0f };
                 }
             }
-            fft_lanes<R, CH>(xin, P, U, T, tw, next);
+            // P: c[j + 64 s] of every channel (a stereo pair: channel-packed); px / py read one channel's parts
+            using PT = std::conditional_t<CH == 2, c2, f2>;
+            PT P[R];
+            auto px = [&](int c, int k) -> float {
+                if constexpr (CH == 2) return c ? P[k].re.y : P[k].re.x;
+                else return P[k].x;
+            };
+            auto py = [&](int c, int k) -> float {
+                if constexpr (CH == 2) return c ? P[k].im.y : P[k].im.x;
+                else return P[k].y;
+            };
+            if constexpr (CH == 2) fft_lanes2<R>(xin, P, U, T, tw, next);
+            else {
+                f2 P1[1][R];
+                fft_lanes<R, 1>(xin, P1, U, T, tw, next);
+#pragma unroll
+                for (int k = 0; k < R; k++) P[k] = P1[0][k];
+            }
             if (!(wprev && wnext)) {
                 // a short neighbour: u of every channel to LDS in natural order for the y(m) accessor below
                 float *const uf = (float *)U;
@@ -607,24 +906,32 @@ __device__ __forceinline__ void walk_body(
 #pragma unroll
                     for (int k = 0; k < R; k++) {
                         const int kk = group_of(lane) + 64 * k;
-                        uf[c * (2 * kChanF2) + 2 * kk] = P[c][k].x;
-                        uf[c * (2 * kChanF2) + kN / 2 - 1 - 2 * kk] = -P[c][k].y;
+                        uf[c * (2 * kChanF2) + 2 * kk] = px(c, k);
+                        uf[c * (2 * kChanF2) + kN / 2 - 1 - 2 * kk] = -py(c, k);
                     }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
             }
             // c[N-1 - k] for k = j + 64 s, s = R/2 .. R-1: slot R-1 - s of lane ^ 32
 #pragma unroll
-            for (int c = 0; c < CH; c++) {
-#pragma unroll
-                for (int k = 0; k < H; k += 2) {
-                    float ax = P[c][k].x, bx = P[c][k + 1].x, ay = P[c][k].y, by = P[c][k + 1].y;
+            for (int k = 0; k < H; k += 2) {
+                if constexpr (CH == 2) {
+                    float ax0 = P[k].re.x, bx0 = P[k + 1].re.x, ax1 = P[k].re.y, bx1 = P[k + 1].re.y;
+                    float ay0 = P[k].im.x, by0 = P[k + 1].im.x, ay1 = P[k].im.y, by1 = P[k + 1].im.y;
+                    cross32(ax0, bx0);
+                    cross32(ax1, bx1);
+                    cross32(ay0, by0);
+                    cross32(ay1, by1);
+                    P[k] = c2{ f2{ ax0, ax1 }, f2{ ay0, ay1 } };
+                    P[k + 1] = c2{ f2{ bx0, bx1 }, f2{ by0, by1 } };
+                } else {
+                    float ax = P[k].x, bx = P[k + 1].x, ay = P[k].y, by = P[k + 1].y;
                     cross32(ax, bx);
                     cross32(ay, by);
-                    P[c][k] = f2{ ax, ay };
-                    P[c][k + 1] = f2{ bx, by };
+                    P[k] = f2{ ax, ay };
+                    P[k + 1] = f2{ bx, by };
                 }
             }
-            // after the crossing P[c][k] holds lane ^ 32's slot k ^ 1: the mirror of s = R/2 + i, slot R/2-1 - i, is P[c][mir(i)]
+            // after the crossing slot k holds lane ^ 32's slot k ^ 1: the mirror of s = R/2 + i, slot R/2-1 - i, is slot mir(i)
             auto mir = [](int i) constexpr { return (H - 1 - i) ^ 1; };
             settle(xin);
             if (emit && wprev) {
@@ -636,17 +943,25 @@ __device__ __forceinline__ void walk_body(
                 for (int i = 0; i < H; i++) {
                     const f2 w0 = wlo[64 * i];                     // w[j0], w[j0+1]
                     const f2 w1 = whi[-64 * i];                    // w[n/2-2-j0], w[n/2-1-j0]
-                    float lo0[CH], lo1[CH], hi0[CH], hi1[CH];
-#pragma unroll
-                    for (int c = 0; c < CH; c++) {
-                        const float a0 = P[c][H + i].x, a1 = -P[c][mir(i)].y, b0 = cb[c][2 * i], b1 = cb[c][2 * i + 1];
-                        lo0[c] = a0 * w0.x - b0 * w1.y;
-                        lo1[c] = a1 * w0.y - b1 * w1.x;
-                        hi1[c] = -a0 * w1.y - b0 * w0.x;
-                        hi0[c] = -a1 * w1.x - b1 * w0.y;
+                    if constexpr (CH == 2) {
+                        // both channels at once: a0 = P.re, a1 = -P.im of the mirror slot, b the carried pair
+                        const f2 a0 = P[H + i].re, a1n = P[mir(i)].im, b0 = cbs[2 * i], b1 = cbs[2 * i + 1];
+                        const f2 lo0 = fma2(-b0, w1.yy, a0 * w0.xx);
+                        const f2 lo1 = fma2(-b1, w1.xx, -(a1n * w0.yy));
+                        const f2 hi1 = fma2(-b0, w0.xx, -(a0 * w1.yy));
+                        const f2 hi0 = fma2(-b1, w0.yy, a1n * w1.xx);
+                        store_pair2<ST>(o, j + 64 * i, lo0, lo1, stride);
+                        store_pair2<ST>(o, (kPts - 1) - j - 64 * i, hi0, hi1, stride);
+                    } else {
+                        float lo0[1], lo1[1], hi0[1], hi1[1];
+                        const float a0 = P[H + i].x, a1 = -P[mir(i)].y, b0 = cbs[2 * i], b1 = cbs[2 * i + 1];
+                        lo0[0] = a0 * w0.x - b0 * w1.y;
+                        lo1[0] = a1 * w0.y - b1 * w1.x;
+                        hi1[0] = -a0 * w1.y - b0 * w0.x;
+                        hi0[0] = -a1 * w1.x - b1 * w0.y;
+                        store_pair<1, ST>(o, j + 64 * i, lo0, lo1, stride);
+                        store_pair<1, ST>(o, (kPts - 1) - j - 64 * i, hi0, hi1, stride);
                     }
-                    store_pair<CH, ST>(o, j + 64 * i, lo0, lo1, stride);
-                    store_pair<CH, ST>(o, (kPts - 1) - j - 64 * i, hi0, hi1, stride);
                 }
             }
             if (!(wprev && wnext)) {
@@ -654,15 +969,30 @@ __device__ __forceinline__ void walk_body(
                 if (emit) {
                     // :2606-2657 on y(m): frames the u-form path above did not write
                     const float *wt = tables + tab0 + bs0 + bs0 / 4;      // window of blocksize_0 (:2245-2251)
-                    for (int jj = (wprev ? kN / 2 : 0) + lane; jj < nout; jj += 64) {
+                    // (the frames that meet previous_window -- the first blocksize_0 / 2 <= 256 -- in four spelled-out
+                    // steps: the carried value of step `it` is a register known at compile time)
+                    int jfrom = wprev ? kN / 2 : 256;
+                    if (!wprev) {
+#pragma unroll
+                        for (int it = 0; it < 4; it++) {
+                            const int jj = lane + 64 * it;
+                            if (jj < nout) {
+                                float v[CH];
+#pragma unroll
+                                for (int c = 0; c < CH; c++) v[c] = y_of_u<kN>(uf + c * (2 * kChanF2), left + jj);
+                                if (jj < pn) {                             // pn = blocksize_0 / 2 here
+                                    const float wa = wt[jj], wb = wt[pn - 1 - jj];
+#pragma unroll
+                                    for (int c = 0; c < CH; c++) v[c] = v[c] * wa + cbget(c, it) * wb;
+                                }
+                                store_frame<CH, ST>(o, jj, v, stride);
+                            }
+                        }
+                    }
+                    for (int jj = jfrom + lane; jj < nout; jj += 64) {
                         float v[CH];
 #pragma unroll
                         for (int c = 0; c < CH; c++) v[c] = y_of_u<kN>(uf + c * (2 * kChanF2), left + jj);
-                        if (!wprev && jj < pn) {                           // pn = blocksize_0 / 2 here
-                            const float wa = wt[jj], wb = wt[pn - 1 - jj];
-#pragma unroll
-                            for (int c = 0; c < CH; c++) v[c] = v[c] * wa + carried(c, jj) * wb;
-                        }
                         store_frame<CH, ST>(o, jj, v, stride);
                     }
                 }
@@ -672,19 +1002,22 @@ __device__ __forceinline__ void walk_body(
                         const int m = right + lane + 64 * i;
                         const bool in = lane + 64 * i < plen;
 #pragma unroll
-                        for (int c = 0; c < CH; c++) cb[c][i] = in ? y_of_u<kN>(uf + c * (2 * kChanF2), m < kN ? m : 0) : 0.0f;
+                        for (int c = 0; c < CH; c++) cbset(c, i, in ? y_of_u<kN>(uf + c * (2 * kChanF2), m < kN ? m : 0) : 0.0f);
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
             }
             if (wnext) {
 #pragma unroll
-                for (int c = 0; c < CH; c++)
-#pragma unroll
-                    for (int i = 0; i < H; i++) {
-                        cb[c][2 * i] = -P[c][H + i].y;               // u[n/2-1 - 2k]
-                        cb[c][2 * i + 1] = P[c][mir(i)].x;           // u[2 (N-1 - k)] = u[n/2-2 - 2k]
+                for (int i = 0; i < H; i++) {
+                    if constexpr (CH == 2) {
+                        cbs[2 * i] = -P[H + i].im;                   // u[n/2-1 - 2k], both channels
+                        cbs[2 * i + 1] = P[mir(i)].re;               // u[2 (N-1 - k)] = u[n/2-2 - 2k]
+                    } else {
+                        cbs[2 * i] = -P[H + i].y;
+                        cbs[2 * i + 1] = P[mir(i)].x;
                     }
+                }
             }
         } else {
             // short block: the reference's own transform (vorbis_core.h) over LDS, previous_window in cb
@@ -697,7 +1030,7 @@ __device__ __forceinline__ void walk_body(
 #pragma unroll
                 for (int c = 0; c < CH; c++) sm[c * (2 * kChanF2) + k] = src[c * n2 + k];
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
 #pragma nounroll
             for (int c = 0; c < CH; c++) {
                 float *const s = sm + c * (2 * kChanF2);
@@ -707,25 +1040,30 @@ __device__ __forceinline__ void walk_body(
             settle(xin);
             if (emit) {
                 const float *wt = Tn + n + n / 4;
-                for (int jj = lane; jj < nout; jj += 64) {
-                    float v[CH];
+                // a short block emits blocksize_0 / 2 <= 256 frames: four spelled-out steps (see above)
 #pragma unroll
-                    for (int c = 0; c < CH; c++) v[c] = sm[c * (2 * kChanF2) + left + jj];
-                    if (jj < pn) {
-                        const float wa = wt[jj], wb = wt[pn - 1 - jj];
+                for (int it = 0; it < 4; it++) {
+                    const int jj = lane + 64 * it;
+                    if (jj < nout) {
+                        float v[CH];
 #pragma unroll
-                        for (int c = 0; c < CH; c++) v[c] = v[c] * wa + carried(c, jj) * wb;
+                        for (int c = 0; c < CH; c++) v[c] = sm[c * (2 * kChanF2) + left + jj];
+                        if (jj < pn) {
+                            const float wa = wt[jj], wb = wt[pn - 1 - jj];
+#pragma unroll
+                            for (int c = 0; c < CH; c++) v[c] = v[c] * wa + cbget(c, it) * wb;
+                        }
+                        store_frame<CH, ST>(o, jj, v, stride);
                     }
-                    store_frame<CH, ST>(o, jj, v, stride);
                 }
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const bool in = lane + 64 * i < plen;
 #pragma unroll
-                for (int c = 0; c < CH; c++) cb[c][i] = in ? sm[c * (2 * kChanF2) + right + lane + 64 * i] : 0.0f;
+                for (int c = 0; c < CH; c++) cbset(c, i, in ? sm[c * (2 * kChanF2) + right + lane + 64 * i] : 0.0f);
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
         }
         previous_length = plen;
     }
@@ -736,7 +1074,11 @@ __device__ __forceinline__ void walk_body(
 // (tables once per workgroup + one transform area per wavefront) at the register budget that pays.  The small shapes
 // have little work per packet beside the fixed cost of a packet (flags, bounds, three or four LDS round trips): four
 // wavefronts per SIMD hide it (mono 1024: 11.5 -> 8.4 ms per C3-sized batch; a handful of spilled registers).
+#ifndef AFG_WALK_W82
+#define AFG_WALK_W82 8      // stereo 2048: wavefronts per workgroup (8: two per SIMD; 12: three, at <= 168 registers)
+#endif
 template <int R, int CH> struct Shape { static constexpr int kWaves = 8, kPerSimd = 2; };
+template <> struct Shape<8, 2> { static constexpr int kWaves = AFG_WALK_W82, kPerSimd = AFG_WALK_W82 / 4; };
 template <> struct Shape<4, 1> { static constexpr int kWaves = 16, kPerSimd = 4; };
 template <> struct Shape<4, 2> { static constexpr int kWaves = 16, kPerSimd = 4; };
 template <> struct Shape<8, 1> { static constexpr int kWaves = 16, kPerSimd = 4; };
@@ -770,7 +1112,7 @@ __global__ __launch_bounds__(64 * WAVES, (Shape<R, CH>::kPerSimd)) void vorbis_w
     f2 *const U = (f2 *)(lds + G::kTabFloats) + wave * (CH * G::kChanF2);
     const f2 *const T = (const f2 *)lds;
     LaneTw<R> tw;
-    if constexpr (kTwRegsW<R, CH>) load_lane_tw<R>(tw, T);
+    if constexpr (kTwAny<R, CH>) load_lane_tw<R>(tw, T);
     if constexpr (ST) {
         // a workgroup draws WAVES consecutive items at a time -- the channels of a segment follow each other -- so that the
         // wavefronts filling the columns of one run of frames share a CU's L2 slice and a moment in time
