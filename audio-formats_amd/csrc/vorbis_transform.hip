@@ -1096,7 +1096,8 @@ __device__ __forceinline__ void vorbis_wave2_body(
 #endif
 constexpr int kWavesPerGroup = AFG_VORBIS_GROUP_WAVES;
 constexpr int kWaveStride = 2 * kWaveLds;             // transform areas of two channels: previous_window is in registers
-constexpr uint32_t kCounterSets = 32, kCountersPerLaunch = 1 + kWalkShapes;
+constexpr uint32_t kMcGroupsMax = 24;          // runs of one (shape, channel count) among the streams with more than two channels
+constexpr uint32_t kCounterSets = 32, kCountersPerLaunch = 1 + kWalkShapes + kMcGroupsMax;
 constexpr uint32_t kBothChannels = 0xffffffffu;       // VorbisSeg.pad of a wavefront that walks both channels of a stereo stream
 
 #ifndef AFG_VORBIS_WAVES_PER_EU
@@ -1201,6 +1202,10 @@ struct afg_vorbis_plan {
     // d_walk_segs.  The same streams' segments for the bit-exact kernels are the first n_wave_walk of d_wave_segs and the
     // last n_segs_walk of d_segs: a launch in tolerance mode with aligned planes skips those.
     uint32_t walk_first[kWalkShapes + 1] = {};
+    // the shapes with more than two channels (6 ..): a workgroup per segment, as many wavefronts as the stream has channels
+    // or pairs of them -- one launch per run of equal channel counts inside the shape's run
+    struct McGroup { int shape; uint32_t first, count, nch; };
+    std::vector<McGroup> mc_groups;
     uint32_t n_wave_walk = 0, n_segs_walk = 0;
     afg::DeviceArray d_walk_segs, d_walk_tables[kWalkShapes];
     uint32_t tab2048 = 0;          // float offset of the n = 2048 table set
@@ -1324,10 +1329,8 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
         }
         for (uint32_t p0 = 0; p0 < packets[s]; p0 += seg_packets) {
             uint32_t cnt = packets[s] - p0 < seg_packets ? packets[s] - p0 : seg_packets;
-            if (shape >= 6)      // one per channel or pair of channels
-                for (uint32_t c = 0; c < channels[s]; c += (uint32_t)walk_shape_channels(shape)) walk_segs[shape].push_back(VorbisSeg{ s, p0, cnt, c });
-            else if (shape >= 0)
-                walk_segs[shape].push_back(VorbisSeg{ s, p0, cnt, 0 });
+            if (shape >= 0)      // (more than two channels: the workgroup's wavefronts share the item; pad = the channel count, the sort key below)
+                walk_segs[shape].push_back(VorbisSeg{ s, p0, cnt, shape >= 6 ? (uint32_t)channels[s] : 0u });
             auto &wave_list = shape >= 0 ? wave_walk : wave_segs;
             if (fast && channels[s] == 2 && !single_only)
                 wave_list.push_back(VorbisSeg{ s, p0, cnt, kBothChannels });                                  // both channels, interleaved
@@ -1344,9 +1347,23 @@ int afg::vorbis_plan_create_at(afg_vorbis_plan **plan, uint32_t n_streams, const
     std::vector<VorbisSeg> all_walk;
     for (int k = 0; k < kWalkShapes; k++) {
         p->walk_first[k] = (uint32_t)all_walk.size();
+        if (k >= 6 && !walk_segs[k].empty()) {
+            std::stable_sort(walk_segs[k].begin(), walk_segs[k].end(), [](const VorbisSeg &a, const VorbisSeg &b) { return a.pad < b.pad; });
+            for (size_t i = 0; i < walk_segs[k].size();) {
+                size_t j = i;
+                while (j < walk_segs[k].size() && walk_segs[k][j].pad == walk_segs[k][i].pad) j++;
+                p->mc_groups.push_back({ k, (uint32_t)(all_walk.size() + i), (uint32_t)(j - i), walk_segs[k][i].pad });
+                i = j;
+            }
+        }
         all_walk.insert(all_walk.end(), walk_segs[k].begin(), walk_segs[k].end());
     }
     p->walk_first[kWalkShapes] = (uint32_t)all_walk.size();
+    if (p->mc_groups.size() > kMcGroupsMax) {
+        afg::set_error("afg_vorbis_plan_create: more than %u different (block size, channel count) groups above two channels", kMcGroupsMax);
+        delete p;
+        return AFG_ERR_UNSUPPORTED;
+    }
     p->n_streams = n_streams;
     p->n_segs = (uint32_t)segs.size();
     p->n_wave_segs = (uint32_t)wave_segs.size();
@@ -1445,13 +1462,21 @@ int afg_vorbis_transform_hip(const afg_vorbis_plan *plan, const float *d_spec, f
     if (walk || plan->n_wave_segs > wave_skip) {
         uint32_t *counter = (uint32_t *)plan->d_counters.ptr + kCountersPerLaunch * (plan->launches.fetch_add(1) % kCounterSets);
         AFG_HIP_CHECK(hipMemsetAsync(counter, 0, kCountersPerLaunch * sizeof(uint32_t), (hipStream_t)hip_stream));
-        for (int k = 0; walk && k < kWalkShapes; k++) {
+        for (int k = 0; walk && k < 6; k++) {
             const uint32_t first = plan->walk_first[k], count = plan->walk_first[k + 1] - first;
             if (!count) continue;
-            if (int rc = walk_launch(k, (const VorbisSeg *)plan->d_walk_segs.ptr + first, count, (const VorbisStream *)plan->d_streams.ptr,
+            if (int rc = walk_launch(k, (const VorbisSeg *)plan->d_walk_segs.ptr + first, count, 0, (const VorbisStream *)plan->d_streams.ptr,
                                      (const uint8_t *)(plan->d_walk_pflags.ptr ? plan->d_walk_pflags.ptr : plan->d_pflags.ptr), (const uint64_t *)plan->d_spec_off.ptr,
                                      (const uint64_t *)plan->d_out_off.ptr, (const float *)plan->d_tables.ptr,
                                      (const float *)plan->d_walk_tables[k].ptr, d_spec, d_out, counter + 1 + k, (hipStream_t)hip_stream))
+                return rc;
+        }
+        for (size_t g = 0; walk && g < plan->mc_groups.size(); g++) {
+            const auto &mg = plan->mc_groups[g];
+            if (int rc = walk_launch(mg.shape, (const VorbisSeg *)plan->d_walk_segs.ptr + mg.first, mg.count, (int)mg.nch, (const VorbisStream *)plan->d_streams.ptr,
+                                     (const uint8_t *)(plan->d_walk_pflags.ptr ? plan->d_walk_pflags.ptr : plan->d_pflags.ptr), (const uint64_t *)plan->d_spec_off.ptr,
+                                     (const uint64_t *)plan->d_out_off.ptr, (const float *)plan->d_tables.ptr,
+                                     (const float *)plan->d_walk_tables[mg.shape].ptr, d_spec, d_out, counter + 1 + kWalkShapes + g, (hipStream_t)hip_stream))
                 return rc;
         }
         if (plan->n_wave_segs > wave_skip) {

@@ -753,6 +753,22 @@ __device__ __forceinline__ void store_pair2(float *o, int pair, f2 f0, f2 f1, in
         *(f2 *)(o + (2 * pair + 1) * stride) = f1;
     } else __builtin_nontemporal_store((f4{ f0.x, f0.y, f1.x, f1.y }), (f4 *)o + pair);
 }
+// Streams with more than two channels (round 6): the wavefronts of a workgroup are the channels (or channel pairs) of ONE
+// segment and walk it in step.  A chunk -- 128 consecutive frames and the 128 mirrored ones of a long block, all channels --
+// is put together in LDS (two chunks alternate, so one barrier per chunk is enough) and leaves as whole interleaved frames,
+// 16 bytes per lane: round 5 stored each wavefront's 4- or 8-byte column of the frames by itself (8-byte pieces at a 24-byte
+// stride for six channels; WRITE_SIZE 1.8 x the bytes, 12-14 ms per C3-sized batch).
+template <int N>
+__device__ __forceinline__ void staged_store(const float *S, float *obase, int i, int nch)
+{
+    __syncthreads();
+    const int half = 32 * nch;                                  // 16-byte pieces of 128 frames
+    float *const lo = obase + (128 * i) * nch, *const hi = obase + (N / 2 - 128 * (i + 1)) * nch;
+    for (int q = (int)threadIdx.x; q < 2 * half; q += (int)blockDim.x) {
+        const f4 v = ((const f4 *)S)[q];
+        __builtin_nontemporal_store(v, q < half ? (f4 *)lo + q : (f4 *)hi + (q - half));
+    }
+}
 template <int CH, bool ST>
 __device__ __forceinline__ void store_frame(float *o, int frame, const float (&v)[CH], int stride)
 {
@@ -768,7 +784,7 @@ template <int R, int CH, bool ST>
 __device__ __forceinline__ void walk_body(
     f2 *U, const f2 *T, const LaneTw<R> &tw, const VorbisSeg &seg, const VorbisStream &st, const uint8_t *__restrict__ pflags,
     const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off, const float *tables,
-    const float *__restrict__ spec, float *__restrict__ out)
+    const float *__restrict__ spec, float *__restrict__ out, float *stage, int first_chan)
 {
     using G = Geo<R>;
     constexpr int kN = G::kN, kPts = G::kPts, kChanF2 = G::kChanF2, H = R / 2;
@@ -776,7 +792,7 @@ __device__ __forceinline__ void walk_body(
     const int bs0 = (int)st.bs[0], bs1 = (int)st.bs[1];
     const uint32_t tab0 = st.tab[0];
     const float *const lwin = (const float *)(T + G::kTwEnd);    // window of the long block (LDS)
-    const int stride = ST ? (int)st.nch : CH, chan = ST ? (int)seg.pad : 0;
+    const int stride = ST ? (int)st.nch : CH, chan = ST ? first_chan : 0;
 
     int previous_length = 0;
     const int p_first = seg.p0 > 0 ? (int)seg.p0 - 1 : 0;
@@ -950,8 +966,19 @@ __device__ __forceinline__ void walk_body(
                         const f2 lo1 = fma2(-b1, w1.xx, -(a1n * w0.yy));
                         const f2 hi1 = fma2(-b0, w0.xx, -(a0 * w1.yy));
                         const f2 hi0 = fma2(-b1, w0.yy, a1n * w1.xx);
-                        store_pair2<ST>(o, j + 64 * i, lo0, lo1, stride);
-                        store_pair2<ST>(o, (kPts - 1) - j - 64 * i, hi0, hi1, stride);
+                        if constexpr (ST) {
+                            // the workgroup's wavefronts -- the channel pairs of this segment -- meet in the staging area:
+                            // frames [128 i, 128 i + 128) and their mirror, whole, then stored 16 bytes per lane
+                            float *const S = stage + (i & 1) * (256 * stride) + chan;
+                            *(f2 *)(S + (2 * j) * stride) = lo0;
+                            *(f2 *)(S + (2 * j + 1) * stride) = lo1;
+                            *(f2 *)(S + (128 + 126 - 2 * j) * stride) = hi0;
+                            *(f2 *)(S + (128 + 127 - 2 * j) * stride) = hi1;
+                            staged_store<kN>(stage + (i & 1) * (256 * stride), o - chan, i, stride);
+                        } else {
+                            store_pair2<ST>(o, j + 64 * i, lo0, lo1, stride);
+                            store_pair2<ST>(o, (kPts - 1) - j - 64 * i, hi0, hi1, stride);
+                        }
                     } else {
                         float lo0[1], lo1[1], hi0[1], hi1[1];
                         const float a0 = P[H + i].x, a1 = -P[mir(i)].y, b0 = cbs[2 * i], b1 = cbs[2 * i + 1];
@@ -959,8 +986,17 @@ __device__ __forceinline__ void walk_body(
                         lo1[0] = a1 * w0.y - b1 * w1.x;
                         hi1[0] = -a0 * w1.y - b0 * w0.x;
                         hi0[0] = -a1 * w1.x - b1 * w0.y;
-                        store_pair<1, ST>(o, j + 64 * i, lo0, lo1, stride);
-                        store_pair<1, ST>(o, (kPts - 1) - j - 64 * i, hi0, hi1, stride);
+                        if constexpr (ST) {
+                            float *const S = stage + (i & 1) * (256 * stride) + chan;
+                            S[(2 * j) * stride] = lo0[0];
+                            S[(2 * j + 1) * stride] = lo1[0];
+                            S[(128 + 126 - 2 * j) * stride] = hi0[0];
+                            S[(128 + 127 - 2 * j) * stride] = hi1[0];
+                            staged_store<kN>(stage + (i & 1) * (256 * stride), o - chan, i, stride);
+                        } else {
+                            store_pair<1, ST>(o, j + 64 * i, lo0, lo1, stride);
+                            store_pair<1, ST>(o, (kPts - 1) - j - 64 * i, hi0, hi1, stride);
+                        }
                     }
                 }
             }
@@ -1084,7 +1120,7 @@ template <> struct Shape<4, 2> { static constexpr int kWaves = 16, kPerSimd = 4;
 template <> struct Shape<8, 1> { static constexpr int kWaves = 16, kPerSimd = 4; };
 template <> struct Shape<16, 2> { static constexpr int kWaves = 7, kPerSimd = 2; };      // 7 x 18432 + 24448 bytes of 160 KB
 
-template <int R, int CH, bool ST, int WAVES>
+template <int R, int CH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (Shape<R, CH>::kPerSimd)) void vorbis_walk_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off,
@@ -1113,67 +1149,117 @@ __global__ __launch_bounds__(64 * WAVES, (Shape<R, CH>::kPerSimd)) void vorbis_w
     const f2 *const T = (const f2 *)lds;
     LaneTw<R> tw;
     if constexpr (kTwAny<R, CH>) load_lane_tw<R>(tw, T);
-    if constexpr (ST) {
-        // a workgroup draws WAVES consecutive items at a time -- the channels of a segment follow each other -- so that the
-        // wavefronts filling the columns of one run of frames share a CU's L2 slice and a moment in time
-        __shared__ uint32_t first;
-        for (;;) {
-            if (threadIdx.x == 0) first = atomicAdd(next_seg, (uint32_t)WAVES);
-            __syncthreads();
-            const uint32_t base = first;
-            __syncthreads();
-            if (base >= n_segs) return;
-            const uint32_t sidx = base + wave;
-            if (sidx < n_segs) {
-                const VorbisSeg seg = segs[sidx];
-                const VorbisStream st = streams[seg.stream];
-                walk_body<R, CH, ST>(U, T, tw, seg, st, pflags, spec_off, out_off, tables, spec, out);
-            }
-        }
-    } else {
-        for (;;) {
-            uint32_t sidx = 0;
-            if ((threadIdx.x & 63) == 0) sidx = atomicAdd(next_seg, 1u);
-            sidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sidx);
-            if (sidx >= n_segs) return;
-            const VorbisSeg seg = segs[sidx];
-            const VorbisStream st = streams[seg.stream];
-            walk_body<R, CH, ST>(U, T, tw, seg, st, pflags, spec_off, out_off, tables, spec, out);
-        }
+    for (;;) {
+        uint32_t sidx = 0;
+        if ((threadIdx.x & 63) == 0) sidx = atomicAdd(next_seg, 1u);
+        sidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sidx);
+        if (sidx >= n_segs) return;
+        const VorbisSeg seg = segs[sidx];
+        const VorbisStream st = streams[seg.stream];
+        walk_body<R, CH, false>(U, T, tw, seg, st, pflags, spec_off, out_off, tables, spec, out, nullptr, 0);
+    }
+}
+
+// Streams with more than two channels: a workgroup is the nch / CH wavefronts of ONE segment (wavefront w: channels w CH ..),
+// every stream of the launch has the same channel count.  LDS: tables | one transform area per wavefront | two staging chunks
+// of 256 frames (staged_store).  At most 8 wavefronts (512 threads): the register budget of the stereo kernels.
+template <int R, int CH>
+__global__ __launch_bounds__(512, (Shape<R, CH>::kPerSimd)) void vorbis_walk_mc_kernel(
+    const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
+    const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off,
+    const float *tables, const float *__restrict__ walk_tables, const float *__restrict__ spec, float *__restrict__ out,
+    uint32_t *__restrict__ next_seg)
+{
+    using G = Geo<R>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = (int)threadIdx.x; i < G::kTabFloats / 4; i += (int)blockDim.x) ((f4 *)lds)[i] = ((const f4 *)walk_tables)[i];
+    __syncthreads();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t waves = blockDim.x >> 6;
+    f2 *const U = (f2 *)(lds + G::kTabFloats) + wave * (CH * G::kChanF2);
+    float *const stage = lds + G::kTabFloats + waves * (CH * 2 * G::kChanF2);
+    const f2 *const T = (const f2 *)lds;
+    LaneTw<R> tw;
+    if constexpr (kTwAny<R, CH>) load_lane_tw<R>(tw, T);
+    __shared__ uint32_t drawn;
+    for (;;) {
+        if (threadIdx.x == 0) drawn = atomicAdd(next_seg, 1u);
+        __syncthreads();
+        const uint32_t sidx = drawn;
+        __syncthreads();
+        if (sidx >= n_segs) return;
+        const VorbisSeg seg = segs[sidx];
+        const VorbisStream st = streams[seg.stream];
+        walk_body<R, CH, true>(U, T, tw, seg, st, pflags, spec_off, out_off, tables, spec, out, stage, (int)wave * CH);
     }
 }
 
 template <int R, int CH>
 constexpr size_t shape_lds() { return sizeof(float) * (Geo<R>::kTabFloats + (size_t)Shape<R, CH>::kWaves * CH * 2 * Geo<R>::kChanF2); }
+// (more than two channels: nch / CH transform areas and two chunks of 256 frames)
+template <int R, int CH>
+constexpr size_t mc_lds(int nch) { return sizeof(float) * (Geo<R>::kTabFloats + (size_t)(nch / CH) * CH * 2 * Geo<R>::kChanF2 + 2 * 256 * (size_t)nch); }
+
+// what one device holds of a kernel, found once per device (whichever host thread gets here first: afg.h allows concurrent
+// launches of one plan) and checked on every call
+struct DevShape {
+    std::once_flag once;
+    hipError_t rc = hipSuccess;
+    int per_cu[17] = {}, cus = 256;
+};
 
 template <int R, int CH, bool ST>
-int launch_shape(const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *streams, const uint8_t *pflags,
+int launch_shape(const VorbisSeg *segs, uint32_t n_segs, int nch, const VorbisStream *streams, const uint8_t *pflags,
                  const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
                  const float *spec, float *out, uint32_t *counter, hipStream_t stream)
 {
-    constexpr int kWaves = Shape<R, CH>::kWaves;
-    constexpr size_t kLds = shape_lds<R, CH>();
-    // once per device, whichever host thread gets here first (afg.h allows concurrent launches of one plan)
-    static std::once_flag attr_once[AFG_MAX_DEVICES];
-    static int per_cu[AFG_MAX_DEVICES];
-    static int cus[AFG_MAX_DEVICES];
+    static DevShape state[AFG_MAX_DEVICES];
     int dev = 0;
     if (int rc = afg::device_slot(&dev, "afg_vorbis_transform_hip")) return rc;
-    hipError_t attr_rc = hipSuccess;
-    std::call_once(attr_once[dev], [&] {
-        const void *fn = (const void *)vorbis_walk_kernel<R, CH, ST, kWaves>;
-        attr_rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        int nb = 1, n_cu = 256, cur = 0;
-        if (attr_rc == hipSuccess && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kWaves, kLds) != hipSuccess) nb = 1;
-        if (hipGetDevice(&cur) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cur);
-        per_cu[dev] = nb < 1 ? 1 : nb;
-        cus[dev] = n_cu;
-    });
-    AFG_HIP_CHECK(attr_rc);
-    // persistent wavefronts: as many workgroups as the device holds at once, each drawing segments from the counter
-    const uint32_t need = (n_segs + kWaves - 1) / kWaves, room = (uint32_t)(per_cu[dev] * cus[dev]);
-    hipLaunchKernelGGL((vorbis_walk_kernel<R, CH, ST, kWaves>), dim3(need < room ? need : room), dim3(64 * kWaves), kLds, stream, segs,
-                       n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter);
+    DevShape &ds = state[dev];
+    if constexpr (ST) {
+        // (walk_shape admits what fits: 4096-sample blocks of 14 or 16 channels would need more than the 160 KB of LDS)
+        constexpr int kMcMax = CH == 2 ? 16 : R == 16 ? 8 : 7;
+        static_assert(mc_lds<R, CH>(kMcMax) <= 160 * 1024, "LDS budget");
+        if (nch < 3 || nch > kMcMax || nch % CH) {
+            afg::set_error("afg_vorbis_transform_hip: %d channels on the %d-channel walk", nch, CH);
+            return AFG_ERR_INVALID;
+        }
+        const void *fn = (const void *)vorbis_walk_mc_kernel<R, CH>;
+        std::call_once(ds.once, [&] {
+            ds.rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mc_lds<R, CH>(kMcMax));
+            int n_cu = 256, cur = 0;
+            if (hipGetDevice(&cur) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cur);
+            ds.cus = n_cu;
+            for (int c = CH == 2 ? 4 : 3; ds.rc == hipSuccess && c <= kMcMax; c += CH) {
+                int nb = 1;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * (c / CH), mc_lds<R, CH>(c)) != hipSuccess) nb = 1;
+                ds.per_cu[c] = nb < 1 ? 1 : nb;
+            }
+        });
+        AFG_HIP_CHECK(ds.rc);
+        const uint32_t room = (uint32_t)(ds.per_cu[nch] * ds.cus);
+        const size_t lds_bytes = mc_lds<R, CH>(nch);
+        hipLaunchKernelGGL((vorbis_walk_mc_kernel<R, CH>), dim3(n_segs < room ? n_segs : room), dim3(64 * (nch / CH)), lds_bytes, stream,
+                           segs, n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter);
+    } else {
+        constexpr int kWaves = Shape<R, CH>::kWaves;
+        constexpr size_t kLds = shape_lds<R, CH>();
+        const void *fn = (const void *)vorbis_walk_kernel<R, CH, kWaves>;
+        std::call_once(ds.once, [&] {
+            ds.rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+            int nb = 1, n_cu = 256, cur = 0;
+            if (ds.rc == hipSuccess && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kWaves, kLds) != hipSuccess) nb = 1;
+            if (hipGetDevice(&cur) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cur);
+            ds.per_cu[0] = nb < 1 ? 1 : nb;
+            ds.cus = n_cu;
+        });
+        AFG_HIP_CHECK(ds.rc);
+        // persistent wavefronts: as many workgroups as the device holds at once, each drawing segments from the counter
+        const uint32_t need = (n_segs + kWaves - 1) / kWaves, room = (uint32_t)(ds.per_cu[0] * ds.cus);
+        hipLaunchKernelGGL((vorbis_walk_kernel<R, CH, kWaves>), dim3(need < room ? need : room), dim3(64 * kWaves), kLds, stream, segs,
+                           n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter);
+    }
     return AFG_OK;
 }
 
@@ -1210,7 +1296,14 @@ int walk_shape(int channels, int blocksize0, int blocksize1)
     if (channels < 1 || (blocksize0 > 512 && blocksize0 != blocksize1) || blocksize0 > blocksize1) return -1;
     const int size = blocksize1 == 1024 ? 0 : blocksize1 == 2048 ? 1 : blocksize1 == 4096 ? 2 : -1;
     if (size < 0) return -1;
-    return channels <= 2 ? 2 * size + (channels - 1) : (channels & 1) ? 6 + size : 9 + size;
+    if (channels <= 2) return 2 * size + (channels - 1);
+    // More than two channels: one workgroup of at most 8 wavefronts per segment.  4096-sample blocks: one wavefront per channel
+    // whatever the count (a pair's transform areas, 18 KB, would leave room for three wavefronts per CU: 15.9 ms per C3-sized
+    // batch of 6 channels, against 13.9 for round 5's column stores), so at most 8 channels; the other sizes 3, 5, 7 or an
+    // even number up to 16.  Everything else stays on the bit-exact kernels.
+    if (size == 2) return channels <= 8 ? 8 : -1;
+    if (channels & 1) return channels <= 7 ? 6 + size : -1;
+    return channels <= 16 ? 9 + size : -1;
 }
 
 int walk_shape_channels(int shape) { return shape < 6 ? (shape & 1) + 1 : shape < 9 ? 1 : 2; }
@@ -1231,12 +1324,12 @@ void walk_build_tables(int shape, float *dst, const float *window)
     else build_tables_r<16>(dst, window);
 }
 
-int walk_launch(int shape, const VorbisSeg *segs, uint32_t n_segs, const VorbisStream *streams, const uint8_t *pflags,
+int walk_launch(int shape, const VorbisSeg *segs, uint32_t n_segs, int nch, const VorbisStream *streams, const uint8_t *pflags,
                 const uint64_t *spec_off, const uint64_t *out_off, const float *tables, const float *walk_tables,
                 const float *spec, float *out, uint32_t *counter, hipStream_t stream)
 {
 #define AFG_WALK_SHAPE(S, R, CH, ST) \
-    case S: return launch_shape<R, CH, ST>(segs, n_segs, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter, stream)
+    case S: return launch_shape<R, CH, ST>(segs, n_segs, nch, streams, pflags, spec_off, out_off, tables, walk_tables, spec, out, counter, stream)
     switch (shape) {
         AFG_WALK_SHAPE(0, 4, 1, false);
         AFG_WALK_SHAPE(1, 4, 2, false);
@@ -1249,7 +1342,6 @@ int walk_launch(int shape, const VorbisSeg *segs, uint32_t n_segs, const VorbisS
         AFG_WALK_SHAPE(8, 16, 1, true);
         AFG_WALK_SHAPE(9, 4, 2, true);
         AFG_WALK_SHAPE(10, 8, 2, true);
-        AFG_WALK_SHAPE(11, 16, 2, true);
     }
 #undef AFG_WALK_SHAPE
     afg::set_error("afg_vorbis_transform_hip: walk shape %d", shape);

@@ -181,8 +181,10 @@ def test_walk_declared_zero_tail(gpu, eighths):
 # ---------------------------------------------------------------- round 5: mono streams, blocksize_1 = 1024 and 4096
 SHAPES = [(1, 256, 2048), (1, 512, 2048), (2, 256, 1024), (1, 256, 1024), (2, 512, 1024), (2, 512, 4096), (1, 512, 4096),
           (2, 256, 4096), (1, 256, 4096),
-          # more than two channels: one wavefront per channel, each storing its own column of the interleaved frames
+          # more than two channels: a workgroup per segment, one wavefront per channel (3, 5, 7) or pair of channels (even counts),
+          # whole interleaved frames put together in LDS
           (3, 256, 2048), (6, 256, 2048), (6, 512, 1024), (4, 512, 4096), (8, 256, 2048), (16, 256, 2048),
+          (5, 256, 1024), (7, 256, 2048), (7, 512, 4096), (8, 512, 4096), (12, 256, 2048), (16, 256, 1024),
           # one block size (libvorbis' lowest 16 / 22 kHz modes): every packet a long block between long blocks
           (2, 1024, 1024), (1, 1024, 1024), (2, 2048, 2048), (3, 1024, 1024)]
 
@@ -206,6 +208,16 @@ def test_walk_shape_is_the_path_under_test(gpu, ch, bs0, bs1):
     got, want = run_both(gpu, packets, channels, [bs0], [bs1], pflags, spec, 4)
     rms, differ = check(got, want)
     assert differ > got.size // 10, "tolerance mode produced the exact kernel's bits"
+
+
+@pytest.mark.parametrize("ch,bs0,bs1", [(9, 256, 2048), (10, 512, 4096), (15, 256, 1024)])
+def test_channel_counts_the_walk_leaves_to_the_exact_kernels(gpu, ch, bs0, bs1):
+    """an odd channel count above 7 and 4096-sample blocks of more than 8 channels (more wavefronts than a 512-thread
+    workgroup has) stay on the bit-exact kernels in the default mode too"""
+    packets = [14, 3]
+    pflags, spec = synthetic.vorbis_batch(9, packets, [ch] * 2, [bs0] * 2, [bs1] * 2, p_short_run=0.2)
+    got, want = run_both(gpu, packets, [ch] * 2, [bs0] * 2, [bs1] * 2, pflags, spec, 4)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
 
 
 @pytest.mark.parametrize("seg", [1, 5, 16, 1000])
