@@ -80,15 +80,81 @@ static bool vorbis_floor_on_device() { return afg::dev_option(afg::kDevVorbisHos
 // FLAC: residual rows that fit 16 bits are packed as int16 (default) or left as int32 (AFG_FLAC_HOST_RES32=1)
 static bool flac_rows_int16() { return afg::dev_option(afg::kDevFlacHostRes32) <= 0; }
 
+// Device buffers of the batch path are kept between calls (round 6).  A batch call used to hipMalloc its planes and hipFree them
+// on the way out; the driver wipes freed video memory with the copy engines, and that wipe ran into the NEXT call's transfers:
+// of back-to-back calls over the 2048-file FLAC batch every one but the first after a pause moved its 0.8 GB in 21.8 ms, the
+// first in 15.4 (AFG_TRACE; the pipeline alone, tools/ubench_pipe.hip: 10.9 ms).  The pool keeps what it has seen, per device,
+// bounded in count and bytes; afg_host_pool_trim() frees it.
+class DevicePool {
+public:
+    int take(size_t bytes, void **out, size_t *cap_out)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        const size_t want = bytes ? bytes : 1;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].dev == dev && free_[i].cap >= want && free_[i].cap <= 2 * want + ((size_t)1 << 20) &&
+                    (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+            if (best != free_.size()) {
+                *out = free_[best].p; *cap_out = free_[best].cap;
+                held_ -= free_[best].cap;
+                free_.erase(free_.begin() + (long)best);
+                return AFG_OK;
+            }
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipErrorOutOfMemory && trim()) e = hipMalloc(&p, want);          // what the pool holds may be what is missing
+        if (e != hipSuccess) { afg::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return AFG_ERR_OOM; }
+        *out = p; *cap_out = want;
+        return AFG_OK;
+    }
+    void give_back(void *p, size_t cap)
+    {
+        int dev = 0;
+        const bool known = hipGetDevice(&dev) == hipSuccess;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (known && free_.size() < 32 && held_ + cap <= ((size_t)64 << 30)) {
+                free_.push_back({ dev, p, cap });
+                held_ += cap;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+    size_t trim()
+    {
+        std::vector<Buf> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            drop.swap(free_);
+            held_ = 0;
+        }
+        size_t bytes = 0;
+        for (auto &b : drop) { (void)hipFree(b.p); bytes += b.cap; }
+        return bytes;
+    }
+private:
+    struct Buf { int dev; void *p; size_t cap; };
+    std::mutex mu_;
+    std::vector<Buf> free_;
+    size_t held_ = 0;
+};
+DevicePool g_devpool;
+
 struct DeviceBuf {
     void *p = nullptr;
-    ~DeviceBuf() { if (p) (void)hipFree(p); }
+    size_t cap = 0;
+    ~DeviceBuf() { if (p) g_devpool.give_back(p, cap); }
     int alloc(size_t bytes)
     {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-        if (e != hipSuccess) { p = nullptr; afg::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return AFG_ERR_OOM; }
-        // AFG_POISON_ALLOC=1 (tests): fresh device buffers hold NaN patterns, so that a stage that reads what nobody wrote shows
-        // (hipMemset runs on the null stream and returns early; the stages copy on non-blocking streams, which do not wait
+        if (int rc = g_devpool.take(bytes, &p, &cap)) { p = nullptr; return rc; }
+        // AFG_POISON_ALLOC=1 (tests): device buffers start out holding NaN patterns, so that a stage that reads what nobody wrote
+        // shows (hipMemset runs on the null stream and returns early; the stages copy on non-blocking streams, which do not wait
         // for it: without the synchronisation the fill can land on top of an upload)
         if (bytes && g_poison_alloc) {
             (void)hipMemset(p, 0xff, bytes);
@@ -177,6 +243,66 @@ private:
     size_t held_ = 0;
 };
 StagingPool g_staging;
+
+// The upload / download stream pair of a device stage, kept between calls.  Creating and destroying two streams cost 2.8 ms of
+// every batch call (hipStreamCreateWithFlags 0.8 ms, hipStreamDestroy 0.6 ms each), and a freshly created pair moves its first
+// several hundred megabytes at half the rate of a pair that has been used before (round 6, AFG_TRACE on the 2048-file FLAC
+// batch: 67 MB downloads 2.8 ms each on new streams, 1.4 ms on streams a probe had just run 1 GB through; `tools/ubench_pipe.hip`
+// is the pipeline alone).  A stage leases a pair (stages of one call may run on two host threads) and gives it back drained.
+class StreamPool {
+public:
+    // `mid` (optional): a third stream for the kernels of a stage whose uploads should never wait behind them
+    hipError_t take(hipStream_t *up, hipStream_t *down, hipStream_t *mid = nullptr)
+    {
+        *up = *down = nullptr;
+        if (mid) *mid = nullptr;
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev)) return e;
+        Pair got{ -1, nullptr, nullptr, nullptr };
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].dev == dev) {
+                    got = free_[i];
+                    free_.erase(free_.begin() + (long)i);
+                    break;
+                }
+        }
+        hipError_t e = hipSuccess;
+        if (!got.up) e = hipStreamCreateWithFlags(&got.up, hipStreamNonBlocking);
+        if (e == hipSuccess && !got.down) e = hipStreamCreateWithFlags(&got.down, hipStreamNonBlocking);
+        if (e == hipSuccess && mid && !got.mid) e = hipStreamCreateWithFlags(&got.mid, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            for (hipStream_t st : { got.up, got.down, got.mid }) if (st) (void)hipStreamDestroy(st);
+            return e;
+        }
+        *up = got.up; *down = got.down;
+        if (mid) *mid = got.mid;
+        else if (got.mid) {                              // not wanted this time: keep it for a later lease
+            std::lock_guard<std::mutex> lk(mu_);
+            spare_mid_.push_back({ dev, got.mid });
+        }
+        return e;
+    }
+    void give(hipStream_t up, hipStream_t down, hipStream_t mid = nullptr)
+    {
+        int dev = 0;
+        const bool known = up && down && hipGetDevice(&dev) == hipSuccess;
+        std::unique_lock<std::mutex> lk(mu_);
+        if (known && !mid)
+            for (size_t i = 0; i < spare_mid_.size(); i++)
+                if (spare_mid_[i].first == dev) { mid = spare_mid_[i].second; spare_mid_.erase(spare_mid_.begin() + (long)i); break; }
+        if (known && free_.size() < 16) { free_.push_back({ dev, up, down, mid }); return; }
+        lk.unlock();
+        for (hipStream_t st : { up, down, mid }) if (st) (void)hipStreamDestroy(st);
+    }
+private:
+    struct Pair { int dev; hipStream_t up, down, mid; };
+    std::vector<std::pair<int, hipStream_t>> spare_mid_;
+    std::mutex mu_;
+    std::vector<Pair> free_;
+};
+StreamPool g_streams;
 
 // AFG_TRACE=1: wall-clock of the host stages on stderr (development aid)
 struct StageTimer {
@@ -350,8 +476,7 @@ struct Mp3Pipe {
             if (int r = g_staging.take(sdesc_cap * sizeof(afg_mp3_sdesc), h_sdesc)) return r;
         }
         d_flags = (uint32_t *)((uint8_t *)d_in.p + coef_bytes);
-        e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+        e = g_streams.take(&up, &down);
         if (e != hipSuccess) { afg::set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
         const size_t tab_bytes = stage.blocks * 32 + 4096;
         if (int r = d_tables.alloc(tab_bytes)) return r;
@@ -433,8 +558,7 @@ struct Mp3Pipe {
         for (afg_mp3_plan *p : plans) afg_mp3_plan_destroy(p);
         for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
         plans.clear(); events.clear();
-        if (up) (void)hipStreamDestroy(up);
-        if (down) (void)hipStreamDestroy(down);
+        g_streams.give(up, down);
         up = down = nullptr;
         if (rc) return rc;
         if (e != hipSuccess) { afg::set_error("MP3 stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
@@ -690,12 +814,21 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             const afg_flac_frame *df = (const afg_flac_frame *)d_in.p;
             const afg_flac_subframe *ds = (const afg_flac_subframe *)(df + fr_total);
             const int32_t *dr = (const int32_t *)((const uint8_t *)d_in.p + rec_pad);
-            hipStream_t up = nullptr, down = nullptr;
+            // three streams: uploads only on `up` (the next chunk's never waits behind this chunk's kernel), kernels on `mid`
+            // behind the upload's event, downloads on `down` behind the kernel's
+            hipStream_t up = nullptr, down = nullptr, mid = nullptr;
             std::vector<hipEvent_t> events;
-            hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+            hipError_t e = g_streams.take(&up, &down, &mid);
             int rc = AFG_OK;
             const size_t target = std::max<size_t>((res_total + 7) / 8, (size_t)4 << 20);
+            // AFG_TRACE: host wall-clock of every chunk's gather and submission, device time of its upload, kernel and download
+            struct ChunkTrace { double t_begin, t_gathered, t_queued; hipEvent_t e_up0, e_up1, e_k1, e_d0, e_d1; };
+            std::vector<ChunkTrace> ctrace;
+            const auto t_stage = std::chrono::steady_clock::now();
+            auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_stage).count(); };
+            hipEvent_t e_stage = nullptr;
+            if (g_trace && e == hipSuccess) { (void)hipEventCreate(&e_stage); (void)hipEventRecord(e_stage, up); }
+            auto mark = [&](hipStream_t st) { hipEvent_t ev = nullptr; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, st); return ev; };
             for (size_t f0 = 0; f0 < nf && !rc && e == hipSuccess;) {
                 size_t f1 = f0, acc = 0;
                 while (f1 < nf && acc < target) { if (fmt_of(parsed[f1]) == AFG_FORMAT_FLAC) acc += parsed[f1].flac.res_size(); f1++; }
@@ -703,6 +836,8 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 for (size_t i = f0; i < f1; i++)
                     if (fmt_of(parsed[i]) == AFG_FORMAT_FLAC) { if (first == nf) first = i; last = i; }
                 if (first == nf) { f0 = f1; continue; }
+                ChunkTrace ct{};
+                ct.t_begin = since();
                 parallel_for(f1 - f0, threads, [&](size_t k) {
                     const size_t i = f0 + k;
                     Parsed &p = parsed[i];
@@ -725,29 +860,57 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 for (size_t q = fr0; q < fr1; q++)                           // (a packed frame keeps the words it was parsed into)
                     r1 = std::max<size_t>(r1, (size_t)(hf[q].res16 ? hf[q].in_off / 2 : hf[q].in_off) + (size_t)hf[q].channels * hf[q].block_size);
                 const size_t o0 = out.files[first].pcm_off, o1 = out.files[last].pcm_off + parsed[last].flac.out_samples;
+                ct.t_gathered = since();
+                if (g_trace) ct.e_up0 = mark(up);
                 e = hipMemcpyAsync((void *)(df + fr0), hf + fr0, (fr1 - fr0) * sizeof(afg_flac_frame), hipMemcpyHostToDevice, up);
                 if (e == hipSuccess) e = hipMemcpyAsync((void *)(ds + sf0), hs + sf0, (sf1 - sf0) * sizeof(afg_flac_subframe), hipMemcpyHostToDevice, up);
                 if (e == hipSuccess) e = hipMemcpyAsync((void *)(dr + r0), hres + r0, (r1 - r0) * 4, hipMemcpyHostToDevice, up);
                 if (e != hipSuccess) break;
+                if (g_trace) ct.e_up1 = mark(up);
+                hipEvent_t landed = nullptr, done = nullptr;
+                e = hipEventCreateWithFlags(&landed, hipEventDisableTiming);
+                if (e != hipSuccess) break;
+                events.push_back(landed);
+                e = hipEventRecord(landed, up);
+                if (e == hipSuccess) e = hipStreamWaitEvent(mid, landed, 0);
+                if (e != hipSuccess) break;
                 // (the records are still here in host memory: only the populated instantiations are launched)
                 rc = afg_flac_transform_variants_hip(fr1 - fr0, df + fr0, ds, dr, nullptr, (float *)d_out.p,
-                                                     afg_flac_variants(fr1 - fr0, hf + fr0, hs), up);
+                                                     afg_flac_variants(fr1 - fr0, hf + fr0, hs), mid);
                 if (rc) break;
-                hipEvent_t done = nullptr;
+                if (g_trace) ct.e_k1 = mark(mid);
                 e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
                 if (e != hipSuccess) break;
                 events.push_back(done);
-                e = hipEventRecord(done, up);
+                e = hipEventRecord(done, mid);
                 if (e == hipSuccess) e = hipStreamWaitEvent(down, done, 0);
+                if (g_trace) ct.e_d0 = mark(down);
                 if (e == hipSuccess)
                     e = hipMemcpyAsync((float *)out.plane.p + o0, (const float *)d_out.p + o0, (o1 - o0) * sizeof(float), hipMemcpyDeviceToHost, down);
+                if (g_trace) { ct.e_d1 = mark(down); ct.t_queued = since(); ctrace.push_back(ct); }
                 f0 = f1;
             }
+            const double t_loop = since();
             if (up) { hipError_t e2 = hipStreamSynchronize(up); if (e == hipSuccess) e = e2; }
+            if (mid) { hipError_t e2 = hipStreamSynchronize(mid); if (e == hipSuccess) e = e2; }
+            const double t_up = since();
             if (down) { hipError_t e2 = hipStreamSynchronize(down); if (e == hipSuccess) e = e2; }
+            if (g_trace) {
+                std::fprintf(stderr, "[afg] flac stage: loop done %.2f ms, up drained %.2f, down drained %.2f\n", t_loop, t_up, since());
+                for (size_t k = 0; k < ctrace.size(); k++) {
+                    const ChunkTrace &c = ctrace[k];
+                    float u0 = 0, u1 = 0, k1 = 0, d0 = 0, d1 = 0;
+                    (void)hipEventElapsedTime(&u0, e_stage, c.e_up0); (void)hipEventElapsedTime(&u1, e_stage, c.e_up1);
+                    (void)hipEventElapsedTime(&k1, e_stage, c.e_k1); (void)hipEventElapsedTime(&d0, e_stage, c.e_d0);
+                    (void)hipEventElapsedTime(&d1, e_stage, c.e_d1);
+                    std::fprintf(stderr, "[afg]   chunk %zu: host begin %.2f gathered %.2f queued %.2f | device up %.2f-%.2f kernel -%.2f down %.2f-%.2f\n",
+                                 k, c.t_begin, c.t_gathered, c.t_queued, u0, u1, k1, d0, d1);
+                    for (hipEvent_t ev : { c.e_up0, c.e_up1, c.e_k1, c.e_d0, c.e_d1 }) (void)hipEventDestroy(ev);
+                }
+                if (e_stage) (void)hipEventDestroy(e_stage);
+            }
             for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
-            if (up) (void)hipStreamDestroy(up);
-            if (down) (void)hipStreamDestroy(down);
+            g_streams.give(up, down, mid);
             if (rc) return rc;
             if (e != hipSuccess) { afg::set_error("FLAC stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
             tm.lap("flac gather | h2d | kernel | d2h (chunks overlapped)");
@@ -811,8 +974,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             if (int rc = g_staging.take(mp3_blocks * sizeof(uint32_t), hfl_lease)) return rc;
             uint32_t *hfl = (uint32_t *)hfl_lease.p;
             hipStream_t up = nullptr, down = nullptr;
-            hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+            hipError_t e = g_streams.take(&up, &down);
             int rc = AFG_OK;
             for (Chunk &c : chunks) {                        // plans first: their tables are uploaded synchronously
                 if (rc || e != hipSuccess) break;
@@ -896,8 +1058,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
                 if (c.plan) afg_mp3_plan_destroy(c.plan);
                 if (c.done) (void)hipEventDestroy(c.done);
             }
-            if (up) (void)hipStreamDestroy(up);
-            if (down) (void)hipStreamDestroy(down);
+            g_streams.give(up, down);
             tm.lap("mp3 h2d | kernel | d2h (chunks overlapped)");
             if (rc) return rc;
             if (e != hipSuccess) { afg::set_error("MP3 stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
@@ -913,8 +1074,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             if (int rc = d_pcm.alloc(ogg_out * sizeof(float))) return rc;
             float *ogg_plane = (float *)out.plane.p + flac_out + qoa_out + mp3_out;
             hipStream_t up = nullptr, down = nullptr;
-            hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+            hipError_t e = g_streams.take(&up, &down);
             int rc = AFG_OK;
             // Files parsed with the floor left to the device: their packets' coupling / floor records go up
             // with the chunk (one page-locked block: packets, curves, points, steps of chunk after chunk) and
@@ -1009,8 +1169,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             }
             if (up) { hipError_t e2 = hipStreamSynchronize(up); if (e == hipSuccess) e = e2; }
             if (down) { hipError_t e2 = hipStreamSynchronize(down); if (e == hipSuccess) e = e2; }
-            if (up) (void)hipStreamDestroy(up);
-            if (down) (void)hipStreamDestroy(down);
+            g_streams.give(up, down);
             if (rc) return rc;
             if (e != hipSuccess) { afg::set_error("Vorbis stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
             // files delivered as several runs (seek-style trims, damaged streams): close the runs up, in place
@@ -1793,7 +1952,9 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
         int cur_dev = 0;
         AFG_HIP_CHECK(hipGetDevice(&cur_dev));
         StageTimer tm;
+        struct ExitLap { StageTimer *t; const char *what; ~ExitLap() { t->lap(what); } } exit_lap{ &tm, "records released (call ends)" };
         std::vector<Parsed> parsed((size_t)n_files);
+        tm.lap("call set-up");
         // default: one thread per physical core of an SMT-2 host (half the logical CPUs).  With one thread per logical
         // CPU the parse stages ran up to 10x longer on a shared 256-CPU box: the stragglers wait for a CPU.
         const unsigned nt = n_threads > 0 ? (unsigned)n_threads : default_threads();
@@ -1927,8 +2088,7 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 hb[seqs_total] = recs_total;
                 hipStream_t up = nullptr, down = nullptr;
                 std::vector<hipEvent_t> events;
-                hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
-                if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+                hipError_t e = g_streams.take(&up, &down);
                 if (e == hipSuccess) e = hipMemcpyAsync(d_in.p, hb, base_bytes, hipMemcpyHostToDevice, up);
                 int rc = AFG_OK;
                 for (size_t f0 = 0; f0 < (size_t)n_files && !rc && e == hipSuccess;) {
@@ -2010,8 +2170,7 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
                 if (up) { hipError_t e2 = hipStreamSynchronize(up); if (e == hipSuccess) e = e2; }
                 if (down) { hipError_t e2 = hipStreamSynchronize(down); if (e == hipSuccess) e = e2; }
                 for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
-                if (up) (void)hipStreamDestroy(up);
-                if (down) (void)hipStreamDestroy(down);
+                g_streams.give(up, down);
                 if (rc) return rc;
                 if (e != hipSuccess) { afg::set_error("Opus stage failed: %s", hipGetErrorString(e)); return AFG_ERR_HIP; }
                 opus_staged = true;
@@ -2203,6 +2362,7 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
             items[i].pcm = (d.status == AFG_OK && d.frames > 0) ? (float *)plane + d.pcm_off : nullptr;
         }
         keep = std::move(guard);
+        tm.lap("items filled");
         return AFG_OK;
     }
 }
@@ -2227,7 +2387,7 @@ int afg_set_device(int device)
     return afg::require_device();
 }
 
-uint64_t afg_host_pool_trim(void) { return (uint64_t)g_staging.trim(); }
+uint64_t afg_host_pool_trim(void) { return (uint64_t)g_staging.trim() + (uint64_t)g_devpool.trim(); }
 
 int afg_get_device(void)
 {
@@ -2363,9 +2523,11 @@ int afg_batch_decode(const uint8_t *const *data, const size_t *length, int n_fil
 void afg_batch_free(afg_batch_result *r)
 {
     if (!r) return;
+    StageTimer tm;
     std::free(r->items);
     delete (BatchOwner *)r->owner;
     r->items = nullptr; r->owner = nullptr; r->n_files = 0;
+    tm.lap("afg_batch_free");
 }
 
 }  // extern "C"

@@ -387,6 +387,9 @@ def compact_line(full, full_record_path=None):
         elif name.endswith("_e2e"):
             e = {"value": _sig(rec.get("samples_per_s_end_to_end")), "cpu": _sig((rec.get("cpu_baseline_e2e") or {}).get("value")),
                  "vs_cpu": _sig(rec.get("vs_cpu_baseline_e2e"), 4), "ok": rec.get("all_ok")}
+            if rec.get("samples_per_s_at_the_cpu_quota"):
+                e["at_cpu_quota"] = _sig(rec["samples_per_s_at_the_cpu_quota"], 4)       # what the host parse alone allows on this box's CPU quota
+                e["host_cpus"] = _sig(rec.get("host_cpus_busy"), 3)
             par = rec.get("parity") or {}
             blocks = list(par.values()) if par and all(isinstance(v, dict) for v in par.values()) else [par]
             e["mismatches"] = sum(int(b.get("mismatches") or 0) for b in blocks)

@@ -562,8 +562,9 @@ int  afg_set_device(int device);
 int  afg_get_device(void);                 /* current device of the calling thread, < 0: afg_status */
 int  afg_batch_decode_ex(const uint8_t *const *data, const size_t *length, int n_files, const afg_batch_opts *opts,
                          afg_batch_result *out);
-/* Page-locked staging buffers are pooled between batch calls (pinning costs about as much as the transfer):
- * this releases every pooled buffer that is not in use and returns the bytes freed. */
+/* Page-locked staging buffers and the device planes of the batch path are pooled between batch calls (pinning costs about
+ * as much as the transfer; freed device memory is wiped by the copy engines the next call's transfers need): this
+ * releases every pooled buffer -- host and device -- that is not in use and returns the bytes freed. */
 uint64_t afg_host_pool_trim(void);
 
 /* ========================================================================== *

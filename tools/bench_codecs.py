@@ -199,15 +199,17 @@ def batch_of(distinct, files):
 
 
 def timed_batch(blobs, threads):
-    """afg_batch_decode over the whole batch, back to back: median seconds per call over E2E_PASSES windows of >= E2E_WINDOW_S."""
+    """afg_batch_decode over the whole batch, back to back: median seconds per call over E2E_PASSES windows of >= E2E_WINDOW_S, and
+    the CPU seconds (all threads of the process) a call consumes -- the host parse is the part of a decode that stays on the
+    host, and on a box with a CPU quota it bounds the end-to-end rate whatever the pipeline does."""
     import time
     import afgpu
     afgpu.batch_decode(blobs[:2], threads)            # warm up (device init, tables)
     job = afgpu.BatchDecoded(blobs, threads)
     job.run()
-    per_call = []
+    per_call, cpu_per_call = [], []
     for _ in range(E2E_PASSES):
-        n, t0 = 0, time.perf_counter()
+        n, t0, c0 = 0, time.perf_counter(), time.process_time()
         while True:
             job.run()                                 # the C call only: parse + H2D + kernels + D2H
             n += 1
@@ -215,8 +217,29 @@ def timed_batch(blobs, threads):
             if dt >= E2E_WINDOW_S:
                 break
         per_call.append(dt / n)
+        cpu_per_call.append((time.process_time() - c0) / n)
+    order = sorted(range(len(per_call)), key=lambda i: per_call[i])
+    mid = order[len(order) // 2]
+    timed_batch.last_cpu_seconds_per_call = cpu_per_call[mid]
     per_call.sort()
     return job, per_call[len(per_call) // 2], per_call
+
+
+def host_cpu_bound(samples, sec):
+    """What the host side of a call costs: CPU seconds per call (process-wide, every helper thread), the CPUs that keeps busy,
+    and -- where the container has a CPU quota -- the rate at which the quota alone would cap back-to-back calls."""
+    sys.path.insert(0, ROOT)
+    from bench import host_cpu_info
+    cpus, quota = host_cpu_info()
+    cpu_s = getattr(timed_batch, "last_cpu_seconds_per_call", None)
+    if not cpu_s:
+        return {}
+    out = {"host_cpu_seconds_per_call": cpu_s, "host_cpus_busy": cpu_s / sec, "cgroup_cpu_quota": quota}
+    if quota:
+        out["samples_per_s_at_the_cpu_quota"] = samples / (cpu_s / quota)
+        out["host_cpu_note"] = ("bitstream parsing stays on the host (north_star): a call needs this many CPU seconds whatever the device does; "
+                                "with the quota's CPUs that alone allows `samples_per_s_at_the_cpu_quota`")
+    return out
 
 
 _CPU_E2E_CACHE = {}
@@ -288,6 +311,7 @@ def e2e_record(kind, name, distinct, files, threads, want_fn, tolerance=False, e
            "samples_per_s_end_to_end": samples / sec, "samples_per_s_best_window": samples / min(windows), "compressed_MBps": sum(len(b) for b in blobs) / sec / 1e6,
            "cpu_baseline_e2e": cpu_e2e(kind, distinct)}
     rec["vs_cpu_baseline_e2e"] = rec["samples_per_s_end_to_end"] / rec["cpu_baseline_e2e"]["value"]
+    rec.update(host_cpu_bound(samples, sec))
     if extra:
         rec.update(extra)
     return rec
@@ -471,7 +495,8 @@ def bench_mixed_e2e(files, gen, threads):
     # CPU side: the four codecs' cpu_baseline_e2e rates combined in this batch's sample proportions (harmonic mean)
     cpu = {k: cpu_e2e(k, gen[k]) for k in per}
     cpu_rate = samples / sum(per[k] / cpu[k]["value"] for k in per)
-    return {"workload": f"{files} mixed files in one batch (40 % MP3, 25 % Ogg Vorbis, 25 % FLAC, 10 % Ogg Opus), {sum(len(v) for v in gen.values())} distinct, each its own buffer",
+    return {**host_cpu_bound(samples, sec),
+            "workload": f"{files} mixed files in one batch (40 % MP3, 25 % Ogg Vorbis, 25 % FLAC, 10 % Ogg Opus), {sum(len(v) for v in gen.values())} distinct, each its own buffer",
             "threads": threads, "all_ok": ok, "parity": parity, "seconds": sec, "seconds_per_call_windows": windows,
             "timing": f"median of {E2E_PASSES} windows of >= {E2E_WINDOW_S} s of back-to-back afg_batch_decode calls",
             "samples": samples, "samples_by_format": per, "samples_per_s_end_to_end": samples / sec,
