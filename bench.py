@@ -229,6 +229,7 @@ def other_workloads(args):
       celt_dense  8192 x Opus/CELT stereo, 200 frames of 960: the CELT kernel on a device-filling batch
       qoa         4096 x QOA stereo 4 s
       vorbis_shapes  C3-sized batches of the other Vorbis stream shapes (mono, blocksize_1 1024 / 4096, 3 and 6 channels)
+      flac_shapes    C4-sized batches of other FLAC stream shapes (24-bit, LPC order 32, mono, 6 channels, blocks of 1152 / 576)
       device_inclusive  SURVEY 8d (b): parsed records in page-locked memory -> H2D + kernels + D2H, overlapped, per headline codec
       *_e2e       SURVEY 8d (c): file bytes in host memory -> afg_batch_decode (host parse, H2D, kernels, D2H) -> floats in
                   host memory; PCIe-inclusive, never `value`.  256 DISTINCT generated files per codec (every blob its own
@@ -291,6 +292,9 @@ def other_workloads(args):
     # the other stream shapes of the Vorbis walk (mono, 1024 / 4096-sample long blocks, more than two channels), C3-sized
     d, err, wall = child([os.path.join(ROOT, "tools", "vorbis_shapes.py"), "--steps", "5", "--files", str(args.files)], 300)
     out["vorbis_shapes"] = {"error": err} if d is None else dict(d["vorbis_shapes"], wall_s=wall, error=d["vorbis_shapes"]["error"] or err)
+    # ... and of the FLAC restore (24-bit material with wide sums, LPC order 32, mono, six channels, short blocks), C4-sized
+    d, err, wall = child([os.path.join(ROOT, "tools", "flac_shapes.py"), "--steps", "5"], 300)
+    out["flac_shapes"] = {"error": err} if d is None else dict(d["flac_shapes"], wall_s=wall, error=d["flac_shapes"]["error"] or err)
     return out
 
 
@@ -396,7 +400,8 @@ def compact_line(full, full_record_path=None):
         elif name == "device_inclusive":
             e = {c: _sig(v.get("samples_per_s_device_inclusive")) for c, v in rec.items() if isinstance(v, dict)}
         elif name in ("vorbis_shapes", "flac_shapes"):
-            e = {"shapes": [[s.get("label") or f"{s.get('channels')}ch/{s.get('blocksize_0')}/{s.get('blocksize_1')}", _sig(s.get("avg_kernel_ms"), 4),
+            e = {"shapes": [[str(s["label"]).split(" ")[0] + ("/i32" if s.get("int16_rows") is False else "") if s.get("label")
+                             else f"{s.get('channels')}ch/{s.get('blocksize_0')}/{s.get('blocksize_1')}", _sig(s.get("avg_kernel_ms"), 4),
                              _sig(s.get("frac"), 3)] for s in rec.get("shapes", [])], "cols": ["shape", "kernel_ms", "frac"]}
             bad = [s for s in rec.get("shapes", []) if s.get("mismatches") or (s.get("rms_error") is not None and not s["rms_error"] <= 1e-5)]
             e["parity_failures"] = len(bad)
