@@ -8,7 +8,7 @@ module audioformats.afgpu;
 
 nothrow @nogc extern (C):
 
-enum AFG_ABI_VERSION = 1;
+enum AFG_ABI_VERSION = 2;
 
 enum afg_status : int
 {

@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define AFG_ABI_VERSION 1
+/* 2 (round 6): afg_dev_option replaced the per-call AFG_* environment knobs of version 1 (round 5 added the call without
+ * counting); afg_host_pool_trim also releases pooled device planes. */
+#define AFG_ABI_VERSION 2
 
 typedef enum afg_status {
     AFG_OK              =  0,

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(afgpu.ABI_SYMBOLS) == names          # the Python binding knows all of them
-    assert lib.afg_abi_version() == 1
+    assert lib.afg_abi_version() == 2
     assert lib.afg_status_string(0) == b"ok"
     assert lib.afg_status_string(-2) == b"no usable gfx950 device"
 

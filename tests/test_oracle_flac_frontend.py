@@ -301,3 +301,45 @@ def test_wasted_bits_are_counted_in_a_byte():
     assert (o["pcm"] == (-3 << 21 << 8)).all() and len(o["pcm"]) == 16
     ok, n = _product_vs_oracle(data)
     assert ok and n == 16
+
+
+def _stream_with_headers(channels, bps, min_bs, max_bs, total, frame_blobs, rate=44100):
+    info = fb.streaminfo(rate, channels, bps, total, min_bs, max_bs)
+    return b"fLaC" + fb.metadata_block(0, info, True) + b"".join(frame_blobs)
+
+
+def test_frame_with_fewer_channels_than_streaminfo():
+    """STREAMINFO says stereo, one frame in the middle is mono (its own header says so).  The reference decodes every frame by
+    its own header and drflac_read_s32 walks frames by their own channel counts: whatever it delivers -- count and values --
+    the product's parser + restore delivers (the product derived a length from STREAMINFO's channel count)."""
+    st = make_pcm(256 * 3, 2, 16, 21)
+    mono = make_pcm(256, 1, 16, 22)
+    f2, s2, r2, _ = enc.encode(st, 16, 256, orders=(2, 8), use_fixed_every=1000)
+    f1, s1, r1, _ = enc.encode(mono, 16, 256, orders=(2,), use_fixed_every=1000)
+    blobs = [fb.write_frame(f2[0], s2, r2, 0, 44100, 16), fb.write_frame(f2[1], s2, r2, 1, 44100, 16),
+             fb.write_frame(f1[0], s1, r1, 2, 44100, 16), fb.write_frame(f2[2], s2, r2, 3, 44100, 16)]
+    for total in (256 * 4, 0):                                   # declared length, and none
+        data = _stream_with_headers(2, 16, 256, 256, total, blobs)
+        o = oraclelib.flac_decode_file(data)
+        assert isinstance(o, dict) and o["n_frames"] >= 2
+        want = o["pcm"] if not o["flags"] else o["pcm"][:o["first_flag_sample"]]
+        got = product_pcm(data)
+        assert got is not None and got.size == want.size, (got.size if got is not None else None, want.size)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_streaminfo_with_zero_max_block():
+    """max_block = 0 in STREAMINFO (a header no encoder writes): the oracle says what the reference's open and read make of it;
+    the product agrees on open / refuse and on every delivered sample."""
+    pcm = make_pcm(192 * 3, 2, 16, 23)
+    f, s, r, _ = enc.encode(pcm, 16, 192, orders=(2, 8), use_fixed_every=1000)
+    blobs = [fb.write_frame(f[i], s, r, i, 44100, 16) for i in range(len(f))]
+    data = _stream_with_headers(2, 16, 0, 0, 192 * 3, blobs)
+    o = oraclelib.flac_decode_file(data)
+    got = product_pcm(data)
+    if not isinstance(o, dict):
+        assert got is None or got.size == 0
+    else:
+        want = o["pcm"] if not o["flags"] else o["pcm"][:o["first_flag_sample"]]
+        assert got is not None and got.size == want.size
+        np.testing.assert_array_equal(got, want)
