@@ -273,6 +273,7 @@ constexpr int kHS = 66;                      // row stride: even (8-byte pair re
 constexpr int kHistRows = 15;
 constexpr int kRegion = kHistRows * kHS;     // float offset of row 15
 constexpr int kLdsFloats = 33 * kHS;
+constexpr int kWinStride = 18;               // floats between the rows of the window table in LDS (9 eight-byte slots: odd)
 
 struct alignas(8) f2 { float x, y; };
 
@@ -316,7 +317,8 @@ __device__ __forceinline__ void mp3_segment(
     const int si = lane & 15;
 
     // window taps of this lane's column pair: row 14-i of g_win (minimp3.d:1336-1352, :1388-1395)
-    const f2 *const wrow = (const f2 *)(Wt + (14 - (si < 15 ? si : 14)) * 16);
+    // (rows kWinStride = 18 floats apart: with 16, the eight 8-byte reads of a granule hit four bank groups from fifteen lanes)
+    const f2 *const wrow = (const f2 *)(Wt + (14 - (si < 15 ? si : 14)) * kWinStride);
 
     // ---- carry state ------------------------------------------------------------
     float ov[9];
@@ -603,9 +605,9 @@ __global__ __launch_bounds__(64, AFG_MP3_MIN_WAVES) void AFG_MP3_KERNEL(
     float *__restrict__ pcm, float *__restrict__ state)
 {
     __shared__ __attribute__((aligned(16))) float H[kLdsFloats];
-    __shared__ __attribute__((aligned(16))) float Wt[15 * 16];      // g_win, re-read every granule (saves 16 VGPRs)
+    __shared__ __attribute__((aligned(16))) float Wt[15 * kWinStride];      // g_win, re-read every granule (saves 16 VGPRs)
     const int lane = threadIdx.x;
-    for (int i = lane; i < 15 * 16; i += 64) Wt[i] = k_win[i];
+    for (int i = lane; i < 15 * 16; i += 64) Wt[(i >> 4) * kWinStride + (i & 15)] = k_win[i];
     const Mp3Seg seg = segs[blockIdx.x];
     const Mp3Stream st = streams[seg.stream];
     if (st.nch == 2) mp3_segment<2>(seg, st, coef, flags, pcm, state, H, Wt);
