@@ -685,13 +685,13 @@ def run_rank(args, world, rank, local_rank):
         tot5 = reduce_sum(float(my5))
         if rank == 0:
             value5 = tot5 * 3 / e5_max
-            ref = (load_traffic("r05_c5.json") or load_traffic("r04_c5.json") or {})
+            ref = (load_traffic("r06_c5.json") or load_traffic("r05_c5.json") or {})
             ref_value = ref.get("value") if ref.get("n_gpus", 1) == 1 else None
             c5_tail = {"workload": f"{args.c5_files}-file mixed corpus file-sharded over {world} GPU(s) by LPT on predicted device time (bench.py --config c5)",
                        "value": value5, "unit": "samples/s", "scaling": "strong", "n_gpus": world, "steps": 3, "ms_per_step": e5_max / 3 * 1e3,
                        "per_rank_ms_per_step": {"min": e5_min / 3 * 1e3, "max": e5_max / 3 * 1e3},
                        "samples_per_step": int(tot5), "waves_per_gpu": len(waves5), "lpt_imbalance": corpus.c5_imbalance(man5, world),
-                       "n1_reference_value": ref_value, "n1_reference_source": "profiles/r05_c5.json (bench.py --config c5 on one GPU)" if ref_value else None,
+                       "n1_reference_value": ref_value, "n1_reference_source": "profiles/r06_c5.json or r05_c5.json (bench.py --config c5 on one GPU)" if ref_value else None,
                        "efficiency_vs_n1": (value5 / (world * ref_value)) if ref_value else None,
                        "kernels": [{"codec": n, "avg_kernel_ms": sum(k["ms"]) / len(k["ms"]), "samples_per_launch": int(k["samples"])} for n, k in kern5.items()],
                        "parity": parity5}
@@ -707,8 +707,8 @@ def run_rank(args, world, rank, local_rank):
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
     # passes over the same full-size batch, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_collect.sh): only
     # for the kernels and batch sizes those passes were taken on
-    pmc_file = {"mp3": "r05_pmc_mp3_tolerance_kernel.json", "vorbis": "r05_pmc_vorbis_walk_kernel.json",
-                "flac": "r05_pmc_flac_restore1_kernel.json"}     # (FLAC: counters calibrated on its own access pattern, both instantiations)
+    pmc_file = {"mp3": "r06_pmc_mp3_tolerance_kernel.json", "vorbis": "r06_pmc_vorbis_walk_kernel.json",
+                "flac": "r06_pmc_flac_restore1_kernel.json"}     # (FLAC: counters calibrated on its own access pattern, both instantiations)
     kernels = []
     for name, k in kern.items():
         avg_ms = sum(k["ms"]) / len(k["ms"])
