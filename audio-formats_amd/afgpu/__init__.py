@@ -158,7 +158,7 @@ _DEV_ENV = {"AFG_CELT_PATH": ("celt_path", {"stream": 1, "split": 2, "walk": 3})
             "AFG_CELT_WHOLE_FRAMES": ("celt_whole_frames", None), "AFG_VORBIS_SINGLE": ("vorbis_single", None),
             "AFG_MP3_CHUNKS": ("mp3_chunks", None), "AFG_MP3_FLOAT_UPLOAD": ("mp3_float_upload", None),
             "AFG_VORBIS_HOST_FLOOR": ("vorbis_host_floor", None), "AFG_FLAC_HOST_RES32": ("flac_host_res32", None),
-            "AFG_VORBIS_SEG_PACKETS": ("vorbis_seg_packets", None)}
+            "AFG_VORBIS_SEG_PACKETS": ("vorbis_seg_packets", None), "AFG_BATCH_GROUPS": ("batch_groups", None)}
 _dev_seen = {}
 
 

@@ -60,10 +60,10 @@ int numeric_mode()
     return AFG_NUMERIC_TOLERANCE;
 }
 
-static std::atomic<long> g_dev_option[kDevCount] = { { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 } };
+static std::atomic<long> g_dev_option[kDevCount] = { { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 }, { -1 } };
 static const char *const k_dev_option_name[kDevCount] = { "celt_path", "celt_de_seq", "celt_de_duo", "celt_seg_recs", "celt_whole_frames",
                                                           "vorbis_single", "mp3_chunks", "mp3_float_upload", "vorbis_host_floor",
-                                                          "flac_host_res32", "vorbis_seg_packets" };
+                                                          "flac_host_res32", "vorbis_seg_packets", "batch_groups" };
 
 long dev_option(DevOption which) { return g_dev_option[which].load(std::memory_order_relaxed); }
 

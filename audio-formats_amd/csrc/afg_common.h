@@ -28,7 +28,7 @@ int numeric_mode();
 // Alternative code paths the test-suite runs side by side with the default ones (afg.h: afg_dev_option).  Set through
 // that call only -- the library reads no environment variable for them -- and -1 while unset.
 enum DevOption { kDevCeltPath, kDevCeltDeSeq, kDevCeltDeDuo, kDevCeltSegRecs, kDevCeltWholeFrames, kDevVorbisSingle,
-                 kDevMp3Chunks, kDevMp3FloatUpload, kDevVorbisHostFloor, kDevFlacHostRes32, kDevVorbisSegPackets, kDevCount };
+                 kDevMp3Chunks, kDevMp3FloatUpload, kDevVorbisHostFloor, kDevFlacHostRes32, kDevVorbisSegPackets, kDevBatchGroups, kDevCount };
 long dev_option(DevOption which);
 
 #define AFG_HIP_CHECK(expr)                                                              \

@@ -118,7 +118,7 @@ public:
         const bool known = hipGetDevice(&dev) == hipSuccess;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            if (known && free_.size() < 32 && held_ + cap <= ((size_t)64 << 30)) {
+            if (known && free_.size() < 128 && held_ + cap <= ((size_t)64 << 30)) {
                 free_.push_back({ dev, p, cap });
                 held_ += cap;
                 return;
@@ -231,7 +231,7 @@ private:
     void give_back(void *p, size_t cap)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        if (free_.size() < 24 && held_ + cap <= ((size_t)24 << 30)) {
+        if (free_.size() < 128 && held_ + cap <= ((size_t)24 << 30)) {      // (a grouped batch leases a set of buffers per group)
             free_.emplace_back(p, cap);
             held_ += cap;
         } else {
@@ -378,7 +378,12 @@ private:
 HelperPool g_helpers;
 // A multi-device batch runs one host thread per device, each with its own helpers (g_helpers serves one job at a time)
 HelperPool g_device_helpers[16];
+// ... and the second host thread of a grouped batch (afg_batch_decode_ex) its own: a pool serves one job at a time, and a
+// group's parse pass must not find it taken by the other group's small gather jobs (it would run on one thread)
+HelperPool g_group_helpers[16];
 thread_local HelperPool *tl_helpers = nullptr;
+// chunks a device stage cuts its files into (8; a group of a grouped batch -- below -- is itself a piece of a pipeline and takes 2)
+thread_local unsigned tl_stage_chunks = 8;
 
 template <typename F>
 void parallel_for(size_t n, unsigned threads, F fn)
@@ -668,7 +673,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
         size_t total = 0;
         for (size_t i = 0; i < nf; i++)
             if (fmt_of(parsed[i]) == AFG_FORMAT_OGG) { total += parsed[i].ogg.n_spec; ogg_packets += parsed[i].ogg.pflags.size(); }
-        const size_t target = std::max<size_t>((total + 7) / 8, (size_t)4 << 20);
+        const size_t target = std::max<size_t>((total + tl_stage_chunks - 1) / tl_stage_chunks, (size_t)4 << 20);
         for (size_t f0 = 0; f0 < nf && ogg_packets;) {
             size_t f1 = f0, acc = 0;
             while (f1 < nf && acc < target) { if (fmt_of(parsed[f1]) == AFG_FORMAT_OGG) acc += parsed[f1].ogg.n_spec; f1++; }
@@ -820,7 +825,7 @@ int decode_parsed(std::vector<Parsed> &parsed, const uint8_t *const *data, const
             std::vector<hipEvent_t> events;
             hipError_t e = g_streams.take(&up, &down, &mid);
             int rc = AFG_OK;
-            const size_t target = std::max<size_t>((res_total + 7) / 8, (size_t)4 << 20);
+            const size_t target = std::max<size_t>((res_total + tl_stage_chunks - 1) / tl_stage_chunks, (size_t)4 << 20);
             // AFG_TRACE: host wall-clock of every chunk's gather and submission, device time of its upload, kernel and download
             struct ChunkTrace { double t_begin, t_gathered, t_queued; hipEvent_t e_up0, e_up1, e_k1, e_d0, e_d1; };
             std::vector<ChunkTrace> ctrace;
@@ -1908,18 +1913,19 @@ double cpu_quota()
 
 // Host threads of a batch when the caller leaves the choice to the library: one per physical core of an SMT-2 host (with one
 // per logical CPU the parse stages ran up to 10x longer on a shared 256-CPU box: the stragglers wait for a CPU) -- and under a
-// cgroup quota no more than FOUR times the quota's CPUs.  The GPU boxes of this project show 256 logical CPUs behind a 16-CPU
-// quota.  Round 3 sized this on single calls, which finish inside the burst the quota allows (128 threads were fastest);
-// sustained -- back-to-back calls for seconds, what a service does and what bench.py times since round 4 -- the parse stages of
-// 2048-file batches run at 4.1 / 3.5 / 2.0e9 samples/s (MP3 / Vorbis / FLAC) with 128 threads, 4.2 / 4.1 / 2.5 with 32 and
-// 5.1 / 4.4 / 2.7 with 64 (tools/gpu_e2e_threads.sh): threads the quota cannot run only get descheduled in the middle of a file.
+// cgroup quota ONE AND A HALF times the quota's CPUs.  The GPU boxes of this project show 256 logical CPUs behind a 16-CPU
+// quota.  What counts for back-to-back calls -- what a service does and what bench.py times -- is the CPU seconds a call
+// costs, and threads the quota cannot run cost more of them (descheduled in the middle of a file, cold caches): round 6, 2048-file
+// batches, CPU seconds per call with 16 / 24 / 32 / 64 threads: FLAC 0.27 / 0.28 / 0.31 / 0.37, Vorbis 1.09 / 1.16 / 1.24 / 1.39,
+// and MP3 5.8e9 samples/s with 64 threads, 7.0e9 with 24 (tools/gpu_r06_e2e_threads.sh, gpu_r06_groups.sh).  Rounds 3-5 used four
+// times the quota, sized on single calls that finish inside the burst the quota allows.
 unsigned default_threads()
 {
     static const unsigned n = [] {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         unsigned t = hw >= 16 ? hw / 2 : hw;
         const double quota = cpu_quota();
-        if (quota > 0) t = std::min(t, std::max(1u, (unsigned)(4 * quota + 0.5)));
+        if (quota > 0) t = std::min(t, std::max(1u, (unsigned)(1.5 * quota + 0.5)));
         return std::max(1u, t);
     }();
     return n;
@@ -1944,8 +1950,10 @@ struct BatchOwner {
 };
 
 // The whole batch path for the files handed in, on the calling thread's current device; fills items[0..n_files).
+// `parse_done` (optional) is called once, when the host passes that keep every helper thread busy are over and what remains is
+// the device stages of decode_parsed: a grouped batch lets its next group start parsing then.
 int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_files, int n_threads, afg_batch_item *items,
-                        std::unique_ptr<BatchOut> &keep)
+                        std::unique_ptr<BatchOut> &keep, const std::function<void()> *parse_done = nullptr)
 {
     {
         if (int rc = afg::require_device()) return rc;
@@ -2338,6 +2346,7 @@ int batch_decode_device(const uint8_t *const *data, const size_t *length, int n_
             if (prc) return prc;
             if (fallback) stage.blocks = 0;                   // decode_parsed does those files from their own buffers
         }
+        if (parse_done) (*parse_done)();
         int rc = decode_parsed(parsed, data, length, nt, *owner, stage.blocks ? &stage : nullptr, ogg_stage.floats ? &ogg_stage : nullptr,
                                split ? nullptr : (flac_stage.words ? &flac_stage : nullptr), split ? own_late.data() : nullptr, nullptr, nullptr,
                                opus_staged ? opus_pcm_at.data() : nullptr);
@@ -2434,8 +2443,83 @@ int afg_batch_decode_ex(const uint8_t *const *data, const size_t *length, int n_
                 AFG_HIP_CHECK(hipGetDevice(&cur));
                 if (cur != devs[0]) { restore = cur; AFG_HIP_CHECK(hipSetDevice(devs[0])); }
             }
-            owner->parts.emplace_back();
-            const int rc = batch_decode_device(data, length, n_files, n_threads, items, owner->parts.back());
+            // A large batch runs as a pipeline of GROUPS of files (round 6): while one group's device stages run -- the host mostly
+            // waiting -- the next group is parsed.  Two host threads take the groups in turn; a token serialises their parse passes
+            // (one set of helper threads at a time), handed on when a group reaches its device stages.  Results do not depend on
+            // the grouping (files are independent).  afg_dev_option("batch_groups", n) forces n (1: off).
+            size_t total_bytes = 0;
+            for (int i = 0; i < n_files; i++) total_bytes += length[i];
+            // By default only batches of (almost only) native FLAC and Ogg Vorbis files, from 512 files and 16 MB up, in 4 groups:
+            // their calls are a parse pass followed by device stages; the MP3 and Opus paths overlap their parsing with their own
+            // transfers already and lose 5-10 % to the split (2048-file batches, 24 helper threads, samples/s ungrouped -> 4 groups:
+            // Vorbis 5.3e9 -> 6.2e9, FLAC 5.0e9 -> 5.7e9, MP3 6.5e9 -> 6.0e9, Opus 2.5e9 -> 2.3e9, mixed 4.9e9 -> 4.5e9).
+            long groups = afg::dev_option(afg::kDevBatchGroups);
+            if (groups <= 0) {
+                groups = 1;
+                if (n_files >= 512 && total_bytes >= ((size_t)16 << 20)) {
+                    int staged = 0;
+                    for (int i = 0; i < n_files; i++) {
+                        const uint8_t *b = data[i];
+                        const size_t n = length[i];
+                        if (n >= 4 && !std::memcmp(b, "fLaC", 4)) staged++;
+                        else if (n >= 28 && !std::memcmp(b, "OggS", 4) && n >= (size_t)27 + b[26] + 7 &&
+                                 !std::memcmp(b + 27 + b[26], "\x01vorbis", 7)) staged++;      // (the first page's payload: the identification header)
+                    }
+                    if ((size_t)staged * 10 >= (size_t)n_files * 9) groups = 4;
+                }
+            }
+            if (groups > n_files) groups = n_files;
+            int rc = AFG_OK;
+            if (groups <= 1) {
+                owner->parts.emplace_back();
+                rc = batch_decode_device(data, length, n_files, n_threads, items, owner->parts.back());
+            } else {
+                const size_t G = (size_t)groups;
+                owner->parts.resize(G);
+                std::vector<int> first(G + 1, n_files);          // contiguous ranges of about equal compressed size
+                {
+                    size_t acc = 0, g = 0;
+                    first[0] = 0;
+                    for (int i = 0; i < n_files && g + 1 < G; i++) {
+                        acc += length[i];
+                        if (acc * G >= total_bytes * (g + 1)) first[++g] = i + 1;
+                    }
+                }
+                int dev = 0;
+                AFG_HIP_CHECK(hipGetDevice(&dev));
+                HelperPool *const helpers = tl_helpers;
+                std::mutex token;
+                std::atomic<bool> failed{ false };
+                struct Job { int rc = AFG_OK; std::string error; } jobs[2];
+                auto work = [&](int w) {
+                    try {
+                        if (w && hipSetDevice(dev) != hipSuccess) { jobs[w].rc = AFG_ERR_HIP; jobs[w].error = "hipSetDevice failed"; failed = true; return; }
+                        tl_helpers = w ? &g_group_helpers[dev & 15] : helpers;
+                        tl_stage_chunks = 2;
+                        for (size_t g = (size_t)w; g < G && !failed; g += 2) {
+                            const int f0 = first[g], f1 = first[g + 1];
+                            if (f1 <= f0) continue;
+                            std::unique_lock<std::mutex> lk(token);
+                            bool released = false;
+                            const std::function<void()> done = [&] { if (!released) { released = true; lk.unlock(); } };
+                            const int r = batch_decode_device(data + f0, length + f0, f1 - f0, n_threads, items + f0, owner->parts[g], &done);
+                            done();
+                            if (r) { jobs[w].rc = r; jobs[w].error = afg_last_error(); failed = true; }
+                        }
+                    } catch (...) {
+                        jobs[w].rc = AFG_ERR_OOM; jobs[w].error = "out of host memory"; failed = true;
+                    }
+                    tl_stage_chunks = 8;
+                    tl_helpers = helpers;
+                };
+                {
+                    struct Joiner { std::thread th; ~Joiner() { if (th.joinable()) th.join(); } } j;
+                    j.th = std::thread(work, 1);
+                    work(0);
+                }
+                for (const Job &jb : jobs)
+                    if (jb.rc && !rc) { afg::set_error("%s", jb.error.c_str()); rc = jb.rc; }
+            }
             if (restore >= 0) (void)hipSetDevice(restore);
             if (rc) return rc;
         } else {

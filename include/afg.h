@@ -75,7 +75,8 @@ int         afg_set_numeric_mode(int mode);
  * "celt_de_duo" (0 / 1), "celt_seg_recs", "celt_whole_frames", "vorbis_single" (1: one channel per wavefront),
  * "mp3_chunks", "mp3_float_upload" (1: float spectra instead of quantised values cross the bus), "vorbis_host_floor"
  * (1: floor curves on the host), "flac_host_res32" (1: int32 residual rows only), "vorbis_seg_packets" (packets per walk
- * item of plans created with seg_packets = 0, instead of the library's choice).  AFG_ERR_INVALID: no such name. */
+ * item of plans created with seg_packets = 0, instead of the library's choice), "batch_groups" (groups of files a batch call
+ * pipelines: 1 = none; default 4 for batches of FLAC / Ogg Vorbis files from 512 files up, else 1).  AFG_ERR_INVALID: no such name. */
 int         afg_dev_option(const char *name, int value);
 int         afg_get_numeric_mode(void);
 int         afg_device_name(int device, char *buf, size_t buflen);

@@ -171,3 +171,44 @@ def test_generated_vorbis_stream_shapes_default_mode(gpu):
         else:
             assert same, (ch, bs)                # the bit-exact kernels
     assert walked >= 7
+
+
+def test_grouped_batch_pipeline_does_not_change_the_samples(gpu):
+    """A large batch call runs as a pipeline of groups of files (afg.h: dev option "batch_groups"; by default from 512 files up):
+    every sample is the one the ungrouped call delivers -- all formats, a broken file and an empty one in the middle, a group
+    count that does not divide the batch."""
+    import opus_bitstream
+    import vorbis_bitstream as vb
+    rng = np.random.default_rng(61)
+    kinds = []
+    for k in range(6):
+        flac, _ = fb.encode_file(make_pcm(3000 + 500 * k, 2 if k % 2 else 1, 16, 30 + k), 16, 576 if k % 2 else 1024)
+        qoa, _ = qoa_file(5000 + 300 * k, 1 + k % 2, 44100, 40 + k)
+        opus, _ = opus_bitstream.random_celt_file(np.random.default_rng(50 + k), 1 + k % 2, 8 + k, preskip=312)
+        kinds += [flac, qoa, opus, vb.make_file(400 + k, n_packets=12 + 3 * k)]
+    kinds += [open(MP3_FIXTURE, "rb").read(), open(OGG_FIXTURE, "rb").read(), b"junk" * 64, b""]
+    files = [bytes(kinds[int(i)]) for i in rng.integers(0, len(kinds), 520)]
+    import os
+    old = os.environ.get("AFG_BATCH_GROUPS")
+    try:
+        os.environ["AFG_BATCH_GROUPS"] = "1"
+        one = afgpu.batch_decode(files, n_threads=6)
+        for groups in ("2", "5", "7"):
+            os.environ["AFG_BATCH_GROUPS"] = groups
+            many = afgpu.batch_decode(files, n_threads=6)
+            for a, b in zip(one, many):
+                assert (a["status"], a["format"], a["frames"], a["channels"], a["samplerate"]) == (b["status"], b["format"], b["frames"], b["channels"], b["samplerate"])
+                if a["pcm"] is not None:
+                    assert np.array_equal(a["pcm"].view(np.uint32), b["pcm"].view(np.uint32))
+        os.environ.pop("AFG_BATCH_GROUPS")
+        auto = afgpu.batch_decode(files, n_threads=6)            # the library's own choice (a mixed batch: not grouped)
+        for a, b in zip(one, auto):
+            assert a["status"] == b["status"] and a["frames"] == b["frames"]
+            if a["pcm"] is not None:
+                assert np.array_equal(a["pcm"].view(np.uint32), b["pcm"].view(np.uint32))
+    finally:
+        if old is None:
+            os.environ.pop("AFG_BATCH_GROUPS", None)
+        else:
+            os.environ["AFG_BATCH_GROUPS"] = old
+    assert sum(o["status"] == 0 for o in one) >= 400 and any(o["status"] != 0 for o in one)
