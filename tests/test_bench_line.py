@@ -45,6 +45,18 @@ def test_compact_line_fits_and_carries_the_contract():
     assert len(ow["vorbis_shapes"]["shapes"]) == len(full["other_workloads"]["vorbis_shapes"]["shapes"])
 
 
+def test_compact_line_of_the_round_6_record():
+    bench = _bench()
+    with open(os.path.join(ROOT, "profiles", "r06_bench_final.json")) as fh:
+        full = json.load(fh)
+    text = bench.compact_line(full, "gpurun_out/bench_full.json")
+    assert len(text) <= 6000
+    line = json.loads(text)
+    assert line["roofline"]["kernel"] == "flac_restore1_kernel" and line["roofline"]["traffic"] and line["roofline"]["traffic_from"].startswith("profiles/r06_pmc_")
+    assert line["cpu_baseline"]["cores"] >= 1 and line["other_workloads"]["flac_e2e"]["at_cpu_quota"] > 0
+    assert len(line["other_workloads"]["flac_shapes"]["shapes"]) == 10
+
+
 def test_compact_line_sheds_detail_rather_than_overflow():
     bench = _bench()
     full = _canned()
