@@ -475,15 +475,18 @@ __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, 
         for (; t0 < max_bs; t0 += kT) {
             if (t0 + kT < max_bs) load_tile1<MODE>(nxt, meta, res, pair, t0 + kT);
             if (t0 < (int)me.bs) restore_tile1<MAXORD, WIDE>(tile, row, slot, t0, order, shift, u64, c, h);
-            __syncthreads();
+            // (the workgroup is one wavefront: ordering points, not __syncthreads(), which also waits for every load and store in
+            // flight.  It is not what makes six channels slow -- 58 ms per C4-sized batch either way: the pair loop is the outer
+            // one, so a 128-byte line of interleaved samples gets its 8-byte pieces from three passes a whole frame apart)
+            wave_sync();
             // make the prefetched residuals resident here: loads and stores share one in-order counter
 #pragma unroll
             for (int i = 0; i < Loads1<MODE>::n; i++)
                 asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y), "+v"(nxt[i].z), "+v"(nxt[i].w) : : "memory");
             store_tile1(tile, meta, row_shift, out_i32, out_f32, pair, t0);
-            __syncthreads();
+            wave_sync();
             if (t0 + kT < max_bs) park_tile1<MODE>(tile, meta, nxt);
-            __syncthreads();
+            wave_sync();
         }
     }
 }
