@@ -1160,11 +1160,18 @@ __global__ __launch_bounds__(64 * WAVES, (Shape<R, CH>::kPerSimd)) void vorbis_w
     }
 }
 
+// wavefronts per SIMD the multi-channel kernels are compiled for (the register budget): as the mono / stereo kernel of the shape unless
+// overridden -- workgroups of 3-7 wavefronts pack a CU differently than the 16-wavefront groups of the small mono / stereo shapes
+#ifndef AFG_MC_PERSIMD_SMALL
+#define AFG_MC_PERSIMD_SMALL 4
+#endif
+template <int R, int CH> struct McPerSimd { static constexpr int k = Shape<R, CH>::kPerSimd == 4 ? AFG_MC_PERSIMD_SMALL : Shape<R, CH>::kPerSimd; };
+
 // Streams with more than two channels: a workgroup is the nch / CH wavefronts of ONE segment (wavefront w: channels w CH ..),
 // every stream of the launch has the same channel count.  LDS: tables | one transform area per wavefront | two staging chunks
 // of 256 frames (staged_store).  At most 8 wavefronts (512 threads): the register budget of the stereo kernels.
 template <int R, int CH>
-__global__ __launch_bounds__(512, (Shape<R, CH>::kPerSimd)) void vorbis_walk_mc_kernel(
+__global__ __launch_bounds__(512, (McPerSimd<R, CH>::k)) void vorbis_walk_mc_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, const VorbisStream *__restrict__ streams,
     const uint8_t *__restrict__ pflags, const uint64_t *__restrict__ spec_off, const uint64_t *__restrict__ out_off,
     const float *tables, const float *__restrict__ walk_tables, const float *__restrict__ spec, float *__restrict__ out,
