@@ -491,6 +491,15 @@ __device__ __forceinline__ void run_frames1(int32_t *tile, const RowMeta *meta, 
     }
 }
 
+// (a wavefront of one multi-channel shape: flac_restore_mc_kernel, below, takes it)
+__device__ __forceinline__ bool mc_wavefront(bool valid, const afg_flac_frame &fr)
+{
+    const int c0 = __builtin_amdgcn_readfirstlane(valid ? (int)fr.channels : 0);      // lane 0's frame is the block's first
+    const int r0 = __builtin_amdgcn_readfirstlane(valid ? (int)(fr.res16 != 0) : 0);
+    const bool ok = !valid || ((int)fr.channels == c0 && fr.assignment == AFG_FLAC_INDEPENDENT && (int)(fr.res16 != 0) == r0);
+    return c0 > 2 && c0 <= 8 && __all(ok);
+}
+
 // One kernel per (order bucket, accumulator width): a wavefront runs only in the instantiation that matches the largest
 // LPC order / widest accumulator among the subframes of its 32 frames and leaves the others at once.
 template <int LO, int MAXORD, bool WIDE>
@@ -525,6 +534,7 @@ __global__ __launch_bounds__(64, 2) void flac_restore1_kernel(
     const int max_order = wave_max(my_order);
     const bool wide = wave_max(my_wide) != 0;
     if (!(max_order > LO && max_order <= MAXORD && wide == WIDE)) return;
+    if (mc_wavefront(valid, fr)) return;                 // more than two channels throughout: flac_restore_mc_kernel's
 
     if (valid) {
         me.in_off = fr.in_off;
@@ -580,6 +590,170 @@ __global__ __launch_bounds__(64, 2) void flac_restore1_kernel(
         run_frames1<MAXORD, WIDE, 2>(tile, meta, me, valid, subframes, sf_index, res, out_i32, out_f32, max_bs, max_pairs, row_shift, rowfast, fastw, mono, min_bs, in_base, out_base);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// More than two channels (round 6).  The general step above walks a frame once per channel PAIR, so a 128-byte line of
+// interleaved samples gets its 8-byte pieces from passes a whole frame apart (six channels: 58 ms per C4-sized batch, 0.14
+// of peak).  A wavefront whose frames all have the same channel count C in 3 .. 8 (independent channels: the only
+// assignment FLAC has above two) and one row width belongs to flac_restore_mc_kernel instead: lane = subframe for
+// floor(64 / C) whole frames at a time, the same 64-sample tile and recurrence, and the tile leaves as whole interleaved
+// frames -- 64 C consecutive samples per frame and step, 256 contiguous bytes per store instruction.
+// ---------------------------------------------------------------------------------------------------------------
+// e / C for e < 4096, C in 3 .. 8: multiply by ceil(2^16 / C) (exact: the error stays below 1 / 16, fractions are at most 7 / 8)
+__device__ __forceinline__ int div_small(int e, int inv) { return (int)(((uint32_t)e * (uint32_t)inv) >> 16); }
+
+template <int LO, int MAXORD, bool WIDE>
+__global__ __launch_bounds__(64, 2) void flac_restore_mc_kernel(
+    const afg_flac_frame *__restrict__ frames, const afg_flac_subframe *__restrict__ subframes,
+    const int32_t *__restrict__ res, int32_t *__restrict__ out_i32, float *__restrict__ out_f32, uint64_t n_frames)
+{
+    __shared__ __attribute__((aligned(16))) int32_t tile[kFpw * kRowWords];      // 64 subframe rows x 64 samples, rows in pairs as above
+    __shared__ RowMeta meta[kFpw];
+    __shared__ uint8_t row_shift[kFpw * 8];
+    const int lane = threadIdx.x;
+    const uint64_t f = (uint64_t)blockIdx.x * kFpw + (lane >> 1);
+    const bool valid = f < n_frames;
+    afg_flac_frame fr;
+    fr.channels = 0; fr.assignment = 0; fr.res16 = 0; fr.sf_index = 0; fr.block_size = 0; fr.bps = 0; fr.in_off = 0; fr.out_off = 0;
+    int my_order = 0, my_wide = 0;
+    if (valid) {
+        fr = frames[f];
+        for (int c = 0; c < (int)fr.channels && c < 8; c++) {
+            const afg_flac_subframe *sf = subframes + fr.sf_index + c;
+            my_order = sf->order > my_order ? sf->order : my_order;
+            my_wide |= sf->use64;
+        }
+    }
+    const int max_order = wave_max(my_order);
+    const bool wide = wave_max(my_wide) != 0;
+    if (!(max_order > LO && max_order <= MAXORD && wide == WIDE)) return;
+    if (!mc_wavefront(valid, fr)) return;
+    const int C = __builtin_amdgcn_readfirstlane((int)fr.channels);
+    const bool r16 = __builtin_amdgcn_readfirstlane((int)(fr.res16 != 0)) != 0;
+    const int inv = (65536 + C - 1) / C;
+    if ((lane & 1) == 0) {
+        RowMeta me;
+        me.in_off = fr.in_off; me.out_off = fr.out_off; me.bs = valid ? fr.block_size : 0u;
+        me.info = (uint32_t)fr.channels | ((uint32_t)fr.sf_index << 8);          // (this kernel's own use of the word: the subframe index)
+        meta[lane >> 1] = me;
+        for (int c = 0; c < 8; c++) {
+            uint32_t sh = 0;
+            if (valid && c < (int)fr.channels) sh = (32u - fr.bps) + subframes[fr.sf_index + c].wasted;       // drflac.d:2883, :2894
+            row_shift[(lane >> 1) * 8 + c] = (uint8_t)(sh & 31u);
+        }
+    }
+    __syncthreads();
+    const uint64_t left = n_frames - (uint64_t)blockIdx.x * kFpw;
+    const int nfr = left < (uint64_t)kFpw ? (int)left : kFpw;                      // frames of this block
+    const int G = 64 / C;                                                          // frames per pass
+    const int g = div_small(lane, inv), ch = lane - g * C;                         // this lane's subframe of a pass
+    const double factor = 1.0 / 2147483647.0;                                      // stream.d:507
+
+    for (int g0 = 0; g0 < nfr; g0 += G) {
+        const int ng = nfr - g0 < G ? nfr - g0 : G;                                // frames of this pass
+        const bool act = lane < ng * C;
+        const RowMeta mine = meta[g0 + (act ? g : 0)];
+        int32_t c[MAXORD], h[MAXORD];
+        int order = 0, shift = 0;
+        bool u64 = false;
+#pragma unroll
+        for (int k = 0; k < MAXORD; k++) { c[k] = 0; h[k] = 0; }
+        if (act) {
+            const afg_flac_subframe *sf = subframes + (mine.info >> 8) + ch;
+            order = sf->order; shift = sf->shift; u64 = sf->use64 != 0;
+#pragma unroll
+            for (int k = 0; k < MAXORD; k++) c[k] = (k < order) ? (int32_t)sf->coef[k] : 0;
+        }
+        const int max_bs = __builtin_amdgcn_readfirstlane(wave_max(act ? (int)mine.bs : 0));
+        // rows in: row rc = (frame, channel) of the pass; 8 (int16 rows: 8 samples) or 16 (int32 rows: 4 samples) lanes per row piece of
+        // a fetch.  int16 rows are fetched a tile ahead into registers (8 per lane) and parked after the stores; int32 rows
+        // (16 registers per lane beside up to 64 of taps and history) go straight to the tile.
+        constexpr int P16 = kPieces / 2;
+        int4 nxt[kLoads / 4];
+        auto fetch16 = [&](int t0) {
+#pragma unroll
+            for (int i = 0; i < kLoads / 4; i++) {
+                const int rc = (64 / P16) * i + lane / P16, p = lane % P16;
+                const int gg = div_small(rc, inv), cc = rc - gg * C, t = t0 + 8 * p;
+                int4 v = make_int4(0, 0, 0, 0);
+                if (rc < ng * C) {
+                    const RowMeta m = meta[g0 + gg];
+                    if (t < (int)m.bs)
+                        v = *(const int4 *)((const int16_t *)res + m.in_off + (uint64_t)cc * (((uint64_t)m.bs + 7u) & ~(uint64_t)7u) + (uint64_t)t);
+                }
+                nxt[i] = v;
+            }
+        };
+        auto park16 = [&]() {
+#pragma unroll
+            for (int i = 0; i < kLoads / 4; i++) {
+                const int rc = (64 / P16) * i + lane / P16, p = lane % P16;
+                const int piece = (rc & 1) * kPieces + 2 * p;
+                const int4 v = nxt[i];
+                *(int4 *)(tile + piece_off(rc >> 1, piece)) = make_int4((int)(int16_t)v.x, v.x >> 16, (int)(int16_t)v.y, v.y >> 16);
+                *(int4 *)(tile + piece_off(rc >> 1, piece + 1)) = make_int4((int)(int16_t)v.z, v.z >> 16, (int)(int16_t)v.w, v.w >> 16);
+            }
+        };
+        auto fill32 = [&](int t0) {
+#pragma unroll
+            for (int i = 0; i < kLoads / 2; i++) {
+                const int rc = (64 / kPieces) * i + lane / kPieces, p = lane % kPieces;
+                const int gg = div_small(rc, inv), cc = rc - gg * C, t = t0 + 4 * p;
+                int4 v = make_int4(0, 0, 0, 0);
+                if (rc < ng * C) {
+                    const RowMeta m = meta[g0 + gg];
+                    if (t < (int)m.bs) {
+                        const int32_t *src = res + m.in_off + (uint64_t)cc * m.bs + (uint64_t)t;
+                        if (t + 3 < (int)m.bs) {
+                            v = *(const int4 *)src;                              // may be 4-byte aligned only (odd block sizes)
+                        } else {
+                            v.x = src[0];
+                            if (t + 1 < (int)m.bs) v.y = src[1];
+                            if (t + 2 < (int)m.bs) v.z = src[2];
+                        }
+                    }
+                }
+                *(int4 *)(tile + piece_off(rc >> 1, (rc & 1) * kPieces + p)) = v;
+            }
+        };
+        if (r16) { fetch16(0); park16(); }
+        for (int t0 = 0; t0 < max_bs; t0 += kT) {
+            if (!r16) fill32(t0);
+            else if (t0 + kT < max_bs) fetch16(t0 + kT);
+            wave_sync();
+            restore_tile1<MAXORD, WIDE>(tile, lane >> 1, lane & 1, t0, order, shift, u64, c, h);
+            wave_sync();
+            if (r16) {                                       // make the prefetched rows resident before the stores enter the queue
+#pragma unroll
+                for (int i = 0; i < kLoads / 4; i++)
+                    asm volatile("" : "+v"(nxt[i].x), "+v"(nxt[i].y), "+v"(nxt[i].z), "+v"(nxt[i].w) : : "memory");
+            }
+            // frames out: element e of a frame's 64 C samples of this step is sample e / C of channel e % C -- 256 contiguous
+            // bytes per store instruction
+            for (int gg = 0; gg < ng; gg++) {
+                const RowMeta m = meta[g0 + gg];
+                const int left_in_frame = (int)m.bs - t0;                         // samples of this frame the step still holds
+                int32_t *const oi = out_i32 ? out_i32 + m.out_off + (uint64_t)t0 * C : nullptr;
+                float *const of = out_f32 ? out_f32 + m.out_off + (uint64_t)t0 * C : nullptr;
+                const uint8_t *const shr = row_shift + (g0 + gg) * 8;
+#pragma unroll 2
+                for (int k = 0; k < C; k++) {
+                    const int e = 64 * k + lane;
+                    const int sm = div_small(e, inv), cc = e - sm * C;
+                    if (sm < left_in_frame) {
+                        const int rc = gg * C + cc;
+                        const int32_t v = shl32(tile[piece_off(rc >> 1, (rc & 1) * kPieces + (sm >> 2)) + (sm & 3)], shr[cc]);
+                        if (oi) __builtin_nontemporal_store(v, oi + e);
+                        if (of) __builtin_nontemporal_store((float)((double)v * factor), of + e);
+                    }
+                }
+            }
+            wave_sync();
+            if (r16 && t0 + kT < max_bs) park16();
+            wave_sync();
+        }
+    }
+}
 }  // namespace
 
 namespace {
@@ -607,7 +781,7 @@ int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg
         afg::set_error("afg_flac_transform_hip: too many frames in one call");
         return AFG_ERR_INVALID;
     }
-    const uint32_t all = 0xffu;                                      // eight instantiations: (order bucket, accumulator width)
+    const uint32_t all = 0xfffu;                                     // eight instantiations: (order bucket, accumulator width) + four of the multi-channel kernel
     variants &= all;
     if (!variants) return AFG_OK;
     // a known set of two or more: alternate between the caller's stream and the device's side stream
@@ -643,6 +817,18 @@ int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg
     AFG_FLAC_LAUNCH2(8, 12, false);  AFG_FLAC_LAUNCH2(8, 12, true);
     AFG_FLAC_LAUNCH2(12, 32, false); AFG_FLAC_LAUNCH2(12, 32, true);
 #undef AFG_FLAC_LAUNCH2
+    // wavefronts of more than two channels throughout: order <= 12 / <= 32 x accumulator width (bits 8 .. 11)
+#define AFG_FLAC_LAUNCH_MC(LO, HI, W)                                                                                  \
+    if (variants & (1u << idx)) {                                                                                      \
+        hipLaunchKernelGGL((flac_restore_mc_kernel<LO, HI, W>), dim3((uint32_t)groups1), dim3(64), 0,                  \
+                           (side && (used & 1)) ? side->stream : stream, d_frames, d_subframes, d_res, d_out_i32,      \
+                           d_out_f32, n_frames);                                                                       \
+        used++;                                                                                                        \
+    }                                                                                                                  \
+    idx++
+    AFG_FLAC_LAUNCH_MC(-1, 12, false); AFG_FLAC_LAUNCH_MC(-1, 12, true);
+    AFG_FLAC_LAUNCH_MC(12, 32, false); AFG_FLAC_LAUNCH_MC(12, 32, true);
+#undef AFG_FLAC_LAUNCH_MC
     if (side) {
         AFG_HIP_CHECK(hipEventRecord(side->join, side->stream));
         AFG_HIP_CHECK(hipStreamWaitEvent(stream, side->join, 0));
@@ -658,17 +844,23 @@ int launch_variants(uint64_t n_frames, const afg_flac_frame *d_frames, const afg
 extern "C" uint32_t afg_flac_variants(uint64_t n_frames, const afg_flac_frame *frames, const afg_flac_subframe *subframes)
 {
     uint32_t mask = 0;
-    if (!frames || !subframes) return 0xffu;
+    if (!frames || !subframes) return 0xfffu;
     for (uint64_t g = 0; g < n_frames; g += kFpw) {
         int order = 0, wide = 0;
-        for (uint64_t f = g; f < n_frames && f < g + kFpw; f++)
+        // (mc_wavefront's test: one channel count in 3 .. 8, independent channels, one row width, in every frame of the group)
+        const int c0 = (int)frames[g].channels, r0 = frames[g].res16 != 0;
+        bool mc = c0 > 2 && c0 <= 8;
+        for (uint64_t f = g; f < n_frames && f < g + kFpw; f++) {
+            mc = mc && (int)frames[f].channels == c0 && frames[f].assignment == AFG_FLAC_INDEPENDENT && (frames[f].res16 != 0) == r0;
             for (int c = 0; c < (int)frames[f].channels && c < 8; c++) {
                 const afg_flac_subframe &sf = subframes[frames[f].sf_index + c];
                 if (sf.order > order) order = sf.order;
                 wide |= sf.use64 != 0;
             }
+        }
         const int bucket = order <= 4 ? 0 : order <= 8 ? 1 : order <= 12 ? 2 : 3;
-        mask |= 1u << (bucket * 2 + wide);
+        if (mc) mask |= 1u << (8 + (order <= 12 ? 0 : 2) + wide);
+        else mask |= 1u << (bucket * 2 + wide);
     }
     return mask;
 }
@@ -681,7 +873,7 @@ extern "C" int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d
                                       const afg_flac_subframe *d_subframes, const int32_t *d_res,
                                       int32_t *d_out_i32, float *d_out_f32, void *hip_stream)
 {
-    return launch_variants(n_frames, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, 0xffu, (hipStream_t)hip_stream);
+    return launch_variants(n_frames, d_frames, d_subframes, d_res, d_out_i32, d_out_f32, 0xfffu, (hipStream_t)hip_stream);
 }
 
 extern "C" int afg_flac_transform_variants_hip(uint64_t n_frames, const afg_flac_frame *d_frames,

@@ -275,9 +275,10 @@ int afg_flac_transform_hip(uint64_t n_frames, const afg_flac_frame *d_frames,
                            int32_t *d_out_i32, float *d_out_f32, void *hip_stream);
 
 /* The restore kernel exists in 8 instantiations (LPC-order bucket <= 4 / 8 / 12 / 32 x 64-bit accumulator, so that each gets
- * the registers it needs and no more); a wavefront of 32 consecutive frames -- a lane per subframe -- runs in the one its
+ * the registers it needs and no more) plus 4 of a kernel for groups of frames with one channel count above two (round 6:
+ * order <= 12 / 32 x accumulator); a wavefront of 32 consecutive frames -- a lane per subframe -- runs in the one its
  * largest order and widest subframe select.  afg_flac_transform_hip is stream-ordered -- the records are read by the
- * device when hip_stream gets there, never by the host at the call -- so it launches all 8; the ones nobody selects exit
+ * device when hip_stream gets there, never by the host at the call -- so it launches all 12; the ones nobody selects exit
  * at once.  A caller that still holds the FINAL records in host memory can say which are populated:
  * afg_flac_variants (host pointers, pure host code) returns the set as a bit mask, and afg_flac_transform_variants_hip
  * launches only those -- two or more of them side by side on the caller's stream and an internal one, joined before

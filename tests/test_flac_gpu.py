@@ -232,3 +232,59 @@ def test_flac_in_range_samples_with_a_wrapping_sum(gpu, order):
     got_i32, _ = run_gpu(gpu, frames, subs, flat, total, want_float=False)
     assert np.array_equal(got_i32, want)
     assert np.abs(flat.astype(np.int64)).max() > 2 ** 28                # sums that wrapped: the residuals had to undo them
+
+
+@pytest.mark.parametrize("ch", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("kw", [
+    dict(n_frames=75, block_size=4096, orders=(8, 12)),                                  # several passes per block of 32 frames, a ragged last block
+    dict(n_frames=40, vary_block=True, orders=(2, 8, 12, 31)),                            # block sizes differ inside a pass, odd sizes, order 31
+    dict(n_frames=33, block_size=1152, bps=24, orders=(12, 32), residual_scale=3000.0),   # wide sums, order 32
+])
+def test_flac_multichannel_kernel_bit_exact(gpu, ch, kw):
+    """groups of frames with one channel count above two: flac_restore_mc_kernel (whole interleaved frames per step), int32
+    rows and int16 rows, both outputs"""
+    frames, subframes, res, total = synthetic.flac_batch(100 + ch, channels=ch, **kw)
+    want_i, want_f = oraclelib.flac_transform(frames, subframes, res, total, want_float=True)
+    got_i, got_f = run_gpu(gpu, frames, subframes, res, total)
+    assert (got_i == want_i).all(), f"{int((got_i != want_i).sum())} int32 mismatches"
+    assert (got_f.view(np.uint32) == want_f.view(np.uint32)).all()
+    mask = afgpu.flac_variants(frames, subframes)
+    assert mask & 0xf00 and not (mask & 0xff), hex(mask)           # only instantiations of the multi-channel kernel
+    if kw.get("bps", 16) == 16:
+        res16 = np.clip(res, -30000, 30000).astype(np.int32)
+        fr16, packed = synthetic.flac_pack16(frames, res16)
+        if (fr16["res16"] != 0).all():
+            want16 = oraclelib.flac_transform(fr16, subframes, packed, total)
+            got16, _ = run_gpu(gpu, fr16, subframes, packed, total, want_float=False)
+            assert (got16 == want16).all()
+
+
+def test_flac_multichannel_and_stereo_groups_in_one_call(gpu):
+    """a batch whose 32-frame groups are of different kinds -- stereo, six channels, a group that mixes channel counts (the
+    general step's), mono -- goes to the right kernels group by group, with and without the variants mask"""
+    import torch
+    parts = [synthetic.flac_batch(7, n_frames=64, block_size=1024, channels=2, orders=(8, 12)),
+             synthetic.flac_batch(8, n_frames=64, block_size=1024, channels=6, orders=(8, 12)),
+             synthetic.flac_batch(9, n_frames=16, block_size=1024, channels=6, orders=(8, 12)),
+             synthetic.flac_batch(10, n_frames=16, block_size=1024, channels=3, orders=(8, 12)),      # with the 16 before: a mixed group
+             synthetic.flac_batch(11, n_frames=40, block_size=1024, channels=1, orders=(8, 12)),
+             synthetic.flac_batch(12, n_frames=32, block_size=1024, channels=4, orders=(2, 32))]
+    frames, subs, ress = [], [], []
+    in_off = out_off = sf_off = 0
+    for fr, sb, rs, tot in parts:
+        fr = fr.copy()
+        fr["in_off"] += np.uint64(in_off); fr["out_off"] += np.uint64(out_off); fr["sf_index"] += np.uint32(sf_off)
+        frames.append(fr); subs.append(sb); ress.append(rs)
+        in_off += len(rs); out_off += tot; sf_off += len(sb)
+    frames, subs, res = np.concatenate(frames), np.concatenate(subs), np.concatenate(ress)
+    want = oraclelib.flac_transform(frames, subs, res, out_off)
+    mask = afgpu.flac_variants(frames, subs)
+    assert mask & 0xf00 and mask & 0xff
+    d_fr = torch.from_numpy(frames.view(np.uint8).copy()).to(gpu)
+    d_sf = torch.from_numpy(subs.view(np.uint8).copy()).to(gpu)
+    d_res = torch.from_numpy(res).to(gpu)
+    for variants in (None, mask):
+        out = torch.full((out_off,), -777, dtype=torch.int32, device=gpu)
+        afgpu.flac_transform(len(frames), d_fr, d_sf, d_res, out, None, None, variants=variants)
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == want).all()
