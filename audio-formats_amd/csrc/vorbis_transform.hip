@@ -58,7 +58,7 @@ using namespace afg_vorbis;
 // T threads walk one channel of a segment, CPG channels per workgroup: (64, up to 8) -- wavefronts that never meet, for block
 // sizes up to 1024 -- or (256, 1), a workgroup per channel with block-wide barriers between the passes, for the long
 // blocks whose passes have work for four wavefronts (one wavefront alone: 4096-sample blocks 75 ms per C3-sized batch,
-// 32 KB of LDS each; four: see DESIGN 3.2).
+// 32 KB of LDS each; four: see HISTORY.md 3.2).
 template <int T, int CPG>
 __global__ __launch_bounds__(T * CPG) void vorbis_channel_kernel(
     const VorbisSeg *__restrict__ segs, uint32_t n_segs, uint32_t chan_floats, const VorbisStream *__restrict__ streams,

@@ -842,7 +842,7 @@ __device__ __forceinline__ void walk_body(
 
     // One packet's spectra are in flight: the pre-twiddle of transform k empties xin, the loads of transform k+1 follow
     // at once and are waited for (settle) just before the PCM stores of transform k enter the queue -- loads and stores
-    // share one in-order counter.
+    // share one in-order counter (HISTORY.md 8).
     f2 xin[CH][R];
     auto issue = [&](int p) {
         const unsigned flp = p < p_end ? flags_of(p) : 0u;

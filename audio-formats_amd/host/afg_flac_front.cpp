@@ -191,7 +191,7 @@ bool flac_residual(BitReader &br, uint32_t block_size, uint32_t order, int32_t *
         // The reference tests the parameter against 16 / 32 (drflac.d:1301, :1304), values a 4- / 5-bit
         // field never takes, so its unencoded-partition branch (:1313-1321) is dead and the FLAC escape
         // codes 15 / 31 are decoded as plain Rice parameters.  Results must be identical to the
-        // reference's, so the same happens here (DESIGN.md "FLAC front-end"); flip kSpecEscape to get
+        // reference's, so the same happens here (HISTORY.md 4, "FLAC front-end"); flip kSpecEscape to get
         // the format's own behaviour.
         constexpr bool kSpecEscape = false;
         const bool escape = kSpecEscape && ((method == 0 && k == 15) || (method == 1 && k == 31));

@@ -9,7 +9,7 @@
  * (AuburnSounds/audio-formats, D) ships no golden vectors, known-answer
  * tests or fixtures for any decoder, and no D compiler exists in this image
  * or on the GPU box, so the reference cannot be run (oracle/_ref is
- * unbuildable).  What pins this restatement instead is listed in DESIGN.md:
+ * unbuildable).  What pins this restatement instead is listed in DESIGN.md 7 (in full: HISTORY.md 4):
  * float64 textbook definitions of every transform (tests/test_oracle_*.py),
  * lossless FLAC/QOA encode->decode round trips, frozen golden vectors under
  * tests/golden/, and -- the one check against code written elsewhere -- the

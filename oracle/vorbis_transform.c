@@ -9,7 +9,7 @@
  *   window bounds                :2333-2349     finish_frame        :2606-2657
  *   interleave                   :3927-3952
  *
- * Numeric choices where the D source leaves room (documented in DESIGN.md):
+ * Numeric choices where the D source leaves room (documented in HISTORY.md 4):
  *   - M_PI is a float enum, so twiddle angles such as 4*k*M_PI/n are evaluated
  *     in float32; cos/sin are then taken in double and rounded to float.
  *   - the window (:872) is evaluated in double with the float-rounded pi and

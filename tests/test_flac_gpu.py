@@ -208,7 +208,7 @@ def test_flac_in_range_samples_with_a_wrapping_sum(gpu, order):
     """Valid-looking 16-bit channels whose prediction sum passes 2^31: coefficients at the int16 limits, every decoded sample
     inside int16 (the residuals are computed against the reference's wrapping int32 recurrence).  Frames 40..47 hold samples
     far beyond int16 as well.  (Written for a packed int16 dot-product form of the recurrence, which turned out slower
-    than the 32-bit multiplies -- DESIGN.md section 8 -- and is not in the product; the cases stay.)"""
+    than the 32-bit multiplies -- HISTORY.md section 8 -- and is not in the product; the cases stay.)"""
     rng = np.random.default_rng(order)
     n_frames, bs = 130, 192
     frames = np.zeros(n_frames, afgpu.FLAC_FRAME_DTYPE)

@@ -147,7 +147,7 @@ def test_stream_api_equals_batch_for_late_delivery_ogg(gpu):
 
 
 def test_unsupported_ogg_does_not_poison_the_batch(gpu):
-    """Vorbis block sizes 64/128 are legal but unsupported: such a file gets its own verdict."""
+    """Vorbis block sizes 64/128 are legal but unsupported (HISTORY.md 4): such a file gets its own verdict."""
     import vorbis_bitstream as vb
     good = vb.make_file(3)
     bad = bytearray(vb.make_file(4))

@@ -240,7 +240,7 @@ def _product_vs_oracle(data):
     o = oraclelib.flac_decode_file(data)
     want = None if isinstance(o, int) else o["pcm"]
     if want is not None and o["flags"] and o["first_flag_sample"] is not None:
-        want = want[:o["first_flag_sample"]]                   # the product ends the stream at a stale-buffer frame
+        want = want[:o["first_flag_sample"]]                   # the product ends the stream at a stale-buffer frame (HISTORY.md 4)
     try:
         info, frames, subframes, res = afgpu.flac_parse(data)
         got = oraclelib.flac_transform(frames, subframes, res, info["out_samples"])

@@ -375,7 +375,7 @@ def bench_device_inclusive(dev, chunks=8, files_per_chunk=16):
     """device-inclusive rate per codec -- transform-stage records already parsed, in page-locked host memory ->
     H2D + kernels + D2H, chunked so that the three overlap (upload + kernel on one stream, download on a second behind an
     event).  What the batch path's device stage costs once parsing is taken away; bound by the bytes that cross the bus in
-    both directions together (57 GB/s in total on this box)."""
+    both directions together (74-89 GB/s on these boxes)."""
     import time
     from afgpu import corpus
     out = {}

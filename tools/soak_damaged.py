@@ -65,7 +65,7 @@ OGG_PHANTOM = {}          # file length -> the delivered frames without upstream
 def want_ogg(data):
     """oracle front-end + transform; a packet whose left window does not have the length of the previous packet's right
     window (damaged flags: the reference mixes the two lengths, stb_vorbis2.d:2618-2627) is where the product ends the
-    stream: expected = everything before it"""
+    stream (HISTORY.md 4): expected = everything before it"""
     rec = oraclelib.vorbis_decode_file(data)
     if rec is None:
         return None
@@ -187,7 +187,7 @@ def run(rounds, seed=2024, streams=True):
                     print("product decoded what the oracle rejects", kind, out["frames"]); bad += 1
                 continue
             if out["status"] != 0:
-                if kind in ("ogg", "opus"):                          # (the product ends a stream at an inconsistent window): counted
+                if kind in ("ogg", "opus"):                          # (the product ends a stream at an inconsistent window, HISTORY.md 4): counted
                     run.refused[kind] += 1
                     continue
                 print("product rejected", kind, out["message"]); bad += 1; continue

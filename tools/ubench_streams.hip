@@ -2,7 +2,7 @@
 //
 // Every headline kernel is a set of resident wavefronts that each read their own contiguous run of the input plane and
 // write their own contiguous run of the output plane, one unit (4.6 - 8 KB) per step, and all of them stop at 5.0 - 5.3
-// TB/s where a plain copy reaches 6.2 - 6.5.  This program moves 16 GB in + 16 GB out with
+// TB/s where a plain copy reaches 6.2 - 6.5 (HISTORY.md 8).  This program moves 16 GB in + 16 GB out with
 //     S   resident wavefronts (S / 256 per CU, 64 lanes each),
 //     B   bytes per wavefront and step (16-byte accesses, B / 1024 instructions each way),
 //     K   steps per segment: a wavefront owns K consecutive units, then takes the next free segment (atomic counter),
