@@ -851,6 +851,21 @@ __device__ __forceinline__ void walk_body(
             // AFG_VORBIS_NZ_EIGHTHS: load r of a channel covers bins 128 r .. 128 r + 127 of n/2 = 128 R, so a load whose
             // bins all lie in the declared-empty eighths is a whole instruction that is not issued (a scalar test)
             const int nz = (int)(flp >> 4) ? (int)(flp >> 4) - 1 : 8;
+#if defined(AFG_WALK_EXP_NOFFT) && AFG_WALK_EXP_NOFFT == 2
+            // (experiment, with the passes compiled out: the same bytes fetched 16 per lane -- is the 8-byte load what sets the floor?)
+            {
+                const f4 *src4 = (const f4 *)((const f2 *)(spec + lane64(so_reg, p)) + chan * kPts) + fresh_lane();
+#pragma unroll
+                for (int c = 0; c < CH; c++)
+#pragma unroll
+                    for (int r = 0; r < R; r += 2) {
+                        f4 v = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                        if (8 * r < nz * R) v = __builtin_nontemporal_load(src4 + c * (kPts / 2) + 64 * (r / 2));
+                        xin[c][r] = f2{ v.x, v.y };
+                        xin[c][r + 1] = f2{ v.z, v.w };
+                    }
+            }
+#else
 #pragma unroll
             for (int c = 0; c < CH; c++)
 #pragma unroll
@@ -858,6 +873,7 @@ __device__ __forceinline__ void walk_body(
                     xin[c][r] = f2{ 0.0f, 0.0f };
                     if (8 * r < nz * R) xin[c][r] = __builtin_nontemporal_load(src + c * kPts + 64 * r);
                 }
+#endif
         } else {
             // nothing reads xin before the next issue(): say so, or the old values are copied around to survive the branch
 #pragma unroll
