@@ -57,6 +57,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-others", action="store_true",
                     help="skip `other_workloads` (the side-by-side step; the C5 corpus, dense CELT, QOA and the end-to-end batches, each in "
                          "a child process after the headline measurement; only at N = 1 with the default config)")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="N = 1, default config: before the run, measure `roofline.traffic` of the three headline kernels in child processes "
+                         "(separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over bench.py --config c2 / c3 / c4, FLAC's counters "
+                         "calibrated on its access pattern: tools/pmc_collect.sh) instead of reading the committed passes under profiles/; "
+                         "adds about four minutes")
     ap.add_argument("--full-line", action="store_true",
                     help="print the full record as the (only) stdout line instead of the compact line (what this script's own child "
                          "runs and the tools that post-process a run read)")
@@ -65,6 +70,44 @@ def parse_args(argv=None):
                     help="testing only: ranks beyond the visible devices share them (rank %% devices); the line says so")
     return ap.parse_args(argv)
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# --measure-traffic: HBM bytes per launch from the PMC counters, measured in child processes before this run
+# ----------------------------------------------------------------------------------------------------------------
+def measure_traffic():
+    """{codec: hbm bytes per launch} from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only -- never combined
+    with tracing) over `bench.py --config cN`, each in its own child process; this process has not touched a GPU yet.  FLAC's
+    counters are calibrated first on the kernel's own access pattern with known byte counts (MI355X_MICROARCH.md asks for that
+    before trusting an access width it does not list).  Returns {} with a message on stderr when rocprofv3 or hipcc is missing."""
+    import shutil
+    if not shutil.which("rocprofv3"):
+        sys.stderr.write("bench.py --measure-traffic: rocprofv3 not found; falling back to the committed passes\n")
+        return {}
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, AFG_PMC_SETS="FETCH_SIZE;WRITE_SIZE")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = {}
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-full-fetch", "--no-others"]
+    jobs = [("mp3", "mp3_tolerance_kernel", "c2", {}), ("vorbis", "vorbis_walk_kernel", "c3", {})]
+    try:
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "pmc_calib_flac.sh")], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        with open(os.path.join(ROOT, "gpurun_out", "calib_flac", "calib.json")) as fh:
+            c = json.load(fh)
+        f = sum(c["FETCH_SIZE_kb_per_launch"]) / len(c["FETCH_SIZE_kb_per_launch"]) * 1024
+        w = sum(c["WRITE_SIZE_kb_per_launch"]) / len(c["WRITE_SIZE_kb_per_launch"]) * 1024
+        jobs.append(("flac", "flac_restore1_kernel", "c4", {"AFG_PMC_FETCH_FACTOR": f"{c['known_read_bytes'] / f:.4f}",
+                                                           "AFG_PMC_WRITE_FACTOR": f"{c['known_write_bytes'] / w:.4f}", "AFG_PMC_DISPATCHES_PER_LAUNCH": "2"}))
+    except Exception as e:
+        sys.stderr.write(f"bench.py --measure-traffic: FLAC calibration failed ({e}); FLAC keeps the committed pass\n")
+    for codec, needle, cfg, extra in jobs:
+        tag = f"live_pmc_{codec}"
+        try:
+            subprocess.run(["bash", os.path.join(ROOT, "tools", "pmc_collect.sh"), tag, needle, "bench.py", "--config", cfg] + common,
+                           env=dict(env, **extra), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            with open(os.path.join(ROOT, "gpurun_out", tag, tag + ".json")) as fh:
+                out[codec] = float(json.load(fh)["derived"]["hbm_bytes_per_launch"])
+        except Exception as e:
+            sys.stderr.write(f"bench.py --measure-traffic: {codec}: {e}\n")
+    return out
 
 # ----------------------------------------------------------------------------------------------------------------
 # launcher: N rank processes, started before this process has touched a GPU (it never does)
@@ -716,13 +759,18 @@ def run_rank(args, world, rank, local_rank):
         tb = None
         # (only for the run those passes describe: full size, the product library, no input-format or segment overrides)
         variant = args.seg or any(os.environ.get(v) for v in ("AFG_LIB_PATH", "AFG_FLAC_RES32", "AFG_MP3_FLOAT_UPLOAD", "AFG_NUMERIC"))
-        if args.config in ("c234", "c2", "c3", "c4") and args.files == 1024 and name in pmc_file and not variant:
+        live = getattr(args, "live_traffic", None) or {}
+        if name in live and not variant:
+            tb = live[name]
+        elif args.config in ("c234", "c2", "c3", "c4") and args.files == 1024 and name in pmc_file and not variant:
             tb = ((load_traffic(pmc_file[name]) or {}).get("derived") or {}).get("hbm_bytes_per_launch")
         kernels.append({"codec": name, "kernel": k["kernel"], "avg_kernel_ms": avg_ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": int(k["alg_bytes"]), "units_per_launch": int(k["units"]),
                         "samples_per_launch": int(k["samples"]), "samples_per_s": k["samples"] / (avg_ms * 1e-3),
                         "traffic": tb, "frac_by_traffic": (tb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None,
-                        "traffic_source": ("profiles/" + pmc_file[name]) if tb else None})
+                        "traffic_source": (("measured before this run (--measure-traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --config "
+                                            + {"mp3": "c2", "vorbis": "c3", "flac": "c4"}.get(name, "?") + ")") if name in live
+                                           else ("profiles/" + pmc_file[name])) if tb else None})
         if k.get("survey_bytes") and k["survey_bytes"] != k["alg_bytes"]:
             # `frac` above is priced on the bytes this launch has to move; SURVEY 8(d)'s per-unit figure is shown beside it
             kernels[-1]["bytes_at_survey_8d"] = int(k["survey_bytes"])
@@ -797,6 +845,8 @@ def main():
         if args.gpus > 1:
             return launch_ranks(args)                  # before anything in this process touches a GPU
         world, rank, local_rank = 1, 0, 0
+        if args.measure_traffic and args.config == "c234" and args.files == 1024:
+            args.live_traffic = measure_traffic()      # child processes: this one has not touched a GPU yet
     else:
         world = int(env_world)
         rank = int(os.environ.get("RANK", "0"))

@@ -7,11 +7,13 @@ tag=$1; shift; needle=$1; shift; prog=$1; shift
 export TMPDIR=/tmp
 cd /tmp
 k=0
-for set in \
-  "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
-  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
-  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR" \
-  "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+# the counter sets, one rocprofv3 pass each (AFG_PMC_SETS="FETCH_SIZE;WRITE_SIZE" restricts them: bench.py --measure-traffic)
+if [ -n "$AFG_PMC_SETS" ]; then IFS=';' read -r -a sets <<< "$AFG_PMC_SETS"; else sets=(
+  "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM"
+  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
+  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"
+  "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"); fi
+for set in "${sets[@]}"; do
   k=$((k+1))
   mkdir -p "$R/gpurun_out/$tag/pass$k"
   echo "$set" > "$R/gpurun_out/$tag/pass$k/counters.txt"
