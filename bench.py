@@ -57,11 +57,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-others", action="store_true",
                     help="skip `other_workloads` (the side-by-side step; the C5 corpus, dense CELT, QOA and the end-to-end batches, each in "
                          "a child process after the headline measurement; only at N = 1 with the default config)")
-    ap.add_argument("--measure-traffic", action="store_true",
-                    help="N = 1, default config: before the run, measure `roofline.traffic` of the three headline kernels in child processes "
-                         "(separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over bench.py --config c2 / c3 / c4, FLAC's counters "
-                         "calibrated on its access pattern: tools/pmc_collect.sh) instead of reading the committed passes under profiles/; "
-                         "adds about four minutes")
+    ap.add_argument("--measure-traffic", action="store_true", default=None,
+                    help="N = 1, default config (where it is the default when rocprofv3 is on the PATH): before the run, measure `roofline.traffic` of "
+                         "the three headline kernels in child processes (separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over bench.py "
+                         "--config c2 / c3 / c4, FLAC's counters calibrated on its access pattern: tools/pmc_collect.sh) instead of reading the "
+                         "committed passes under profiles/; adds about half a minute")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false",
+                    help="read `roofline.traffic` from the committed passes under profiles/ (labelled `traffic_from`)")
     ap.add_argument("--full-line", action="store_true",
                     help="print the full record as the (only) stdout line instead of the compact line (what this script's own child "
                          "runs and the tools that post-process a run read)")
@@ -83,13 +85,13 @@ def measure_traffic():
     if not shutil.which("rocprofv3"):
         sys.stderr.write("bench.py --measure-traffic: rocprofv3 not found; falling back to the committed passes\n")
         return {}
-    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, AFG_PMC_SETS="FETCH_SIZE;WRITE_SIZE")
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, AFG_PMC_SETS="FETCH_SIZE;WRITE_SIZE", AFG_BENCH_NESTED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     out = {}
     common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-full-fetch", "--no-others"]
     jobs = [("mp3", "mp3_tolerance_kernel", "c2", {}), ("vorbis", "vorbis_walk_kernel", "c3", {})]
     try:
-        subprocess.run(["bash", os.path.join(ROOT, "tools", "pmc_calib_flac.sh")], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "pmc_calib_flac.sh")], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
         with open(os.path.join(ROOT, "gpurun_out", "calib_flac", "calib.json")) as fh:
             c = json.load(fh)
         f = sum(c["FETCH_SIZE_kb_per_launch"]) / len(c["FETCH_SIZE_kb_per_launch"]) * 1024
@@ -102,7 +104,7 @@ def measure_traffic():
         tag = f"live_pmc_{codec}"
         try:
             subprocess.run(["bash", os.path.join(ROOT, "tools", "pmc_collect.sh"), tag, needle, "bench.py", "--config", cfg] + common,
-                           env=dict(env, **extra), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+                           env=dict(env, **extra), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
             with open(os.path.join(ROOT, "gpurun_out", tag, tag + ".json")) as fh:
                 out[codec] = float(json.load(fh)["derived"]["hbm_bytes_per_launch"])
         except Exception as e:
@@ -845,7 +847,9 @@ def main():
         if args.gpus > 1:
             return launch_ranks(args)                  # before anything in this process touches a GPU
         world, rank, local_rank = 1, 0, 0
-        if args.measure_traffic and args.config == "c234" and args.files == 1024:
+        # (by default only in the full default run -- the one the driver times -- and never inside this script's own children)
+        want = args.measure_traffic if args.measure_traffic is not None else (not args.no_others and not os.environ.get("AFG_BENCH_NESTED"))
+        if want and args.config == "c234" and args.files == 1024:
             args.live_traffic = measure_traffic()      # child processes: this one has not touched a GPU yet
     else:
         world = int(env_world)
